@@ -1,0 +1,216 @@
+"""ctypes front-end to oracle/liboracle.so (plain-C restatement of the reference hot path).
+
+TEST INFRASTRUCTURE -- not part of the product.  Only tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py may import this module, and only as checker / baseline.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboracle.so")
+
+IX, IL, KX, MX, NX, IY = 96, 48, 8, 31, 32, 24
+
+
+class Tables(C.Structure):
+    _fields_ = [
+        ("hsg", C.c_double * 9), ("dhs", C.c_double * 8), ("fsg", C.c_double * 8), ("dhsr", C.c_double * 8),
+        ("fsgr", C.c_double * 8),
+        ("radang", C.c_double * 48), ("coriol", C.c_double * 48), ("sia", C.c_double * 48), ("coa", C.c_double * 48),
+        ("sia_half", C.c_double * 24), ("coa_half", C.c_double * 24), ("cosgr", C.c_double * 48),
+        ("cosgr2", C.c_double * 48),
+        ("sigl", C.c_double * 8), ("sigh", C.c_double * 9), ("grdsig", C.c_double * 8), ("grdscp", C.c_double * 8),
+        ("wvi", C.c_double * 16),
+        ("epsi", C.c_double * (32 * 33)), ("repsi", C.c_double * (32 * 33)), ("cpol", C.c_double * (62 * 32 * 24)),
+        ("wt", C.c_double * 24), ("nsh2", C.c_int * 32),
+        ("work", C.c_double * 96), ("ifac", C.c_int * 15),
+        ("el2", C.c_double * 992), ("elm2", C.c_double * 992), ("el4", C.c_double * 992), ("trfilt", C.c_double * 992),
+        ("gradym", C.c_double * 992), ("gradyp", C.c_double * 992), ("uvdx", C.c_double * 992),
+        ("uvdym", C.c_double * 992), ("uvdyp", C.c_double * 992), ("vddym", C.c_double * 992),
+        ("vddyp", C.c_double * 992), ("gradx", C.c_double * 31),
+        ("fband", C.c_double * (301 * 4)),
+    ]
+
+
+TABLE_SHAPES = {
+    "wvi": (8, 2), "epsi": (32, 33), "repsi": (32, 33), "cpol": (62, 32, 24), "fband": (301, 4),
+    **{k: (31, 32) for k in ("el2", "elm2", "el4", "trfilt", "gradym", "gradyp", "uvdx", "uvdym", "uvdyp", "vddym",
+                             "vddyp")},
+}
+
+
+class PhysIO(C.Structure):
+    _fields_ = (
+        [(n, C.c_void_p) for n in ("ug", "vg", "tg", "qg_in", "phig", "pslg", "utend", "vtend", "ttend", "qtend",
+                                   "fmask_land", "phis0", "forog", "sst_am", "alb_land", "alb_sea", "snowc",
+                                   "land_temp", "soil_avail_water",
+                                   "flux_solar_in", "flux_ozone_upper", "flux_ozone_lower", "zenit_correction",
+                                   "stratospheric_correction", "alb_surface")]
+        + [("air_absortivity_co2", C.c_double), ("compute_shortwave", C.c_int)]
+        + [(n, C.c_void_p) for n in ("precnv", "precls", "cbmf", "slrd", "slr", "olr",
+                                     "slru", "ustr", "vstr", "shf", "evap", "hfluxn", "rad_st4a", "rad_flux",
+                                     "tt_rsw", "rad_tau2", "rad_strat_corr", "tsr", "ssrd", "ssr", "qcloud_equiv",
+                                     "iptop", "icltop", "ts", "tskin", "u0", "v0", "t0", "cloudc", "clstr")]
+    )
+
+
+def build():
+    """(Re)build liboracle.so with gcc.  Building the checker is not using it."""
+    subprocess.run(["make", "-s", "-C", HERE, "liboracle.so"], check=True)
+
+
+_lib = None
+_tables = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+    return _lib
+
+
+def tables():
+    global _tables
+    if _tables is None:
+        _tables = Tables()
+        lib().orc_tables_init(C.byref(_tables))
+    return _tables
+
+
+def table(name):
+    """Oracle table as a Fortran-ordered numpy array (copy)."""
+    t = tables()
+    a = np.ctypeslib.as_array(getattr(t, name)).copy()
+    if name in TABLE_SHAPES:
+        a = a.reshape(TABLE_SHAPES[name], order="F")
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _call(name, *args):
+    fn = getattr(lib(), "orc_" + name)
+    cargs = [C.byref(tables())]
+    for a in args:
+        if isinstance(a, np.ndarray):
+            cargs.append(_p(a))
+        elif isinstance(a, (int, np.integer)):
+            cargs.append(C.c_int(int(a)))
+        else:
+            raise TypeError(type(a))
+    fn(*cargs)
+
+
+def _r(a):
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+def _c(a):
+    return np.asfortranarray(a, dtype=np.complex128)
+
+
+def legendre_inv(x):
+    out = np.zeros((62, 48), order="F")
+    _call("legendre_inv", _r(x), out)
+    return out
+
+
+def legendre(x):
+    out = np.zeros((62, 32), order="F")
+    _call("legendre", _r(x), out)
+    return out
+
+
+def fourier_inv(x, kcos=1):
+    out = np.zeros((96, 48), order="F")
+    _call("fourier_inv", _r(x), out, kcos)
+    return out
+
+
+def fourier(x):
+    out = np.zeros((62, 48), order="F")
+    _call("fourier", _r(x), out)
+    return out
+
+
+def spec2grid(spec, kcos=1):
+    out = np.zeros((96, 48), order="F")
+    _call("spec2grid", _c(spec), out, kcos)
+    return out
+
+
+def grid2spec(grid):
+    out = np.zeros((31, 32), dtype=np.complex128, order="F")
+    _call("grid2spec", _r(grid), out)
+    return out
+
+
+def spec2grid_batch(spec, kcos=1):
+    """spec: C-contiguous [B, 32, 31] complex (i.e. Fortran (31,32) per field) -> [B, 48, 96]."""
+    spec = np.ascontiguousarray(spec, dtype=np.complex128)
+    B = spec.shape[0]
+    out = np.zeros((B, 48, 96))
+    _call("spec2grid_batch", spec, out, kcos, B)
+    return out
+
+
+def grid2spec_batch(grid):
+    grid = np.ascontiguousarray(grid, dtype=np.float64)
+    B = grid.shape[0]
+    out = np.zeros((B, 32, 31), dtype=np.complex128)
+    _call("grid2spec_batch", grid, out, B)
+    return out
+
+
+def vort2vel(vor, div):
+    u = np.zeros((31, 32), dtype=np.complex128, order="F")
+    v = np.zeros_like(u)
+    _call("vort2vel", _c(vor), _c(div), u, v)
+    return u, v
+
+
+def vel2vort(u, v):
+    vor = np.zeros((31, 32), dtype=np.complex128, order="F")
+    div = np.zeros_like(vor)
+    _call("vel2vort", _c(u), _c(v), vor, div)
+    return vor, div
+
+
+def grid_vel2vort(ug, vg, kcos):
+    vor = np.zeros((31, 32), dtype=np.complex128, order="F")
+    div = np.zeros_like(vor)
+    _call("grid_vel2vort", _r(ug), _r(vg), vor, div, kcos)
+    return vor, div
+
+
+def gradient(psi):
+    dx = np.zeros((31, 32), dtype=np.complex128, order="F")
+    dy = np.zeros_like(dx)
+    _call("gradient", _c(psi), dx, dy)
+    return dx, dy
+
+
+def laplacian(x, inverse=False):
+    out = np.zeros((31, 32), dtype=np.complex128, order="F")
+    _call("laplacian", _c(x), out, int(inverse))
+    return out
+
+
+def truncate(x):
+    out = _c(x).copy(order="F")
+    _call("truncate", out)
+    return out
+
+
+def grid_filter(g):
+    out = np.zeros((96, 48), order="F")
+    _call("grid_filter", _r(g), out)
+    return out
