@@ -1,0 +1,103 @@
+"""ctypes binding of the C ABI declared in include/pyspeedy_amd.h.
+
+The HIP library is the product: if it is missing or cannot be loaded this module raises -- there is no
+CPU fallback (the CPU oracle under oracle/ is test infrastructure and is never imported from here).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpyspeedy_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+IX, IL, IY, KX, MX, NX, TRUNC = 96, 48, 24, 8, 31, 32, 30
+NSPEC, NFOUR, NGRID = MX * NX, 2 * MX * IL, IX * IL
+
+SPD_OK, SPD_E_ARG, SPD_E_DEVICE, SPD_E_SIZE = 0, -1, -2, -3
+
+
+class SpeedyHipError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into pyspeedy_amd/libpyspeedy_amd.so (hipcc cross-compiles)."""
+    cmd = ["make", "-C", CSRC, "-j4"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.run(cmd, check=True)
+    if not os.path.isfile(LIB_PATH):
+        raise SpeedyHipError("build did not produce " + LIB_PATH)
+
+
+_PHYS_PTR_FIELDS = [
+    "ug", "vg", "tg", "qg", "phig", "pslg", "utend", "vtend", "ttend", "qtend",
+    "fmask_land", "phis0", "forog", "sst_am", "alb_land", "alb_sea", "snowc", "land_temp", "soil_avail_water",
+    "flux_solar_in", "flux_ozone_upper", "flux_ozone_lower", "zenit_correction", "stratospheric_correction",
+    "alb_surface",
+    "precnv", "precls", "cbmf", "slrd", "slr", "olr",
+    "slru", "ustr", "vstr", "shf", "evap", "hfluxn", "rad_st4a", "rad_flux",
+    "tt_rsw", "rad_tau2", "rad_strat_corr", "tsr", "ssrd", "ssr", "qcloud_equiv",
+    "iptop", "icltop", "ts", "tskin", "u0", "v0", "t0", "cloudc", "clstr",
+]
+
+
+class PhysicsArgs(C.Structure):
+    """Mirror of spd_physics_args (include/pyspeedy_amd.h)."""
+    _fields_ = [(n, C.c_void_p) for n in _PHYS_PTR_FIELDS] + [
+        ("air_absortivity_co2", C.c_double), ("compute_shortwave", C.c_int32), ("reserved", C.c_int32)]
+
+
+_SIGNATURES = {
+    "spd_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "spd_destroy": (C.c_int, [C.c_void_p]),
+    "spd_device": (C.c_int, [C.c_void_p]),
+    "spd_last_error": (C.c_char_p, []),
+    "spd_version": (C.c_char_p, []),
+    "spd_get_table_host": (C.c_long, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "spd_spec2grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "spd_grid2spec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "spd_legendre_inv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "spd_legendre": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "spd_fourier_inv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "spd_fourier": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "spd_vort2vel": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p]),
+    "spd_vel2vort": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p]),
+    "spd_grid_vel2vort": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p]),
+    "spd_gradient": (C.c_int, [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p]),
+    "spd_laplacian": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "spd_truncate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "spd_grid_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "spd_physics": (C.c_int, [C.c_void_p, C.POINTER(PhysicsArgs), C.c_int, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (once).  Raises SpeedyHipError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise SpeedyHipError(
+                "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C pyspeedy_amd/csrc`).  There is no CPU fallback." % LIB_PATH)
+        try:
+            handle = C.CDLL(LIB_PATH)
+        except OSError as exc:
+            raise SpeedyHipError("cannot load %s: %s" % (LIB_PATH, exc))
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != SPD_OK:
+        msg = lib().spd_last_error()
+        raise SpeedyHipError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))

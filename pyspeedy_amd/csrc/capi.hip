@@ -1,0 +1,333 @@
+// C ABI of pyspeedy_amd (include/pyspeedy_amd.h): context lifecycle, table upload, argument checking and
+// kernel dispatch.  No numerics live here.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pyspeedy_amd.h"
+#include "device_tables.hpp"
+
+namespace spd {
+hipError_t run_spec2grid(const DeviceTables &T, int stage, const double *src, double *dst, int kcos, int nfields,
+                         hipStream_t stream, int fpw);
+hipError_t run_grid2spec(const DeviceTables &T, int stage, const double *src, double *dst, int prescale, int nfields,
+                         hipStream_t stream, int fpw);
+hipError_t run_vort2vel(const DeviceTables &T, const double *vor, const double *div, double *ucos, double *vcos,
+                        int nfields, hipStream_t s);
+hipError_t run_vel2vort(const DeviceTables &T, const double *ucos, const double *vcos, double *vor, double *div,
+                        int nfields, hipStream_t s);
+hipError_t run_gradient(const DeviceTables &T, const double *psi, double *psdx, double *psdy, int nfields, hipStream_t s);
+hipError_t run_scale(const double *in, double *out, const double *table, double sign, int nfields, hipStream_t s);
+hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nmembers, hipStream_t s);
+}  // namespace spd
+
+using namespace spd;
+
+struct spd_context {
+    int device = 0;
+    HostTables host;
+    DeviceTables dev{};
+    std::vector<void *> allocations;
+    // scratch for composite operators (grid_vel2vort, grid_filter); grows on demand, never shrinks
+    double *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    std::mutex scratch_mutex;
+    int fpw = 0;  // fields per workgroup override (0 = automatic), env PYSPEEDY_AMD_FPW
+};
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+static int hip_fail(hipError_t e, const char *what) {
+    return fail(SPD_E_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define SPD_HIP(call)                                  \
+    do {                                               \
+        hipError_t e_ = (call);                        \
+        if (e_ != hipSuccess) return hip_fail(e_, #call); \
+    } while (0)
+
+static int upload(spd_context *c, const double *src, size_t n, const double **dst) {
+    void *p = nullptr;
+    SPD_HIP(hipMalloc(&p, n * sizeof(double)));
+    c->allocations.push_back(p);
+    SPD_HIP(hipMemcpy(p, src, n * sizeof(double), hipMemcpyHostToDevice));
+    *dst = static_cast<const double *>(p);
+    return SPD_OK;
+}
+
+// kernel-friendly polynomial layouts (device_tables.hpp)
+static std::vector<double> make_pinv(const HostTables &h) {
+    std::vector<double> p(static_cast<size_t>(NX) * 6 * MX * 4, 0.0);
+    for (int n = 0; n < NX; ++n)
+        for (int jq = 0; jq < 6; ++jq)
+            for (int m = 0; m < MX; ++m)
+                for (int q = 0; q < 4; ++q)
+                    if (m + n <= TRUNC + 1)  // nsh2 mask, legendre.f90:73
+                        p[((static_cast<size_t>(n) * 6 + jq) * MX + m) * 4 + q] = h.poly[m + MX * (n + NX * (4 * jq + q))];
+    return p;
+}
+
+static std::vector<double> make_pdir(const HostTables &h) {
+    std::vector<double> p(static_cast<size_t>(IY) * 8 * MX * 4, 0.0);
+    for (int j = 0; j < IY; ++j)
+        for (int nq = 0; nq < 8; ++nq)
+            for (int m = 0; m < MX; ++m)
+                for (int q = 0; q < 4; ++q) {
+                    const int n = 4 * nq + q;
+                    if (n <= TRUNC && m + n <= TRUNC + 1)  // n = 1..trunc+1 (1-based) and nsh2, legendre.f90:206-217
+                        p[((static_cast<size_t>(j) * 8 + nq) * MX + m) * 4 + q] = h.poly[m + MX * (n + NX * j)];
+                }
+    return p;
+}
+
+extern "C" {
+
+const char *spd_version(void) { return "pyspeedy_amd 0.1 (gfx950)"; }
+const char *spd_last_error(void) { return g_last_error.c_str(); }
+
+int spd_create(spd_handle *out, int device) {
+    if (!out) return fail(SPD_E_ARG, "spd_create: out is null");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(SPD_E_DEVICE, "spd_create: no HIP device available");
+    if (device < 0 || device >= ndev) return fail(SPD_E_ARG, "spd_create: device index out of range");
+    SPD_HIP(hipSetDevice(device));
+    spd_context *c = new spd_context();
+    c->device = device;
+    if (const char *env = getenv("PYSPEEDY_AMD_FPW")) c->fpw = atoi(env);
+    const HostTables &h = c->host;
+    DeviceTables &d = c->dev;
+    int rc = SPD_OK;
+    auto up = [&](const double *src, size_t n, const double **dst) {
+        if (rc == SPD_OK) rc = upload(c, src, n, dst);
+    };
+    const std::vector<double> pinv = make_pinv(h), pdir = make_pdir(h);
+    up(pinv.data(), pinv.size(), &d.pinv);
+    up(pdir.data(), pdir.size(), &d.pdir);
+    up(h.work.data(), 96, &d.work);
+    up(h.cosgr.data(), 48, &d.cosgr);
+    up(h.cosgr2.data(), 48, &d.cosgr2);
+    up(h.wt.data(), 24, &d.wt);
+    up(h.el2.data(), NSPEC, &d.el2);
+    up(h.elm2.data(), NSPEC, &d.elm2);
+    up(h.trfilt.data(), NSPEC, &d.trfilt);
+    up(h.gradx.data(), MX, &d.gradx);
+    up(h.gradym.data(), NSPEC, &d.gradym);
+    up(h.gradyp.data(), NSPEC, &d.gradyp);
+    up(h.uvdx.data(), NSPEC, &d.uvdx);
+    up(h.uvdym.data(), NSPEC, &d.uvdym);
+    up(h.uvdyp.data(), NSPEC, &d.uvdyp);
+    up(h.vddym.data(), NSPEC, &d.vddym);
+    up(h.vddyp.data(), NSPEC, &d.vddyp);
+    up(h.fband.data(), h.fband.size(), &d.fband);
+    up(h.coa.data(), 48, &d.coa);
+    if (rc != SPD_OK) {
+        spd_destroy(c);
+        return rc;
+    }
+    d.fft_scale = static_cast<double>(1.0f / static_cast<float>(IX));
+    for (int k = 0; k < 8; ++k) {
+        d.fsg[k] = h.fsg[k]; d.dhs[k] = h.dhs[k]; d.sigl[k] = h.sigl[k];
+        d.grdsig[k] = h.grdsig[k]; d.grdscp[k] = h.grdscp[k];
+    }
+    for (int k = 0; k < 9; ++k) d.sigh[k] = h.sigh[k];
+    for (int k = 0; k < 16; ++k) d.wvi[k] = h.wvi[k];
+    *out = c;
+    return SPD_OK;
+}
+
+int spd_destroy(spd_handle h) {
+    if (!h) return SPD_OK;
+    (void)hipSetDevice(h->device);
+    for (void *p : h->allocations) (void)hipFree(p);
+    if (h->scratch) (void)hipFree(h->scratch);
+    delete h;
+    return SPD_OK;
+}
+
+int spd_device(spd_handle h) { return h ? h->device : SPD_E_ARG; }
+
+long spd_get_table_host(spd_handle h, const char *name, double *buf, size_t buf_elems) {
+    if (!name) return fail(SPD_E_ARG, "spd_get_table_host: null name");
+    // h == NULL: device-less query (host table construction only), used by the CPU test tier
+    static const HostTables deviceless;
+    const HostTables &t = h ? h->host : deviceless;
+    std::vector<double> tmp;
+    const double *src = nullptr;
+    size_t n = 0;
+    auto arr = [&](const auto &a) { src = a.data(); n = a.size(); };
+    const std::string s(name);
+    if (s == "hsg") arr(t.hsg); else if (s == "sigh") arr(t.sigh); else if (s == "dhs") arr(t.dhs);
+    else if (s == "fsg") arr(t.fsg); else if (s == "dhsr") arr(t.dhsr); else if (s == "fsgr") arr(t.fsgr);
+    else if (s == "sigl") arr(t.sigl); else if (s == "grdsig") arr(t.grdsig); else if (s == "grdscp") arr(t.grdscp);
+    else if (s == "wvi") arr(t.wvi); else if (s == "radang") arr(t.radang); else if (s == "coriol") arr(t.coriol);
+    else if (s == "sia") arr(t.sia); else if (s == "coa") arr(t.coa); else if (s == "cosgr") arr(t.cosgr);
+    else if (s == "cosgr2") arr(t.cosgr2); else if (s == "sia_half") arr(t.sia_half);
+    else if (s == "coa_half") arr(t.coa_half); else if (s == "wt") arr(t.wt); else if (s == "epsi") arr(t.epsi);
+    else if (s == "repsi") arr(t.repsi); else if (s == "poly") arr(t.poly); else if (s == "work") arr(t.work);
+    else if (s == "el2") arr(t.el2); else if (s == "elm2") arr(t.elm2); else if (s == "el4") arr(t.el4);
+    else if (s == "trfilt") arr(t.trfilt); else if (s == "gradym") arr(t.gradym); else if (s == "gradyp") arr(t.gradyp);
+    else if (s == "uvdx") arr(t.uvdx); else if (s == "uvdym") arr(t.uvdym); else if (s == "uvdyp") arr(t.uvdyp);
+    else if (s == "vddym") arr(t.vddym); else if (s == "vddyp") arr(t.vddyp); else if (s == "gradx") arr(t.gradx);
+    else if (s == "fband") arr(t.fband);
+    else if (s == "cpol") { tmp = t.cpol(); arr(tmp); }
+    else if (s == "nsh2") { tmp.assign(t.nsh2.begin(), t.nsh2.end()); arr(tmp); }
+    else if (s == "ifac") { tmp.assign(t.ifac.begin(), t.ifac.end()); arr(tmp); }
+    else return fail(SPD_E_ARG, "spd_get_table_host: unknown table '" + s + "'");
+    if (buf) {
+        if (buf_elems < n) return fail(SPD_E_SIZE, "spd_get_table_host: buffer too small for '" + s + "'");
+        std::memcpy(buf, src, n * sizeof(double));
+    }
+    return static_cast<long>(n);
+}
+
+}  // extern "C"
+
+// ---- dispatch helpers -------------------------------------------------------------------------------
+static int check(spd_handle h, int nfields, const char *fn, std::initializer_list<const void *> ptrs) {
+    if (!h) return fail(SPD_E_ARG, std::string(fn) + ": null handle");
+    if (nfields < 0) return fail(SPD_E_ARG, std::string(fn) + ": negative field count");
+    if (nfields > 0)
+        for (const void *p : ptrs)
+            if (!p) return fail(SPD_E_ARG, std::string(fn) + ": null device pointer");
+    return SPD_OK;
+}
+
+static int done(hipError_t e, const char *fn) { return e == hipSuccess ? SPD_OK : hip_fail(e, fn); }
+
+static int get_scratch(spd_handle h, size_t bytes, double **out) {
+    std::lock_guard<std::mutex> lock(h->scratch_mutex);
+    if (bytes > h->scratch_bytes) {
+        // growing the scratch is not stream-ordered: callers that capture graphs must size it first by
+        // issuing one un-captured call with the largest batch.
+        SPD_HIP(hipDeviceSynchronize());
+        if (h->scratch) SPD_HIP(hipFree(h->scratch));
+        h->scratch = nullptr;
+        h->scratch_bytes = 0;
+        void *p = nullptr;
+        SPD_HIP(hipMalloc(&p, bytes));
+        h->scratch = static_cast<double *>(p);
+        h->scratch_bytes = bytes;
+    }
+    *out = h->scratch;
+    return SPD_OK;
+}
+
+extern "C" {
+
+int spd_spec2grid(spd_handle h, const double *spec, double *grid, int kcos, int nfields, void *stream) {
+    if (int rc = check(h, nfields, "spd_spec2grid", {spec, grid})) return rc;
+    return done(run_spec2grid(h->dev, 0, spec, grid, kcos, nfields, static_cast<hipStream_t>(stream), h->fpw), "spd_spec2grid");
+}
+
+int spd_grid2spec(spd_handle h, const double *grid, double *spec, int nfields, void *stream) {
+    if (int rc = check(h, nfields, "spd_grid2spec", {grid, spec})) return rc;
+    return done(run_grid2spec(h->dev, 0, grid, spec, 0, nfields, static_cast<hipStream_t>(stream), h->fpw), "spd_grid2spec");
+}
+
+int spd_legendre_inv(spd_handle h, const double *spec, double *four, int nfields, void *stream) {
+    if (int rc = check(h, nfields, "spd_legendre_inv", {spec, four})) return rc;
+    return done(run_spec2grid(h->dev, 1, spec, four, 1, nfields, static_cast<hipStream_t>(stream), h->fpw), "spd_legendre_inv");
+}
+
+int spd_legendre(spd_handle h, const double *four, double *spec, int nfields, void *stream) {
+    if (int rc = check(h, nfields, "spd_legendre", {four, spec})) return rc;
+    return done(run_grid2spec(h->dev, 1, four, spec, 0, nfields, static_cast<hipStream_t>(stream), h->fpw), "spd_legendre");
+}
+
+int spd_fourier_inv(spd_handle h, const double *four, double *grid, int kcos, int nfields, void *stream) {
+    if (int rc = check(h, nfields, "spd_fourier_inv", {four, grid})) return rc;
+    return done(run_spec2grid(h->dev, 2, four, grid, kcos, nfields, static_cast<hipStream_t>(stream), h->fpw), "spd_fourier_inv");
+}
+
+int spd_fourier(spd_handle h, const double *grid, double *four, int nfields, void *stream) {
+    if (int rc = check(h, nfields, "spd_fourier", {grid, four})) return rc;
+    return done(run_grid2spec(h->dev, 2, grid, four, 0, nfields, static_cast<hipStream_t>(stream), h->fpw), "spd_fourier");
+}
+
+int spd_vort2vel(spd_handle h, const double *vor, const double *div, double *ucos, double *vcos, int nfields, void *stream) {
+    if (int rc = check(h, nfields, "spd_vort2vel", {vor, div, ucos, vcos})) return rc;
+    return done(run_vort2vel(h->dev, vor, div, ucos, vcos, nfields, static_cast<hipStream_t>(stream)), "spd_vort2vel");
+}
+
+int spd_vel2vort(spd_handle h, const double *ucos, const double *vcos, double *vor, double *div, int nfields, void *stream) {
+    if (int rc = check(h, nfields, "spd_vel2vort", {ucos, vcos, vor, div})) return rc;
+    return done(run_vel2vort(h->dev, ucos, vcos, vor, div, nfields, static_cast<hipStream_t>(stream)), "spd_vel2vort");
+}
+
+int spd_grid_vel2vort(spd_handle h, const double *ug, const double *vg, double *vor, double *div, int kcos, int nfields,
+                      void *stream) {
+    if (int rc = check(h, nfields, "spd_grid_vel2vort", {ug, vg, vor, div})) return rc;
+    if (nfields == 0) return SPD_OK;
+    double *tmp = nullptr;
+    const size_t per = static_cast<size_t>(nfields) * 2 * NSPEC;  // doubles per spectral batch
+    if (int rc = get_scratch(h, 2 * per * sizeof(double), &tmp)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int prescale = (kcos == 2) ? 1 : 2;  // spectral.f90:229-243
+    hipError_t e = run_grid2spec(h->dev, 0, ug, tmp, prescale, nfields, s, h->fpw);
+    if (e == hipSuccess) e = run_grid2spec(h->dev, 0, vg, tmp + per, prescale, nfields, s, h->fpw);
+    if (e == hipSuccess) e = run_vel2vort(h->dev, tmp, tmp + per, vor, div, nfields, s);
+    return done(e, "spd_grid_vel2vort");
+}
+
+int spd_gradient(spd_handle h, const double *psi, double *psdx, double *psdy, int nfields, void *stream) {
+    if (int rc = check(h, nfields, "spd_gradient", {psi, psdx, psdy})) return rc;
+    return done(run_gradient(h->dev, psi, psdx, psdy, nfields, static_cast<hipStream_t>(stream)), "spd_gradient");
+}
+
+int spd_laplacian(spd_handle h, const double *in, double *out, int inverse, int nfields, void *stream) {
+    if (int rc = check(h, nfields, "spd_laplacian", {in, out})) return rc;
+    return done(run_scale(in, out, inverse ? h->dev.elm2 : h->dev.el2, -1.0, nfields, static_cast<hipStream_t>(stream)),
+                "spd_laplacian");
+}
+
+int spd_truncate(spd_handle h, double *field, int nfields, void *stream) {
+    if (int rc = check(h, nfields, "spd_truncate", {field})) return rc;
+    return done(run_scale(field, field, h->dev.trfilt, 1.0, nfields, static_cast<hipStream_t>(stream)), "spd_truncate");
+}
+
+int spd_grid_filter(spd_handle h, const double *fg1, double *fg2, int nfields, void *stream) {
+    if (int rc = check(h, nfields, "spd_grid_filter", {fg1, fg2})) return rc;
+    if (nfields == 0) return SPD_OK;
+    double *tmp = nullptr;
+    const size_t per = static_cast<size_t>(nfields) * 2 * NSPEC;
+    if (int rc = get_scratch(h, per * sizeof(double), &tmp)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = run_grid2spec(h->dev, 0, fg1, tmp, 0, nfields, s, h->fpw);
+    if (e == hipSuccess) e = run_scale(tmp, tmp, h->dev.trfilt, 1.0, nfields, s);  // spectral.f90:308-313
+    if (e == hipSuccess) e = run_spec2grid(h->dev, 0, tmp, fg2, 1, nfields, s, h->fpw);
+    return done(e, "spd_grid_filter");
+}
+
+int spd_physics(spd_handle h, const spd_physics_args *a, int nmembers, void *stream) {
+    if (!h || !a) return fail(SPD_E_ARG, "spd_physics: null argument");
+    if (nmembers < 0) return fail(SPD_E_ARG, "spd_physics: negative member count");
+    if (nmembers == 0) return SPD_OK;
+    const void *required[] = {a->ug, a->vg, a->tg, a->qg, a->phig, a->pslg, a->utend, a->vtend, a->ttend, a->qtend,
+                              a->fmask_land, a->phis0, a->forog, a->sst_am, a->alb_land, a->alb_sea, a->snowc,
+                              a->land_temp, a->soil_avail_water, a->precnv, a->precls, a->cbmf, a->slrd, a->slr, a->olr,
+                              a->slru, a->ustr, a->vstr, a->shf, a->evap, a->hfluxn, a->rad_st4a, a->rad_flux, a->tt_rsw,
+                              a->rad_tau2, a->rad_strat_corr, a->tsr, a->ssrd, a->ssr, a->qcloud_equiv};
+    for (const void *p : required)
+        if (!p) return fail(SPD_E_ARG, "spd_physics: a required device pointer is null");
+    if (a->compute_shortwave) {
+        const void *sw[] = {a->flux_solar_in, a->flux_ozone_upper, a->flux_ozone_lower, a->zenit_correction,
+                            a->stratospheric_correction, a->alb_surface};
+        for (const void *p : sw)
+            if (!p) return fail(SPD_E_ARG, "spd_physics: shortwave forcing pointer is null on a shortwave step");
+    }
+    return done(run_physics(h->dev, *a, nmembers, static_cast<hipStream_t>(stream)), "spd_physics");
+}
+
+}  // extern "C"

@@ -1,0 +1,26 @@
+// Device-resident constant tables, passed by value to every kernel (all pointers are device memory owned by
+// the spd_context).  Layouts are chosen for the kernels, not for the reference: see the comments.
+#pragma once
+#include "tables.hpp"
+
+namespace spd {
+
+struct DeviceTables {
+    // inverse-Legendre polynomials  [n=32][jq=6][m=31][4 lat pairs]  (zero where m + n > 31)
+    const double *pinv;
+    // direct-Legendre polynomials   [j=24][nq=8][m=31][4 n]          (zero where n > min(30, 31-m))
+    const double *pdir;
+    const double *work;    // FFTPACK twiddles, 96
+    const double *cosgr;   // 48
+    const double *cosgr2;  // 48
+    const double *wt;      // 24 Gaussian weights
+    double fft_scale;      // fp32(1/96) widened (fourier.f90:113)
+    // spectral-operator coefficients, (31,32) each
+    const double *el2, *elm2, *trfilt, *gradx, *gradym, *gradyp, *uvdx, *uvdym, *uvdyp, *vddym, *vddyp;
+    // physics
+    const double *fband;   // (301,4)
+    const double *coa;     // 48, cos(latitude)
+    double fsg[8], dhs[8], sigl[8], sigh[9], grdsig[8], grdscp[8], wvi[16];
+};
+
+}  // namespace spd

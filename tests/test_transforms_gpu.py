@@ -1,0 +1,197 @@
+"""GPU tier: the HIP spectral path (through the C ABI) against (1) the committed golden vectors captured from the
+reference Fortran, (2) the CPU oracle on seeded inputs, (3) size-independent properties at full batch sizes.
+
+Tolerance (fp64): per transform max|diff| <= 1e-13 * max|reference field|; the device code may
+contract a*b+c into FMAs and sums the same terms in the same order, so observed differences are O(1e-16) relative.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-13
+
+
+def dev(a, dtype=None):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
+
+
+def spec_dev(a):
+    """golden [..., m, n] -> device layout [..., n, m]"""
+    return dev(np.swapaxes(np.asarray(a, dtype=np.complex128), -1, -2))
+
+
+def grid_dev(a):
+    return dev(np.swapaxes(np.asarray(a, dtype=np.float64), -1, -2))
+
+
+def back(t):
+    return np.swapaxes(t.cpu().numpy(), -1, -2)
+
+
+def close(got, ref, tol=TOL, what=""):
+    scale = max(np.abs(ref).max(), 1e-300)
+    err = np.abs(got - ref).max() / scale
+    assert err <= tol, "%s: scaled max error %.3e > %.1e" % (what, err, tol)
+    return err
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(golden_dir + "/transforms.npz")
+
+
+@pytest.mark.parametrize("fpw", [1, 2])
+def test_golden_transforms(gold, fpw, monkeypatch):
+    import pyspeedy_amd
+    monkeypatch.setenv("PYSPEEDY_AMD_FPW", str(fpw))
+    sp = pyspeedy_amd.ModSpectral()
+    spec = spec_dev(gold["spec_in"])
+    close(back(sp.spec2grid(spec, 1)), gold["spec2grid_k1"], what="spec2grid kcos=1")
+    close(back(sp.spec2grid(spec, 2)), gold["spec2grid_k2"], what="spec2grid kcos=2")
+    close(back(sp.legendre_inv(spec)), gold["legendre_inv"], what="legendre_inv")
+    four = grid_dev(gold["legendre_inv"])
+    close(back(sp.fourier_inv(four, 1)), gold["spec2grid_k1"], what="fourier_inv")
+    close(back(sp.fourier_inv(four, 2)), gold["spec2grid_k2"], what="fourier_inv kcos=2")
+    grid = grid_dev(gold["grid_in"])
+    close(back(sp.grid2spec(grid)), gold["grid2spec"], what="grid2spec")
+    close(back(sp.fourier(grid)), gold["fourier"], what="fourier")
+    leg = gold["legendre"][:, 0::2, :] + 1j * gold["legendre"][:, 1::2, :]  # real (62,32) view -> complex (31,32)
+    close(back(sp.legendre(grid_dev(gold["fourier"]))), leg, what="legendre")
+    # stage-only direct Legendre with a non-zero Im(m=0) input row (reference keeps it, legendre.f90:193-195)
+    rng = np.random.default_rng(3)
+    four = rng.standard_normal((2, 62, 48))
+    import oracle as orc
+    ref = np.stack([orc.legendre(four[i]) for i in range(2)])
+    close(back(sp.legendre(grid_dev(four))), ref[:, 0::2, :] + 1j * ref[:, 1::2, :], what="legendre raw plane")
+    spec_full = gold["spec_in"][6:8]
+    refi = np.stack([orc.legendre_inv(np.ascontiguousarray(spec_full[i].T).view(np.float64).reshape(32, 62).T) for i in range(2)])
+    close(back(sp.legendre_inv(spec_dev(spec_full))), refi, what="legendre_inv incl. Im(m=0)")
+    sp.close()
+
+
+def test_golden_known_answers(spectral, gold):
+    g = torch.full((1, 48, 96), 280.0, dtype=torch.float64, device="cuda")
+    f = spectral.fourier(g).cpu().numpy()
+    assert abs(f[0, 0, 0] - 280.00000834465027) < 1e-11
+    s = spectral.grid2spec(g).cpu().numpy()
+    assert abs(s[0, 0, 0].real - 395.9798024886781) < 1e-11
+    assert np.all(s[0, 31, :] == 0)  # n = 32 column is never filled (legendre.f90:206)
+    assert np.all(s[0, :, 0].imag == 0)  # Im of zonal-mean coefficients is exactly zero
+
+
+def test_golden_spectral_operators(spectral, gold):
+    spec = gold["spec_in"]
+    for k, (a, b) in enumerate(gold["pairs"]):
+        A, B = spec_dev(spec[a][None]), spec_dev(spec[b][None])
+        u, v = spectral.vort2vel(A, B)
+        close(back(u)[0], gold["vort2vel"][k][0], what="vort2vel u")
+        close(back(v)[0], gold["vort2vel"][k][1], what="vort2vel v")
+        vo, di = spectral.vel2vort(A, B)
+        close(back(vo)[0], gold["vel2vort"][k][0], what="vel2vort vor")
+        close(back(di)[0], gold["vel2vort"][k][1], what="vel2vort div")
+        dx, dy = spectral.gradient(A)
+        close(back(dx)[0], gold["gradient"][k][0], what="gradient x")
+        close(back(dy)[0], gold["gradient"][k][1], what="gradient y")
+        close(back(spectral.laplacian(A))[0], gold["laplacian"][k], what="laplacian")
+        close(back(spectral.laplacian_inv(A))[0], gold["laplacian_inv"][k], what="laplacian_inv")
+        close(back(spectral.truncate(A.clone()))[0], gold["truncate"][k], what="truncate")
+    ug, vg = grid_dev(gold["grid_in"][0][None]), grid_dev(gold["grid_in"][5][None])
+    for i, kc in enumerate((1, 2)):
+        vo, di = spectral.grid_vel2vort(ug, vg, kc)
+        close(back(vo)[0], gold["grid_vel2vort_k1k2"][i][0], what="grid_vel2vort vor kcos=%d" % kc)
+        close(back(di)[0], gold["grid_vel2vort_k1k2"][i][1], what="grid_vel2vort div kcos=%d" % kc)
+    for i, b in enumerate((4, 8)):
+        close(back(spectral.grid_filter(grid_dev(gold["grid_in"][b][None])))[0], gold["grid_filter"][i], what="grid_filter")
+
+
+def seeded_spectra(n, seed=1234, triangular=True):
+    rng = np.random.default_rng(seed)
+    nn, mm = np.meshgrid(np.arange(32), np.arange(31), indexing="ij")
+    ll = mm + nn
+    s = (rng.standard_normal((n, 32, 31)) + 1j * rng.standard_normal((n, 32, 31))) / (1.0 + ll)
+    if triangular:
+        s[:, ll > 30] = 0.0
+    s[:, :, 0] = s[:, :, 0].real
+    return s
+
+
+@pytest.mark.parametrize("nfields", [1, 2, 3, 8, 64, 513])
+def test_against_oracle_seeded(spectral, oracle, nfields):
+    """Ragged batch sizes (odd counts exercise the half-filled last workgroup of the 2-fields-per-workgroup kernel)."""
+    spec = seeded_spectra(nfields)
+    ref = oracle.spec2grid_batch(spec, 1)
+    got = spectral.spec2grid(dev(spec), 1).cpu().numpy()
+    close(got, ref, what="spec2grid B=%d" % nfields)
+    ref2 = oracle.spec2grid_batch(spec, 2)
+    close(spectral.spec2grid(dev(spec), 2).cpu().numpy(), ref2, what="spec2grid kcos=2 B=%d" % nfields)
+    rng = np.random.default_rng(4321)
+    grids = rng.standard_normal((nfields, 48, 96))
+    close(spectral.grid2spec(dev(grids)).cpu().numpy(), oracle.grid2spec_batch(grids), what="grid2spec raw B=%d" % nfields)
+    close(spectral.grid2spec(dev(ref)).cpu().numpy(), oracle.grid2spec_batch(ref), what="grid2spec band-limited")
+
+
+@pytest.mark.parametrize("fpw", [1, 2])
+def test_fpw_variants_agree_with_oracle(oracle, fpw, monkeypatch):
+    import pyspeedy_amd
+    monkeypatch.setenv("PYSPEEDY_AMD_FPW", str(fpw))
+    sp = pyspeedy_amd.ModSpectral()
+    spec = seeded_spectra(37, seed=7, triangular=False)
+    close(sp.spec2grid(dev(spec), 1).cpu().numpy(), oracle.spec2grid_batch(spec, 1), what="fpw=%d" % fpw)
+    g = np.random.default_rng(5).standard_normal((37, 48, 96))
+    close(sp.grid2spec(dev(g)).cpu().numpy(), oracle.grid2spec_batch(g), what="fpw=%d fwd" % fpw)
+    sp.close()
+
+
+def test_empty_batch_and_bad_arguments(spectral):
+    e = torch.empty((0, 32, 31), dtype=torch.complex128, device="cuda")
+    assert spectral.spec2grid(e).shape == (0, 48, 96)
+    assert spectral.grid2spec(torch.empty((0, 48, 96), dtype=torch.float64, device="cuda")).shape == (0, 32, 31)
+    with pytest.raises(ValueError):
+        spectral.spec2grid(torch.zeros((2, 31, 32), dtype=torch.complex128, device="cuda"))
+    with pytest.raises(ValueError):
+        spectral.grid2spec(torch.zeros((2, 48, 96), dtype=torch.float32, device="cuda"))
+    with pytest.raises(ValueError):
+        spectral.spec2grid(torch.zeros((2, 32, 31), dtype=torch.complex128))  # host tensor
+
+
+def test_full_size_properties(spectral):
+    """BASELINE-size batch (64 members x 91 inverse transforms = 5824 fields): properties that need no oracle.
+    (a) linearity, (b) batch independence (a field's result does not depend on its neighbours or position),
+    (c) truncated spectra survive spec->grid->spec up to the reference's own quadrature error (the
+        fp32-approximate Gaussian latitudes make the round trip inexact at the 1e-3 level, identically in the reference)."""
+    B = 5824
+    g = torch.Generator(device="cuda").manual_seed(11)
+    a = torch.randn((B, 32, 31, 2), dtype=torch.float64, device="cuda", generator=g)
+    b = torch.randn((B, 32, 31, 2), dtype=torch.float64, device="cuda", generator=g)
+    a, b = torch.view_as_complex(a), torch.view_as_complex(b)
+    ga, gb = spectral.spec2grid(a), spectral.spec2grid(b)
+    gs = spectral.spec2grid(2.0 * a - 0.5 * b)
+    lin = (gs - (2.0 * ga - 0.5 * gb)).abs().max().item() / gs.abs().max().item()
+    assert lin < 1e-13, lin
+    # batch independence: reversed batch gives reversed output, bit for bit
+    gr = spectral.spec2grid(torch.flip(a, dims=[0]).contiguous())
+    assert torch.equal(torch.flip(gr, dims=[0]), ga)
+    # single-field launches agree bitwise with the batched launch (different kernel variant, same arithmetic)
+    for idx in (0, 1, B - 1):
+        assert torch.equal(spectral.spec2grid(a[idx:idx + 1].contiguous())[0], ga[idx])
+    sa = spectral.grid2spec(ga)
+    sb = spectral.grid2spec(gb)
+    ss = spectral.grid2spec(gs)
+    lin2 = (ss - (2.0 * sa - 0.5 * sb)).abs().max().item() / ss.abs().max().item()
+    assert lin2 < 1e-13, lin2
+    assert torch.all(sa[:, 31, :] == 0)
+
+
+def test_stream_ordering(spectral):
+    """Work is enqueued on the caller's current stream (no hidden synchronisation / default-stream use)."""
+    s = torch.cuda.Stream()
+    x = torch.view_as_complex(torch.randn((16, 32, 31, 2), dtype=torch.float64, device="cuda"))
+    ref = spectral.spec2grid(x)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        y = x * 2.0
+        out = spectral.spec2grid(y)
+    s.synchronize()
+    assert (out - 2.0 * ref).abs().max().item() <= 1e-13 * ref.abs().max().item()
