@@ -214,3 +214,60 @@ def grid_filter(g):
     out = np.zeros((96, 48), order="F")
     _call("grid_filter", _r(g), out)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# column physics
+# ---------------------------------------------------------------------------------------------------
+PHYS_IN_3D = ("ug", "vg", "tg", "qg_in", "phig")
+PHYS_IN_2D = ("pslg", "fmask_land", "phis0", "forog", "sst_am", "alb_land", "alb_sea", "snowc", "land_temp",
+              "soil_avail_water", "flux_solar_in", "flux_ozone_upper", "flux_ozone_lower", "zenit_correction",
+              "stratospheric_correction", "alb_surface")
+PHYS_TEND = ("utend", "vtend", "ttend", "qtend")
+PHYS_OUT_SHAPES = {
+    "precnv": (96, 48), "precls": (96, 48), "cbmf": (96, 48), "slrd": (96, 48), "slr": (96, 48), "olr": (96, 48),
+    "slru": (96, 48, 3), "ustr": (96, 48, 3), "vstr": (96, 48, 3), "shf": (96, 48, 3), "evap": (96, 48, 3),
+    "hfluxn": (96, 48, 3), "rad_st4a": (96, 48, 8, 2), "rad_flux": (96, 48, 4),
+}
+PHYS_PERSIST_SHAPES = {
+    "tt_rsw": (96, 48, 8), "rad_tau2": (96, 48, 8, 4), "rad_strat_corr": (96, 48, 2), "tsr": (96, 48),
+    "ssrd": (96, 48), "ssr": (96, 48), "qcloud_equiv": (96, 48),
+}
+PHYS_DIAG_F = ("ts", "tskin", "u0", "v0", "t0", "cloudc", "clstr")
+PHYS_DIAG_I = ("iptop", "icltop")
+
+
+def physics(inputs, compute_shortwave, air_absortivity_co2):
+    """Run orc_physics on one member.
+
+    inputs: dict with PHYS_IN_3D (96,48,8), PHYS_IN_2D (96,48), PHYS_TEND (96,48,8) and -- for a non-shortwave
+    step -- the persisted fields of PHYS_PERSIST_SHAPES (rad_flux is fully rewritten by the longwave scheme).
+    Returns dict of all outputs (tendencies, PHYS_OUT_SHAPES, PHYS_PERSIST_SHAPES, diagnostics), Fortran order.
+    """
+    io = PhysIO()
+    keep = {}
+
+    def put(name, arr):
+        keep[name] = arr
+        setattr(io, name, arr.ctypes.data_as(C.c_void_p).value)
+
+    for n in PHYS_IN_3D + PHYS_IN_2D:
+        put(n, np.asfortranarray(inputs[n], dtype=np.float64))
+    for n in PHYS_TEND:
+        put(n, np.array(inputs[n], dtype=np.float64, order="F", copy=True))
+    for n, shp in PHYS_OUT_SHAPES.items():
+        put(n, np.zeros(shp, order="F"))
+    for n, shp in PHYS_PERSIST_SHAPES.items():
+        if n in inputs:
+            put(n, np.array(inputs[n], dtype=np.float64, order="F", copy=True))
+        else:
+            put(n, np.zeros(shp, order="F"))
+    for n in PHYS_DIAG_F:
+        put(n, np.zeros((96, 48), order="F"))
+    for n in PHYS_DIAG_I:
+        put(n, np.zeros((96, 48), dtype=np.int32, order="F"))
+    io.air_absortivity_co2 = float(air_absortivity_co2)
+    io.compute_shortwave = int(bool(compute_shortwave))
+    lib().orc_physics(C.byref(tables()), C.byref(io))
+    out = {n: keep[n] for n in PHYS_TEND + tuple(PHYS_OUT_SHAPES) + tuple(PHYS_PERSIST_SHAPES) + PHYS_DIAG_F + PHYS_DIAG_I}
+    return out

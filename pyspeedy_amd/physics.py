@@ -1,0 +1,187 @@
+"""Host-side mirror of the reference's column-physics driver ``get_physical_tendencies``
+(speedy.f90/physics.f90:14-256) on MI355X.
+
+The reference routine does two things: (1) 41 spectral->grid transforms of the time-level-1 state
+(physics.f90:89-101) and (2) the per-column schemes.  Here (1) is issued through ModSpectral (batched over levels
+and ensemble members) and (2) is ONE fused HIP kernel (pyspeedy_amd/csrc/physics.hip) behind spd_physics.
+
+Arrays are torch float64 CUDA tensors, member-major, the reference's Fortran order inside one member:
+    (ix,il)       -> [M, 48, 96]          (ix,il,kx)    -> [M, 8, 48, 96]
+    (ix,il,3)     -> [M, 3, 48, 96]       (ix,il,kx,4)  -> [M, 4, 8, 48, 96]   (ix,il,kx,2) -> [M, 2, 8, 48, 96]
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import IL, IX, KX, MX, NX, PhysicsArgs, check
+
+STATE_IN_3D = ("ug", "vg", "tg", "qg", "phig")
+STATE_IN_2D = ("pslg",)
+TENDENCIES = ("utend", "vtend", "ttend", "qtend")
+SURFACE_IN = ("fmask_land", "phis0", "forog", "sst_am", "alb_land", "alb_sea", "snowc", "land_temp",
+              "soil_avail_water")
+SHORTWAVE_IN = ("flux_solar_in", "flux_ozone_upper", "flux_ozone_lower", "zenit_correction",
+                "stratospheric_correction", "alb_surface")
+OUT_2D = ("precnv", "precls", "cbmf", "slrd", "slr", "olr")
+OUT_AUX = ("slru", "ustr", "vstr", "shf", "evap", "hfluxn")
+PERSIST_2D = ("tsr", "ssrd", "ssr", "qcloud_equiv")
+DIAG_F = ("ts", "tskin", "u0", "v0", "t0", "cloudc", "clstr")
+DIAG_I = ("iptop", "icltop")
+
+
+def shapes(M):
+    s = {}
+    for n in STATE_IN_3D + TENDENCIES + ("tt_rsw",):
+        s[n] = (M, KX, IL, IX)
+    for n in STATE_IN_2D + SURFACE_IN + SHORTWAVE_IN + OUT_2D + PERSIST_2D + DIAG_F + DIAG_I:
+        s[n] = (M, IL, IX)
+    for n in OUT_AUX:
+        s[n] = (M, 3, IL, IX)
+    s["rad_st4a"] = (M, 2, KX, IL, IX)
+    s["rad_flux"] = (M, 4, IL, IX)
+    s["rad_tau2"] = (M, 4, KX, IL, IX)
+    s["rad_strat_corr"] = (M, 2, IL, IX)
+    return s
+
+
+class PhysicsState:
+    """Device-resident output / persisted-radiation arrays of `nmembers` members (the physics part of ModelState_t)."""
+
+    def __init__(self, nmembers, device, diagnostics=False):
+        self.nmembers = nmembers
+        shp = shapes(nmembers)
+        names = OUT_2D + OUT_AUX + PERSIST_2D + ("rad_st4a", "rad_flux", "tt_rsw", "rad_tau2", "rad_strat_corr")
+        for n in names:
+            setattr(self, n, torch.zeros(shp[n], dtype=torch.float64, device=device))
+        self.diagnostics = diagnostics
+        if diagnostics:
+            for n in DIAG_F:
+                setattr(self, n, torch.zeros(shp[n], dtype=torch.float64, device=device))
+            for n in DIAG_I:
+                setattr(self, n, torch.zeros(shp[n], dtype=torch.int32, device=device))
+
+
+class ColumnPhysics:
+    """``get_physical_tendencies`` for a batch of ensemble members on one GPU."""
+
+    def __init__(self, spectral):
+        self.sp = spectral
+        self.device = spectral.device
+        self._lib = _lib.lib()
+
+    def grid_fields_from_spectral(self, vor, div, t, q, phi, ps):
+        """physics.f90:89-101 for M members: spectral time-level-1 state -> ug, vg, tg, qg, phig, pslg.
+
+        vor, div, t, q, phi: complex128 [M, 8, 32, 31]; ps: [M, 32, 31].  41*M transforms in three launches."""
+        ucos, vcos = self.sp.vort2vel(vor, div)
+        uv = self.sp.spec2grid(torch.stack([ucos, vcos]), 2)
+        tqp = self.sp.spec2grid(torch.stack([t, q, phi]), 1)
+        pslg = self.sp.spec2grid(ps, 1)
+        return dict(ug=uv[0], vg=uv[1], tg=tqp[0], qg=tqp[1], phig=tqp[2], pslg=pslg)
+
+    def __call__(self, fields, tend, forcing, state, compute_shortwave, air_absortivity_co2):
+        """Run the fused column kernel.
+
+        fields : dict ug, vg, tg, qg, phig [M,8,48,96], pslg [M,48,96]
+        tend   : dict utend, vtend, ttend, qtend [M,8,48,96] -- updated IN PLACE like the reference's arguments
+        forcing: dict with SURFACE_IN (always) and SHORTWAVE_IN (needed on shortwave steps) [M,48,96]
+        state  : PhysicsState (outputs and persisted radiation fields, updated in place)
+        """
+        M = state.nmembers
+        shp = shapes(M)
+        args = PhysicsArgs()
+        keep = []
+
+        def put(name, tensor, dtype=torch.float64):
+            if tensor is None:
+                setattr(args, name, None)
+                return
+            if tensor.dtype != dtype or tuple(tensor.shape) != shp[name] or tensor.device != self.device:
+                raise ValueError("%s: expected %s %s on %s, got %s %s on %s" % (
+                    name, dtype, shp[name], self.device, tensor.dtype, tuple(tensor.shape), tensor.device))
+            if not tensor.is_contiguous():
+                raise ValueError("%s must be contiguous (it is passed to the kernel by pointer)" % name)
+            keep.append(tensor)
+            setattr(args, name, tensor.data_ptr())
+
+        for n in STATE_IN_3D + STATE_IN_2D:
+            put(n, fields[n])
+        for n in TENDENCIES:
+            put(n, tend[n])
+        for n in SURFACE_IN:
+            put(n, forcing[n])
+        for n in SHORTWAVE_IN:
+            put(n, forcing.get(n) if compute_shortwave else forcing.get(n, None))
+        for n in OUT_2D + OUT_AUX + PERSIST_2D + ("rad_st4a", "rad_flux", "tt_rsw", "rad_tau2", "rad_strat_corr"):
+            put(n, getattr(state, n))
+        for n in DIAG_F:
+            put(n, getattr(state, n, None) if state.diagnostics else None)
+        for n in DIAG_I:
+            put(n, getattr(state, n, None) if state.diagnostics else None, torch.int32)
+        args.air_absortivity_co2 = float(air_absortivity_co2)
+        args.compute_shortwave = 1 if compute_shortwave else 0
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(self._lib.spd_physics(self.sp.handle, C.byref(args), M, stream), "spd_physics")
+        return tend
+
+
+# ---- helpers shared by tests / smoke / bench: golden snapshot <-> device layout -----------------------------
+def to_device_layout(a):
+    """reference host array (ix, il[, ...]) -> [..., il, ix] contiguous numpy (reversed axis order)."""
+    import numpy as np
+    a = np.asarray(a)
+    return np.ascontiguousarray(a.transpose(tuple(range(a.ndim - 1, -1, -1))))
+
+
+def from_device_layout(t):
+    a = t.cpu().numpy()
+    return a.transpose(tuple(range(a.ndim - 1, -1, -1)))
+
+
+def smoke_check(sp, orc):
+    """One member of column physics on synthetic-but-physical inputs, HIP vs the CPU oracle.  Returns the worst
+    scaled error over the tendencies."""
+    import numpy as np
+    inp = synthetic_member(seed=0)
+    ref = orc.physics({("qg_in" if k == "qg" else k): v for k, v in inp.items()}, True, 0.3)
+    phys = ColumnPhysics(sp)
+    st = PhysicsState(1, sp.device)
+    dev = lambda a: torch.from_numpy(to_device_layout(a)[None]).to(sp.device)
+    fields = {n: dev(inp[n]) for n in STATE_IN_3D + STATE_IN_2D}
+    tend = {n: dev(inp[n]) for n in TENDENCIES}
+    forcing = {n: dev(inp[n]) for n in SURFACE_IN + SHORTWAVE_IN}
+    phys(fields, tend, forcing, st, True, 0.3)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for n in TENDENCIES:
+        got = from_device_layout(tend[n][0])
+        worst = max(worst, float(np.abs(got - ref[n]).max() / max(np.abs(ref[n]).max(), 1e-300)))
+    assert worst < 1e-11, worst
+    return worst
+
+
+def synthetic_member(seed=0):
+    """Physically plausible synthetic inputs for one member, reference host layout (ix, il[, kx])."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    fsg = np.array([0.025, 0.095, 0.2, 0.34, 0.51, 0.685, 0.835, 0.95])
+    lat = np.linspace(-87.2, 87.2, IL)[None, :, None] * np.ones((IX, 1, 1))
+    tsfc = 288.0 - 40.0 * np.sin(np.deg2rad(lat)) ** 2
+    tg = tsfc * fsg[None, None, :] ** 0.19 + rng.standard_normal((IX, IL, KX))
+    tg = np.maximum(tg, 205.0)
+    qg = 12.0 * np.exp(-(1 - fsg[None, None, :]) * 6.0) * np.cos(np.deg2rad(lat)) ** 2 * rng.uniform(0.3, 1.1, (IX, IL, KX))
+    phig = 287.0 * 260.0 * np.log(1.0 / fsg)[None, None, :] + 50.0 * rng.standard_normal((IX, IL, KX))
+    u = 10.0 * rng.standard_normal((IX, IL, KX))
+    v = 5.0 * rng.standard_normal((IX, IL, KX))
+    two = lambda lo, hi: rng.uniform(lo, hi, (IX, IL))
+    fmask = (two(0, 1) > 0.6) * two(0.2, 1.0)
+    inp = dict(ug=u, vg=v, tg=tg, qg=qg, phig=phig, pslg=np.log(two(0.85, 1.03)),
+               utend=1e-5 * rng.standard_normal((IX, IL, KX)), vtend=1e-5 * rng.standard_normal((IX, IL, KX)),
+               ttend=1e-5 * rng.standard_normal((IX, IL, KX)), qtend=1e-6 * rng.standard_normal((IX, IL, KX)),
+               fmask_land=fmask, phis0=two(0, 3000.0) * (fmask > 0), forog=two(1.0, 1.3),
+               sst_am=tsfc[:, :, 0] + two(-2, 2), alb_land=two(0.1, 0.5), alb_sea=two(0.07, 0.3), snowc=two(0, 1) ** 4,
+               land_temp=tsfc[:, :, 0] + two(-5, 5), soil_avail_water=two(0, 1),
+               flux_solar_in=two(0, 450.0), flux_ozone_upper=two(0, 8.0), flux_ozone_lower=two(0, 8.0),
+               zenit_correction=two(1.0, 1.8), stratospheric_correction=two(0, 6.0), alb_surface=two(0.07, 0.5))
+    return {k: np.asfortranarray(v.astype(np.float64)) for k, v in inp.items()}
