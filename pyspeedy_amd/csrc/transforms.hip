@@ -284,10 +284,12 @@ static hipError_t launch_g2s(const double *src, double *dst, const DeviceTables 
     return hipGetLastError();
 }
 
-// fields-per-workgroup policy: 2 when the batch still fills the chip, else 1
+// fields-per-workgroup policy.  Measured on MI355X (tools/perf_transforms.py): one field per workgroup (74.5 KB of
+// LDS -> two workgroups per CU) beats two fields per workgroup (149 KB -> one per CU) at every batch size, because
+// the kernel is latency-bound and needs the occupancy; the 2-field variant stays available for experiments.
 static inline int pick_fpw(int nfields, int forced) {
-    if (forced == 1 || forced == 2) return forced;
-    return nfields >= 1024 ? 2 : 1;
+    (void)nfields;
+    return forced == 2 ? 2 : 1;
 }
 
 hipError_t run_spec2grid(const DeviceTables &T, int stage, const double *src, double *dst, int kcos, int nfields,
