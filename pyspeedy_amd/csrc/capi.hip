@@ -65,28 +65,32 @@ static int upload(spd_context *c, const double *src, size_t n, const double **ds
     return SPD_OK;
 }
 
-// kernel-friendly polynomial layouts (device_tables.hpp)
+// kernel-friendly polynomial layouts (device_tables.hpp, transforms.hip)
 static std::vector<double> make_pinv(const HostTables &h) {
-    std::vector<double> p(static_cast<size_t>(NX) * 6 * MX * 4, 0.0);
+    // [n = 32][lane = m*12 + jq][2]: latitude pairs 2jq, 2jq+1; zero outside the triangle (nsh2, legendre.f90:73)
+    std::vector<double> p(static_cast<size_t>(NX) * MX * 12 * 2, 0.0);
     for (int n = 0; n < NX; ++n)
-        for (int jq = 0; jq < 6; ++jq)
-            for (int m = 0; m < MX; ++m)
-                for (int q = 0; q < 4; ++q)
-                    if (m + n <= TRUNC + 1)  // nsh2 mask, legendre.f90:73
-                        p[((static_cast<size_t>(n) * 6 + jq) * MX + m) * 4 + q] = h.poly[m + MX * (n + NX * (4 * jq + q))];
+        for (int m = 0; m < MX; ++m)
+            for (int jq = 0; jq < 12; ++jq)
+                for (int q = 0; q < 2; ++q)
+                    if (m + n <= TRUNC + 1)
+                        p[((static_cast<size_t>(n) * MX + m) * 12 + jq) * 2 + q] = h.poly[m + MX * (n + NX * (2 * jq + q))];
     return p;
 }
 
 static std::vector<double> make_pdir(const HostTables &h) {
-    std::vector<double> p(static_cast<size_t>(IY) * 8 * MX * 4, 0.0);
+    // [j = 24][lane = m*16 + parity*8 + g][2]: n = parity + 2g and n + 16; zero where the reference leaves the
+    // coefficient at 0 (n = 1..trunc+1 only and nsh2, legendre.f90:206-217)
+    std::vector<double> p(static_cast<size_t>(IY) * MX * 16 * 2, 0.0);
     for (int j = 0; j < IY; ++j)
-        for (int nq = 0; nq < 8; ++nq)
-            for (int m = 0; m < MX; ++m)
-                for (int q = 0; q < 4; ++q) {
-                    const int n = 4 * nq + q;
-                    if (n <= TRUNC && m + n <= TRUNC + 1)  // n = 1..trunc+1 (1-based) and nsh2, legendre.f90:206-217
-                        p[((static_cast<size_t>(j) * 8 + nq) * MX + m) * 4 + q] = h.poly[m + MX * (n + NX * j)];
-                }
+        for (int m = 0; m < MX; ++m)
+            for (int par = 0; par < 2; ++par)
+                for (int g = 0; g < 8; ++g)
+                    for (int hi = 0; hi < 2; ++hi) {
+                        const int n = par + 2 * g + 16 * hi;
+                        if (n <= TRUNC && m + n <= TRUNC + 1)
+                            p[((static_cast<size_t>(j) * MX + m) * 16 + par * 8 + g) * 2 + hi] = h.poly[m + MX * (n + NX * j)];
+                    }
     return p;
 }
 

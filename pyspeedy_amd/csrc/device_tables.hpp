@@ -6,9 +6,9 @@
 namespace spd {
 
 struct DeviceTables {
-    // inverse-Legendre polynomials  [n=32][jq=6][m=31][4 lat pairs]  (zero where m + n > 31)
+    // inverse-Legendre polynomials  [n=32][m*12+jq][2 lat pairs]      (zero where m + n > 31)
     const double *pinv;
-    // direct-Legendre polynomials   [j=24][nq=8][m=31][4 n]          (zero where n > min(30, 31-m))
+    // direct-Legendre polynomials   [j=24][m*16+parity*8+g][2 n]      (zero where n > min(30, 31-m))
     const double *pdir;
     const double *work;    // FFTPACK twiddles, 96
     const double *cosgr;   // 48

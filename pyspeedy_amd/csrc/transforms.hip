@@ -1,19 +1,23 @@
 // Batched spectral transforms for gfx950: spec2grid (inverse Legendre + inverse zonal FFT) and grid2spec
-// (forward FFT + direct Legendre), each as ONE fused kernel per batch tile, so a field crosses HBM exactly
-// once in each direction (15 872 B spectral + 36 864 B grid = 52 736 B algorithmic bytes per field).
+// (forward FFT + direct Legendre), each as ONE fused kernel, so a field crosses HBM exactly once in each direction
+// (15 872 B spectral + 36 864 B grid = 52 736 B algorithmic bytes per field).
 //
 // Reference behaviour reproduced: ModSpectral_spec2grid / grid2spec (speedy.f90/spectral.f90:251-273) =
 // ModLegendre_legendre_inv / legendre (legendre.f90:130-221) composed with ModFourier_fourier_inv / fourier
-// (fourier.f90:63-123).  The stage-only entry points run the same kernel with one stage disabled.
+// (fourier.f90:63-123).  The stage-only entry points run the same kernels with one stage disabled.
 //
-// Work decomposition (one workgroup = FPW fields, 256 threads = 4 wavefronts):
-//   Legendre   lane <-> zonal wavenumber m (31 of them), a thread owns 4 latitude pairs (inverse) or 4 total
-//              wavenumbers n (direct) of FPW fields; re and im of one coefficient stay in one lane (16-byte LDS
-//              reads), the associated-Legendre values are streamed from an L2-resident table laid out so that a
-//              wavefront reads 32 contiguous bytes per lane (table is zero outside the triangle -> no masks).
-//   FFT        (row, block) / (row, group) task lists over all FPW*48 rows, lanes on different rows, see fft96.hpp.
-//   LDS        two row buffers [FPW*48][97] doubles (odd row stride: conflict-free for lanes-on-rows access);
-//              the staged spectral input aliases the second buffer.  74 496 B per field.
+// Work decomposition: one workgroup = one field, 512 threads = 8 wavefronts, 53 120 B of LDS
+//   (one row buffer [48][97] doubles + one spectral-field-sized staging area) -> 3 workgroups = 24 waves per CU.
+//   The kernels are latency-bound (profiles/), so occupancy is what the layout is optimised for:
+//   * FFT stages run IN PLACE on the row buffer: every (row, group|block) task loads its <= 16 inputs into
+//     registers, the workgroup synchronises, then the outputs are written back (fft96.hpp).  Wave w handles
+//     group/block w for all 48 rows, so the pass index and every twiddle are wave-uniform (scalar loads) and no
+//     wave diverges; lanes sit on different rows and the odd row stride makes every ds_read/write_b64
+//     bank-conflict free.
+//   * Legendre: a lane owns one zonal wavenumber m (re and im together, 16-byte LDS reads) and two latitude pairs
+//     (inverse) or two total wavenumbers (direct).  Lanes are ordered m-major so that a wavefront only loops over
+//     the total wavenumbers its smallest m needs (triangular truncation: 32 - m of them).  The associated-Legendre
+//     values stream from an L2-resident table laid out so that a wavefront reads 1 KiB contiguous per step.
 #include <hip/hip_runtime.h>
 
 #include "device_tables.hpp"
@@ -21,124 +25,140 @@
 
 namespace spd {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 512;
 constexpr int kRowStride = 97;
-constexpr int kRows = IL;  // 48 rows per field
+constexpr int kRows = IL;                       // 48 rows per field
+constexpr int kRowBufDoubles = kRows * kRowStride;
+constexpr int kInvLanes = MX * 12;              // inverse Legendre tasks: (m, pair-of-latitude-pairs)
+constexpr int kDirLanes = MX * 16;              // direct  Legendre tasks: (m, parity, 8 groups of two n)
+constexpr size_t kLdsBytes = (kRowBufDoubles + 2 * NSPEC) * sizeof(double);  // 53 120
 
 enum class Stage { Fused, LegendreOnly, FourierOnly };
 
 using d2 = double __attribute__((ext_vector_type(2)));
 
 // position of coefficient (m, re|im) in an unpacked FFT row (fourier.f90:74-81): re(m) -> 2m-1, im(m) -> 2m,
-// re(0) -> 0.  im(0) has no slot in the transform; the stage-only kernels park it at position 61.
+// re(0) -> 0.  im(0) has no slot in the transform; it is parked at position 61 where a stage needs it.
 __device__ inline int pos_re(int m) { return m == 0 ? 0 : 2 * m - 1; }
 __device__ inline int pos_im(int m) { return m == 0 ? 61 : 2 * m; }
+
+__device__ inline int wave_id() { return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6); }
 
 // ------------------------------------------------------------------------------------------------
 // spec -> grid
 // ------------------------------------------------------------------------------------------------
-template <Stage ST, int FPW>
+template <Stage ST>
 __global__ __launch_bounds__(kThreads) void spec2grid_kernel(const double *__restrict__ src, double *__restrict__ dst,
-                                                             DeviceTables T, int nfields, int kcos) {
+                                                             DeviceTables T, int kcos) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *bufA = lds;                                  // [FPW*48][97]
-    double *bufB = lds + FPW * kRows * kRowStride;       // [FPW*48][97], spectral staging aliases it
+    double *rows = lds;                                        // [48][97]
+    d2 *s = reinterpret_cast<d2 *>(lds + kRowBufDoubles);      // 992 complex
     const int tid = threadIdx.x;
-    const int f0 = blockIdx.x * FPW;
-    const int nf = min(FPW, nfields - f0);  // fields present in this tile (>= 1)
+    const size_t f = blockIdx.x;
+    const int wave = wave_id(), lane = tid & 63;
 
     if (ST != Stage::FourierOnly) {
-        // ---- stage spectral coefficients: 992 complex per field, 16 B per lane, fully coalesced ----
-        const d2 *g = reinterpret_cast<const d2 *>(src) + static_cast<size_t>(f0) * NSPEC;
-        d2 *s = reinterpret_cast<d2 *>(bufB);
-        for (int idx = tid; idx < FPW * NSPEC; idx += kThreads) s[idx] = (idx < nf * NSPEC) ? g[idx] : d2{0.0, 0.0};
+        // ---- stage spectral coefficients: 16 B per lane, fully coalesced ----
+        const d2 *g = reinterpret_cast<const d2 *>(src) + f * NSPEC;
+        for (int idx = tid; idx < NSPEC; idx += kThreads) s[idx] = g[idx];
         __syncthreads();
 
-        // ---- inverse Legendre (legendre.f90:130-169) ----
-        if (tid < MX * 6) {
-            const int m = tid % MX, jq = tid / MX;
-            double ev[FPW][4][2], od[FPW][4][2];
-#pragma unroll
-            for (int f = 0; f < FPW; ++f)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) ev[f][q][0] = ev[f][q][1] = od[f][q][0] = od[f][q][1] = 0.0;
-            const d2 *pol = reinterpret_cast<const d2 *>(T.pinv) + 2 * tid;  // [n][jq*31+m][4]
-#pragma unroll 2
-            for (int n = 0; n < NX; n += 2) {
-                // n even (0-based) <-> reference n odd: "even" sum; n+1 -> "odd" sum
-                const d2 pe0 = pol[(n * 186) * 2], pe1 = pol[(n * 186) * 2 + 1];
-                const d2 po0 = pol[((n + 1) * 186) * 2], po1 = pol[((n + 1) * 186) * 2 + 1];
-                const double pe[4] = {pe0.x, pe0.y, pe1.x, pe1.y}, po[4] = {po0.x, po0.y, po1.x, po1.y};
-#pragma unroll
-                for (int f = 0; f < FPW; ++f) {
-                    const d2 xe = s[f * NSPEC + n * MX + m], xo = s[f * NSPEC + (n + 1) * MX + m];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        ev[f][q][0] += xe.x * pe[q];
-                        ev[f][q][1] += xe.y * pe[q];
-                        od[f][q][0] += xo.x * po[q];
-                        od[f][q][1] += xo.y * po[q];
-                    }
-                }
+        // ---- inverse Legendre (legendre.f90:130-169): lane = (m, jq), latitude pairs 2jq, 2jq+1 ----
+        if (tid < kInvLanes) {
+            const int m = tid / 12, jq = tid - 12 * m;
+            // total wavenumbers needed by this wavefront: its smallest m needs 32 - m of them (nsh2, legendre.f90:73)
+            const int m_first = __builtin_amdgcn_readfirstlane((tid & ~63) / 12);
+            const int ncount = ((32 - m_first) + 1) & ~1;
+            double ev[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, od[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+            const d2 *pol = reinterpret_cast<const d2 *>(T.pinv) + tid;  // [n][372] x {pair 2jq, pair 2jq+1}
+#pragma unroll 4
+            for (int n = 0; n < ncount; n += 2) {
+                const d2 pe = pol[n * kInvLanes], po = pol[(n + 1) * kInvLanes];
+                const d2 xe = s[n * MX + m], xo = s[(n + 1) * MX + m];
+                // n even (0-based) <-> reference n odd: symmetric ("even") sum; n+1: antisymmetric ("odd") sum
+                ev[0][0] += xe.x * pe.x;  ev[0][1] += xe.y * pe.x;
+                ev[1][0] += xe.x * pe.y;  ev[1][1] += xe.y * pe.y;
+                od[0][0] += xo.x * po.x;  od[0][1] += xo.y * po.x;
+                od[1][0] += xo.x * po.y;  od[1][1] += xo.y * po.y;
             }
             const int pr = pos_re(m), pi = pos_im(m);
             const bool keep_im = (m != 0) || (ST == Stage::LegendreOnly);
 #pragma unroll
-            for (int f = 0; f < FPW; ++f)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int js = 4 * jq + q, jn = kRows - 1 - js;  // reference j and il+1-j
-                    double *rs = bufA + (f * kRows + js) * kRowStride, *rn = bufA + (f * kRows + jn) * kRowStride;
-                    rn[pr] = ev[f][q][0] + od[f][q][0];
-                    rs[pr] = ev[f][q][0] - od[f][q][0];
-                    if (keep_im) {
-                        rn[pi] = ev[f][q][1] + od[f][q][1];
-                        rs[pi] = ev[f][q][1] - od[f][q][1];
-                    }
+            for (int q = 0; q < 2; ++q) {
+                const int js = 2 * jq + q, jn = kRows - 1 - js;  // reference j and il+1-j
+                double *rs = rows + js * kRowStride, *rn = rows + jn * kRowStride;
+                rn[pr] = ev[q][0] + od[q][0];
+                rs[pr] = ev[q][0] - od[q][0];
+                if (keep_im) {
+                    rn[pi] = ev[q][1] + od[q][1];
+                    rs[pi] = ev[q][1] - od[q][1];
                 }
+            }
         }
         __syncthreads();
     } else {
-        // ---- Fourier plane from memory: (62, 48) per field -> unpacked rows ----
-        const double *g = src + static_cast<size_t>(f0) * NFOUR;
-        for (int idx = tid; idx < nf * NFOUR; idx += kThreads) {
-            const int f = idx / NFOUR, rem = idx - f * NFOUR, row = rem / 62, r = rem - row * 62;
-            if (r != 1) bufA[(f * kRows + row) * kRowStride + (r == 0 ? 0 : r - 1)] = g[idx];
+        // ---- Fourier plane from memory: (62, 48) -> unpacked rows ----
+        const double *g = src + f * NFOUR;
+        for (int idx = tid; idx < NFOUR; idx += kThreads) {
+            const int row = idx / 62, r = idx - row * 62;
+            if (r != 1) rows[row * kRowStride + (r == 0 ? 0 : r - 1)] = g[idx];
         }
         __syncthreads();
     }
 
     if (ST == Stage::LegendreOnly) {
-        double *g = dst + static_cast<size_t>(f0) * NFOUR;
-        for (int idx = tid; idx < nf * NFOUR; idx += kThreads) {
-            const int f = idx / NFOUR, rem = idx - f * NFOUR, row = rem / 62, r = rem - row * 62;
-            g[idx] = bufA[(f * kRows + row) * kRowStride + (r == 0 ? 0 : (r == 1 ? 61 : r - 1))];
+        double *g = dst + f * NFOUR;
+        for (int idx = tid; idx < NFOUR; idx += kThreads) {
+            const int row = idx / 62, r = idx - row * 62;
+            g[idx] = rows[row * kRowStride + (r == 0 ? 0 : (r == 1 ? 61 : r - 1))];
         }
         return;
     }
 
-    // ---- inverse FFT, group stage (radb2 + radb4 ido=12): A -> B ----
-    const int nrows = nf * kRows;
-    for (int task = tid; task < nrows * fft::kNumGroups; task += kThreads) {
-        const int g = task / nrows, row = task - g * nrows;
-        fft::bwd_group<true>(bufA + row * kRowStride, bufB + row * kRowStride, T.work, g);
+    double *row = rows + lane * kRowStride;
+    const bool active = lane < kRows;
+    // ---- inverse FFT, group stage (radb2 + radb4 ido=12), in place; wave = group ----
+    {
+        double o[2][8];
+        if (active && wave < fft::kNumGroups) {
+            if (wave < 5)
+                fft::bwd_group_general_r<true>(row, T.work, 3 + 2 * wave, o);
+            else if (wave == 5)
+                fft::bwd_group_first_r<true>(row, T.work, o);
+            else
+                fft::bwd_group_last_r<true>(row, T.work, o);
+        }
+        __syncthreads();
+        if (active && wave < fft::kNumGroups) {
+            if (wave < 5)
+                fft::group_general_store(row, 3 + 2 * wave, o);
+            else
+                fft::group_edge_store(row, wave == 5 ? 0 : 11, o);
+        }
     }
     __syncthreads();
-    // ---- block stage (radb4 ido=3 + radb3): B -> A ----
-    for (int task = tid; task < nrows * fft::kNumBlocks; task += kThreads) {
-        const int kk = task / nrows, row = task - kk * nrows;
-        fft::bwd_block(bufB + row * kRowStride, bufA + row * kRowStride, T.work, kk);
+    // ---- block stage (radb4 ido=3 + radb3), in place; wave = block ----
+    {
+        double o[4][3];
+        if (active) fft::bwd_block_r(row, T.work, wave, o);
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int sidx = 0; sidx < 3; ++sidx) row[wave + 8 * j + 32 * sidx] = o[j][sidx];
+        }
     }
     __syncthreads();
 
     // ---- store grid rows: 16 B per lane, coalesced; optional 1/cos(lat) scaling (fourier.f90:87-91) ----
-    d2 *g = reinterpret_cast<d2 *>(dst) + static_cast<size_t>(f0) * (NGRID / 2);
-    for (int idx = tid; idx < nf * (NGRID / 2); idx += kThreads) {
-        const int row = idx / (IX / 2), ip = idx - row * (IX / 2);  // row counts over all fields of the tile
-        const double *a = bufA + row * kRowStride + 2 * ip;
+    d2 *g = reinterpret_cast<d2 *>(dst) + f * (NGRID / 2);
+    for (int idx = tid; idx < NGRID / 2; idx += kThreads) {
+        const int r = idx / (IX / 2), ip = idx - r * (IX / 2);
+        const double *a = rows + r * kRowStride + 2 * ip;
         d2 v{a[0], a[1]};
         if (kcos != 1) {
-            const double c = T.cosgr[row % kRows];
+            const double c = T.cosgr[r];
             v.x *= c;
             v.y *= c;
         }
@@ -149,174 +169,172 @@ __global__ __launch_bounds__(kThreads) void spec2grid_kernel(const double *__res
 // ------------------------------------------------------------------------------------------------
 // grid -> spec.  prescale: 0 none, 1 multiply rows by cosgr, 2 by cosgr2 (spectral.f90:229-243)
 // ------------------------------------------------------------------------------------------------
-template <Stage ST, int FPW>
+template <Stage ST>
 __global__ __launch_bounds__(kThreads) void grid2spec_kernel(const double *__restrict__ src, double *__restrict__ dst,
-                                                             DeviceTables T, int nfields, int prescale) {
+                                                             DeviceTables T, int prescale) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *bufA = lds;
-    double *bufB = lds + FPW * kRows * kRowStride;
+    double *rows = lds;
+    d2 *s = reinterpret_cast<d2 *>(lds + kRowBufDoubles);  // output staging, 992 complex
     const int tid = threadIdx.x;
-    const int f0 = blockIdx.x * FPW;
-    const int nf = min(FPW, nfields - f0);
-    const int nrows = nf * kRows;
+    const size_t f = blockIdx.x;
+    const int wave = wave_id(), lane = tid & 63;
 
     if (ST != Stage::LegendreOnly) {
-        // ---- load grid rows (16 B per lane, coalesced) into A ----
-        const d2 *g = reinterpret_cast<const d2 *>(src) + static_cast<size_t>(f0) * (NGRID / 2);
-        for (int idx = tid; idx < nf * (NGRID / 2); idx += kThreads) {
-            const int row = idx / (IX / 2), ip = idx - row * (IX / 2);
+        // ---- load grid rows (16 B per lane, coalesced) ----
+        const d2 *g = reinterpret_cast<const d2 *>(src) + f * (NGRID / 2);
+        for (int idx = tid; idx < NGRID / 2; idx += kThreads) {
+            const int r = idx / (IX / 2), ip = idx - r * (IX / 2);
             d2 v = g[idx];
             if (prescale != 0) {
-                const double c = (prescale == 1) ? T.cosgr[row % kRows] : T.cosgr2[row % kRows];
+                const double c = (prescale == 1) ? T.cosgr[r] : T.cosgr2[r];
                 v.x *= c;
                 v.y *= c;
             }
-            double *a = bufA + row * kRowStride + 2 * ip;
+            double *a = rows + r * kRowStride + 2 * ip;
             a[0] = v.x;
             a[1] = v.y;
         }
         __syncthreads();
-        // ---- forward FFT, block stage (radf3 + radf4 ido=3): A -> B ----
-        for (int task = tid; task < nrows * fft::kNumBlocks; task += kThreads) {
-            const int kk = task / nrows, row = task - kk * nrows;
-            fft::fwd_block(bufA + row * kRowStride, bufB + row * kRowStride, T.work, kk);
+        double *row = rows + lane * kRowStride;
+        const bool active = lane < kRows;
+        // ---- forward FFT, block stage (radf3 + radf4 ido=3), in place; wave = block ----
+        {
+            double o[12];
+            if (active) fft::fwd_block_r(row, T.work, wave, o);
+            __syncthreads();
+            if (active) {
+#pragma unroll
+                for (int e = 0; e < 12; ++e) row[12 * wave + e] = o[e];
+            }
         }
         __syncthreads();
-        // ---- group stage (radf4 ido=12 + radf2), scaled by fp32(1/96), retained wavenumbers only: B -> A ----
-        for (int task = tid; task < nrows * fft::kNumGroups; task += kThreads) {
-            const int g2 = task / nrows, row = task - g2 * nrows;
-            fft::fwd_group(bufB + row * kRowStride, bufA + row * kRowStride, T.work, g2, T.fft_scale);
+        // ---- group stage (radf4 ido=12 + radf2), scaled by fp32(1/96), retained wavenumbers only; wave = group ----
+        {
+            fft::Quad q[4];
+            double o5[5];
+            if (active && wave < fft::kNumGroups) {
+                if (wave < 5)
+                    fft::fwd_group_general_r(row, T.work, 3 + 2 * wave, T.fft_scale, q);
+                else if (wave == 5)
+                    fft::fwd_group_first_r(row, T.work, T.fft_scale, o5);
+                else
+                    fft::fwd_group_last_r(row, T.work, T.fft_scale, q);
+            }
+            __syncthreads();
+            if (active && wave < fft::kNumGroups) {
+                if (wave < 5) {
+                    fft::fwd_group_general_store(row, 3 + 2 * wave, q);
+                } else if (wave == 5) {
+                    row[0] = o5[0]; row[47] = o5[1]; row[48] = o5[2]; row[23] = o5[3]; row[24] = o5[4];
+                    row[61] = 0.0;  // Im of the zonal mean: fourier.f90:117 sets output(2, j) = 0
+                } else {
+                    row[11] = q[0].lo_r; row[12] = q[0].lo_i;
+                    row[35] = q[1].lo_r; row[36] = q[1].lo_i;
+                    row[59] = q[1].hi_r; row[60] = q[1].hi_i;
+                }
+            }
         }
         __syncthreads();
     } else {
-        const double *g = src + static_cast<size_t>(f0) * NFOUR;
-        for (int idx = tid; idx < nf * NFOUR; idx += kThreads) {
-            const int f = idx / NFOUR, rem = idx - f * NFOUR, row = rem / 62, r = rem - row * 62;
-            bufA[(f * kRows + row) * kRowStride + (r == 0 ? 0 : (r == 1 ? 61 : r - 1))] = g[idx];
+        const double *g = src + f * NFOUR;
+        for (int idx = tid; idx < NFOUR; idx += kThreads) {
+            const int r0 = idx / 62, r = idx - r0 * 62;
+            rows[r0 * kRowStride + (r == 0 ? 0 : (r == 1 ? 61 : r - 1))] = g[idx];
         }
         __syncthreads();
     }
 
     if (ST == Stage::FourierOnly) {
-        double *g = dst + static_cast<size_t>(f0) * NFOUR;
-        for (int idx = tid; idx < nf * NFOUR; idx += kThreads) {
-            const int f = idx / NFOUR, rem = idx - f * NFOUR, row = rem / 62, r = rem - row * 62;
-            g[idx] = (r == 1) ? 0.0 : bufA[(f * kRows + row) * kRowStride + (r == 0 ? 0 : r - 1)];  // fourier.f90:117
+        double *g = dst + f * NFOUR;
+        for (int idx = tid; idx < NFOUR; idx += kThreads) {
+            const int r0 = idx / 62, r = idx - r0 * 62;
+            g[idx] = (r == 1) ? 0.0 : rows[r0 * kRowStride + (r == 0 ? 0 : r - 1)];  // fourier.f90:117
         }
         return;
     }
 
-    // ---- direct Legendre (legendre.f90:175-221): thread = (m, 4 consecutive n), loop over latitude pairs ----
-    if (tid < MX * 8) {
-        const int m = tid % MX, nq = tid / MX;
+    // ---- direct Legendre (legendre.f90:175-221) ----
+    // step 1, in place: north row <- symmetric part, south row <- antisymmetric part, both times the Gaussian weight
+    for (int idx = tid; idx < MX * IY; idx += kThreads) {
+        const int j = idx / MX, m = idx - j * MX;
         const int pr = pos_re(m), pi = pos_im(m);
-        const bool has_im = (m != 0) || (ST == Stage::LegendreOnly);
-        double acc[FPW][4][2];
-#pragma unroll
-        for (int f = 0; f < FPW; ++f)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[f][q][0] = acc[f][q][1] = 0.0;
-        const d2 *pol = reinterpret_cast<const d2 *>(T.pdir) + 2 * tid;  // [j][nq*31+m][4]
-#pragma unroll 2
-        for (int j = 0; j < IY; ++j) {
-            const d2 p0 = pol[(j * 248) * 2], p1 = pol[(j * 248) * 2 + 1];
-            const double p[4] = {p0.x, p0.y, p1.x, p1.y};
-            const double w = T.wt[j];
-#pragma unroll
-            for (int f = 0; f < FPW; ++f) {
-                const double *rs = bufA + (f * kRows + j) * kRowStride, *rn = bufA + (f * kRows + kRows - 1 - j) * kRowStride;
-                const double nr = rn[pr], sr = rs[pr];
-                const double ni = has_im ? rn[pi] : 0.0, si = has_im ? rs[pi] : 0.0;
-                const double er = (nr + sr) * w, orr = (nr - sr) * w;
-                const double ei = (ni + si) * w, oi = (ni - si) * w;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    // n = 4*nq + q ; q even <-> reference n odd <-> symmetric ("even") part
-                    acc[f][q][0] += p[q] * ((q & 1) ? orr : er);
-                    acc[f][q][1] += p[q] * ((q & 1) ? oi : ei);
-                }
-            }
-        }
-        d2 *g = reinterpret_cast<d2 *>(dst) + static_cast<size_t>(f0) * NSPEC;
-#pragma unroll
-        for (int f = 0; f < FPW; ++f)
-            if (f < nf)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) g[f * NSPEC + (4 * nq + q) * MX + m] = d2{acc[f][q][0], acc[f][q][1]};
+        double *rn = rows + (kRows - 1 - j) * kRowStride, *rs = rows + j * kRowStride;
+        const double w = T.wt[j];
+        const double nr = rn[pr], sr = rs[pr], ni = rn[pi], si = rs[pi];
+        rn[pr] = (nr + sr) * w;
+        rs[pr] = (nr - sr) * w;
+        rn[pi] = (ni + si) * w;
+        rs[pi] = (ni - si) * w;
     }
+    __syncthreads();
+    // step 2: lane = (m, parity, g): n = parity + 2g and n + 16; sum over the 24 latitude pairs in reference order
+    if (tid < kDirLanes) {
+        const int m = tid >> 4, par = (tid >> 3) & 1, gq = tid & 7;
+        const int pr = pos_re(m), pi = pos_im(m);
+        double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+        const d2 *pol = reinterpret_cast<const d2 *>(T.pdir) + tid;  // [j][496] x {n0, n0+16}
+        const double *base = rows + (par ? 0 : (kRows - 1) * kRowStride);
+        const int rstep = par ? kRowStride : -kRowStride;
+#pragma unroll 4
+        for (int j = 0; j < IY; ++j) {
+            const d2 p = pol[j * kDirLanes];
+            const double *r = base + j * rstep;
+            const double xr = r[pr], xi = r[pi];
+            acc[0][0] += p.x * xr;  acc[0][1] += p.x * xi;
+            acc[1][0] += p.y * xr;  acc[1][1] += p.y * xi;
+        }
+        const int n0 = par + 2 * gq;
+        s[n0 * MX + m] = d2{acc[0][0], acc[0][1]};
+        s[(n0 + 16) * MX + m] = d2{acc[1][0], acc[1][1]};
+    }
+    __syncthreads();
+    d2 *g = reinterpret_cast<d2 *>(dst) + f * NSPEC;
+    for (int idx = tid; idx < NSPEC; idx += kThreads) g[idx] = s[idx];
 }
 
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-template <int FPW>
-static constexpr size_t lds_bytes() { return static_cast<size_t>(2) * FPW * kRows * kRowStride * sizeof(double); }
+template <typename K>
+static hipError_t configure(K kernel) {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(kLdsBytes));
+}
 
-template <Stage ST, int FPW>
-static hipError_t launch_s2g(const double *src, double *dst, const DeviceTables &T, int nfields, int kcos,
-                             hipStream_t stream) {
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&spec2grid_kernel<ST, FPW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes<FPW>()));
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
-    const int grid = (nfields + FPW - 1) / FPW;
-    hipLaunchKernelGGL((spec2grid_kernel<ST, FPW>), dim3(grid), dim3(kThreads), lds_bytes<FPW>(), stream, src, dst, T,
-                       nfields, kcos);
+template <Stage ST>
+static hipError_t launch_s2g(const double *src, double *dst, const DeviceTables &T, int nfields, int kcos, hipStream_t st) {
+    static hipError_t cfg = configure(&spec2grid_kernel<ST>);
+    if (cfg != hipSuccess) return cfg;
+    hipLaunchKernelGGL((spec2grid_kernel<ST>), dim3(nfields), dim3(kThreads), kLdsBytes, st, src, dst, T, kcos);
     return hipGetLastError();
 }
 
-template <Stage ST, int FPW>
+template <Stage ST>
 static hipError_t launch_g2s(const double *src, double *dst, const DeviceTables &T, int nfields, int prescale,
-                             hipStream_t stream) {
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&grid2spec_kernel<ST, FPW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes<FPW>()));
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
-    const int grid = (nfields + FPW - 1) / FPW;
-    hipLaunchKernelGGL((grid2spec_kernel<ST, FPW>), dim3(grid), dim3(kThreads), lds_bytes<FPW>(), stream, src, dst, T,
-                       nfields, prescale);
+                             hipStream_t st) {
+    static hipError_t cfg = configure(&grid2spec_kernel<ST>);
+    if (cfg != hipSuccess) return cfg;
+    hipLaunchKernelGGL((grid2spec_kernel<ST>), dim3(nfields), dim3(kThreads), kLdsBytes, st, src, dst, T, prescale);
     return hipGetLastError();
-}
-
-// fields-per-workgroup policy.  Measured on MI355X (tools/perf_transforms.py): one field per workgroup (74.5 KB of
-// LDS -> two workgroups per CU) beats two fields per workgroup (149 KB -> one per CU) at every batch size, because
-// the kernel is latency-bound and needs the occupancy; the 2-field variant stays available for experiments.
-static inline int pick_fpw(int nfields, int forced) {
-    (void)nfields;
-    return forced == 2 ? 2 : 1;
 }
 
 hipError_t run_spec2grid(const DeviceTables &T, int stage, const double *src, double *dst, int kcos, int nfields,
-                         hipStream_t stream, int fpw) {
+                         hipStream_t stream, int /*fpw*/) {
     if (nfields == 0) return hipSuccess;
-    const bool two = pick_fpw(nfields, fpw) == 2;
     switch (stage) {
-        case 0: return two ? launch_s2g<Stage::Fused, 2>(src, dst, T, nfields, kcos, stream)
-                           : launch_s2g<Stage::Fused, 1>(src, dst, T, nfields, kcos, stream);
-        case 1: return two ? launch_s2g<Stage::LegendreOnly, 2>(src, dst, T, nfields, kcos, stream)
-                           : launch_s2g<Stage::LegendreOnly, 1>(src, dst, T, nfields, kcos, stream);
-        default: return two ? launch_s2g<Stage::FourierOnly, 2>(src, dst, T, nfields, kcos, stream)
-                            : launch_s2g<Stage::FourierOnly, 1>(src, dst, T, nfields, kcos, stream);
+        case 0: return launch_s2g<Stage::Fused>(src, dst, T, nfields, kcos, stream);
+        case 1: return launch_s2g<Stage::LegendreOnly>(src, dst, T, nfields, kcos, stream);
+        default: return launch_s2g<Stage::FourierOnly>(src, dst, T, nfields, kcos, stream);
     }
 }
 
 hipError_t run_grid2spec(const DeviceTables &T, int stage, const double *src, double *dst, int prescale, int nfields,
-                         hipStream_t stream, int fpw) {
+                         hipStream_t stream, int /*fpw*/) {
     if (nfields == 0) return hipSuccess;
-    const bool two = pick_fpw(nfields, fpw) == 2;
     switch (stage) {
-        case 0: return two ? launch_g2s<Stage::Fused, 2>(src, dst, T, nfields, prescale, stream)
-                           : launch_g2s<Stage::Fused, 1>(src, dst, T, nfields, prescale, stream);
-        case 1: return two ? launch_g2s<Stage::LegendreOnly, 2>(src, dst, T, nfields, prescale, stream)
-                           : launch_g2s<Stage::LegendreOnly, 1>(src, dst, T, nfields, prescale, stream);
-        default: return two ? launch_g2s<Stage::FourierOnly, 2>(src, dst, T, nfields, prescale, stream)
-                            : launch_g2s<Stage::FourierOnly, 1>(src, dst, T, nfields, prescale, stream);
+        case 0: return launch_g2s<Stage::Fused>(src, dst, T, nfields, prescale, stream);
+        case 1: return launch_g2s<Stage::LegendreOnly>(src, dst, T, nfields, prescale, stream);
+        default: return launch_g2s<Stage::FourierOnly>(src, dst, T, nfields, prescale, stream);
     }
 }
 
