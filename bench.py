@@ -233,6 +233,16 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in hp.ev]))
     nfields = 57 * args.members
     achieved = (S_BYTES + G_BYTES) * nfields / (kern_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the committed PMC measurement of this kernel (rocprofv3 cannot run inside bench.py):
+    # bytes per field measured at 3648 fields/launch, FETCH_SIZE doubled as the gfx950 guide prescribes.
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+            tj = json.load(fh)
+        traffic = tj["spec2grid_fused_hbm_bytes_per_field"] * nfields
+        traffic_src = "profiles/r01_pmc_transforms_v2.csv (per-field bytes measured at %d fields/launch)" % tj["fields_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         total_members = args.members * world
@@ -252,7 +262,8 @@ def main():
             "roofline": {
                 "kernel": "spec2grid_kernel<Fused> (inverse Legendre + inverse FFT-96), %d fields/launch" % nfields,
                 "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                "algorithmic_bytes_per_field": S_BYTES + G_BYTES, "avg_launch_ms": kern_ms, "traffic": None,
+                "algorithmic_bytes_per_field": S_BYTES + G_BYTES, "avg_launch_ms": kern_ms, "traffic": traffic,
+                "traffic_source": traffic_src,
             },
         }
         if not args.no_cpu_baseline:
