@@ -197,18 +197,13 @@ def cpu_baseline(seconds):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from pyspeedy_amd import ensemble as E
+    world, rank, local = E.dist_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+    dist = E.init_process_group("nccl", device)  # RCCL; only used for the barrier and the max-over-ranks time
 
     def barrier():
         if dist is not None:
@@ -225,10 +220,7 @@ def main():
         hp.step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = E.max_over_ranks(elapsed, dist, device)
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in hp.ev]))
     nfields = 57 * args.members
@@ -246,7 +238,7 @@ def main():
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         total_members = args.members * world
-        value = total_members * 86400.0 / (ms_step * 1e-3 * STEPS_PER_YEAR)
+        value = E.simulated_years_per_day(total_members, ms_step * 1e-3, STEPS_PER_YEAR)
         line = {
             "metric": "simulated-years/day (whole node), T30L8", "value": value, "unit": "simulated-years/day",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,

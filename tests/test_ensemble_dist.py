@@ -1,0 +1,79 @@
+"""CPU tier: the N>1 path (member sharding + barrier + max-over-ranks timing) with world_size 2 on gloo."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_members_partitions_everything():
+    from pyspeedy_amd.ensemble import shard_members
+    for total in (0, 1, 7, 64, 65, 256):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                first, count = shard_members(total, world, r)
+                seen.extend(range(first, first + count))
+            assert seen == list(range(total))
+            counts = [shard_members(total, world, r)[1] for r in range(world)]
+            assert max(counts) - min(counts) <= 1
+    with pytest.raises(ValueError):
+        shard_members(8, 2, 2)
+
+
+def test_throughput_formula():
+    from pyspeedy_amd.ensemble import simulated_years_per_day
+    # one member at 14 ms/step (the flang reference on one core) -> ~470 simulated years per day
+    assert abs(simulated_years_per_day(1, 14e-3) - 86400 / (14e-3 * 13140)) < 1e-9
+    assert simulated_years_per_day(64, 1e-3) == 64 * simulated_years_per_day(1, 1e-3)
+
+
+WORKER = textwrap.dedent("""
+    import os, sys, time
+    sys.path.insert(0, %(root)r)
+    from pyspeedy_amd import ensemble as E
+    world, rank, local = E.dist_env()
+    dist = E.init_process_group("gloo")
+    assert dist is not None and dist.get_world_size() == 2
+    first, count = E.shard_members(65, world, rank)
+    dist.barrier()
+    elapsed = 0.010 * (rank + 1)          # rank 1 is the slow one
+    slowest = E.max_over_ranks(elapsed, dist)
+    total = E.sum_over_ranks(count, dist)
+    assert abs(slowest - 0.020) < 1e-12, slowest
+    assert total == 65, total
+    if rank == 0:
+        print("RESULT", first, count, E.simulated_years_per_day(total, slowest))
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_ranks_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    port = str(free_port())
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, WORLD_SIZE="2", RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    line = [l for l in outs[0].splitlines() if l.startswith("RESULT")][0].split()
+    assert int(line[1]) == 0 and int(line[2]) == 33
+    assert abs(float(line[3]) - 65 * 86400.0 / (0.020 * 13140)) < 1e-6
