@@ -19,6 +19,8 @@
 // reference to ~1e-15 relative, not bit for bit.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/pyspeedy_amd.h"
 #include "device_tables.hpp"
 
@@ -61,7 +63,10 @@ struct Col {  // per-column pointers resolved once
 
 }  // namespace
 
-__global__ __launch_bounds__(kPhysThreads) void physics_kernel(spd_physics_args a, DeviceTables T, int nmembers) {
+// W = minimum waves per SIMD the register allocator must leave room for (launch-bounds hint); selected at run time
+// (PYSPEEDY_AMD_PHYS_WAVES) so the occupancy / spill trade-off can be measured on the same binary.
+template <int W>
+__global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_args a, DeviceTables T, int nmembers) {
     const int gid = blockIdx.x * kPhysThreads + threadIdx.x;
     if (gid >= nmembers * NG) return;
     const int mem = gid / NG, p = gid - mem * NG, j = p / IX;
@@ -237,6 +242,67 @@ __global__ __launch_bounds__(kPhysThreads) void physics_kernel(spd_physics_args 
     }
     a.precls[o2] = precls;
 
+    const double gse = (se[nl1 - 1] - se[KX - 1]) / (phi[nl1 - 1] - phi[KX - 1]);  // physics.f90:152 (used on shortwave steps)
+    const double phi_kx = phi[KX - 1];
+    // ------------------------------------------------------------------ vertical diffusion (vertical_diffusion.f90)
+    // Evaluated here, right after the moist schemes, although the reference calls it after the radiation: it only
+    // depends on se, rh, qa, qsat, phi and icnv, and computing it now lets those 40 per-column values die before the
+    // register-hungry radiation sweeps.  Its tendencies are ADDED in the reference's order at the end.
+    const double trshc = 6.0f, trvdi = 24.0f, trvds = 6.0f, redshc = 0.5f, rhgrad = 0.5f, segrad = 0.1f;
+    const double cshc = T.dhs[KX - 1] / 3600.0f;
+    const double cvdi = (T.sigh[nl1] - T.sigh[1]) / (static_cast<float>(nl1 - 1) * 3600.0f);
+    const double fshcq = cshc / trshc, fshcse = cshc / (trshc * CP);
+    const double fvdiq = cvdi / trvdi, fvdise = cvdi / (trvds * CP);
+    double ttv[KX], qtv[KX];
+#pragma unroll
+    for (int k = 0; k < KX; ++k) ttv[k] = qtv[k] = 0.0;
+    {
+        const double rs_nl1 = 1.0f / T.dhs[nl1 - 1], rs_kx = 1.0f / T.dhs[KX - 1];
+        const double drh0 = rhgrad * (T.fsg[KX - 1] - T.fsg[nl1 - 1]);
+        const double fvdiq2 = fvdiq * T.sigh[nl1];
+        const double dmse = se[KX - 1] - se[nl1 - 1] + ALHC * (qa[KX - 1] - qsat[nl1 - 1]);
+        const double drh = rh[KX - 1] - rh[nl1 - 1];
+        if (dmse >= 0.0) {
+            const double fcnv = (icnv > 0) ? redshc : static_cast<double>(1.0f);
+            const double fluxse = fcnv * fshcse * dmse;
+            ttv[nl1 - 1] = fluxse * rs_nl1;
+            ttv[KX - 1] = -fluxse * rs_kx;
+            if (drh >= 0.0) {
+                const double fluxq = fcnv * fshcq * qsat[KX - 1] * drh;
+                qtv[nl1 - 1] = fluxq * rs_nl1;
+                qtv[KX - 1] = -fluxq * rs_kx;
+            }
+        } else if (drh > drh0) {
+            const double fluxq = fvdiq2 * qsat[nl1 - 1] * drh;
+            qtv[nl1 - 1] = fluxq * rs_nl1;
+            qtv[KX - 1] = -fluxq * rs_kx;
+        }
+    }
+#pragma unroll
+    for (int k = 3; k <= KX - 2; ++k) {
+        if (T.sigh[k] > 0.5f) {
+            const double drh0 = rhgrad * (T.fsg[k] - T.fsg[k - 1]);
+            const double fvdiq2 = fvdiq * T.sigh[k];
+            const double drh = rh[k] - rh[k - 1];
+            if (drh >= drh0) {
+                const double fluxq = fvdiq2 * qsat[k - 1] * drh;
+                qtv[k - 1] = qtv[k - 1] + fluxq * (1.0f / T.dhs[k - 1]);
+                qtv[k] = qtv[k] - fluxq * (1.0f / T.dhs[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 1; k <= nl1; ++k) {
+        const double se0 = se[k] + segrad * (phi[k - 1] - phi[k]);
+        if (se[k - 1] < se0) {
+            const double fluxse = fvdise * (se0 - se[k - 1]);
+            ttv[k - 1] = ttv[k - 1] + fluxse * (1.0f / T.dhs[k - 1]);
+            const double r1 = 1.0f / (1.0f - T.sigh[k]);
+#pragma unroll
+            for (int k1 = k + 1; k1 <= KX; ++k1) ttv[k1 - 1] = ttv[k1 - 1] - fluxse * r1;
+        }
+    }
+
     // ------------------------------------------------------------------ clouds + shortwave (every nstrad-th step)
     double tau[KX][4];   // rad_tau2(k, band)
     double tt_rsw[KX];
@@ -249,7 +315,6 @@ __global__ __launch_bounds__(kPhysThreads) void physics_kernel(spd_physics_args 
                      absaer = 0.033f, abswv1 = 0.022f, abswv2 = 15.000f, abscl1 = 0.015f, abscl2 = 0.15f,
                      ablwin = 0.3f, ablwv1 = 0.7f, ablwv2 = 50.0f, ablcl1 = 12.0f, ablcl2 = 0.6f;
         const double fmask = a.fmask_land[o2];
-        const double gse = (se[nl1 - 1] - se[KX - 1]) / (phi[nl1 - 1] - phi[KX - 1]);  // physics.f90:152
         // clouds, shortwave_radiation.f90:325-404
         const double rrcl = 1.f / (rhcl2 - rhcl1);
         if (rh[nl1 - 1] > rhcl1) {
@@ -416,15 +481,16 @@ __global__ __launch_bounds__(kPhysThreads) void physics_kernel(spd_physics_args 
         }
 #pragma unroll
         for (int k = 0; k < KX; ++k) dfabs[k] = 0.0;
-        double fb[KX][4];  // fband(nint(ta(k)), band), shared by both sweeps
+        int itab[KX];  // nint(ta(k)) - 100, clamped: row of fband for level k (both sweeps)
 #pragma unroll
-        for (int k = 0; k < KX; ++k)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) fb[k][b] = fband_at(T.fband, ta[k], b);
+        for (int k = 0; k < KX; ++k) {
+            int it = static_cast<int>(round(ta[k]));
+            itab[k] = (it < 100 ? 100 : (it > 400 ? 400 : it)) - 100;
+        }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {  // stratosphere
             const double emis = 1.0f - tau[0][b];
-            const double brad = fb[0][b] * (st4a[0][0] + emis * st4a[0][1]);
+            const double brad = T.fband[itab[0] + 301 * b] * (st4a[0][0] + emis * st4a[0][1]);
             flux[b] = emis * brad;
             dfabs[0] = dfabs[0] - flux[b];
         }
@@ -434,7 +500,7 @@ __global__ __launch_bounds__(kPhysThreads) void physics_kernel(spd_physics_args 
 #pragma unroll
             for (int k = 2; k <= KX; ++k) {
                 const double emis = 1.0f - tau[k - 1][b];
-                const double brad = fb[k - 1][b] * (st4a[k - 1][0] + emis * st4a[k - 1][1]);
+                const double brad = T.fband[itab[k - 1] + 301 * b] * (st4a[k - 1][0] + emis * st4a[k - 1][1]);
                 dfabs[k - 1] = dfabs[k - 1] + flux[b];
                 flux[b] = tau[k - 1][b] * flux[b] + emis * brad;
                 dfabs[k - 1] = dfabs[k - 1] - flux[b];
@@ -464,7 +530,7 @@ __global__ __launch_bounds__(kPhysThreads) void physics_kernel(spd_physics_args 
         const double dt1 = T.wvi[8 + KX - 1] * (ta[KX - 1] - ta[nl1 - 1]);
         double t1l = ta[KX - 1] + dt1;
         double t1s = t1l - phi0 * dt1 / (RGAS * 288.0f * T.sigl[KX - 1]);
-        const double t2s = ta[KX - 1] + rcp * phi[KX - 1];
+        const double t2s = ta[KX - 1] + rcp * phi_kx;
         const double t2l = t2s - rcp * phi0;
         if (ta[KX - 1] > ta[nl1 - 1]) {
             t1l = ftemp0 * t1l + gtemp0 * t2l;
@@ -537,7 +603,7 @@ __global__ __launch_bounds__(kPhysThreads) void physics_kernel(spd_physics_args 
 #pragma unroll
             for (int k = KX; k >= 2; --k) {
                 const double emis = 1.0f - tau[k - 1][b];
-                const double brad = fb[k - 1][b] * (st4a[k - 1][0] - emis * st4a[k - 1][1]);
+                const double brad = T.fband[itab[k - 1] + 301 * b] * (st4a[k - 1][0] - emis * st4a[k - 1][1]);
                 dfabs[k - 1] = dfabs[k - 1] + flux[b];
                 flux[b] = tau[k - 1][b] * flux[b] + emis * brad;
                 dfabs[k - 1] = dfabs[k - 1] - flux[b];
@@ -545,7 +611,7 @@ __global__ __launch_bounds__(kPhysThreads) void physics_kernel(spd_physics_args 
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const double emis = 1.0f - tau[0][b];
-            const double brad = fb[0][b] * (st4a[0][0] - emis * st4a[0][1]);
+            const double brad = T.fband[itab[0] + 301 * b] * (st4a[0][0] - emis * st4a[0][1]);
             dfabs[0] = dfabs[0] + flux[b];
             flux[b] = tau[0][b] * flux[b] + emis * brad;
             dfabs[0] = dfabs[0] - flux[b];
@@ -564,61 +630,6 @@ __global__ __launch_bounds__(kPhysThreads) void physics_kernel(spd_physics_args 
 #pragma unroll
         for (int k = 0; k < KX; ++k) ttend[k] = ttend[k] + tt_rsw[k] + dfabs[k] * rps * T.grdscp[k];
 
-        // -------------------------------------------------------------- vertical diffusion (vertical_diffusion.f90)
-        const double trshc = 6.0f, trvdi = 24.0f, trvds = 6.0f, redshc = 0.5f, rhgrad = 0.5f, segrad = 0.1f;
-        const double cshc = T.dhs[KX - 1] / 3600.0f;
-        const double cvdi = (T.sigh[nl1] - T.sigh[1]) / (static_cast<float>(nl1 - 1) * 3600.0f);
-        const double fshcq = cshc / trshc, fshcse = cshc / (trshc * CP);
-        const double fvdiq = cvdi / trvdi, fvdise = cvdi / (trvds * CP);
-        double ttv[KX], qtv[KX];
-#pragma unroll
-        for (int k = 0; k < KX; ++k) ttv[k] = qtv[k] = 0.0;
-        {
-            const double rs_nl1 = 1.0f / T.dhs[nl1 - 1], rs_kx = 1.0f / T.dhs[KX - 1];
-            const double drh0 = rhgrad * (T.fsg[KX - 1] - T.fsg[nl1 - 1]);
-            const double fvdiq2 = fvdiq * T.sigh[nl1];
-            const double dmse = se[KX - 1] - se[nl1 - 1] + ALHC * (qa[KX - 1] - qsat[nl1 - 1]);
-            const double drh = rh[KX - 1] - rh[nl1 - 1];
-            if (dmse >= 0.0) {
-                const double fcnv = (icnv > 0) ? redshc : static_cast<double>(1.0f);
-                const double fluxse = fcnv * fshcse * dmse;
-                ttv[nl1 - 1] = fluxse * rs_nl1;
-                ttv[KX - 1] = -fluxse * rs_kx;
-                if (drh >= 0.0) {
-                    const double fluxq = fcnv * fshcq * qsat[KX - 1] * drh;
-                    qtv[nl1 - 1] = fluxq * rs_nl1;
-                    qtv[KX - 1] = -fluxq * rs_kx;
-                }
-            } else if (drh > drh0) {
-                const double fluxq = fvdiq2 * qsat[nl1 - 1] * drh;
-                qtv[nl1 - 1] = fluxq * rs_nl1;
-                qtv[KX - 1] = -fluxq * rs_kx;
-            }
-        }
-#pragma unroll
-        for (int k = 3; k <= KX - 2; ++k) {
-            if (T.sigh[k] > 0.5f) {
-                const double drh0 = rhgrad * (T.fsg[k] - T.fsg[k - 1]);
-                const double fvdiq2 = fvdiq * T.sigh[k];
-                const double drh = rh[k] - rh[k - 1];
-                if (drh >= drh0) {
-                    const double fluxq = fvdiq2 * qsat[k - 1] * drh;
-                    qtv[k - 1] = qtv[k - 1] + fluxq * (1.0f / T.dhs[k - 1]);
-                    qtv[k] = qtv[k] - fluxq * (1.0f / T.dhs[k]);
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 1; k <= nl1; ++k) {
-            const double se0 = se[k] + segrad * (phi[k - 1] - phi[k]);
-            if (se[k - 1] < se0) {
-                const double fluxse = fvdise * (se0 - se[k - 1]);
-                ttv[k - 1] = ttv[k - 1] + fluxse * (1.0f / T.dhs[k - 1]);
-                const double r1 = 1.0f / (1.0f - T.sigh[k]);
-#pragma unroll
-                for (int k1 = k + 1; k1 <= KX; ++k1) ttv[k1 - 1] = ttv[k1 - 1] - fluxse * r1;
-            }
-        }
         // physics.f90:223-231: surface-flux tendencies at the lowest level, then accumulate
         const double ut_kx = 0.0 + ustr3 * rps * T.grdsig[KX - 1];
         const double vt_kx = 0.0 + vstr3 * rps * T.grdsig[KX - 1];
@@ -642,7 +653,16 @@ __global__ __launch_bounds__(kPhysThreads) void physics_kernel(spd_physics_args 
 hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nmembers, hipStream_t s) {
     const long total = static_cast<long>(nmembers) * NG;
     const unsigned blocks = static_cast<unsigned>((total + kPhysThreads - 1) / kPhysThreads);
-    hipLaunchKernelGGL(physics_kernel, dim3(blocks), dim3(kPhysThreads), 0, s, a, T, nmembers);
+    static const int waves = [] {
+        const char *e = getenv("PYSPEEDY_AMD_PHYS_WAVES");
+        return e ? atoi(e) : 1;
+    }();
+    switch (waves) {
+        case 2: hipLaunchKernelGGL(physics_kernel<2>, dim3(blocks), dim3(kPhysThreads), 0, s, a, T, nmembers); break;
+        case 3: hipLaunchKernelGGL(physics_kernel<3>, dim3(blocks), dim3(kPhysThreads), 0, s, a, T, nmembers); break;
+        case 4: hipLaunchKernelGGL(physics_kernel<4>, dim3(blocks), dim3(kPhysThreads), 0, s, a, T, nmembers); break;
+        default: hipLaunchKernelGGL(physics_kernel<1>, dim3(blocks), dim3(kPhysThreads), 0, s, a, T, nmembers); break;
+    }
     return hipGetLastError();
 }
 

@@ -6,8 +6,11 @@
 // ModLegendre_legendre_inv / legendre (legendre.f90:130-221) composed with ModFourier_fourier_inv / fourier
 // (fourier.f90:63-123).  The stage-only entry points run the same kernels with one stage disabled.
 //
-// Work decomposition: one workgroup = one field, 512 threads = 8 wavefronts, 53 120 B of LDS
-//   (one row buffer [48][97] doubles + one spectral-field-sized staging area) -> 3 workgroups = 24 waves per CU.
+// Work decomposition: one workgroup = one field, 512 threads = 8 wavefronts, 40 064 B of LDS -> 4 workgroups =
+//   32 waves per CU (the hardware maximum).  LDS plan: a compact Fourier-coefficient buffer C[48][63] (24 192 B,
+//   only wavenumbers 0..30 are ever non-zero) followed by a spectral-field staging area S (15 872 B); the full-length
+//   FFT row buffer R[48][97] (37 248 B) ALIASES both, which is legal because the FFT "group" stage moves every value
+//   through registers across a workgroup barrier (C -> registers -> barrier -> R, or R -> registers -> barrier -> C).
 //   The kernels are latency-bound (profiles/), so occupancy is what the layout is optimised for:
 //   * FFT stages run IN PLACE on the row buffer: every (row, group|block) task loads its <= 16 inputs into
 //     registers, the workgroup synchronises, then the outputs are written back (fft96.hpp).  Wave w handles
@@ -28,10 +31,12 @@ namespace spd {
 constexpr int kThreads = 512;
 constexpr int kRowStride = 97;
 constexpr int kRows = IL;                       // 48 rows per field
-constexpr int kRowBufDoubles = kRows * kRowStride;
+constexpr int kCStride = 63;                    // compact row: positions 0..60 + the parked Im(m=0) at 61
+constexpr int kCBufDoubles = kRows * kCStride;  // 3024 doubles = 24 192 B
 constexpr int kInvLanes = MX * 12;              // inverse Legendre tasks: (m, pair-of-latitude-pairs)
 constexpr int kDirLanes = MX * 16;              // direct  Legendre tasks: (m, parity, 8 groups of two n)
-constexpr size_t kLdsBytes = (kRowBufDoubles + 2 * NSPEC) * sizeof(double);  // 53 120
+constexpr size_t kLdsBytes = (kCBufDoubles + 2 * NSPEC) * sizeof(double);  // 40 064
+static_assert(kRows * kRowStride <= kCBufDoubles + 2 * NSPEC, "R must fit inside C + S");
 
 enum class Stage { Fused, LegendreOnly, FourierOnly };
 
@@ -51,8 +56,9 @@ template <Stage ST>
 __global__ __launch_bounds__(kThreads) void spec2grid_kernel(const double *__restrict__ src, double *__restrict__ dst,
                                                              DeviceTables T, int kcos) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *rows = lds;                                        // [48][97]
-    d2 *s = reinterpret_cast<d2 *>(lds + kRowBufDoubles);      // 992 complex
+    double *cbuf = lds;                                        // C[48][63]
+    double *rows = lds;                                        // R[48][97], aliases C and S (see header)
+    d2 *s = reinterpret_cast<d2 *>(lds + kCBufDoubles);        // S: 992 complex
     const int tid = threadIdx.x;
     const size_t f = blockIdx.x;
     const int wave = wave_id(), lane = tid & 63;
@@ -86,7 +92,7 @@ __global__ __launch_bounds__(kThreads) void spec2grid_kernel(const double *__res
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int js = 2 * jq + q, jn = kRows - 1 - js;  // reference j and il+1-j
-                double *rs = rows + js * kRowStride, *rn = rows + jn * kRowStride;
+                double *rs = cbuf + js * kCStride, *rn = cbuf + jn * kCStride;
                 rn[pr] = ev[q][0] + od[q][0];
                 rs[pr] = ev[q][0] - od[q][0];
                 if (keep_im) {
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(kThreads) void spec2grid_kernel(const double *__res
         const double *g = src + f * NFOUR;
         for (int idx = tid; idx < NFOUR; idx += kThreads) {
             const int row = idx / 62, r = idx - row * 62;
-            if (r != 1) rows[row * kRowStride + (r == 0 ? 0 : r - 1)] = g[idx];
+            if (r != 1) cbuf[row * kCStride + (r == 0 ? 0 : r - 1)] = g[idx];
         }
         __syncthreads();
     }
@@ -110,23 +116,25 @@ __global__ __launch_bounds__(kThreads) void spec2grid_kernel(const double *__res
         double *g = dst + f * NFOUR;
         for (int idx = tid; idx < NFOUR; idx += kThreads) {
             const int row = idx / 62, r = idx - row * 62;
-            g[idx] = rows[row * kRowStride + (r == 0 ? 0 : (r == 1 ? 61 : r - 1))];
+            g[idx] = cbuf[row * kCStride + (r == 0 ? 0 : (r == 1 ? 61 : r - 1))];
         }
         return;
     }
 
     double *row = rows + lane * kRowStride;
+    const double *crow = cbuf + lane * kCStride;
     const bool active = lane < kRows;
-    // ---- inverse FFT, group stage (radb2 + radb4 ido=12), in place; wave = group ----
+    // ---- inverse FFT, group stage (radb2 + radb4 ido=12): C -> registers -> barrier -> R; wave = group ----
+    // (positions beyond 60 of a compact row are never used: the ZeroPad variants substitute the structural zeros)
     {
         double o[2][8];
         if (active && wave < fft::kNumGroups) {
             if (wave < 5)
-                fft::bwd_group_general_r<true>(row, T.work, 3 + 2 * wave, o);
+                fft::bwd_group_general_r<true>(crow, T.work, 3 + 2 * wave, o);
             else if (wave == 5)
-                fft::bwd_group_first_r<true>(row, T.work, o);
+                fft::bwd_group_first_r<true>(crow, T.work, o);
             else
-                fft::bwd_group_last_r<true>(row, T.work, o);
+                fft::bwd_group_last_r<true>(crow, T.work, o);
         }
         __syncthreads();
         if (active && wave < fft::kNumGroups) {
@@ -173,8 +181,9 @@ template <Stage ST>
 __global__ __launch_bounds__(kThreads) void grid2spec_kernel(const double *__restrict__ src, double *__restrict__ dst,
                                                              DeviceTables T, int prescale) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *rows = lds;
-    d2 *s = reinterpret_cast<d2 *>(lds + kRowBufDoubles);  // output staging, 992 complex
+    double *rows = lds;                                    // R[48][97] while the FFT runs
+    double *cbuf = lds;                                    // C[48][63] afterwards (aliases R)
+    d2 *s = reinterpret_cast<d2 *>(lds + kCBufDoubles);    // output staging, 992 complex (aliases the tail of R)
     const int tid = threadIdx.x;
     const size_t f = blockIdx.x;
     const int wave = wave_id(), lane = tid & 63;
@@ -221,16 +230,17 @@ __global__ __launch_bounds__(kThreads) void grid2spec_kernel(const double *__res
                     fft::fwd_group_last_r(row, T.work, T.fft_scale, q);
             }
             __syncthreads();
+            double *crow = cbuf + lane * kCStride;  // R -> registers -> barrier -> C
             if (active && wave < fft::kNumGroups) {
                 if (wave < 5) {
-                    fft::fwd_group_general_store(row, 3 + 2 * wave, q);
+                    fft::fwd_group_general_store(crow, 3 + 2 * wave, q);
                 } else if (wave == 5) {
-                    row[0] = o5[0]; row[47] = o5[1]; row[48] = o5[2]; row[23] = o5[3]; row[24] = o5[4];
-                    row[61] = 0.0;  // Im of the zonal mean: fourier.f90:117 sets output(2, j) = 0
+                    crow[0] = o5[0]; crow[47] = o5[1]; crow[48] = o5[2]; crow[23] = o5[3]; crow[24] = o5[4];
+                    crow[61] = 0.0;  // Im of the zonal mean: fourier.f90:117 sets output(2, j) = 0
                 } else {
-                    row[11] = q[0].lo_r; row[12] = q[0].lo_i;
-                    row[35] = q[1].lo_r; row[36] = q[1].lo_i;
-                    row[59] = q[1].hi_r; row[60] = q[1].hi_i;
+                    crow[11] = q[0].lo_r; crow[12] = q[0].lo_i;
+                    crow[35] = q[1].lo_r; crow[36] = q[1].lo_i;
+                    crow[59] = q[1].hi_r; crow[60] = q[1].hi_i;
                 }
             }
         }
@@ -239,7 +249,7 @@ __global__ __launch_bounds__(kThreads) void grid2spec_kernel(const double *__res
         const double *g = src + f * NFOUR;
         for (int idx = tid; idx < NFOUR; idx += kThreads) {
             const int r0 = idx / 62, r = idx - r0 * 62;
-            rows[r0 * kRowStride + (r == 0 ? 0 : (r == 1 ? 61 : r - 1))] = g[idx];
+            cbuf[r0 * kCStride + (r == 0 ? 0 : (r == 1 ? 61 : r - 1))] = g[idx];
         }
         __syncthreads();
     }
@@ -248,7 +258,7 @@ __global__ __launch_bounds__(kThreads) void grid2spec_kernel(const double *__res
         double *g = dst + f * NFOUR;
         for (int idx = tid; idx < NFOUR; idx += kThreads) {
             const int r0 = idx / 62, r = idx - r0 * 62;
-            g[idx] = (r == 1) ? 0.0 : rows[r0 * kRowStride + (r == 0 ? 0 : r - 1)];  // fourier.f90:117
+            g[idx] = (r == 1) ? 0.0 : cbuf[r0 * kCStride + (r == 0 ? 0 : r - 1)];  // fourier.f90:117
         }
         return;
     }
@@ -258,7 +268,7 @@ __global__ __launch_bounds__(kThreads) void grid2spec_kernel(const double *__res
     for (int idx = tid; idx < MX * IY; idx += kThreads) {
         const int j = idx / MX, m = idx - j * MX;
         const int pr = pos_re(m), pi = pos_im(m);
-        double *rn = rows + (kRows - 1 - j) * kRowStride, *rs = rows + j * kRowStride;
+        double *rn = cbuf + (kRows - 1 - j) * kCStride, *rs = cbuf + j * kCStride;
         const double w = T.wt[j];
         const double nr = rn[pr], sr = rs[pr], ni = rn[pi], si = rs[pi];
         rn[pr] = (nr + sr) * w;
@@ -273,8 +283,8 @@ __global__ __launch_bounds__(kThreads) void grid2spec_kernel(const double *__res
         const int pr = pos_re(m), pi = pos_im(m);
         double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
         const d2 *pol = reinterpret_cast<const d2 *>(T.pdir) + tid;  // [j][496] x {n0, n0+16}
-        const double *base = rows + (par ? 0 : (kRows - 1) * kRowStride);
-        const int rstep = par ? kRowStride : -kRowStride;
+        const double *base = cbuf + (par ? 0 : (kRows - 1) * kCStride);
+        const int rstep = par ? kCStride : -kCStride;
 #pragma unroll 4
         for (int j = 0; j < IY; ++j) {
             const d2 p = pol[j * kDirLanes];
