@@ -271,3 +271,88 @@ def physics(inputs, compute_shortwave, air_absortivity_co2):
     lib().orc_physics(C.byref(tables()), C.byref(io))
     out = {n: keep[n] for n in PHYS_TEND + tuple(PHYS_OUT_SHAPES) + tuple(PHYS_PERSIST_SHAPES) + PHYS_DIAG_F + PHYS_DIAG_I}
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# dynamics / time stepping (callers of the hot path)
+# ---------------------------------------------------------------------------------------------------
+class DynTables(C.Structure):
+    _fields_ = [(n, C.c_double * 992) for n in ("dmp", "dmpd", "dmps", "dmp1", "dmp1d", "dmp1s")] + [
+        ("tcorv", C.c_double * 8), ("qcorv", C.c_double * 8), ("tref", C.c_double * 8), ("tref2", C.c_double * 8),
+        ("tref3", C.c_double * 8), ("dhsx", C.c_double * 8), ("xc", C.c_double * 64), ("xd", C.c_double * 64),
+        ("xj", C.c_double * 4096), ("elz", C.c_double * 992), ("xgeop1", C.c_double * 8), ("xgeop2", C.c_double * 8)]
+
+
+DYN_SHAPES = {**{k: (31, 32) for k in ("dmp", "dmpd", "dmps", "dmp1", "dmp1d", "dmp1s", "elz")},
+              "xc": (8, 8), "xd": (8, 8), "xj": (8, 8, 64)}
+
+
+class State(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("vor", "div", "t", "tr", "ps", "phi", "phis", "tcorh", "qcorh")] + [("ph", PhysIO)]
+
+
+STATE_SPEC = {"vor": (31, 32, 8, 2), "div": (31, 32, 8, 2), "t": (31, 32, 8, 2), "tr": (31, 32, 8, 2), "ps": (31, 32, 2),
+              "phi": (31, 32, 8), "phis": (31, 32), "tcorh": (31, 32), "qcorh": (31, 32)}
+
+
+def dyn_tables(dt=None):
+    """orc_dyn_tables after initialisation and (optionally) set_time_step(dt)."""
+    d = DynTables()
+    lib().orc_dyn_tables_init(C.byref(tables()), C.byref(d))
+    if dt is not None:
+        lib().orc_dyn_set_time_step(C.byref(tables()), C.byref(d), C.c_double(dt))
+    return d
+
+
+def dyn_table(d, name):
+    a = np.ctypeslib.as_array(getattr(d, name)).copy()
+    if name in DYN_SHAPES:
+        a = a.reshape(DYN_SHAPES[name], order="F")
+    return a
+
+
+class ModelState:
+    """Host copy of the part of ModelState_t that one model step touches (Fortran layouts)."""
+
+    def __init__(self, arrays, compute_shortwave, air_absortivity_co2):
+        self.a = {}
+        self.c = State()
+        for n, shp in STATE_SPEC.items():
+            v = np.array(arrays[n], dtype=np.complex128, order="F", copy=True) if n in arrays else np.zeros(shp, np.complex128, order="F")
+            assert v.shape == shp, (n, v.shape)
+            self.a[n] = v
+            setattr(self.c, n, v.ctypes.data_as(C.c_void_p).value)
+        ph = self.c.ph
+        f2 = PHYS_IN_2D[1:]  # everything but pslg
+        for n in f2:
+            self._put(ph, n, np.array(arrays[n], dtype=np.float64, order="F", copy=True))
+        for n, shp in {**PHYS_OUT_SHAPES, **PHYS_PERSIST_SHAPES}.items():
+            self._put(ph, n, np.array(arrays[n], dtype=np.float64, order="F", copy=True) if n in arrays else np.zeros(shp, order="F"))
+        ph.air_absortivity_co2 = float(air_absortivity_co2)
+        ph.compute_shortwave = int(bool(compute_shortwave))
+
+    def _put(self, ph, n, v):
+        self.a[n] = v
+        setattr(ph, n, v.ctypes.data_as(C.c_void_p).value)
+
+    def set_shortwave(self, flag):
+        self.c.ph.compute_shortwave = int(bool(flag))
+
+
+def step(state, dyn, j1, j2, dt):
+    lib().orc_step(C.byref(tables()), C.byref(dyn), C.byref(state.c), C.c_int(j1), C.c_int(j2), C.c_double(dt))
+
+
+def get_tendencies(state, dyn, j2):
+    out = {n: np.zeros((31, 32, 8), np.complex128, order="F") for n in ("vordt", "divdt", "tdt", "trdt")}
+    out["psdt"] = np.zeros((31, 32), np.complex128, order="F")
+    lib().orc_get_tendencies(C.byref(tables()), C.byref(dyn), C.byref(state.c), _p(out["vordt"]), _p(out["divdt"]),
+                             _p(out["tdt"]), _p(out["psdt"]), _p(out["trdt"]), C.c_int(j2))
+    return out
+
+
+def check_diagnostics(state, time_lev):
+    diag = np.zeros((8, 3), order="F")
+    lib().orc_check_diagnostics.restype = C.c_int
+    rc = lib().orc_check_diagnostics(C.byref(tables()), C.byref(state.c), C.c_int(time_lev), _p(diag))
+    return rc, diag

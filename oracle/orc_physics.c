@@ -741,3 +741,27 @@ void orc_physics(const orc_tables *t, orc_phys_io *io) {
     free(iptop);
     free(w);
 }
+
+/* ---------------------------------------------------------------- physics.f90:89-101 + the column schemes */
+void orc_physics_from_spectral(const orc_tables *t, orc_state *s, int j1, double *utend, double *vtend, double *ttend,
+                               double *qtend) {
+    const size_t n3 = (size_t)NG * KX, ns2 = 2 * 31 * 32, lev = ns2 * KX;
+    double *g = (double *)malloc(sizeof(double) * (n3 * 5 + NG));
+    double *ug = g, *vg = ug + n3, *tg = vg + n3, *qg = tg + n3, *phig = qg + n3, *pslg = phig + n3;
+    double ucos[2 * 31 * 32], vcos[2 * 31 * 32];
+    for (int k = 0; k < KX; ++k) {
+        const size_t o = ns2 * k + lev * (j1 - 1);
+        orc_vort2vel(t, s->vor + o, s->div + o, ucos, vcos);
+        orc_spec2grid(t, ucos, ug + (size_t)NG * k, 2);
+        orc_spec2grid(t, vcos, vg + (size_t)NG * k, 2);
+        orc_spec2grid(t, s->t + o, tg + (size_t)NG * k, 1);
+        orc_spec2grid(t, s->tr + o, qg + (size_t)NG * k, 1);
+        orc_spec2grid(t, s->phi + ns2 * k, phig + (size_t)NG * k, 1);
+    }
+    orc_spec2grid(t, s->ps + ns2 * (j1 - 1), pslg, 1);
+    s->ph.ug = ug; s->ph.vg = vg; s->ph.tg = tg; s->ph.qg_in = qg; s->ph.phig = phig; s->ph.pslg = pslg;
+    s->ph.utend = utend; s->ph.vtend = vtend; s->ph.ttend = ttend; s->ph.qtend = qtend;
+    orc_physics(t, &s->ph);
+    s->ph.ug = s->ph.vg = s->ph.tg = s->ph.qg_in = s->ph.phig = s->ph.pslg = NULL;
+    free(g);
+}

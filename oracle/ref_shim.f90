@@ -342,4 +342,33 @@ contains
         call step(s, j1, j2, dt)
     end subroutine
 
+
+    !> Tables of ModImplicit_t / ModHorizontalDiffusion_t (implicit.f90:17-22, horizontal_diffusion.f90:16-30).
+    subroutine shim_implicit_tables(cnt, dmp, dmpd, dmps, dmp1, dmp1d, dmp1s, tcorv, qcorv, tcorh, qcorh, &
+            tref, tref2, tref3, dhsx, xc, xd, xj, elz) bind(C, name = "shim_implicit_tables")
+        integer(c_int64_t), value :: cnt
+        real(c_double), intent(out), dimension(mx, nx) :: dmp, dmpd, dmps, dmp1, dmp1d, dmp1s, elz
+        real(c_double), intent(out) :: tcorv(kx), qcorv(kx), tref(kx), tref2(kx), tref3(kx), dhsx(kx)
+        complex(c_double_complex), intent(out) :: tcorh(mx, nx), qcorh(mx, nx)
+        real(c_double), intent(out) :: xc(kx, kx), xd(kx, kx), xj(kx, kx, mx + nx + 1)
+        type(ModelState_t), pointer :: s
+        s => state_of(cnt)
+        dmp = s%mod_implicit%dmp; dmpd = s%mod_implicit%dmpd; dmps = s%mod_implicit%dmps
+        dmp1 = s%mod_implicit%dmp1; dmp1d = s%mod_implicit%dmp1d; dmp1s = s%mod_implicit%dmp1s
+        tcorv = s%mod_implicit%tcorv; qcorv = s%mod_implicit%qcorv
+        tcorh = s%mod_implicit%tcorh; qcorh = s%mod_implicit%qcorh
+        tref = s%mod_implicit%tref; tref2 = s%mod_implicit%tref2; tref3 = s%mod_implicit%tref3
+        dhsx = s%mod_implicit%dhsx; xc = s%mod_implicit%xc; xd = s%mod_implicit%xd; xj = s%mod_implicit%xj
+        elz = s%mod_implicit%elz
+    end subroutine
+
+    subroutine shim_set_geopotential(cnt, time_level) bind(C, name = "shim_set_geopotential")
+        use geopotential, only : set_geopotential
+        integer(c_int64_t), value :: cnt
+        integer(c_int), value :: time_level
+        type(ModelState_t), pointer :: s
+        s => state_of(cnt)
+        call set_geopotential(s, time_level)
+    end subroutine
+
 end module

@@ -118,6 +118,36 @@ void orc_surface_fluxes(const orc_tables *t, const double *psa, const double *ua
 void orc_vdiff(const orc_tables *t, const double *se, const double *rh, const double *qa, const double *qsat,
                const double *phi, const int *icnv, double *ut, double *vt, double *tt, double *qt);
 
+
+/* ---- callers of the hot path ("next #1"): dynamics, implicit solver, time stepping ---- */
+typedef struct orc_dyn_tables {
+    /* horizontal_diffusion.f90:16-30 */
+    double dmp[31 * 32], dmpd[31 * 32], dmps[31 * 32], dmp1[31 * 32], dmp1d[31 * 32], dmp1s[31 * 32];
+    double tcorv[8], qcorv[8];
+    /* implicit.f90:20-22 (dt-dependent parts are set by orc_dyn_set_time_step) */
+    double tref[8], tref2[8], tref3[8], dhsx[8];
+    double xc[64], xd[64], xj[64 * 64], elz[31 * 32]; /* xj(kx, kx, mx+nx+1) */
+    /* geopotential.f90:16-31 */
+    double xgeop1[8], xgeop2[8];
+} orc_dyn_tables;
+
+typedef struct orc_state {
+    /* prognostic spectral state, complex: vor/div/t/tr (mx,nx,kx,2), ps (mx,nx,2), phi (mx,nx,kx), phis (mx,nx) */
+    double *vor, *div, *t, *tr, *ps, *phi, *phis;
+    double *tcorh, *qcorh; /* complex (mx,nx), forcing.f90:84,101 */
+    orc_phys_io ph;        /* physics-side state; the grid-field / tendency pointers are filled per call */
+} orc_state;
+
+void orc_dyn_tables_init(const orc_tables *t, orc_dyn_tables *d);
+void orc_dyn_set_time_step(const orc_tables *t, orc_dyn_tables *d, double dt);
+void orc_geopotential(const orc_tables *t, const orc_dyn_tables *d, const double *tt, const double *phis, double *phi);
+void orc_physics_from_spectral(const orc_tables *t, orc_state *s, int j1, double *utend, double *vtend, double *ttend,
+                               double *qtend);
+void orc_get_tendencies(const orc_tables *t, const orc_dyn_tables *d, orc_state *s, double *vordt, double *divdt,
+                        double *tdt, double *psdt, double *trdt, int j2);
+void orc_step(const orc_tables *t, const orc_dyn_tables *d, orc_state *s, int j1, int j2, double dt);
+int orc_check_diagnostics(const orc_tables *t, const orc_state *s, int time_lev, double *diag);
+
 #ifdef __cplusplus
 }
 #endif
