@@ -119,6 +119,36 @@ typedef struct spd_physics_args {
 
 int spd_physics(spd_handle h, const spd_physics_args *args, int nmembers, void *stream);
 
+/* ---- ensemble model object: device-resident state of M members and the model time step ------------------------
+ * Replaces, for M members at once, the reference's ModelState_t container (model_state.f90) and
+ * time_stepping.f90:38-147 `step` (get_tendencies -> horizontal diffusion -> leapfrog + Robert/Williams filter), i.e. what
+ * speedy_driver.f90.j2:43-79 (`step`, `parallel_step`) reach through do_single_step.  The state never leaves HBM; every
+ * array is member-major with the reference's Fortran order inside a member, so get/set are plain copies.
+ * Variable names are the registry names of registry/model_state_def.py (vor, div, t, tr, ps, phi, phis, precnv, ...,
+ * rad_tau2, ...); two arrays the registry does not expose are added: tcorh, qcorh (mod_implicit%tcorh/qcorh,
+ * forcing.f90:84,101). */
+typedef struct spd_model *spd_model_handle;
+
+int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out);
+int spd_model_destroy(spd_model_handle m);
+int spd_model_members(spd_model_handle m);
+/* bytes of one member's copy of `name`, or a negative error */
+long spd_model_var_bytes(spd_model_handle m, const char *name);
+/* host <-> device copy of one member's array (get_<v>/set_<v> of speedy_driver.f90.j2:250-334); member = -1 in
+ * spd_model_set broadcasts the same host array to every member.  Synchronous. */
+int spd_model_set(spd_model_handle m, const char *name, int member, const void *host_buf, size_t bytes);
+int spd_model_get(spd_model_handle m, const char *name, int member, void *host_buf, size_t bytes);
+/* device base pointer of a registry array ([nmembers][...]), for zero-copy users */
+void *spd_model_device_ptr(spd_model_handle m, const char *name);
+int spd_model_set_co2(spd_model_handle m, double air_absortivity_co2);
+/* ModImplicit_set_time_step (implicit.f90:83-218): rebuilds the dt-dependent tables (8x8 inversions on the host) */
+int spd_model_set_time_step(spd_model_handle m, double dt);
+/* time_stepping.f90 `step(state, j1, j2, dt)` for all members; j1, j2 = 1 or 2 as in the reference */
+int spd_model_step_dynamics(spd_model_handle m, int j1, int j2, double dt, int compute_shortwave, void *stream);
+/* check_diagnostics (diagnostics.f90:16-76) for every member: error_codes_host[i] = 0 or -2; diag_host may be NULL or
+ * receive [nmembers][3][kx] (eddy KE of vor, of div, global-mean T).  Synchronises `stream`. */
+int spd_model_check(spd_model_handle m, int time_level, int32_t *error_codes_host, double *diag_host, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

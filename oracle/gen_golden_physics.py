@@ -85,9 +85,53 @@ def gen_physics():
     return m
 
 
+STEP_2D = ("fmask_land", "phis0", "forog", "sst_am", "alb_land", "alb_sea", "snowc", "land_temp", "soil_avail_water",
+           "flux_solar_in", "flux_ozone_upper", "flux_ozone_lower", "zenit_correction", "stratospheric_correction",
+           "alb_surface")
+STEP_SPEC = ("vor", "div", "t", "tr", "ps")
+
+
+def implicit_arrays(m):
+    T = dict(dmp=z(31, 32), dmpd=z(31, 32), dmps=z(31, 32), dmp1=z(31, 32), dmp1d=z(31, 32), dmp1s=z(31, 32), tcorv=z(8),
+             qcorv=z(8), tcorh=z(31, 32, dt=np.complex128), qcorh=z(31, 32, dt=np.complex128), tref=z(8), tref2=z(8),
+             tref3=z(8), dhsx=z(8), xc=z(8, 8), xd=z(8, 8), xj=z(8, 8, 64), elz=z(31, 32))
+    m.call("implicit_tables", *T.values())
+    return T
+
+
 def gen_steps():
-    print("step snapshots: not generated yet (dynamics glue is a later row of SURVEY section 8f)")
+    """step.npz: the model state of the example_bc run before step 42 (a shortwave step) and after steps 42 and 43, as the
+    reference's do_single_step produces them, plus the dt-dependent tables of ModImplicit_t for dt = 2*delt."""
+    bc = np.load(os.path.join(GOLD, "example_bc.npz"))
+    m = R.RefModel()
+    m.set_bc(bc)
+    for _ in range(42):
+        assert m.step() == 0
+    assert m.get("current_step") == 42
+    d = {}
+    T = implicit_arrays(m)
+    for k, v in T.items():
+        d["tab_" + k] = v
+    spec = lambda n: (m.get(n)[..., 0] if n == "tr" else m.get(n))
+    for n in STEP_SPEC + ("phis",):
+        d["s0_" + n] = spec(n)
+    for n in STEP_2D:
+        d["s0_" + n] = m.get(n)
+    d["air_absortivity_co2"] = np.float64(m.get("air_absortivity_co2"))
+    for istep in (1, 2):
+        assert m.step() == 0
+        for n in STEP_SPEC:
+            d["s%d_" % istep + n] = spec(n)
+        for n in ("olr", "precnv", "ssrd", "tsr"):
+            d["s%d_" % istep + n] = m.get(n)
+        m.call("set_geopotential", 1)
+        if istep == 1:  # surface fields as the per-step coupler left them for the next step
+            for n in ("sst_am", "land_temp", "soil_avail_water", "snowc", "alb_land", "alb_sea", "alb_surface"):
+                d["s1_" + n] = m.get(n)
+    np.savez_compressed(os.path.join(GOLD, "step.npz"), **d)
+    print("step.npz", sum(v.nbytes for v in d.values()) // 1024, "KiB raw")
 
 
 if __name__ == "__main__":
     gen_physics()
+    gen_steps()

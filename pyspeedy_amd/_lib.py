@@ -70,6 +70,17 @@ _SIGNATURES = {
     "spd_truncate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "spd_grid_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "spd_physics": (C.c_int, [C.c_void_p, C.POINTER(PhysicsArgs), C.c_int, C.c_void_p]),
+    "spd_model_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "spd_model_destroy": (C.c_int, [C.c_void_p]),
+    "spd_model_members": (C.c_int, [C.c_void_p]),
+    "spd_model_var_bytes": (C.c_long, [C.c_void_p, C.c_char_p]),
+    "spd_model_set": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "spd_model_get": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "spd_model_device_ptr": (C.c_void_p, [C.c_void_p, C.c_char_p]),
+    "spd_model_set_co2": (C.c_int, [C.c_void_p, C.c_double]),
+    "spd_model_set_time_step": (C.c_int, [C.c_void_p, C.c_double]),
+    "spd_model_step_dynamics": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]),
+    "spd_model_check": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/pyspeedy_amd.h"
+#include "context.hpp"
 #include "device_tables.hpp"
 
 namespace spd {
@@ -27,24 +28,14 @@ hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nme
 
 using namespace spd;
 
-struct spd_context {
-    int device = 0;
-    HostTables host;
-    DeviceTables dev{};
-    std::vector<void *> allocations;
-    // scratch for composite operators (grid_vel2vort, grid_filter); grows on demand, never shrinks
-    double *scratch = nullptr;
-    size_t scratch_bytes = 0;
-    std::mutex scratch_mutex;
-    int fpw = 0;  // fields per workgroup override (0 = automatic), env PYSPEEDY_AMD_FPW
-};
-
 static thread_local std::string g_last_error;
 
 static int fail(int code, const std::string &msg) {
     g_last_error = msg;
     return code;
 }
+
+int spd_set_error(int code, const std::string &msg) { return fail(code, msg); }
 
 static int hip_fail(hipError_t e, const char *what) {
     return fail(SPD_E_DEVICE, std::string(what) + ": " + hipGetErrorString(e));

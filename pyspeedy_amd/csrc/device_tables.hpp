@@ -23,4 +23,13 @@ struct DeviceTables {
     double fsg[8], dhs[8], sigl[8], sigh[9], grdsig[8], grdscp[8], wvi[16];
 };
 
+// One transform of a descriptor-table launch: a spectral->grid entry carries kcos in `flag`, a grid->spectral entry the
+// pre-scale mode (0 none, 1 cosgr, 2 cosgr2).
+struct FieldDesc {
+    const double *src;
+    double *dst;
+    int flag;
+    int reserved;
+};
+
 }  // namespace spd

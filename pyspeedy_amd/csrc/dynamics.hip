@@ -1,0 +1,457 @@
+// The callers of the hot path, on the device (SURVEY.md section 8f "next #1"): everything do_single_step does between
+// the spectral transforms and the column physics, so that a model step never leaves HBM.
+//
+//   model_uvgrad_kernel     vort2vel at two time levels + gradient(ln ps)       spectral.f90:190-214, 275-296
+//   geopotential_kernel     hydrostatic integration in spectral space           geopotential.f90:49-77
+//   dyn_grid_kernel         grid-point dynamics tendencies of one column        tendencies.f90:125-224
+//   spectral_step_kernel    vel2vort + spectral tendencies + semi-implicit correction + horizontal diffusion +
+//                           leapfrog / Robert-Asselin-Williams filter           tendencies.f90:238-352, implicit.f90:234-289,
+//                                                                               time_stepping.f90:71-188
+//   diagnostics_kernel      global-mean T / eddy KE range check                 diagnostics.f90:16-76
+//
+// Layouts (member-major, the reference's Fortran order inside a member):
+//   vor, div, t, tr  complex [M][2 time levels][8][32][31] ; ps [M][2][32][31] ; phi [M][8][32][31] ; phis [M][32][31]
+//   grid fields      [M][8][48][96] or [M][48][96]
+// One lane per spectral coefficient (all 8 levels in registers) or per grid column; all accesses unit-stride over lanes.
+#include <hip/hip_runtime.h>
+
+#include "device_tables.hpp"
+#include "model.hpp"
+
+namespace spd {
+
+namespace {
+using d2 = double __attribute__((ext_vector_type(2)));
+constexpr int NG = IX * IL;
+constexpr int kT = 256;
+
+__device__ constexpr double CPd = 1004.0f;
+__device__ constexpr double AKAPd = 2.0f / 7.0f;
+__device__ constexpr double RGASd = AKAPd * CPd;
+__device__ constexpr double ROBd = 0.05f, WILd = 0.53f, TDRSd = 24.0f * 30.0f;
+
+__device__ inline d2 times_i(d2 z) { return d2{-z.y, z.x}; }
+__device__ inline d2 operator_scale(double c, d2 z) { return d2{c * z.x, c * z.y}; }
+
+// vort2vel (MODE 0, tables uvdx/uvdym/uvdyp) or vel2vort (MODE 1, gradx/vddym/vddyp) at coefficient k = m + 31 n of
+// the fields a, b (pointers to the field start); returns the two results.
+template <int MODE>
+__device__ inline void uv_stencil(const d2 *a, const d2 *b, int k, int m, int n, const DeviceTables &T, d2 &ra, d2 &rb) {
+    const double *tym = MODE == 0 ? T.uvdym : T.vddym, *typ = MODE == 0 ? T.uvdyp : T.vddyp;
+    const double dx = MODE == 0 ? T.uvdx[k] : T.gradx[m];
+    const double cm = tym[k], cp = typ[k];
+    const d2 za = a[k], zb = b[k];
+    const d2 zp = times_i(d2{dx * za.x, dx * za.y}), zc = times_i(d2{dx * zb.x, dx * zb.y});
+    if (n == 0) {
+        const d2 an = a[k + MX], bn = b[k + MX];
+        ra = d2{zc.x - cp * an.x, zc.y - cp * an.y};
+        rb = d2{zp.x + cp * bn.x, zp.y + cp * bn.y};
+    } else if (n == NX - 1) {
+        const d2 ap = a[k - MX], bp = b[k - MX];
+        ra = d2{cm * ap.x, cm * ap.y};
+        rb = d2{-cm * bp.x, -cm * bp.y};
+    } else {
+        const d2 ap = a[k - MX], bp = b[k - MX], an = a[k + MX], bn = b[k + MX];
+        ra = d2{cm * ap.x - cp * an.x + zc.x, cm * ap.y - cp * an.y + zc.y};
+        rb = d2{-cm * bp.x + cp * bn.x + zp.x, -cm * bp.y + cp * bn.y + zp.y};
+    }
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// u, v (cos-weighted) from vor, div at time levels j2 (dynamics) and j1 = 1 (physics); grad ln ps at level j2
+// grid: x = coefficient, y = member*8 + level (plus one extra "level" 8 per member for the gradient)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void model_uvgrad_kernel(ModelPtrs P, DeviceTables T, int M, int j2) {
+    const int k = blockIdx.x * kT + threadIdx.x;
+    if (k >= NSPEC) return;
+    const int n = k / MX, m = k - n * MX;
+    const int mem = blockIdx.y / 9, lev = blockIdx.y - mem * 9;
+    if (lev == 8) {  // gradient of ln ps (tendencies.f90:144)
+        const d2 *psi = reinterpret_cast<const d2 *>(P.ps) + (static_cast<size_t>(mem) * 2 + j2) * NSPEC;
+        d2 *dx = reinterpret_cast<d2 *>(P.gps) + static_cast<size_t>(mem) * NSPEC;
+        d2 *dy = dx + static_cast<size_t>(M) * NSPEC;
+        const d2 z = psi[k];
+        const double g = T.gradx[m];
+        dx[k] = times_i(d2{g * z.x, g * z.y});
+        d2 r;
+        if (n == 0) {
+            const d2 zn = psi[k + MX];
+            r = d2{T.gradyp[k] * zn.x, T.gradyp[k] * zn.y};
+        } else if (n == NX - 1) {
+            const d2 zp = psi[k - MX];
+            r = d2{-T.gradym[k] * zp.x, -T.gradym[k] * zp.y};
+        } else {
+            const d2 zp = psi[k - MX], zn = psi[k + MX];
+            r = d2{-T.gradym[k] * zp.x + T.gradyp[k] * zn.x, -T.gradym[k] * zp.y + T.gradyp[k] * zn.y};
+        }
+        dy[k] = r;
+        return;
+    }
+    const size_t fl = (static_cast<size_t>(mem) * 8 + lev) * NSPEC;  // field offset inside an [M][8] work array
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {  // 0: level j2, 1: level 0 (= reference time level 1)
+        const int tl = which == 0 ? j2 : 0;
+        if (which == 1 && j2 == 0) {  // same level: copy instead of recomputing
+            d2 *u0 = reinterpret_cast<d2 *>(P.sv) + fl, *v0 = u0 + static_cast<size_t>(M) * 8 * NSPEC;
+            d2 *u1 = v0 + static_cast<size_t>(M) * 8 * NSPEC, *v1 = u1 + static_cast<size_t>(M) * 8 * NSPEC;
+            u1[k] = u0[k];
+            v1[k] = v0[k];
+            break;
+        }
+        const size_t so = ((static_cast<size_t>(mem) * 2 + tl) * 8 + lev) * NSPEC;
+        const d2 *vor = reinterpret_cast<const d2 *>(P.vor) + so, *div = reinterpret_cast<const d2 *>(P.div) + so;
+        d2 u, v;
+        uv_stencil<0>(vor, div, k, m, n, T, u, v);
+        d2 *ud = reinterpret_cast<d2 *>(P.sv) + static_cast<size_t>(which) * 2 * M * 8 * NSPEC + fl;
+        ud[k] = u;
+        ud[static_cast<size_t>(M) * 8 * NSPEC + k] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// geopotential from temperature at time level `tl` (geopotential.f90:49-77)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void geopotential_kernel(ModelPtrs P, DynDeviceTables D, int M, int tl) {
+    const int gid = blockIdx.x * kT + threadIdx.x;
+    if (gid >= M * NSPEC) return;
+    const int mem = gid / NSPEC, k = gid - mem * NSPEC, m = k % MX;
+    const d2 *t = reinterpret_cast<const d2 *>(P.t) + (static_cast<size_t>(mem) * 2 + tl) * 8 * NSPEC + k;
+    d2 *phi = reinterpret_cast<d2 *>(P.phi) + static_cast<size_t>(mem) * 8 * NSPEC + k;
+    d2 tt[KX], ph[KX];
+#pragma unroll
+    for (int l = 0; l < KX; ++l) tt[l] = t[static_cast<size_t>(l) * NSPEC];
+    const d2 phis = reinterpret_cast<const d2 *>(P.phis)[static_cast<size_t>(mem) * NSPEC + k];
+    ph[KX - 1] = d2{phis.x + D.xgeop1[KX - 1] * tt[KX - 1].x, phis.y + D.xgeop1[KX - 1] * tt[KX - 1].y};
+#pragma unroll
+    for (int l = KX - 2; l >= 0; --l) {
+        ph[l].x = ph[l + 1].x + D.xgeop2[l + 1] * tt[l + 1].x + D.xgeop1[l] * tt[l].x;
+        ph[l].y = ph[l + 1].y + D.xgeop2[l + 1] * tt[l + 1].y + D.xgeop1[l] * tt[l].y;
+    }
+    if (m == 0) {
+#pragma unroll
+        for (int l = 1; l < KX - 1; ++l) {
+            ph[l].x = ph[l].x + D.geo_corf[l] * (tt[l + 1].x - tt[l - 1].x);
+            ph[l].y = ph[l].y + D.geo_corf[l] * (tt[l + 1].y - tt[l - 1].y);
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < KX; ++l) phi[static_cast<size_t>(l) * NSPEC] = ph[l];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// grid-point dynamics of one column (tendencies.f90:125-224) + the products the forward transforms need (:242-266)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void dyn_grid_kernel(ModelPtrs P, DynDeviceTables D, int M) {
+    const int gid = blockIdx.x * kT + threadIdx.x;
+    if (gid >= M * NG) return;
+    const int mem = gid / NG, p = gid - mem * NG, j = p / IX;
+    const size_t o3 = static_cast<size_t>(mem) * KX * NG + p, o2 = static_cast<size_t>(mem) * NG + p;
+    double ug[KX], vg[KX], tg[KX], trg[KX], vorg[KX], divg[KX];
+    const double cor = D.coriol[j];
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        ug[k] = P.ug2[o3 + NG * k];
+        vg[k] = P.vg2[o3 + NG * k];
+        tg[k] = P.tg2[o3 + NG * k];
+        trg[k] = P.trg2[o3 + NG * k];
+        vorg[k] = P.vorg[o3 + NG * k] + cor;
+        divg[k] = P.divg[o3 + NG * k];
+    }
+    const double px = P.px[o2], py = P.py[o2];
+    double umean = 0.0, vmean = 0.0, dmean = 0.0;
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        umean = umean + ug[k] * D.dhs[k];
+        vmean = vmean + vg[k] * D.dhs[k];
+        dmean = dmean + divg[k] * D.dhs[k];
+    }
+    P.psdtg[o2] = -umean * px - vmean * py;
+    double puv[KX], sigdt[KX + 1], sigm[KX + 1], tgg[KX], temp[KX + 1];
+    sigdt[0] = 0.0;
+    sigm[0] = 0.0;
+#pragma unroll
+    for (int k = 0; k < KX; ++k) puv[k] = (ug[k] - umean) * px + (vg[k] - vmean) * py;
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        sigdt[k + 1] = sigdt[k] - D.dhs[k] * (puv[k] + divg[k] - dmean);
+        sigm[k + 1] = sigm[k] - D.dhs[k] * puv[k];
+    }
+    // (tendencies.f90:153-156 zeroes level kx+1 BEFORE this loop; the loop's last iteration stores it again, so the
+    //  value used below is the accumulated one, ~1e-17, exactly as in the reference)
+#pragma unroll
+    for (int k = 0; k < KX; ++k) tgg[k] = tg[k] - D.tref[k];
+    temp[0] = 0.0;
+    temp[KX] = 0.0;
+    // zonal wind
+#pragma unroll
+    for (int k = 1; k < KX; ++k) temp[k] = sigdt[k] * (ug[k] - ug[k - 1]);
+#pragma unroll
+    for (int k = 0; k < KX; ++k)
+        P.utend[o3 + NG * k] = vg[k] * vorg[k] - tgg[k] * RGASd * px - (temp[k + 1] + temp[k]) * D.dhsr[k];
+    // meridional wind
+#pragma unroll
+    for (int k = 1; k < KX; ++k) temp[k] = sigdt[k] * (vg[k] - vg[k - 1]);
+#pragma unroll
+    for (int k = 0; k < KX; ++k)
+        P.vtend[o3 + NG * k] = -ug[k] * vorg[k] - tgg[k] * RGASd * py - (temp[k + 1] + temp[k]) * D.dhsr[k];
+    // temperature
+#pragma unroll
+    for (int k = 1; k < KX; ++k) temp[k] = sigdt[k] * (tgg[k] - tgg[k - 1]) + sigm[k] * (D.tref[k] - D.tref[k - 1]);
+#pragma unroll
+    for (int k = 0; k < KX; ++k)
+        P.ttend[o3 + NG * k] = tgg[k] * divg[k] - (temp[k + 1] + temp[k]) * D.dhsr[k] +
+                               D.fsgr[k] * tgg[k] * (sigdt[k + 1] + sigdt[k]) + D.tref3[k] * (sigm[k + 1] + sigm[k]) +
+                               AKAPd * (tg[k] * puv[k] - tgg[k] * dmean);
+    // tracer
+#pragma unroll
+    for (int k = 1; k < KX; ++k) temp[k] = sigdt[k] * (trg[k] - trg[k - 1]);
+    temp[1] = 0.0;
+    temp[2] = 0.0;
+#pragma unroll
+    for (int k = 0; k < KX; ++k) P.trtend[o3 + NG * k] = trg[k] * divg[k] - (temp[k + 1] + temp[k]) * D.dhsr[k];
+    // inputs of the forward transforms (tendencies.f90:247-266)
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        P.keg[o3 + NG * k] = 0.5f * (ug[k] * ug[k] + vg[k] * vg[k]);
+        P.utg[o3 + NG * k] = -ug[k] * tgg[k];
+        P.vtg[o3 + NG * k] = -vg[k] * tgg[k];
+        P.uqg[o3 + NG * k] = -ug[k] * trg[k];
+        P.vqg[o3 + NG * k] = -vg[k] * trg[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// everything in spectral space after the forward transforms, for one coefficient (m, n) and all 8 levels
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTables T, DynDeviceTables D, int M, int j1,
+                                                           double dt, double eps) {
+    const int gid = blockIdx.x * kT + threadIdx.x;
+    if (gid >= M * NSPEC) return;
+    const int mem = gid / NSPEC, k = gid - mem * NSPEC, n = k / MX, m = k - n * MX;
+    const size_t f8 = static_cast<size_t>(mem) * 8 * NSPEC;        // [M][8] work arrays
+    const size_t pair = static_cast<size_t>(M) * 8 * NSPEC;        // stride between the three (u,v)-pair outputs
+    const d2 *su = reinterpret_cast<const d2 *>(P.specu) + f8, *sv = reinterpret_cast<const d2 *>(P.specv) + f8;
+    d2 vordt[KX], divdt[KX], tdt[KX], trdt[KX];
+    const double el2 = T.el2[k];
+#pragma unroll
+    for (int l = 0; l < KX; ++l) {
+        const size_t fo = static_cast<size_t>(l) * NSPEC;
+        d2 dump;
+        uv_stencil<1>(su + fo, sv + fo, k, m, n, T, vordt[l], divdt[l]);                    // grid_vel2vort(utend, vtend)
+        const d2 ke = reinterpret_cast<const d2 *>(P.spec_ke)[f8 + fo + k];
+        const d2 lap = d2{-ke.x * el2, -ke.y * el2};                                         // laplacian(grid2spec(KE))
+        divdt[l] = d2{divdt[l].x - lap.x, divdt[l].y - lap.y};
+        uv_stencil<1>(su + pair + fo, sv + pair + fo, k, m, n, T, dump, tdt[l]);             // div of (-uT', -vT')
+        const d2 stt = reinterpret_cast<const d2 *>(P.spec_tt)[f8 + fo + k];
+        tdt[l] = d2{tdt[l].x + stt.x, tdt[l].y + stt.y};
+        uv_stencil<1>(su + 2 * pair + fo, sv + 2 * pair + fo, k, m, n, T, dump, trdt[l]);   // div of (-uq, -vq)
+        const d2 str = reinterpret_cast<const d2 *>(P.spec_tr)[f8 + fo + k];
+        trdt[l] = d2{trdt[l].x + str.x, trdt[l].y + str.y};
+    }
+    d2 psdt = reinterpret_cast<const d2 *>(P.spec_ps)[static_cast<size_t>(mem) * NSPEC + k];
+    if (k == 0) psdt = d2{0.0, 0.0};
+
+    // ---- state at time level 1 (index 0) ----
+    const size_t s0 = static_cast<size_t>(mem) * 2 * 8 * NSPEC + k;  // level index 0, vertical level 0
+    const size_t lvl = static_cast<size_t>(8) * NSPEC;               // distance between the two time levels
+    d2 *vorS = reinterpret_cast<d2 *>(P.vor) + s0, *divS = reinterpret_cast<d2 *>(P.div) + s0;
+    d2 *tS = reinterpret_cast<d2 *>(P.t) + s0, *trS = reinterpret_cast<d2 *>(P.tr) + s0;
+    d2 *psS = reinterpret_cast<d2 *>(P.ps) + static_cast<size_t>(mem) * 2 * NSPEC + k;
+    d2 div1[KX];
+#pragma unroll
+    for (int l = 0; l < KX; ++l) div1[l] = divS[static_cast<size_t>(l) * NSPEC];
+    const d2 ps1 = psS[0];
+
+    // ---- spectral tendencies (tendencies.f90:283-352, called with time level 1 because alph = 0.5) ----
+    d2 dmeanc{0.0, 0.0};
+#pragma unroll
+    for (int l = 0; l < KX; ++l) dmeanc = d2{dmeanc.x + div1[l].x * D.dhs[l], dmeanc.y + div1[l].y * D.dhs[l]};
+    psdt = d2{psdt.x - dmeanc.x, psdt.y - dmeanc.y};
+    if (k == 0) psdt = d2{0.0, 0.0};
+    d2 sig[KX + 1], dumk[KX + 1];
+    sig[0] = d2{0.0, 0.0};
+    sig[KX] = d2{0.0, 0.0};
+#pragma unroll
+    for (int l = 0; l < KX - 1; ++l)
+        sig[l + 1] = d2{sig[l].x - D.dhs[l] * (div1[l].x - dmeanc.x), sig[l].y - D.dhs[l] * (div1[l].y - dmeanc.y)};
+    dumk[0] = d2{0.0, 0.0};
+    dumk[KX] = d2{0.0, 0.0};
+#pragma unroll
+    for (int l = 1; l < KX; ++l) {
+        const double dtr = D.tref[l] - D.tref[l - 1];
+        dumk[l] = d2{sig[l].x * dtr, sig[l].y * dtr};
+    }
+#pragma unroll
+    for (int l = 0; l < KX; ++l) {
+        tdt[l].x = tdt[l].x - (dumk[l + 1].x + dumk[l].x) * D.dhsr[l] + D.tref3[l] * (sig[l + 1].x + sig[l].x) - D.tref2[l] * dmeanc.x;
+        tdt[l].y = tdt[l].y - (dumk[l + 1].y + dumk[l].y) * D.dhsr[l] + D.tref3[l] * (sig[l + 1].y + sig[l].y) - D.tref2[l] * dmeanc.y;
+    }
+    {   // geopotential (already valid for time level 1: geopotential_kernel ran before the physics) and its Laplacian
+        const d2 *phi = reinterpret_cast<const d2 *>(P.phi) + f8 + k;
+#pragma unroll
+        for (int l = 0; l < KX; ++l) {
+            const d2 ph = phi[static_cast<size_t>(l) * NSPEC];
+            const double c = RGASd * D.tref[l];
+            const d2 x = d2{ph.x + c * ps1.x, ph.y + c * ps1.y};
+            const d2 lap = d2{-x.x * el2, -x.y * el2};
+            divdt[l] = d2{divdt[l].x - lap.x, divdt[l].y - lap.y};
+        }
+    }
+
+    // ---- semi-implicit correction (implicit.f90:234-289) ----
+    {
+        d2 ye[KX], yf[KX];
+#pragma unroll
+        for (int l = 0; l < KX; ++l) ye[l] = d2{0.0, 0.0};
+#pragma unroll
+        for (int k1 = 0; k1 < KX; ++k1)
+#pragma unroll
+            for (int l = 0; l < KX; ++l) {
+                const double x = D.xd[l + KX * k1];
+                ye[l] = d2{ye[l].x + x * tdt[k1].x, ye[l].y + x * tdt[k1].y};
+            }
+        const double elz = D.elz[k];
+#pragma unroll
+        for (int l = 0; l < KX; ++l) {
+            const double c = RGASd * D.tref[l];
+            ye[l] = d2{ye[l].x + c * psdt.x, ye[l].y + c * psdt.y};
+            yf[l] = d2{divdt[l].x + elz * ye[l].x, divdt[l].y + elz * ye[l].y};
+            divdt[l] = d2{0.0, 0.0};
+        }
+        const int l_tot = m + n;  // total wavenumber; xj(:, :, l_tot) with 1-based third index
+        if (l_tot != 0) {
+            const double *xj = D.xj + static_cast<size_t>(KX) * KX * (l_tot - 1);
+#pragma unroll
+            for (int k1 = 0; k1 < KX; ++k1)
+#pragma unroll
+                for (int l = 0; l < KX; ++l) {
+                    const double x = xj[l + KX * k1];
+                    divdt[l] = d2{divdt[l].x + x * yf[k1].x, divdt[l].y + x * yf[k1].y};
+                }
+        }
+#pragma unroll
+        for (int l = 0; l < KX; ++l) psdt = d2{psdt.x - divdt[l].x * D.dhsx[l], psdt.y - divdt[l].y * D.dhsx[l]};
+#pragma unroll
+        for (int l = 0; l < KX; ++l)
+#pragma unroll
+            for (int k1 = 0; k1 < KX; ++k1) {
+                const double x = D.xc[l + KX * k1];
+                tdt[l] = d2{tdt[l].x + x * divdt[k1].x, tdt[l].y + x * divdt[k1].y};
+            }
+    }
+
+    // ---- horizontal diffusion (time_stepping.f90:78-122) and time integration (:130-188) ----
+    const double dmp = D.dmp[k], dmp1 = D.dmp1[k], dmpd = D.dmpd[k], dmp1d = D.dmp1d[k], dmps = D.dmps[k], dmp1s = D.dmp1s[k];
+    const double trf = T.trfilt[k];
+    const d2 tcorh = reinterpret_cast<const d2 *>(P.tcorh)[static_cast<size_t>(mem) * NSPEC + k];
+    const d2 qcorh = reinterpret_cast<const d2 *>(P.qcorh)[static_cast<size_t>(mem) * NSPEC + k];
+    const double sdrag = 1.0f / (TDRSd * 3600.0f);
+    auto diffuse = [](d2 field, d2 fdt, double a, double b) { return d2{(fdt.x - a * field.x) * b, (fdt.y - a * field.y) * b}; };
+    auto advance = [&](d2 *base, size_t off, d2 fdt) {  // step_field_2d, time_stepping.f90:164-188
+        const d2 o1 = base[off], o2 = base[off + lvl];
+        fdt = d2{fdt.x * trf, fdt.y * trf};
+        const d2 oj = (j1 == 0) ? o1 : o2;
+        const d2 fnew = d2{o1.x + dt * fdt.x, o1.y + dt * fdt.y};
+        const double we = WILd * eps;
+        const d2 n1 = d2{oj.x + we * (o1.x - 2 * oj.x + fnew.x), oj.y + we * (o1.y - 2 * oj.y + fnew.y)};
+        const d2 oja = (j1 == 0) ? n1 : oj;
+        const double we2 = (1.0f - WILd) * eps;
+        const d2 n2 = d2{fnew.x - we2 * (n1.x - 2.0f * oja.x + fnew.x), fnew.y - we2 * (n1.y - 2.0f * oja.y + fnew.y)};
+        base[off] = n1;
+        base[off + lvl] = n2;
+    };
+#pragma unroll
+    for (int l = 0; l < KX; ++l) {
+        const size_t off = static_cast<size_t>(l) * NSPEC;
+        const d2 vor1 = vorS[off], t1 = tS[off], tr1 = trS[off];
+        d2 vd = diffuse(vor1, vordt[l], dmp, dmp1);
+        d2 dd = diffuse(div1[l], divdt[l], dmpd, dmp1d);
+        const d2 ct = d2{t1.x + tcorh.x * D.tcorv[l], t1.y + tcorh.y * D.tcorv[l]};
+        d2 td = diffuse(ct, tdt[l], dmp, dmp1);
+        if (l == 0 && m == 0) {  // stratospheric zonal-wind drag on the zonal-mean flow of the top level
+            vd = d2{vd.x - sdrag * vor1.x, vd.y - sdrag * vor1.y};
+            dd = d2{dd.x - sdrag * div1[l].x, dd.y - sdrag * div1[l].y};
+        }
+        vd = diffuse(vor1, vd, dmps, dmp1s);
+        dd = diffuse(div1[l], dd, dmps, dmp1s);
+        td = diffuse(ct, td, dmps, dmp1s);
+        const d2 cq = d2{tr1.x + qcorh.x * D.qcorv[l], tr1.y + qcorh.y * D.qcorv[l]};
+        const d2 qd = diffuse(cq, trdt[l], dmpd, dmp1d);
+        advance(vorS, off, vd);
+        advance(divS, off, dd);
+        advance(tS, off, td);
+        advance(trS, off, qd);
+    }
+    {   // ln ps has no vertical index: the two time levels are NSPEC apart
+        const d2 o1 = psS[0], o2 = psS[NSPEC];
+        const d2 fdt = d2{psdt.x * trf, psdt.y * trf};
+        const d2 oj = (j1 == 0) ? o1 : o2;
+        const d2 fnew = d2{o1.x + dt * fdt.x, o1.y + dt * fdt.y};
+        const double we = WILd * eps, we2 = (1.0f - WILd) * eps;
+        const d2 n1 = d2{oj.x + we * (o1.x - 2 * oj.x + fnew.x), oj.y + we * (o1.y - 2 * oj.y + fnew.y)};
+        const d2 oja = (j1 == 0) ? n1 : oj;
+        psS[0] = n1;
+        psS[NSPEC] = d2{fnew.x - we2 * (n1.x - 2.0f * oja.x + fnew.x), fnew.y - we2 * (n1.y - 2.0f * oja.y + fnew.y)};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// diagnostics (diagnostics.f90:16-76): one wavefront per (member, level); sets err[member] = -2 when out of range
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void diagnostics_kernel(ModelPtrs P, DeviceTables T, int M, int tl, int *err, double *diag) {
+    const int mem = blockIdx.x / KX, l = blockIdx.x - mem * KX, lane = threadIdx.x;
+    const size_t so = ((static_cast<size_t>(mem) * 2 + tl) * 8 + l) * NSPEC;
+    const d2 *vor = reinterpret_cast<const d2 *>(P.vor) + so, *div = reinterpret_cast<const d2 *>(P.div) + so;
+    double d1 = 0.0, d2s = 0.0;
+    for (int k = lane; k < NSPEC; k += 64) {
+        if (k % MX == 0) continue;  // m = 1 (zonal mean) is excluded: only the eddies count
+        const double e = T.elm2[k];
+        const d2 a = vor[k], b = div[k];
+        // temp = -x * elm2 ; diag -= real(temp * conjg(x))
+        d1 = d1 - ((-a.x * e) * a.x + (-a.y * e) * a.y);
+        d2s = d2s - ((-b.x * e) * b.x + (-b.y * e) * b.y);
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        d1 += __shfl_down(d1, s, 64);
+        d2s += __shfl_down(d2s, s, 64);
+    }
+    if (lane == 0) {
+        const double tmean = 0.707106769084930420 /* sqrt(0.5) in fp32 */ * P.t[2 * so];
+        if (diag) {
+            double *dg = diag + static_cast<size_t>(mem) * KX * 3;
+            dg[l] = d1;
+            dg[l + KX] = d2s;
+            dg[l + 2 * KX] = tmean;
+        }
+        if (d1 > 500.0f || d2s > 500.0f || tmean < 180.0f || tmean > 320.0f) atomicExch(&err[mem], -2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------
+hipError_t run_model_uvgrad(const ModelPtrs &P, const DeviceTables &T, int M, int j2, hipStream_t s) {
+    hipLaunchKernelGGL(model_uvgrad_kernel, dim3((NSPEC + kT - 1) / kT, M * 9), dim3(kT), 0, s, P, T, M, j2);
+    return hipGetLastError();
+}
+hipError_t run_geopotential(const ModelPtrs &P, const DynDeviceTables &D, int M, int tl, hipStream_t s) {
+    hipLaunchKernelGGL(geopotential_kernel, dim3((M * NSPEC + kT - 1) / kT), dim3(kT), 0, s, P, D, M, tl);
+    return hipGetLastError();
+}
+hipError_t run_dyn_grid(const ModelPtrs &P, const DynDeviceTables &D, int M, hipStream_t s) {
+    hipLaunchKernelGGL(dyn_grid_kernel, dim3((M * NG + kT - 1) / kT), dim3(kT), 0, s, P, D, M);
+    return hipGetLastError();
+}
+hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const DynDeviceTables &D, int M, int j1, double dt,
+                             double eps, hipStream_t s) {
+    hipLaunchKernelGGL(spectral_step_kernel, dim3((M * NSPEC + kT - 1) / kT), dim3(kT), 0, s, P, T, D, M, j1, dt, eps);
+    return hipGetLastError();
+}
+hipError_t run_diagnostics(const ModelPtrs &P, const DeviceTables &T, int M, int tl, int *err, double *diag, hipStream_t s) {
+    hipLaunchKernelGGL(diagnostics_kernel, dim3(M * KX), dim3(64), 0, s, P, T, M, tl, err, diag);
+    return hipGetLastError();
+}
+
+}  // namespace spd

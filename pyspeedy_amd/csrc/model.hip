@@ -1,0 +1,363 @@
+// Ensemble model object: device-resident state of M members + the step driver (time_stepping.f90:38-147 `step`,
+// tendencies.f90:11-39 `get_tendencies`) built from the hot-path kernels and the dynamics kernels.
+// C ABI: the spd_model_* functions of include/pyspeedy_amd.h.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pyspeedy_amd.h"
+#include "context.hpp"
+#include "model.hpp"
+
+namespace spd {
+hipError_t run_spec2grid_table(const DeviceTables &T, const FieldDesc *table, int nfields, hipStream_t st);
+hipError_t run_grid2spec_table(const DeviceTables &T, const FieldDesc *table, int nfields, hipStream_t st);
+hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nmembers, hipStream_t s);
+hipError_t run_model_uvgrad(const ModelPtrs &P, const DeviceTables &T, int M, int j2, hipStream_t s);
+hipError_t run_geopotential(const ModelPtrs &P, const DynDeviceTables &D, int M, int tl, hipStream_t s);
+hipError_t run_dyn_grid(const ModelPtrs &P, const DynDeviceTables &D, int M, hipStream_t s);
+hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const DynDeviceTables &D, int M, int j1, double dt,
+                             double eps, hipStream_t s);
+hipError_t run_diagnostics(const ModelPtrs &P, const DeviceTables &T, int M, int tl, int *err, double *diag, hipStream_t s);
+}  // namespace spd
+
+using namespace spd;
+
+namespace {
+constexpr int NG = IX * IL;
+constexpr size_t C = 2;  // doubles per complex
+
+struct RegEntry {
+    void *ptr;            // device base
+    size_t bytes_member;  // bytes per member
+};
+}  // namespace
+
+struct spd_model {
+    spd_context *ctx = nullptr;
+    int M = 0;
+    ModelPtrs P{};
+    DynHostTables *dynh = nullptr;
+    DynDeviceTables D{};
+    spd_physics_args pa{};
+    std::vector<void *> allocs;
+    std::map<std::string, RegEntry> reg;
+    FieldDesc *inv_table[2] = {nullptr, nullptr};  // by dynamics time level j2 (0-based)
+    FieldDesc *fwd_table = nullptr;
+    int *d_err = nullptr;
+    double *d_diag = nullptr;
+    double air_absortivity_co2 = 6.0;  // model_state_def.py:320 default
+    // device copies of the dt-dependent tables (re-uploaded by set_time_step)
+    double *d_dmp1 = nullptr, *d_dmp1d = nullptr, *d_dmp1s = nullptr, *d_elz = nullptr, *d_xj = nullptr, *d_xc = nullptr,
+           *d_xd = nullptr;
+};
+
+static int m_fail(int code, const std::string &msg) { return spd_set_error(code, msg); }
+
+#define M_HIP(call)                                                                   \
+    do {                                                                              \
+        hipError_t e_ = (call);                                                       \
+        if (e_ != hipSuccess) return m_fail(SPD_E_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+static int dalloc(spd_model *m, size_t doubles, double **out, const char *name = nullptr, size_t bytes_member = 0) {
+    void *p = nullptr;
+    M_HIP(hipMalloc(&p, doubles * sizeof(double)));
+    M_HIP(hipMemset(p, 0, doubles * sizeof(double)));
+    m->allocs.push_back(p);
+    *out = static_cast<double *>(p);
+    if (name) m->reg[name] = RegEntry{p, bytes_member};
+    return SPD_OK;
+}
+
+static int upload_const(spd_model *m, const double *src, size_t n, const double **dst) {
+    double *p = nullptr;
+    if (int rc = dalloc(m, n, &p)) return rc;
+    M_HIP(hipMemcpy(p, src, n * sizeof(double), hipMemcpyHostToDevice));
+    *dst = p;
+    return SPD_OK;
+}
+
+static int build_tables(spd_model *m) {
+    const int M = m->M;
+    const ModelPtrs &P = m->P;
+    const spd_physics_args &pa = m->pa;
+    auto spec = [](double *base, size_t field) { return base + field * NSPEC * C; };
+    auto grid = [](double *base, size_t field) { return base + field * NG; };
+    for (int j2 = 0; j2 < 2; ++j2) {
+        std::vector<FieldDesc> t;
+        t.reserve(static_cast<size_t>(M) * 91);
+        for (int i = 0; i < M; ++i) {
+            const size_t w = static_cast<size_t>(i) * 8, st = (static_cast<size_t>(i) * 2 + j2) * 8, s1 = static_cast<size_t>(i) * 2 * 8;
+            const size_t quad = static_cast<size_t>(M) * 8;  // fields per [M][8] block inside sv
+            for (int k = 0; k < 8; ++k) {
+                t.push_back({spec(P.vor, st + k), grid(P.vorg, w + k), 1, 0});
+                t.push_back({spec(P.div, st + k), grid(P.divg, w + k), 1, 0});
+                t.push_back({spec(P.t, st + k), grid(P.tg2, w + k), 1, 0});
+                t.push_back({spec(P.tr, st + k), grid(P.trg2, w + k), 1, 0});
+                t.push_back({spec(P.sv, w + k), grid(P.ug2, w + k), 2, 0});
+                t.push_back({spec(P.sv, quad + w + k), grid(P.vg2, w + k), 2, 0});
+                t.push_back({spec(P.sv, 2 * quad + w + k), grid(const_cast<double *>(pa.ug), w + k), 2, 0});
+                t.push_back({spec(P.sv, 3 * quad + w + k), grid(const_cast<double *>(pa.vg), w + k), 2, 0});
+                t.push_back({spec(P.t, s1 + k), grid(const_cast<double *>(pa.tg), w + k), 1, 0});
+                t.push_back({spec(P.tr, s1 + k), grid(const_cast<double *>(pa.qg), w + k), 1, 0});
+                t.push_back({spec(P.phi, w + k), grid(const_cast<double *>(pa.phig), w + k), 1, 0});
+            }
+            t.push_back({spec(P.gps, i), grid(P.px, i), 2, 0});
+            t.push_back({spec(P.gps, static_cast<size_t>(M) + i), grid(P.py, i), 2, 0});
+            t.push_back({spec(P.ps, static_cast<size_t>(i) * 2), grid(const_cast<double *>(pa.pslg), i), 1, 0});
+        }
+        void *d = nullptr;
+        M_HIP(hipMalloc(&d, t.size() * sizeof(FieldDesc)));
+        m->allocs.push_back(d);
+        M_HIP(hipMemcpy(d, t.data(), t.size() * sizeof(FieldDesc), hipMemcpyHostToDevice));
+        m->inv_table[j2] = static_cast<FieldDesc *>(d);
+    }
+    std::vector<FieldDesc> t;
+    t.reserve(static_cast<size_t>(M) * 73);
+    const size_t pair = static_cast<size_t>(M) * 8;
+    for (int i = 0; i < M; ++i) {
+        const size_t w = static_cast<size_t>(i) * 8;
+        for (int k = 0; k < 8; ++k) {
+            // grid_vel2vort(..., kcos = 2): rows pre-multiplied by cosgr (spectral.f90:229-235) -> flag 1
+            t.push_back({grid(P.utend, w + k), spec(P.specu, w + k), 1, 0});
+            t.push_back({grid(P.vtend, w + k), spec(P.specv, w + k), 1, 0});
+            t.push_back({grid(P.utg, w + k), spec(P.specu, pair + w + k), 1, 0});
+            t.push_back({grid(P.vtg, w + k), spec(P.specv, pair + w + k), 1, 0});
+            t.push_back({grid(P.uqg, w + k), spec(P.specu, 2 * pair + w + k), 1, 0});
+            t.push_back({grid(P.vqg, w + k), spec(P.specv, 2 * pair + w + k), 1, 0});
+            t.push_back({grid(P.ttend, w + k), spec(P.spec_tt, w + k), 0, 0});
+            t.push_back({grid(P.trtend, w + k), spec(P.spec_tr, w + k), 0, 0});
+            t.push_back({grid(P.keg, w + k), spec(P.spec_ke, w + k), 0, 0});
+        }
+        t.push_back({grid(P.psdtg, i), spec(P.spec_ps, i), 0, 0});
+    }
+    void *d = nullptr;
+    M_HIP(hipMalloc(&d, t.size() * sizeof(FieldDesc)));
+    m->allocs.push_back(d);
+    M_HIP(hipMemcpy(d, t.data(), t.size() * sizeof(FieldDesc), hipMemcpyHostToDevice));
+    m->fwd_table = static_cast<FieldDesc *>(d);
+    return SPD_OK;
+}
+
+extern "C" {
+
+int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
+    if (!h || !out) return m_fail(SPD_E_ARG, "spd_model_create: null argument");
+    if (nmembers <= 0) return m_fail(SPD_E_ARG, "spd_model_create: nmembers must be positive");
+    *out = nullptr;
+    M_HIP(hipSetDevice(h->device));
+    spd_model *m = new spd_model();
+    m->ctx = h;
+    m->M = nmembers;
+    const size_t M = nmembers, S = NSPEC * C, G3 = static_cast<size_t>(8) * NG;
+    ModelPtrs &P = m->P;
+    spd_physics_args &pa = m->pa;
+    int rc = SPD_OK;
+#define A(ptr, doubles, name, per)                      \
+    if (rc == SPD_OK) rc = dalloc(m, (doubles), &(ptr), name, (per) * sizeof(double))
+    // prognostic state (registry names of model_state_def.py:129-153)
+    A(P.vor, M * 2 * 8 * S, "vor", 2 * 8 * S);
+    A(P.div, M * 2 * 8 * S, "div", 2 * 8 * S);
+    A(P.t, M * 2 * 8 * S, "t", 2 * 8 * S);
+    A(P.tr, M * 2 * 8 * S, "tr", 2 * 8 * S);
+    A(P.ps, M * 2 * S, "ps", 2 * S);
+    A(P.phi, M * 8 * S, "phi", 8 * S);
+    A(P.phis, M * S, "phis", S);
+    A(P.tcorh, M * S, "tcorh", S);
+    A(P.qcorh, M * S, "qcorh", S);
+    A(P.sv, 4 * M * 8 * S, nullptr, 0);
+    A(P.gps, 2 * M * S, nullptr, 0);
+    A(P.vorg, M * G3, nullptr, 0); A(P.divg, M * G3, nullptr, 0); A(P.tg2, M * G3, nullptr, 0);
+    A(P.trg2, M * G3, nullptr, 0); A(P.ug2, M * G3, nullptr, 0); A(P.vg2, M * G3, nullptr, 0);
+    A(P.px, M * NG, nullptr, 0); A(P.py, M * NG, nullptr, 0);
+    A(P.utend, M * G3, nullptr, 0); A(P.vtend, M * G3, nullptr, 0); A(P.ttend, M * G3, nullptr, 0);
+    A(P.trtend, M * G3, nullptr, 0); A(P.keg, M * G3, nullptr, 0); A(P.utg, M * G3, nullptr, 0);
+    A(P.vtg, M * G3, nullptr, 0); A(P.uqg, M * G3, nullptr, 0); A(P.vqg, M * G3, nullptr, 0);
+    A(P.psdtg, M * NG, nullptr, 0);
+    A(P.specu, 3 * M * 8 * S, nullptr, 0); A(P.specv, 3 * M * 8 * S, nullptr, 0);
+    A(P.spec_tt, M * 8 * S, nullptr, 0); A(P.spec_tr, M * 8 * S, nullptr, 0); A(P.spec_ke, M * 8 * S, nullptr, 0);
+    A(P.spec_ps, M * S, nullptr, 0);
+    // physics: grid-point inputs (work) ...
+    double *tmp = nullptr;
+#define PA_IN(field, doubles, name, per)                            \
+    A(tmp, doubles, name, per);                                     \
+    pa.field = tmp
+    PA_IN(ug, M * G3, "u_grid_phys", G3); PA_IN(vg, M * G3, "v_grid_phys", G3); PA_IN(tg, M * G3, "t_grid_phys", G3);
+    PA_IN(qg, M * G3, "q_grid_phys", G3); PA_IN(phig, M * G3, "phi_grid_phys", G3); PA_IN(pslg, M * NG, "pslg_phys", NG);
+    pa.utend = P.utend; pa.vtend = P.vtend; pa.ttend = P.ttend; pa.qtend = P.trtend;
+    // ... surface / forcing fields and outputs under their registry names (model_state_def.py:202-457)
+#define PA2(field) PA_IN(field, M * NG, #field, NG)
+    PA2(fmask_land); PA2(phis0); PA2(forog); PA2(sst_am); PA2(alb_land); PA2(alb_sea); PA2(snowc); PA2(land_temp);
+    PA2(soil_avail_water); PA2(flux_solar_in); PA2(flux_ozone_upper); PA2(flux_ozone_lower); PA2(zenit_correction);
+    PA2(stratospheric_correction); PA2(alb_surface);
+    PA2(precnv); PA2(precls); PA2(cbmf); PA2(slrd); PA2(slr); PA2(olr); PA2(tsr); PA2(ssrd); PA2(ssr); PA2(qcloud_equiv);
+#define PA3(field) PA_IN(field, M * 3 * NG, #field, 3 * NG)
+    PA3(slru); PA3(ustr); PA3(vstr); PA3(shf); PA3(evap); PA3(hfluxn);
+    PA_IN(rad_st4a, M * 2 * G3, "rad_st4a", 2 * G3);
+    PA_IN(rad_flux, M * 4 * NG, "rad_flux", 4 * NG);
+    PA_IN(tt_rsw, M * G3, "tt_rsw", G3);
+    PA_IN(rad_tau2, M * 4 * G3, "rad_tau2", 4 * G3);
+    PA_IN(rad_strat_corr, M * 2 * NG, "rad_strat_corr", 2 * NG);
+#undef PA3
+#undef PA2
+#undef PA_IN
+#undef A
+    if (rc != SPD_OK) {
+        spd_model_destroy(m);
+        return rc;
+    }
+    // dynamics tables
+    m->dynh = new DynHostTables(h->host);
+    const DynHostTables &dh = *m->dynh;
+    DynDeviceTables &D = m->D;
+    auto up = [&](const double *src, size_t n, const double **dst) {
+        if (rc == SPD_OK) rc = upload_const(m, src, n, dst);
+    };
+    up(dh.dmp.data(), NSPEC, &D.dmp); up(dh.dmpd.data(), NSPEC, &D.dmpd); up(dh.dmps.data(), NSPEC, &D.dmps);
+    up(dh.dmp1.data(), NSPEC, &D.dmp1); up(dh.dmp1d.data(), NSPEC, &D.dmp1d); up(dh.dmp1s.data(), NSPEC, &D.dmp1s);
+    up(dh.elz.data(), NSPEC, &D.elz); up(dh.xj.data(), dh.xj.size(), &D.xj);
+    up(dh.xc.data(), 64, &D.xc); up(dh.xd.data(), 64, &D.xd);
+    up(h->host.coriol.data(), 48, &D.coriol);
+    if (rc == SPD_OK) {
+        m->d_dmp1 = const_cast<double *>(D.dmp1); m->d_dmp1d = const_cast<double *>(D.dmp1d);
+        m->d_dmp1s = const_cast<double *>(D.dmp1s); m->d_elz = const_cast<double *>(D.elz);
+        m->d_xj = const_cast<double *>(D.xj); m->d_xc = const_cast<double *>(D.xc); m->d_xd = const_cast<double *>(D.xd);
+        for (int k = 0; k < 8; ++k) {
+            D.tcorv[k] = dh.tcorv[k]; D.qcorv[k] = dh.qcorv[k]; D.tref[k] = dh.tref[k]; D.tref2[k] = dh.tref2[k];
+            D.tref3[k] = dh.tref3[k]; D.dhsx[k] = dh.dhsx[k]; D.xgeop1[k] = dh.xgeop1[k]; D.xgeop2[k] = dh.xgeop2[k];
+            D.geo_corf[k] = dh.geo_corf[k]; D.dhs[k] = h->host.dhs[k]; D.dhsr[k] = h->host.dhsr[k]; D.fsgr[k] = h->host.fsgr[k];
+        }
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, sizeof(int) * M);
+        if (e == hipSuccess) { m->allocs.push_back(p); m->d_err = static_cast<int *>(p); e = hipMemset(p, 0, sizeof(int) * M); }
+        if (e == hipSuccess) e = hipMalloc(&p, sizeof(double) * M * 24);
+        if (e == hipSuccess) { m->allocs.push_back(p); m->d_diag = static_cast<double *>(p); }
+        if (e != hipSuccess) rc = m_fail(SPD_E_DEVICE, std::string("spd_model_create: ") + hipGetErrorString(e));
+    }
+    if (rc == SPD_OK) rc = build_tables(m);
+    if (rc != SPD_OK) {
+        spd_model_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return SPD_OK;
+}
+
+int spd_model_destroy(spd_model_handle m) {
+    if (!m) return SPD_OK;
+    (void)hipSetDevice(m->ctx->device);
+    for (void *p : m->allocs) (void)hipFree(p);
+    delete m->dynh;
+    delete m;
+    return SPD_OK;
+}
+
+int spd_model_members(spd_model_handle m) { return m ? m->M : SPD_E_ARG; }
+
+long spd_model_var_bytes(spd_model_handle m, const char *name) {
+    if (!m || !name) return m_fail(SPD_E_ARG, "spd_model_var_bytes: null argument");
+    auto it = m->reg.find(name);
+    if (it == m->reg.end()) return m_fail(SPD_E_ARG, std::string("spd_model_var_bytes: unknown variable '") + name + "'");
+    return static_cast<long>(it->second.bytes_member);
+}
+
+static int xfer(spd_model_handle m, const char *name, int member, void *host, size_t bytes, bool to_device) {
+    if (!m || !name || !host) return m_fail(SPD_E_ARG, "spd_model_get/set: null argument");
+    auto it = m->reg.find(name);
+    if (it == m->reg.end()) return m_fail(SPD_E_ARG, std::string("spd_model_get/set: unknown variable '") + name + "'");
+    const RegEntry &e = it->second;
+    if (bytes != e.bytes_member)
+        return m_fail(SPD_E_SIZE, std::string("spd_model_get/set: '") + name + "' needs exactly " + std::to_string(e.bytes_member) + " bytes per member");
+    if (member < -1 || member >= m->M) return m_fail(SPD_E_ARG, "spd_model_get/set: member index out of range");
+    if (member == -1 && !to_device) return m_fail(SPD_E_ARG, "spd_model_get: member = -1 (broadcast) is only valid for set");
+    M_HIP(hipSetDevice(m->ctx->device));
+    const int first = member < 0 ? 0 : member, last = member < 0 ? m->M - 1 : member;
+    for (int i = first; i <= last; ++i) {
+        char *dev = static_cast<char *>(e.ptr) + static_cast<size_t>(i) * e.bytes_member;
+        if (to_device)
+            M_HIP(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
+        else
+            M_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+    }
+    return SPD_OK;
+}
+
+int spd_model_set(spd_model_handle m, const char *name, int member, const void *host, size_t bytes) {
+    return xfer(m, name, member, const_cast<void *>(host), bytes, true);
+}
+int spd_model_get(spd_model_handle m, const char *name, int member, void *host, size_t bytes) {
+    return xfer(m, name, member, host, bytes, false);
+}
+
+void *spd_model_device_ptr(spd_model_handle m, const char *name) {
+    if (!m || !name) return nullptr;
+    auto it = m->reg.find(name);
+    return it == m->reg.end() ? nullptr : it->second.ptr;
+}
+
+int spd_model_set_co2(spd_model_handle m, double air_absortivity_co2) {
+    if (!m) return m_fail(SPD_E_ARG, "spd_model_set_co2: null model");
+    m->air_absortivity_co2 = air_absortivity_co2;
+    return SPD_OK;
+}
+
+int spd_model_set_time_step(spd_model_handle m, double dt) {
+    if (!m) return m_fail(SPD_E_ARG, "spd_model_set_time_step: null model");
+    M_HIP(hipSetDevice(m->ctx->device));
+    m->dynh->set_time_step(m->ctx->host, dt);
+    const DynHostTables &dh = *m->dynh;
+    M_HIP(hipDeviceSynchronize());  // kernels in flight may still read the old tables
+    M_HIP(hipMemcpy(m->d_dmp1, dh.dmp1.data(), NSPEC * sizeof(double), hipMemcpyHostToDevice));
+    M_HIP(hipMemcpy(m->d_dmp1d, dh.dmp1d.data(), NSPEC * sizeof(double), hipMemcpyHostToDevice));
+    M_HIP(hipMemcpy(m->d_dmp1s, dh.dmp1s.data(), NSPEC * sizeof(double), hipMemcpyHostToDevice));
+    M_HIP(hipMemcpy(m->d_elz, dh.elz.data(), NSPEC * sizeof(double), hipMemcpyHostToDevice));
+    M_HIP(hipMemcpy(m->d_xj, dh.xj.data(), dh.xj.size() * sizeof(double), hipMemcpyHostToDevice));
+    M_HIP(hipMemcpy(m->d_xc, dh.xc.data(), 64 * sizeof(double), hipMemcpyHostToDevice));
+    M_HIP(hipMemcpy(m->d_xd, dh.xd.data(), 64 * sizeof(double), hipMemcpyHostToDevice));
+    for (int k = 0; k < 8; ++k) m->D.dhsx[k] = dh.dhsx[k];
+    return SPD_OK;
+}
+
+// time_stepping.f90 `step(state, j1, j2, dt)`; j1, j2 are the reference's 1-based time-level indices.
+int spd_model_step_dynamics(spd_model_handle m, int j1, int j2, double dt, int compute_shortwave, void *stream) {
+    if (!m) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: null model");
+    if (j1 < 1 || j1 > 2 || j2 < 1 || j2 > 2) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: time levels are 1 or 2");
+    if (m->dynh->dt == 0.0) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: call spd_model_set_time_step first");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const DeviceTables &T = m->ctx->dev;
+    const int M = m->M;
+    hipError_t e = run_model_uvgrad(m->P, T, M, j2 - 1, s);
+    if (e == hipSuccess) e = run_geopotential(m->P, m->D, M, 0, s);                       // tendencies.f90:229
+    if (e == hipSuccess) e = run_spec2grid_table(T, m->inv_table[j2 - 1], 91 * M, s);     // :109-146, physics.f90:89-101
+    if (e == hipSuccess) e = run_dyn_grid(m->P, m->D, M, s);                              // :151-224
+    if (e == hipSuccess) {
+        m->pa.compute_shortwave = compute_shortwave ? 1 : 0;
+        m->pa.air_absortivity_co2 = m->air_absortivity_co2;
+        e = run_physics(T, m->pa, M, s);                                                  // :231
+    }
+    if (e == hipSuccess) e = run_grid2spec_table(T, m->fwd_table, 73 * M, s);             // :238-268
+    const double eps = (j1 == 1) ? 0.0 : static_cast<double>(0.05f);                      // rob, time_stepping.f90:130-134
+    if (e == hipSuccess) e = run_spectral_step(m->P, T, m->D, M, j1 - 1, dt, eps, s);
+    if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_step_dynamics: ") + hipGetErrorString(e));
+    return SPD_OK;
+}
+
+// diagnostics.f90 check_diagnostics for every member; synchronises the stream and returns the reference's codes.
+int spd_model_check(spd_model_handle m, int time_level, int32_t *error_codes_host, double *diag_host, void *stream) {
+    if (!m || !error_codes_host) return m_fail(SPD_E_ARG, "spd_model_check: null argument");
+    if (time_level < 1 || time_level > 2) return m_fail(SPD_E_ARG, "spd_model_check: time level is 1 or 2");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    M_HIP(hipMemsetAsync(m->d_err, 0, sizeof(int) * m->M, s));
+    hipError_t e = run_diagnostics(m->P, m->ctx->dev, m->M, time_level - 1, m->d_err, m->d_diag, s);
+    if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_check: ") + hipGetErrorString(e));
+    M_HIP(hipMemcpyAsync(error_codes_host, m->d_err, sizeof(int) * m->M, hipMemcpyDeviceToHost, s));
+    if (diag_host) M_HIP(hipMemcpyAsync(diag_host, m->d_diag, sizeof(double) * m->M * 24, hipMemcpyDeviceToHost, s));
+    M_HIP(hipStreamSynchronize(s));
+    return SPD_OK;
+}
+
+}  // extern "C"

@@ -2,6 +2,7 @@
 #include "tables.hpp"
 
 #include <cmath>
+#include <utility>
 
 namespace spd {
 namespace {
@@ -221,6 +222,180 @@ HostTables::HostTables() {
     build_fft(*this);
     build_spectral(*this);
     build_fband(*this);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dynamics tables
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+constexpr double kGamma = 6.0f, kHscale = 7.5f, kHshum = 2.5f, kThd = 2.4f, kThdd = 2.4f, kThds = 12.0f, kAlph = 0.5f;
+
+// LU decomposition with implicit scaling and partial pivoting, then column-by-column back substitution:
+// the algorithm of matrix_inversion.f90 (Numerical Recipes ludcmp/lubksb), n = 8.
+struct Lu8 {
+    static constexpr int N = KX;
+    double a[N * N];
+    int piv[N];
+    double &at(int i, int j) { return a[i + N * j]; }
+    void factor() {
+        const double tiny = 1.0e-20f;
+        double scale[N];
+        for (int i = 0; i < N; ++i) {
+            double big = 0.;
+            for (int j = 0; j < N; ++j) big = std::fabs(at(i, j)) > big ? std::fabs(at(i, j)) : big;
+            scale[i] = 1. / big;
+        }
+        int imax = 0;
+        for (int j = 0; j < N; ++j) {
+            for (int i = 0; i < j; ++i) {
+                double sum = at(i, j);
+                if (i > 0) {
+                    for (int k = 0; k < i; ++k) sum = sum - at(i, k) * at(k, j);
+                    at(i, j) = sum;
+                }
+            }
+            double big = 0.;
+            for (int i = j; i < N; ++i) {
+                double sum = at(i, j);
+                if (j > 0) {
+                    for (int k = 0; k < j; ++k) sum = sum - at(i, k) * at(k, j);
+                    at(i, j) = sum;
+                }
+                const double merit = scale[i] * std::fabs(sum);
+                if (merit >= big) {
+                    imax = i;
+                    big = merit;
+                }
+            }
+            if (j != imax) {
+                for (int k = 0; k < N; ++k) std::swap(at(imax, k), at(j, k));
+                scale[imax] = scale[j];
+            }
+            piv[j] = imax;
+            if (j != N - 1) {
+                if (at(j, j) == 0) at(j, j) = tiny;
+                const double inv = 1. / at(j, j);
+                for (int i = j + 1; i < N; ++i) at(i, j) = at(i, j) * inv;
+            }
+        }
+        if (at(N - 1, N - 1) == 0.) at(N - 1, N - 1) = tiny;
+    }
+    void solve(double *b) {
+        int first = -1;
+        for (int i = 0; i < N; ++i) {
+            const int ll = piv[i];
+            double sum = b[ll];
+            b[ll] = b[i];
+            if (first >= 0) {
+                for (int j = first; j < i; ++j) sum = sum - at(i, j) * b[j];
+            } else if (sum != 0) {
+                first = i;
+            }
+            b[i] = sum;
+        }
+        for (int i = N - 1; i >= 0; --i) {
+            double sum = b[i];
+            for (int j = i + 1; j < N; ++j) sum = sum - at(i, j) * b[j];
+            b[i] = sum / at(i, i);
+        }
+    }
+};
+}  // namespace
+
+DynHostTables::DynHostTables(const HostTables &t) {
+    dmp.assign(NSPEC, 0.0); dmpd.assign(NSPEC, 0.0); dmps.assign(NSPEC, 0.0);
+    dmp1.assign(NSPEC, 0.0); dmp1d.assign(NSPEC, 0.0); dmp1s.assign(NSPEC, 0.0); elz.assign(NSPEC, 0.0);
+    xj.assign(static_cast<size_t>(KX) * KX * (MX + NX + 1), 0.0);
+    // horizontal_diffusion.f90:80-107
+    const double hdiff = 1.f / (kThd * 3600.f), hdifd = 1.f / (kThdd * 3600.f), hdifs = 1.f / (kThds * 3600.f);
+    const double rlap = static_cast<double>(1.f / static_cast<float>(TRUNC * (TRUNC + 1)));
+    for (int n = 0; n < NX; ++n)
+        for (int m = 0; m < MX; ++m) {
+            const double twn = static_cast<double>(static_cast<float>(m + n));
+            const double elap = (twn * (twn + 1.f) * rlap);
+            const double elap4 = ((elap * elap) * elap) * elap;  // elap**npowhd, expanded sequentially like flang does
+            dmp[m + MX * n] = hdiff * elap4;
+            dmpd[m + MX * n] = hdifd * elap4;
+            dmps[m + MX * n] = hdifs * elap;
+        }
+    const double rgam = phc::rgas * kGamma / (1000.f * phc::grav);
+    const double qexp = kHscale / kHshum;
+    for (int k = 1; k < KX; ++k) {
+        tcorv[k] = std::pow(t.fsg[k], rgam);
+        if (k > 1) qcorv[k] = std::pow(t.fsg[k], qexp);
+    }
+    // implicit.f90:71-78
+    for (int k = 0; k < KX; ++k) {
+        const double f = t.fsg[k] > 0.2f ? t.fsg[k] : static_cast<double>(0.2f);
+        tref[k] = 288.f * std::pow(f, rgam);
+        tref2[k] = phc::akap * tref[k];
+        tref3[k] = t.fsgr[k] * tref[k];
+    }
+    // geopotential.f90:25-28 and :72-73
+    for (int k = 0; k < KX; ++k) {
+        xgeop1[k] = phc::rgas * std::log(t.hsg[k + 1] / t.fsg[k]);
+        if (k != KX - 1) xgeop2[k + 1] = phc::rgas * std::log(t.fsg[k + 1] / t.hsg[k + 1]);
+    }
+    for (int k = 1; k < KX - 1; ++k)
+        geo_corf[k] = xgeop1[k] * 0.5f * std::log(t.hsg[k + 1] / t.fsg[k]) / std::log(t.fsg[k + 1] / t.fsg[k - 1]);
+}
+
+void DynHostTables::set_time_step(const HostTables &t, double step) {  // implicit.f90:83-218
+    dt = step;
+    for (int i = 0; i < NSPEC; ++i) {
+        dmp1[i] = 1.f / (1.f + dmp[i] * dt);
+        dmp1d[i] = 1.f / (1.f + dmpd[i] * dt);
+        dmp1s[i] = 1.f / (1.f + dmps[i] * dt);
+    }
+    const double xi = dt * kAlph, a2 = phc::rearth * phc::rearth;
+    const double xxi = xi / a2;
+    for (int k = 0; k < KX; ++k) dhsx[k] = xi * t.dhs[k];
+    for (int n = 0; n < NX; ++n)
+        for (int m = 0; m < MX; ++m)
+            elz[m + MX * n] = static_cast<double>(static_cast<float>(m + n) * static_cast<float>(m + n + 1)) * xxi;
+    auto M = [](std::array<double, 64> &a, int k, int k1) -> double & { return a[k + KX * k1]; };
+    std::array<double, 64> xa{}, xb{}, xe{}, ya{};
+    for (int k = 0; k < KX; ++k)
+        for (int k1 = 0; k1 < KX; ++k1) M(ya, k, k1) = -phc::akap * tref[k] * t.dhs[k1];
+    for (int k = 1; k < KX; ++k)
+        M(xa, k, k - 1) = 0.5f * (phc::akap * tref[k] / t.fsg[k] - (tref[k] - tref[k - 1]) / t.dhs[k]);
+    for (int k = 0; k < KX - 1; ++k)
+        M(xa, k, k) = 0.5f * (phc::akap * tref[k] / t.fsg[k] - (tref[k + 1] - tref[k]) / t.dhs[k]);
+    std::array<double, 8> dsum{};
+    dsum[0] = t.dhs[0];
+    for (int k = 1; k < KX; ++k) dsum[k] = dsum[k - 1] + t.dhs[k];
+    for (int k = 0; k < KX - 1; ++k)
+        for (int k1 = 0; k1 < KX; ++k1) {
+            M(xb, k, k1) = t.dhs[k1] * dsum[k];
+            if (k1 <= k) M(xb, k, k1) = M(xb, k, k1) - t.dhs[k1];
+        }
+    for (int k = 0; k < KX; ++k)
+        for (int k1 = 0; k1 < KX; ++k1) {
+            M(xc, k, k1) = M(ya, k, k1);
+            for (int k2 = 0; k2 < KX - 1; ++k2) M(xc, k, k1) = M(xc, k, k1) + M(xa, k, k2) * M(xb, k2, k1);
+        }
+    xd.fill(0.0);
+    for (int k = 0; k < KX; ++k)
+        for (int k1 = k + 1; k1 < KX; ++k1) M(xd, k, k1) = phc::rgas * std::log(t.hsg[k1 + 1] / t.hsg[k1]);
+    for (int k = 0; k < KX; ++k) M(xd, k, k) = phc::rgas * std::log(t.hsg[k + 1] / t.fsg[k]);
+    for (int k = 0; k < KX; ++k)
+        for (int k1 = 0; k1 < KX; ++k1) {
+            M(xe, k, k1) = 0.;
+            for (int k2 = 0; k2 < KX; ++k2) M(xe, k, k1) = M(xe, k, k1) + M(xd, k, k2) * M(xc, k2, k1);
+        }
+    for (int l = 1; l <= MX + NX + 1; ++l) {
+        const double xxx = static_cast<double>(static_cast<float>(l) * static_cast<float>(l + 1)) / a2;
+        Lu8 lu;
+        for (int k = 0; k < KX; ++k)
+            for (int k1 = 0; k1 < KX; ++k1) lu.at(k, k1) = xi * xi * xxx * (phc::rgas * tref[k] * t.dhs[k1] - M(xe, k, k1));
+        for (int k = 0; k < KX; ++k) lu.at(k, k) = lu.at(k, k) + 1.f;
+        double *y = xj.data() + static_cast<size_t>(KX) * KX * (l - 1);
+        for (int i = 0; i < KX * KX; ++i) y[i] = 0.0;
+        for (int i = 0; i < KX; ++i) y[i + KX * i] = 1.;
+        lu.factor();
+        for (int i = 0; i < KX; ++i) lu.solve(y + KX * i);
+    }
+    for (auto &v : xc) v = v * xi;
 }
 
 std::vector<double> HostTables::cpol() const {

@@ -50,4 +50,18 @@ struct HostTables {
     std::vector<double> cpol() const;
 };
 
+// Tables of the callers of the hot path: horizontal diffusion (horizontal_diffusion.f90:50-110), semi-implicit
+// gravity-wave correction (implicit.f90:44-218, matrix_inversion.f90), geopotential (geopotential.f90:16-31).
+struct DynHostTables {
+    std::vector<double> dmp, dmpd, dmps, dmp1, dmp1d, dmp1s, elz;  // (mx,nx)
+    std::array<double, 8> tcorv{}, qcorv{}, tref{}, tref2{}, tref3{}, dhsx{}, xgeop1{}, xgeop2{};
+    std::array<double, 8> geo_corf{};                              // lapse-rate correction factors, geopotential.f90:73
+    std::array<double, 64> xc{}, xd{};                             // (kx,kx) column-major
+    std::vector<double> xj;                                        // (kx,kx,mx+nx+1)
+    double dt = 0.0;
+
+    explicit DynHostTables(const HostTables &t);
+    void set_time_step(const HostTables &t, double dt);            // ModImplicit_set_time_step
+};
+
 }  // namespace spd

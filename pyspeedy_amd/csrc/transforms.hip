@@ -52,20 +52,20 @@ __device__ inline int wave_id() { return __builtin_amdgcn_readfirstlane(static_c
 // ------------------------------------------------------------------------------------------------
 // spec -> grid
 // ------------------------------------------------------------------------------------------------
+// src / dst point at ONE field (spectral field or Fourier plane in, Fourier plane or grid field out)
 template <Stage ST>
-__global__ __launch_bounds__(kThreads) void spec2grid_kernel(const double *__restrict__ src, double *__restrict__ dst,
-                                                             DeviceTables T, int kcos) {
+__device__ __forceinline__ void spec2grid_body(const double *__restrict__ src, double *__restrict__ dst,
+                                               const DeviceTables &T, int kcos) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *cbuf = lds;                                        // C[48][63]
     double *rows = lds;                                        // R[48][97], aliases C and S (see header)
     d2 *s = reinterpret_cast<d2 *>(lds + kCBufDoubles);        // S: 992 complex
     const int tid = threadIdx.x;
-    const size_t f = blockIdx.x;
     const int wave = wave_id(), lane = tid & 63;
 
     if (ST != Stage::FourierOnly) {
         // ---- stage spectral coefficients: 16 B per lane, fully coalesced ----
-        const d2 *g = reinterpret_cast<const d2 *>(src) + f * NSPEC;
+        const d2 *g = reinterpret_cast<const d2 *>(src);
         for (int idx = tid; idx < NSPEC; idx += kThreads) s[idx] = g[idx];
         __syncthreads();
 
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kThreads) void spec2grid_kernel(const double *__res
         __syncthreads();
     } else {
         // ---- Fourier plane from memory: (62, 48) -> unpacked rows ----
-        const double *g = src + f * NFOUR;
+        const double *g = src;
         for (int idx = tid; idx < NFOUR; idx += kThreads) {
             const int row = idx / 62, r = idx - row * 62;
             if (r != 1) cbuf[row * kCStride + (r == 0 ? 0 : r - 1)] = g[idx];
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kThreads) void spec2grid_kernel(const double *__res
     }
 
     if (ST == Stage::LegendreOnly) {
-        double *g = dst + f * NFOUR;
+        double *g = dst;
         for (int idx = tid; idx < NFOUR; idx += kThreads) {
             const int row = idx / 62, r = idx - row * 62;
             g[idx] = cbuf[row * kCStride + (r == 0 ? 0 : (r == 1 ? 61 : r - 1))];
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kThreads) void spec2grid_kernel(const double *__res
     __syncthreads();
 
     // ---- store grid rows: 16 B per lane, coalesced; optional 1/cos(lat) scaling (fourier.f90:87-91) ----
-    d2 *g = reinterpret_cast<d2 *>(dst) + f * (NGRID / 2);
+    d2 *g = reinterpret_cast<d2 *>(dst);
     for (int idx = tid; idx < NGRID / 2; idx += kThreads) {
         const int r = idx / (IX / 2), ip = idx - r * (IX / 2);
         const double *a = rows + r * kRowStride + 2 * ip;
@@ -178,19 +178,18 @@ __global__ __launch_bounds__(kThreads) void spec2grid_kernel(const double *__res
 // grid -> spec.  prescale: 0 none, 1 multiply rows by cosgr, 2 by cosgr2 (spectral.f90:229-243)
 // ------------------------------------------------------------------------------------------------
 template <Stage ST>
-__global__ __launch_bounds__(kThreads) void grid2spec_kernel(const double *__restrict__ src, double *__restrict__ dst,
-                                                             DeviceTables T, int prescale) {
+__device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, double *__restrict__ dst,
+                                               const DeviceTables &T, int prescale) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *rows = lds;                                    // R[48][97] while the FFT runs
     double *cbuf = lds;                                    // C[48][63] afterwards (aliases R)
     d2 *s = reinterpret_cast<d2 *>(lds + kCBufDoubles);    // output staging, 992 complex (aliases the tail of R)
     const int tid = threadIdx.x;
-    const size_t f = blockIdx.x;
     const int wave = wave_id(), lane = tid & 63;
 
     if (ST != Stage::LegendreOnly) {
         // ---- load grid rows (16 B per lane, coalesced) ----
-        const d2 *g = reinterpret_cast<const d2 *>(src) + f * (NGRID / 2);
+        const d2 *g = reinterpret_cast<const d2 *>(src);
         for (int idx = tid; idx < NGRID / 2; idx += kThreads) {
             const int r = idx / (IX / 2), ip = idx - r * (IX / 2);
             d2 v = g[idx];
@@ -246,7 +245,7 @@ __global__ __launch_bounds__(kThreads) void grid2spec_kernel(const double *__res
         }
         __syncthreads();
     } else {
-        const double *g = src + f * NFOUR;
+        const double *g = src;
         for (int idx = tid; idx < NFOUR; idx += kThreads) {
             const int r0 = idx / 62, r = idx - r0 * 62;
             cbuf[r0 * kCStride + (r == 0 ? 0 : (r == 1 ? 61 : r - 1))] = g[idx];
@@ -255,7 +254,7 @@ __global__ __launch_bounds__(kThreads) void grid2spec_kernel(const double *__res
     }
 
     if (ST == Stage::FourierOnly) {
-        double *g = dst + f * NFOUR;
+        double *g = dst;
         for (int idx = tid; idx < NFOUR; idx += kThreads) {
             const int r0 = idx / 62, r = idx - r0 * 62;
             g[idx] = (r == 1) ? 0.0 : cbuf[r0 * kCStride + (r == 0 ? 0 : r - 1)];  // fourier.f90:117
@@ -298,8 +297,37 @@ __global__ __launch_bounds__(kThreads) void grid2spec_kernel(const double *__res
         s[(n0 + 16) * MX + m] = d2{acc[1][0], acc[1][1]};
     }
     __syncthreads();
-    d2 *g = reinterpret_cast<d2 *>(dst) + f * NSPEC;
+    d2 *g = reinterpret_cast<d2 *>(dst);
     for (int idx = tid; idx < NSPEC; idx += kThreads) g[idx] = s[idx];
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels: contiguous batch (C ABI) and descriptor table (model step: one launch for all fields of all members)
+// ------------------------------------------------------------------------------------------------
+template <Stage ST>
+__global__ __launch_bounds__(kThreads) void spec2grid_kernel(const double *__restrict__ src, double *__restrict__ dst,
+                                                             DeviceTables T, int kcos) {
+    const size_t f = blockIdx.x;
+    constexpr size_t in = (ST == Stage::FourierOnly) ? NFOUR : 2 * NSPEC, out = (ST == Stage::LegendreOnly) ? NFOUR : NGRID;
+    spec2grid_body<ST>(src + f * in, dst + f * out, T, kcos);
+}
+
+template <Stage ST>
+__global__ __launch_bounds__(kThreads) void grid2spec_kernel(const double *__restrict__ src, double *__restrict__ dst,
+                                                             DeviceTables T, int prescale) {
+    const size_t f = blockIdx.x;
+    constexpr size_t in = (ST == Stage::LegendreOnly) ? NFOUR : NGRID, out = (ST == Stage::FourierOnly) ? NFOUR : 2 * NSPEC;
+    grid2spec_body<ST>(src + f * in, dst + f * out, T, prescale);
+}
+
+__global__ __launch_bounds__(kThreads) void spec2grid_table_kernel(const FieldDesc *__restrict__ table, DeviceTables T) {
+    const FieldDesc e = table[blockIdx.x];
+    spec2grid_body<Stage::Fused>(e.src, e.dst, T, e.flag);
+}
+
+__global__ __launch_bounds__(kThreads) void grid2spec_table_kernel(const FieldDesc *__restrict__ table, DeviceTables T) {
+    const FieldDesc e = table[blockIdx.x];
+    grid2spec_body<Stage::Fused>(e.src, e.dst, T, e.flag);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -325,6 +353,22 @@ static hipError_t launch_g2s(const double *src, double *dst, const DeviceTables 
     static hipError_t cfg = configure(&grid2spec_kernel<ST>);
     if (cfg != hipSuccess) return cfg;
     hipLaunchKernelGGL((grid2spec_kernel<ST>), dim3(nfields), dim3(kThreads), kLdsBytes, st, src, dst, T, prescale);
+    return hipGetLastError();
+}
+
+hipError_t run_spec2grid_table(const DeviceTables &T, const FieldDesc *table, int nfields, hipStream_t st) {
+    if (nfields == 0) return hipSuccess;
+    static hipError_t cfg = configure(&spec2grid_table_kernel);
+    if (cfg != hipSuccess) return cfg;
+    hipLaunchKernelGGL(spec2grid_table_kernel, dim3(nfields), dim3(kThreads), kLdsBytes, st, table, T);
+    return hipGetLastError();
+}
+
+hipError_t run_grid2spec_table(const DeviceTables &T, const FieldDesc *table, int nfields, hipStream_t st) {
+    if (nfields == 0) return hipSuccess;
+    static hipError_t cfg = configure(&grid2spec_table_kernel);
+    if (cfg != hipSuccess) return cfg;
+    hipLaunchKernelGGL(grid2spec_table_kernel, dim3(nfields), dim3(kThreads), kLdsBytes, st, table, T);
     return hipGetLastError();
 }
 
