@@ -149,6 +149,22 @@ int spd_model_step_dynamics(spd_model_handle m, int j1, int j2, double dt, int c
  * receive [nmembers][3][kx] (eddy KE of vor, of div, global-mean T).  Synchronises `stream`. */
 int spd_model_check(spd_model_handle m, int time_level, int32_t *error_codes_host, double *diag_host, void *stream);
 
+/* initialize_state (initialization.f90:13-91) for every member from the boundary fields stored beforehand with
+ * spd_model_set (orog, fmask_orig, alb0, veg_high, veg_low, stl12, snowd12, soil_wc_l1, soil_wc_l2, sst12,
+ * sea_ice_frac12 and optionally sst_anom, i.e. what pyspeedy/speedy.py:279-296 sets): land/sea preprocessing, spectrally
+ * truncated orography, resting reference atmosphere, coupler initialisation, forcing, first_step. */
+int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, int minute, void *stream);
+/* do_single_step (speedy.f90:20-74) `nsteps` times for all members: daily forcing, shortwave every third step, leapfrog
+ * step, date advance, land/sea coupling.  Stream-ordered, no synchronisation; returns SPD_E_ARG when the state was not
+ * initialised (the reference's error code -1).  spd_model_check runs the reference's per-step range check on demand. */
+int spd_model_step(spd_model_handle m, int nsteps, void *stream);
+int spd_model_current_step(spd_model_handle m);
+int spd_model_get_date(spd_model_handle m, int *ymdhm /* 5 ints */);
+/* declare a state loaded through spd_model_set (e.g. a restart) as initialised, with its step counter and date */
+int spd_model_mark_initialized(spd_model_handle m, int current_step, int year, int month, int day, int hour, int minute);
+/* registry scalars land_coupling_flag, sst_anomaly_coupling_flag, increase_co2 (model_state_def.py:305-418) */
+int spd_model_set_flags(spd_model_handle m, int land_coupling_flag, int sst_anomaly_coupling_flag, int increase_co2);
+
 #ifdef __cplusplus
 }
 #endif

@@ -132,6 +132,41 @@ def gen_steps():
     print("step.npz", sum(v.nbytes for v in d.values()) // 1024, "KiB raw")
 
 
+RUN_2D = ("land_temp", "sst_am", "stl_lm", "tice_om", "sst_om", "snowc", "alb_surface", "soil_avail_water", "phis0", "forog",
+          "fmask_land", "olr", "precnv", "hfluxn")
+
+
+def gen_run():
+    """run.npz: the reference model right after init (pyspeedy.Speedy.set_bc: rest atmosphere + first_step) and after 36
+    and 108 calls of step (1 and 3 simulated days from 1982-01-01, example_bc, zero SST anomaly) -- the same run the
+    reference's own test_speedy_run checks against its NetCDF fixtures."""
+    bc = np.load(os.path.join(GOLD, "example_bc.npz"))
+    m = R.RefModel()
+    m.set_bc(bc)
+    d = {}
+    spec = lambda n: (m.get(n)[..., 0] if n == "tr" else m.get(n))
+
+    def snap(tag):
+        for n in STEP_SPEC + ("phis",):
+            d[tag + n] = spec(n)
+        for n in RUN_2D:
+            R.SHAPES.setdefault(n, (np.float64, (IX, IL)))
+            d[tag + n] = m.get(n)
+        T = implicit_arrays(m)
+        d[tag + "tcorh"], d[tag + "qcorh"] = T["tcorh"], T["qcorh"]
+
+    snap("d0_")
+    for _ in range(36):
+        assert m.step() == 0
+    snap("d1_")
+    for _ in range(72):
+        assert m.step() == 0
+    snap("d3_")
+    np.savez_compressed(os.path.join(GOLD, "run.npz"), **d)
+    print("run.npz", sum(v.nbytes for v in d.values()) // 1024, "KiB raw")
+
+
 if __name__ == "__main__":
     gen_physics()
     gen_steps()
+    gen_run()

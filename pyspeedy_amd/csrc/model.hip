@@ -3,6 +3,7 @@
 // C ABI: the spd_model_* functions of include/pyspeedy_amd.h.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <string>
@@ -11,6 +12,7 @@
 #include "../../include/pyspeedy_amd.h"
 #include "context.hpp"
 #include "model.hpp"
+#include "surface.hpp"
 
 namespace spd {
 hipError_t run_spec2grid_table(const DeviceTables &T, const FieldDesc *table, int nfields, hipStream_t st);
@@ -22,6 +24,19 @@ hipError_t run_dyn_grid(const ModelPtrs &P, const DynDeviceTables &D, int M, hip
 hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const DynDeviceTables &D, int M, int j1, double dt,
                              double eps, hipStream_t s);
 hipError_t run_diagnostics(const ModelPtrs &P, const DeviceTables &T, int M, int tl, int *err, double *diag, hipStream_t s);
+hipError_t run_coupler(const SurfacePtrs &S, int M, const TimeInterp &w, int day, int land_coupling, int sst_anomaly,
+                       int anom_planes, hipStream_t s);
+hipError_t run_forcing(const SurfacePtrs &S, int M, const ZonalDevice &Z, double gamlat, double *corh_t, double *corh_q,
+                       hipStream_t s);
+hipError_t run_rest_state(const RestPtrs &R, int M, const RestConsts &c, hipStream_t s);
+hipError_t run_scale_orog(const double *orog, double *phi0, long n, hipStream_t s);
+hipError_t run_rest_surface(const double *phis0, double *forog, double *surf_ps, double *surf_q, const RestConsts &c, long n,
+                            hipStream_t s);
+hipError_t run_grid2spec(const DeviceTables &T, int stage, const double *src, double *dst, int prescale, int nfields,
+                         hipStream_t stream, int fpw);
+hipError_t run_spec2grid(const DeviceTables &T, int stage, const double *src, double *dst, int kcos, int nfields,
+                         hipStream_t stream, int fpw);
+hipError_t run_scale(const double *in, double *out, const double *table, double sign, int nfields, hipStream_t s);
 }  // namespace spd
 
 using namespace spd;
@@ -51,6 +66,16 @@ struct spd_model {
     double *d_diag = nullptr;
     double air_absortivity_co2 = 6.0;  // model_state_def.py:320 default
     // device copies of the dt-dependent tables (re-uploaded by set_time_step)
+    // surface / coupler state, calendar and run control (do_single_step, speedy.f90:20-74)
+    SurfacePtrs S{};
+    Calendar cal;
+    int current_step = 0;
+    bool initialized = false;
+    int land_coupling_flag = 1, sst_anomaly_flag = 1, increase_co2 = 0, anom_planes = 3;
+    double ablco2_ref = 6.0;
+    double *corh_t = nullptr, *corh_q = nullptr, *scratch_spec = nullptr;  // [M][NG], [M][NG], [2][M][992] complex
+    double *orog = nullptr, *phi0 = nullptr, *fmask_orig = nullptr, *veg_high = nullptr, *veg_low = nullptr,
+           *soil_wc_l1 = nullptr, *soil_wc_l2 = nullptr, *soil_wc_l3 = nullptr, *bmask_land = nullptr, *bmask_sea = nullptr;
     double *d_dmp1 = nullptr, *d_dmp1d = nullptr, *d_dmp1s = nullptr, *d_elz = nullptr, *d_xj = nullptr, *d_xc = nullptr,
            *d_xd = nullptr;
 };
@@ -202,6 +227,32 @@ int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
     PA_IN(tt_rsw, M * G3, "tt_rsw", G3);
     PA_IN(rad_tau2, M * 4 * G3, "rad_tau2", 4 * G3);
     PA_IN(rad_strat_corr, M * 2 * NG, "rad_strat_corr", 2 * NG);
+    // surface / coupler arrays under their registry names (model_state_def.py:250-410)
+    SurfacePtrs &SF = m->S;
+    const size_t G12 = static_cast<size_t>(12) * NG;
+    A(SF.stl12, M * G12, "stl12", G12); A(SF.snowd12, M * G12, "snowd12", G12); A(SF.soilw12, M * G12, "soilw12", G12);
+    A(SF.sst12, M * G12, "sst12", G12); A(SF.sea_ice_frac12, M * G12, "sea_ice_frac12", G12);
+    A(SF.sst_anom, M * 3 * NG, "sst_anom", 3 * NG);
+    A(m->soil_wc_l1, M * G12, "soil_wc_l1", G12); A(m->soil_wc_l2, M * G12, "soil_wc_l2", G12);
+    A(m->soil_wc_l3, M * G12, "soil_wc_l3", G12);
+#define S2(field) A(SF.field, M * NG, #field, NG)
+    S2(stlcl_obs); S2(snowdcl_obs); S2(soilwcl_obs); S2(stl_lm); S2(snow_depth); S2(cdland); S2(rhcapl);
+    S2(sstcl_ob); S2(sicecl_ob); S2(ticecl_ob); S2(sstan_ob); S2(sst_om); S2(tice_om); S2(sice_om); S2(sstan_am);
+    S2(sice_am); S2(tice_am); S2(ssti_om); S2(cdsea); S2(cdice); S2(rhcaps); S2(rhcapi); S2(hfseacl); S2(fmask_sea);
+#undef S2
+    A(tmp, M * NG, "alb0", NG); SF.alb0 = tmp;
+    A(m->orog, M * NG, "orog", NG); A(m->phi0, M * NG, "phi0", NG); A(m->fmask_orig, M * NG, "fmask_orig", NG);
+    A(m->veg_high, M * NG, "veg_high", NG); A(m->veg_low, M * NG, "veg_low", NG);
+    A(m->bmask_land, M * NG, "bmask_land", NG); A(m->bmask_sea, M * NG, "bmask_sea", NG);
+    A(m->corh_t, M * NG, nullptr, 0); A(m->corh_q, M * NG, nullptr, 0); A(m->scratch_spec, 2 * M * S, nullptr, 0);
+    SF.land_temp = const_cast<double *>(pa.land_temp); SF.soil_avail_water = const_cast<double *>(pa.soil_avail_water);
+    SF.sst_am = const_cast<double *>(pa.sst_am); SF.hfluxn = pa.hfluxn; SF.shf = pa.shf; SF.evap = pa.evap; SF.ssrd = pa.ssrd;
+    SF.flux_solar_in = const_cast<double *>(pa.flux_solar_in); SF.flux_ozone_upper = const_cast<double *>(pa.flux_ozone_upper);
+    SF.flux_ozone_lower = const_cast<double *>(pa.flux_ozone_lower); SF.zenit_correction = const_cast<double *>(pa.zenit_correction);
+    SF.stratospheric_correction = const_cast<double *>(pa.stratospheric_correction);
+    SF.snowc = const_cast<double *>(pa.snowc); SF.alb_land = const_cast<double *>(pa.alb_land);
+    SF.alb_sea = const_cast<double *>(pa.alb_sea); SF.alb_surface = const_cast<double *>(pa.alb_surface);
+    SF.fmask_land = pa.fmask_land; SF.phis0 = pa.phis0;
 #undef PA3
 #undef PA2
 #undef PA_IN
@@ -357,6 +408,174 @@ int spd_model_check(spd_model_handle m, int time_level, int32_t *error_codes_hos
     M_HIP(hipMemcpyAsync(error_codes_host, m->d_err, sizeof(int) * m->M, hipMemcpyDeviceToHost, s));
     if (diag_host) M_HIP(hipMemcpyAsync(diag_host, m->d_diag, sizeof(double) * m->M * 24, hipMemcpyDeviceToHost, s));
     M_HIP(hipStreamSynchronize(s));
+    return SPD_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// run control: initialize_state (initialization.f90:13-91) and do_single_step (speedy.f90:20-74)
+// ---------------------------------------------------------------------------------------------------------------
+static int set_forcing(spd_model *m, int imode, hipStream_t s) {  // forcing.f90:15-102
+    const int M = m->M;
+    if (imode == 0) m->ablco2_ref = m->air_absortivity_co2;  // radset / forog are handled at initialisation
+    const ZonalForcing z = zonal_average_fields(m->ctx->host, m->cal.tyear);
+    ZonalDevice zd;
+    for (int j = 0; j < 48; ++j) {
+        zd.v[0][j] = z.flux_solar_in[j]; zd.v[1][j] = z.flux_ozone_upper[j]; zd.v[2][j] = z.flux_ozone_lower[j];
+        zd.v[3][j] = z.zenit_correction[j]; zd.v[4][j] = z.stratospheric_correction[j];
+    }
+    if (m->increase_co2) {
+        const double del_co2 = 0.005f;
+        m->air_absortivity_co2 = m->ablco2_ref * std::exp(del_co2 * (m->cal.year + m->cal.tyear - 1950));
+    }
+    const double gamlat = static_cast<double>(6.0f) / (1000.f * static_cast<double>(9.81f));  // setgam, forcing.f90:105-117
+    hipError_t e = run_forcing(m->S, M, zd, gamlat, m->corh_t, m->corh_q, s);
+    if (e == hipSuccess) e = run_grid2spec(m->ctx->dev, 0, m->corh_t, m->P.tcorh, 0, M, s, 0);
+    if (e == hipSuccess) e = run_grid2spec(m->ctx->dev, 0, m->corh_q, m->P.qcorh, 0, M, s, 0);
+    if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("set_forcing: ") + hipGetErrorString(e));
+    return SPD_OK;
+}
+
+static int couple(spd_model *m, int day, hipStream_t s) {  // couple_sea_land, coupler.f90:35-48
+    const TimeInterp w = time_interp(m->cal);
+    if (m->sst_anomaly_flag && (w.a0 < 0 || w.a1 < 0 || w.a0 >= m->anom_planes || w.a1 >= m->anom_planes))
+        return m_fail(SPD_E_ARG, "SST anomaly planes do not cover the simulated period (speedy.py:338-372)");
+    hipError_t e = run_coupler(m->S, m->M, w, day, m->land_coupling_flag, m->sst_anomaly_flag, m->anom_planes, s);
+    if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("couple_sea_land: ") + hipGetErrorString(e));
+    return SPD_OK;
+}
+
+// initialize_state for every member from the boundary fields previously stored with spd_model_set:
+// orog, fmask_orig, alb0, veg_high, veg_low, stl12, snowd12, soil_wc_l1, soil_wc_l2, sst12, sea_ice_frac12 [, sst_anom].
+int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, int minute, void *stream) {
+    if (!m) return m_fail(SPD_E_ARG, "spd_model_init: null model");
+    if (month < 1 || month > 12 || day < 1 || day > 31) return m_fail(SPD_E_ARG, "spd_model_init: bad start date");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int M = m->M;
+    const DeviceTables &T = m->ctx->dev;
+    M_HIP(hipSetDevice(m->ctx->device));
+    M_HIP(hipStreamSynchronize(s));
+    m->cal.set(year, month, day, hour, minute);
+    m->current_step = 0;
+    // ---- land_model_init / sea_model_init on the host, member by member (runs once)
+    const size_t G12 = static_cast<size_t>(12) * NG;
+    auto down = [&](const double *dev, size_t n, int i, std::vector<double> &v) {
+        v.resize(n);
+        return hipMemcpy(v.data(), dev + static_cast<size_t>(i) * n, n * sizeof(double), hipMemcpyDeviceToHost);
+    };
+    auto up = [&](double *dev, size_t n, int i, const std::vector<double> &v) {
+        return hipMemcpy(dev + static_cast<size_t>(i) * n, v.data(), n * sizeof(double), hipMemcpyHostToDevice);
+    };
+    for (int i = 0; i < M; ++i) {
+        SurfaceFields sf;
+        M_HIP(down(m->fmask_orig, NG, i, sf.fmask_orig)); M_HIP(down(m->S.alb0, NG, i, sf.alb0));
+        M_HIP(down(m->veg_high, NG, i, sf.veg_high)); M_HIP(down(m->veg_low, NG, i, sf.veg_low));
+        M_HIP(down(m->S.stl12, G12, i, sf.stl12)); M_HIP(down(m->S.snowd12, G12, i, sf.snowd12));
+        M_HIP(down(m->soil_wc_l1, G12, i, sf.soil_wc_l1)); M_HIP(down(m->soil_wc_l2, G12, i, sf.soil_wc_l2));
+        M_HIP(down(m->S.sst12, G12, i, sf.sst12)); M_HIP(down(m->S.sea_ice_frac12, G12, i, sf.sea_ice_frac12));
+        M_HIP(down(m->S.sst_anom, static_cast<size_t>(m->anom_planes) * NG, i, sf.sst_anom));
+        land_sea_init(m->ctx->host, sf);
+        M_HIP(up(const_cast<double *>(m->pa.fmask_land), NG, i, sf.fmask_land)); M_HIP(up(m->bmask_land, NG, i, sf.bmask_land));
+        M_HIP(up(m->S.fmask_sea, NG, i, sf.fmask_sea)); M_HIP(up(m->bmask_sea, NG, i, sf.bmask_sea));
+        M_HIP(up(m->S.stl12, G12, i, sf.stl12)); M_HIP(up(m->S.snowd12, G12, i, sf.snowd12));
+        M_HIP(up(m->S.soilw12, G12, i, sf.soilw12)); M_HIP(up(m->S.sst12, G12, i, sf.sst12));
+        M_HIP(up(m->S.sea_ice_frac12, G12, i, sf.sea_ice_frac12));
+        M_HIP(up(m->S.sst_anom, static_cast<size_t>(m->anom_planes) * NG, i, sf.sst_anom));
+        M_HIP(up(m->S.rhcapl, NG, i, sf.rhcapl)); M_HIP(up(m->S.cdland, NG, i, sf.cdland));
+        M_HIP(up(m->S.rhcaps, NG, i, sf.rhcaps)); M_HIP(up(m->S.rhcapi, NG, i, sf.rhcapi));
+        M_HIP(up(m->S.cdsea, NG, i, sf.cdsea)); M_HIP(up(m->S.cdice, NG, i, sf.cdice));
+    }
+    // ---- initialize_boundaries (boundaries.f90:22-37): phi0 = g * orog, phis0 = spectrally truncated phi0
+    double *phis0 = const_cast<double *>(m->pa.phis0);
+    hipError_t e = run_scale_orog(m->orog, m->phi0, static_cast<long>(M) * NG, s);
+    if (e == hipSuccess) e = run_grid2spec(T, 0, m->phi0, m->scratch_spec, 0, M, s, 0);
+    if (e == hipSuccess) e = run_scale(m->scratch_spec, m->scratch_spec, T.trfilt, 1.0, M, s);
+    if (e == hipSuccess) e = run_spec2grid(T, 0, m->scratch_spec, phis0, 1, M, s, 0);
+    // ---- initialize_from_rest_state (prognostics.f90:29-120)
+    RestConsts rc{};
+    const DynHostTables &dh = *m->dynh;
+    rc.gam1 = static_cast<double>(6.0f) / (1000.0f * static_cast<double>(9.81f));
+    rc.tref = 288.0f;
+    rc.ttop = 216.0f;
+    rc.sqrt2 = static_cast<double>(std::sqrt(2.0f));
+    {
+        const double rgam = phc::rgas * rc.gam1, qexp = static_cast<double>(7.5f) / static_cast<double>(2.5f);
+        for (int k = 0; k < 8; ++k) {
+            rc.fsg_rgam[k] = std::pow(m->ctx->host.fsg[k], rgam);
+            rc.fsg_qexp[k] = std::pow(m->ctx->host.fsg[k], qexp);
+        }
+    }
+    (void)dh;
+    if (e == hipSuccess) e = run_grid2spec(T, 0, phis0, m->P.phis, 0, M, s, 0);
+    if (e == hipSuccess)
+        e = run_rest_surface(phis0, const_cast<double *>(m->pa.forog), m->corh_t, m->corh_q, rc, static_cast<long>(M) * NG, s);
+    if (e == hipSuccess) e = run_grid2spec(T, 0, m->corh_t, m->scratch_spec, 0, M, s, 0);                       // ln ps
+    if (e == hipSuccess) e = run_grid2spec(T, 0, m->corh_q, m->scratch_spec + static_cast<size_t>(M) * NSPEC * C, 0, M, s, 0);  // q_sfc
+    if (e == hipSuccess) {
+        M_HIP(hipMemsetAsync(m->P.vor, 0, static_cast<size_t>(M) * 16 * NSPEC * C * sizeof(double), s));
+        M_HIP(hipMemsetAsync(m->P.div, 0, static_cast<size_t>(M) * 16 * NSPEC * C * sizeof(double), s));
+        M_HIP(hipMemsetAsync(m->P.t, 0, static_cast<size_t>(M) * 16 * NSPEC * C * sizeof(double), s));
+        M_HIP(hipMemsetAsync(m->P.tr, 0, static_cast<size_t>(M) * 16 * NSPEC * C * sizeof(double), s));
+        M_HIP(hipMemsetAsync(m->P.ps, 0, static_cast<size_t>(M) * 2 * NSPEC * C * sizeof(double), s));
+        RestPtrs R{m->P.vor, m->P.div, m->P.t, m->P.tr, m->P.ps, m->P.phis, m->scratch_spec,
+                   m->scratch_spec + static_cast<size_t>(M) * NSPEC * C, T.trfilt};
+        e = run_rest_state(R, M, rc, s);
+    }
+    if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_init: ") + hipGetErrorString(e));
+    // ---- initialize_coupler (day 0), set_forcing(imode = 0), first_step (time_stepping.f90:13-27)
+    if (int rc2 = couple(m, 0, s)) return rc2;
+    if (int rc2 = set_forcing(m, 0, s)) return rc2;
+    const double delt = 86400.0 / 36;
+    int rc2 = spd_model_set_time_step(m, 0.5 * delt);
+    if (rc2 == SPD_OK) rc2 = spd_model_step_dynamics(m, 1, 1, 0.5 * delt, 1, stream);
+    if (rc2 == SPD_OK) rc2 = spd_model_set_time_step(m, delt);
+    if (rc2 == SPD_OK) rc2 = spd_model_step_dynamics(m, 1, 2, delt, 1, stream);
+    if (rc2 == SPD_OK) rc2 = spd_model_set_time_step(m, 2 * delt);
+    if (rc2 != SPD_OK) return rc2;
+    m->initialized = true;
+    return SPD_OK;
+}
+
+// do_single_step (speedy.f90:20-74) `nsteps` times for all members.  Nothing synchronises; the range check of
+// diagnostics.f90 is available separately through spd_model_check (the reference runs it after every step).
+int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
+    if (!m) return m_fail(SPD_E_ARG, "spd_model_step: null model");
+    if (!m->initialized) return m_fail(SPD_E_ARG, "spd_model_step: model state not initialized (error code -1 of the reference)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const double delt = 86400.0 / 36;
+    for (int it = 0; it < nsteps; ++it) {
+        if (m->current_step % 36 == 0)
+            if (int rc = set_forcing(m, 1, s)) return rc;
+        const int sw = (m->current_step % 3 == 0) ? 1 : 0;
+        if (int rc = spd_model_step_dynamics(m, 2, 2, 2 * delt, sw, stream)) return rc;
+        m->current_step += 1;
+        m->cal.advance();
+        if (int rc = couple(m, 1 + m->current_step / 36, s)) return rc;
+    }
+    return SPD_OK;
+}
+
+int spd_model_current_step(spd_model_handle m) { return m ? m->current_step : SPD_E_ARG; }
+
+int spd_model_mark_initialized(spd_model_handle m, int current_step, int year, int month, int day, int hour, int minute) {
+    if (!m) return m_fail(SPD_E_ARG, "spd_model_mark_initialized: null model");
+    m->cal.set(year, month, day, hour, minute);
+    m->current_step = current_step;
+    m->initialized = true;
+    return SPD_OK;
+}
+
+int spd_model_get_date(spd_model_handle m, int *ymdhm) {
+    if (!m || !ymdhm) return m_fail(SPD_E_ARG, "spd_model_get_date: null argument");
+    ymdhm[0] = m->cal.year; ymdhm[1] = m->cal.month; ymdhm[2] = m->cal.day; ymdhm[3] = m->cal.hour; ymdhm[4] = m->cal.minute;
+    return SPD_OK;
+}
+
+int spd_model_set_flags(spd_model_handle m, int land_coupling_flag, int sst_anomaly_coupling_flag, int increase_co2) {
+    if (!m) return m_fail(SPD_E_ARG, "spd_model_set_flags: null model");
+    m->land_coupling_flag = land_coupling_flag ? 1 : 0;
+    m->sst_anomaly_flag = sst_anomaly_coupling_flag ? 1 : 0;
+    m->increase_co2 = increase_co2 ? 1 : 0;
     return SPD_OK;
 }
 

@@ -27,7 +27,21 @@ for _n in ("fmask_land", "phis0", "forog", "sst_am", "alb_land", "alb_sea", "sno
 for _n in ("slru", "ustr", "vstr", "shf", "evap", "hfluxn"):
     SHAPES[_n] = (_F, (96, 48, 3))
 
+for _n in ("stl12", "snowd12", "soilw12", "sst12", "sea_ice_frac12", "soil_wc_l1", "soil_wc_l2", "soil_wc_l3"):
+    SHAPES[_n] = (_F, (96, 48, 12))
+SHAPES["sst_anom"] = (_F, (96, 48, 3))
+for _n in ("stlcl_obs", "snowdcl_obs", "soilwcl_obs", "stl_lm", "snow_depth", "cdland", "rhcapl", "sstcl_ob", "sicecl_ob",
+           "ticecl_ob", "sstan_ob", "sst_om", "tice_om", "sice_om", "sstan_am", "sice_am", "tice_am", "ssti_om", "cdsea",
+           "cdice", "rhcaps", "rhcapi", "hfseacl", "fmask_sea", "alb0", "orog", "phi0", "fmask_orig", "veg_high", "veg_low",
+           "bmask_land", "bmask_sea"):
+    SHAPES[_n] = (_F, (96, 48))
+
 DELT = 86400.0 / 36  # params.f90:33
+
+# boundary-condition file variable -> registry variable (pyspeedy/speedy.py:279-296)
+BC_MAP = (("orog", "orog"), ("fmask_orig", "lsm"), ("alb0", "alb"), ("veg_high", "vegh"), ("veg_low", "vegl"),
+          ("stl12", "stl"), ("snowd12", "snowd"), ("soil_wc_l1", "swl1"), ("soil_wc_l2", "swl2"), ("soil_wc_l3", "swl3"),
+          ("sst12", "sst"), ("sea_ice_frac12", "icec"))
 
 
 class EnsembleModel:
@@ -70,6 +84,35 @@ class EnsembleModel:
 
     def set_co2(self, value):
         check(self._lib.spd_model_set_co2(self._m, float(value)), "spd_model_set_co2")
+
+    # ---- lifecycle (pyspeedy/speedy.py:217-301, 375-405) ----------------------------------------------------
+    def set_bc(self, bc, start_date=(1982, 1, 1, 0, 0), member=-1):
+        """Load the 12 boundary fields (mapping like example_bc.nc, dims (lon, lat[, month])) and run the reference's
+        `init`: land/sea preprocessing, rest atmosphere, coupler, forcing, first_step.  Zero SST anomaly unless
+        `sst_anom` was set before."""
+        for state_name, bc_name in BC_MAP:
+            self.set(state_name, np.asarray(bc[bc_name], dtype=np.float64), member)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(self._lib.spd_model_init(self._m, *[int(v) for v in start_date], stream), "spd_model_init")
+
+    def run(self, nsteps):
+        """`nsteps` model steps (40 simulated minutes each) for every member; asynchronous."""
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(self._lib.spd_model_step(self._m, int(nsteps), stream), "spd_model_step")
+
+    @property
+    def current_step(self):
+        return int(self._lib.spd_model_current_step(self._m))
+
+    @property
+    def current_date(self):
+        buf = (C.c_int * 5)()
+        check(self._lib.spd_model_get_date(self._m, buf), "spd_model_get_date")
+        return tuple(buf)
+
+    def set_flags(self, land_coupling_flag=True, sst_anomaly_coupling_flag=True, increase_co2=False):
+        check(self._lib.spd_model_set_flags(self._m, int(land_coupling_flag), int(sst_anomaly_coupling_flag),
+                                            int(increase_co2)), "spd_model_set_flags")
 
     # ---- time stepping -------------------------------------------------------------------------------------
     def set_time_step(self, dt):
