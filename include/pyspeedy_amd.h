@@ -162,6 +162,10 @@ int spd_model_current_step(spd_model_handle m);
 int spd_model_get_date(spd_model_handle m, int *ymdhm /* 5 ints */);
 /* declare a state loaded through spd_model_set (e.g. a restart) as initialised, with its step counter and date */
 int spd_model_mark_initialized(spd_model_handle m, int current_step, int year, int month, int day, int hour, int minute);
+/* measurement hook: bracket the dominant kernel of every step (the 91*M-field spectral->grid launch) with HIP events on the
+ * launch stream; _read synchronises them and returns the mean launch time in ms */
+int spd_model_profile(spd_model_handle m, int enable);
+int spd_model_profile_read(spd_model_handle m, double *mean_ms, int *launches, int *fields_per_launch);
 /* registry scalars land_coupling_flag, sst_anomaly_coupling_flag, increase_co2 (model_state_def.py:305-418) */
 int spd_model_set_flags(spd_model_handle m, int land_coupling_flag, int sst_anomaly_coupling_flag, int increase_co2);
 

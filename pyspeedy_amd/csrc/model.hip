@@ -7,6 +7,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/pyspeedy_amd.h"
@@ -76,6 +77,10 @@ struct spd_model {
     double *corh_t = nullptr, *corh_q = nullptr, *scratch_spec = nullptr;  // [M][NG], [M][NG], [2][M][992] complex
     double *orog = nullptr, *phi0 = nullptr, *fmask_orig = nullptr, *veg_high = nullptr, *veg_low = nullptr,
            *soil_wc_l1 = nullptr, *soil_wc_l2 = nullptr, *soil_wc_l3 = nullptr, *bmask_land = nullptr, *bmask_sea = nullptr;
+    // optional profiling of the dominant kernel (the spec2grid table launch): HIP events on the launch stream
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    size_t prof_used = 0;
     double *d_dmp1 = nullptr, *d_dmp1d = nullptr, *d_dmp1s = nullptr, *d_elz = nullptr, *d_xj = nullptr, *d_xc = nullptr,
            *d_xd = nullptr;
 };
@@ -302,6 +307,10 @@ int spd_model_destroy(spd_model_handle m) {
     if (!m) return SPD_OK;
     (void)hipSetDevice(m->ctx->device);
     for (void *p : m->allocs) (void)hipFree(p);
+    for (auto &pr : m->prof_events) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
     delete m->dynh;
     delete m;
     return SPD_OK;
@@ -383,7 +392,21 @@ int spd_model_step_dynamics(spd_model_handle m, int j1, int j2, double dt, int c
     const int M = m->M;
     hipError_t e = run_model_uvgrad(m->P, T, M, j2 - 1, s);
     if (e == hipSuccess) e = run_geopotential(m->P, m->D, M, 0, s);                       // tendencies.f90:229
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (m->profile && e == hipSuccess) {
+        if (m->prof_used == m->prof_events.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) m->prof_events.emplace_back(a, b);
+        }
+        if (m->prof_used < m->prof_events.size()) {
+            ev0 = m->prof_events[m->prof_used].first;
+            ev1 = m->prof_events[m->prof_used].second;
+            ++m->prof_used;
+            (void)hipEventRecord(ev0, s);
+        }
+    }
     if (e == hipSuccess) e = run_spec2grid_table(T, m->inv_table[j2 - 1], 91 * M, s);     // :109-146, physics.f90:89-101
+    if (ev1) (void)hipEventRecord(ev1, s);
     if (e == hipSuccess) e = run_dyn_grid(m->P, m->D, M, s);                              // :151-224
     if (e == hipSuccess) {
         m->pa.compute_shortwave = compute_shortwave ? 1 : 0;
@@ -556,6 +579,30 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
 }
 
 int spd_model_current_step(spd_model_handle m) { return m ? m->current_step : SPD_E_ARG; }
+
+// Profiling of the dominant kernel: when enabled, every step brackets its 91*M-field spec2grid launch with HIP events
+// on the launch stream.  spd_model_profile_read synchronises those events and returns the mean launch time.
+int spd_model_profile(spd_model_handle m, int enable) {
+    if (!m) return m_fail(SPD_E_ARG, "spd_model_profile: null model");
+    m->profile = enable != 0;
+    m->prof_used = 0;
+    return SPD_OK;
+}
+
+int spd_model_profile_read(spd_model_handle m, double *mean_ms, int *launches, int *fields_per_launch) {
+    if (!m || !mean_ms || !launches || !fields_per_launch) return m_fail(SPD_E_ARG, "spd_model_profile_read: null argument");
+    double sum = 0.0;
+    for (size_t i = 0; i < m->prof_used; ++i) {
+        float ms = 0.f;
+        M_HIP(hipEventSynchronize(m->prof_events[i].second));
+        M_HIP(hipEventElapsedTime(&ms, m->prof_events[i].first, m->prof_events[i].second));
+        sum += ms;
+    }
+    *launches = static_cast<int>(m->prof_used);
+    *mean_ms = m->prof_used ? sum / m->prof_used : 0.0;
+    *fields_per_launch = 91 * m->M;
+    return SPD_OK;
+}
 
 int spd_model_mark_initialized(spd_model_handle m, int current_step, int year, int month, int day, int hour, int minute) {
     if (!m) return m_fail(SPD_E_ARG, "spd_model_mark_initialized: null model");

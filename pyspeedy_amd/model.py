@@ -110,6 +110,15 @@ class EnsembleModel:
         check(self._lib.spd_model_get_date(self._m, buf), "spd_model_get_date")
         return tuple(buf)
 
+    def profile(self, enable=True):
+        check(self._lib.spd_model_profile(self._m, int(bool(enable))), "spd_model_profile")
+
+    def profile_read(self):
+        """(mean launch time in ms, number of launches, fields per launch) of the spectral->grid kernel since profile(True)."""
+        ms, n, f = C.c_double(), C.c_int(), C.c_int()
+        check(self._lib.spd_model_profile_read(self._m, C.byref(ms), C.byref(n), C.byref(f)), "spd_model_profile_read")
+        return ms.value, n.value, f.value
+
     def set_flags(self, land_coupling_flag=True, sst_anomaly_coupling_flag=True, increase_co2=False):
         check(self._lib.spd_model_set_flags(self._m, int(land_coupling_flag), int(sst_anomaly_coupling_flag),
                                             int(increase_co2)), "spd_model_set_flags")
