@@ -303,9 +303,21 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         }
     }
 
+    // The diffusion tendencies join ttend / qtend now (the reference adds them last, physics.f90:229-231; the sums differ
+    // from its order by rounding only) so that ttv / qtv do not stay live through the radiation.  qtend is final above the
+    // lowest level: store it.
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        ttend[k] = ttend[k] + ttv[k];
+        qtend[k] = qtend[k] + qtv[k];
+    }
+#pragma unroll
+    for (int k = 0; k < KX - 1; ++k) a.qtend[o3 + NG * k] = qtend[k];
+    const double qtend_kx = qtend[KX - 1];
+
     // ------------------------------------------------------------------ clouds + shortwave (every nstrad-th step)
-    double tau[KX][4];   // rad_tau2(k, band)
-    double tt_rsw[KX];
+    // rad_tau2(k, band) lives in HBM between shortwave steps (physics.f90 keeps it in the model state); the longwave sweeps
+    // below re-load one band at a time instead of holding all 32 transmissivities in registers.
     double ssrd, strat1, strat2;
     int icltop = 0;
     double cloudc = 0.0, clstr = 0.0;
@@ -373,6 +385,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
 
         const double solar = a.flux_solar_in[o2];
         double tsr = solar;
+        double tt_rsw[KX];
         double f1 = solar * fband1, f2 = solar * fband2;
         tt_rsw[0] = f1;
         f1 = tsw1[0] * (f1 - a.flux_ozone_upper[o2] * psa);
@@ -411,35 +424,38 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         for (int k = 0; k < KX; ++k) {
             tt_rsw[k] = tt_rsw[k] * rps * T.grdscp[k];
             a.tt_rsw[o3 + NG * k] = tt_rsw[k];
+            ttend[k] = ttend[k] + tt_rsw[k];
         }
 
         // longwave transmissivities, shortwave_radiation.f90:170-208
         const double co2 = a.air_absortivity_co2;
-        tau[0][0] = exp(-psa * T.dhs[0] * ablwin);
-        tau[0][1] = exp(-psa * T.dhs[0] * co2);
-        tau[0][2] = 1.0;
-        tau[0][3] = 1.0;
+        const size_t NGs = static_cast<size_t>(NG);
+        a.rad_tau2[ot + NGs * (0 + KX * 0)] = exp(-psa * T.dhs[0] * ablwin);
+        a.rad_tau2[ot + NGs * (0 + KX * 1)] = exp(-psa * T.dhs[0] * co2);
+        a.rad_tau2[ot + NGs * (0 + KX * 2)] = 1.0;
+        a.rad_tau2[ot + NGs * (0 + KX * 3)] = 1.0;
         acloud = cloudc * ablcl2;
 #pragma unroll
         for (int k = 2; k <= KX; ++k) {
+            double t0, t1, t2, t3;
             if (k == 2 || k == KX) {
-                tau[k - 1][0] = exp(-psa * T.dhs[k - 1] * ablwin);
-                tau[k - 1][1] = exp(-psa * T.dhs[k - 1] * co2);
-                tau[k - 1][2] = exp(-psa * T.dhs[k - 1] * ablwv1 * qa[k - 1]);
-                tau[k - 1][3] = exp(-psa * T.dhs[k - 1] * ablwv2 * qa[k - 1]);
+                t0 = exp(-psa * T.dhs[k - 1] * ablwin);
+                t1 = exp(-psa * T.dhs[k - 1] * co2);
+                t2 = exp(-psa * T.dhs[k - 1] * ablwv1 * qa[k - 1]);
+                t3 = exp(-psa * T.dhs[k - 1] * ablwv2 * qa[k - 1]);
             } else {
                 const double deltap = psa * T.dhs[k - 1];
                 const double acloud1 = (k < icltop) ? acloud : ablcl1 * cloudc;
-                tau[k - 1][0] = exp(-deltap * (ablwin + acloud1));
-                tau[k - 1][1] = exp(-deltap * co2);
-                tau[k - 1][2] = exp(-deltap * dmax(ablwv1 * qa[k - 1], acloud));
-                tau[k - 1][3] = exp(-deltap * dmax(ablwv2 * qa[k - 1], acloud));
+                t0 = exp(-deltap * (ablwin + acloud1));
+                t1 = exp(-deltap * co2);
+                t2 = exp(-deltap * dmax(ablwv1 * qa[k - 1], acloud));
+                t3 = exp(-deltap * dmax(ablwv2 * qa[k - 1], acloud));
             }
+            a.rad_tau2[ot + NGs * (k - 1 + KX * 0)] = t0;
+            a.rad_tau2[ot + NGs * (k - 1 + KX * 1)] = t1;
+            a.rad_tau2[ot + NGs * (k - 1 + KX * 2)] = t2;
+            a.rad_tau2[ot + NGs * (k - 1 + KX * 3)] = t3;
         }
-#pragma unroll
-        for (int k = 0; k < KX; ++k)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) a.rad_tau2[ot + static_cast<size_t>(NG) * (k + KX * b)] = tau[k][b];
         const double eps1 = EPSLW / (T.dhs[0] + T.dhs[1]);
         strat1 = a.stratospheric_correction[o2] * psa;
         strat2 = eps1 * psa;
@@ -447,11 +463,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         a.rad_strat_corr[oc + NG] = strat2;
     } else {
 #pragma unroll
-        for (int k = 0; k < KX; ++k) {
-            tt_rsw[k] = a.tt_rsw[o3 + NG * k];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) tau[k][b] = a.rad_tau2[ot + static_cast<size_t>(NG) * (k + KX * b)];
-        }
+        for (int k = 0; k < KX; ++k) ttend[k] = ttend[k] + a.tt_rsw[o3 + NG * k];
         ssrd = a.ssrd[o2];
         strat1 = a.rad_strat_corr[oc];
         strat2 = a.rad_strat_corr[oc + NG];
@@ -487,24 +499,33 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
             int it = static_cast<int>(round(ta[k]));
             itab[k] = (it < 100 ? 100 : (it > 400 ? 400 : it)) - 100;
         }
+        const double *tau_col = a.rad_tau2 + ot;  // tau_col[NG * (k + KX * b)]
+        const size_t NGt = static_cast<size_t>(NG);
+        // Stratosphere (bands 1-2, :73-79) first for both bands, as the reference does: dfabs(1) sums in that order.
+        double tau0[2];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {  // stratosphere
-            const double emis = 1.0f - tau[0][b];
+        for (int b = 0; b < 2; ++b) {
+            tau0[b] = tau_col[NGt * (KX * b)];
+            const double emis = 1.0f - tau0[b];
             const double brad = T.fband[itab[0] + 301 * b] * (st4a[0][0] + emis * st4a[0][1]);
             flux[b] = emis * brad;
             dfabs[0] = dfabs[0] - flux[b];
         }
         flux[2] = flux[3] = 0.0;
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < 4; ++b) {
+            double tb[KX];
+#pragma unroll
+            for (int k = 2; k <= KX; ++k) tb[k - 1] = tau_col[NGt * (k - 1 + KX * b)];
 #pragma unroll
             for (int k = 2; k <= KX; ++k) {
-                const double emis = 1.0f - tau[k - 1][b];
+                const double emis = 1.0f - tb[k - 1];
                 const double brad = T.fband[itab[k - 1] + 301 * b] * (st4a[k - 1][0] + emis * st4a[k - 1][1]);
                 dfabs[k - 1] = dfabs[k - 1] + flux[b];
-                flux[b] = tau[k - 1][b] * flux[b] + emis * brad;
+                flux[b] = tb[k - 1] * flux[b] + emis * brad;
                 dfabs[k - 1] = dfabs[k - 1] - flux[b];
             }
+        }
         double slrd = 0.0;
 #pragma unroll
         for (int b = 0; b < 4; ++b) slrd = slrd + EMISFC * flux[b];
@@ -599,21 +620,25 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         for (int b = 0; b < 4; ++b) flux[b] = fband_at(T.fband, tsfc, b) * slru3 + refsfc * flux[b];
         dfabs[KX - 1] = dfabs[KX - 1] + EPSLW * slru3;
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < 4; ++b) {
+            double tb[KX];
+#pragma unroll
+            for (int k = 2; k <= KX; ++k) tb[k - 1] = tau_col[NGt * (k - 1 + KX * b)];
 #pragma unroll
             for (int k = KX; k >= 2; --k) {
-                const double emis = 1.0f - tau[k - 1][b];
+                const double emis = 1.0f - tb[k - 1];
                 const double brad = T.fband[itab[k - 1] + 301 * b] * (st4a[k - 1][0] - emis * st4a[k - 1][1]);
                 dfabs[k - 1] = dfabs[k - 1] + flux[b];
-                flux[b] = tau[k - 1][b] * flux[b] + emis * brad;
+                flux[b] = tb[k - 1] * flux[b] + emis * brad;
                 dfabs[k - 1] = dfabs[k - 1] - flux[b];
             }
+        }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const double emis = 1.0f - tau[0][b];
+            const double emis = 1.0f - tau0[b];
             const double brad = T.fband[itab[0] + 301 * b] * (st4a[0][0] - emis * st4a[0][1]);
             dfabs[0] = dfabs[0] + flux[b];
-            flux[b] = tau[0][b] * flux[b] + emis * brad;
+            flux[b] = tau0[b] * flux[b] + emis * brad;
             dfabs[0] = dfabs[0] - flux[b];
         }
         const double corlw1 = T.dhs[0] * strat2 * st4a[0][0] + strat1;
@@ -628,21 +653,18 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         for (int b = 0; b < 4; ++b) a.rad_flux[of4 + static_cast<size_t>(NG) * b] = flux[b];
         // physics.f90:207-211: ttend = ttend + tt_rsw + tt_rlw
 #pragma unroll
-        for (int k = 0; k < KX; ++k) ttend[k] = ttend[k] + tt_rsw[k] + dfabs[k] * rps * T.grdscp[k];
+        for (int k = 0; k < KX; ++k) ttend[k] = ttend[k] + dfabs[k] * rps * T.grdscp[k];
 
         // physics.f90:223-231: surface-flux tendencies at the lowest level, then accumulate
         const double ut_kx = 0.0 + ustr3 * rps * T.grdsig[KX - 1];
         const double vt_kx = 0.0 + vstr3 * rps * T.grdsig[KX - 1];
-        ttv[KX - 1] = ttv[KX - 1] + shf3 * rps * T.grdscp[KX - 1];
-        qtv[KX - 1] = qtv[KX - 1] + evap3 * rps * T.grdsig[KX - 1];
+        ttend[KX - 1] = ttend[KX - 1] + shf3 * rps * T.grdscp[KX - 1];
         const size_t okx = o3 + static_cast<size_t>(NG) * (KX - 1);
         a.utend[okx] = a.utend[okx] + ut_kx;  // ut_pbl, vt_pbl are zero above the lowest level
         a.vtend[okx] = a.vtend[okx] + vt_kx;
 #pragma unroll
-        for (int k = 0; k < KX; ++k) {
-            a.ttend[o3 + NG * k] = ttend[k] + ttv[k];
-            a.qtend[o3 + NG * k] = qtend[k] + qtv[k];
-        }
+        for (int k = 0; k < KX; ++k) a.ttend[o3 + NG * k] = ttend[k];
+        a.qtend[okx] = qtend_kx + evap3 * rps * T.grdsig[KX - 1];
     }
     if (a.iptop) a.iptop[o2] = iptop;
     if (a.icltop) a.icltop[o2] = icltop;
@@ -655,7 +677,7 @@ hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nme
     const unsigned blocks = static_cast<unsigned>((total + kPhysThreads - 1) / kPhysThreads);
     static const int waves = [] {
         const char *e = getenv("PYSPEEDY_AMD_PHYS_WAVES");
-        return e ? atoi(e) : 1;
+        return e ? atoi(e) : 2;
     }();
     switch (waves) {
         case 2: hipLaunchKernelGGL(physics_kernel<2>, dim3(blocks), dim3(kPhysThreads), 0, s, a, T, nmembers); break;

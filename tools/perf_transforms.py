@@ -1,5 +1,7 @@
-"""Micro-benchmark of the transform kernels: algorithmic GB/s vs batch size and fields-per-workgroup.
-Usage (GPU box): python tools/perf_transforms.py [B ...]"""
+"""Micro-benchmark of the transform kernels: algorithmic GB/s vs batch size.
+Usage (GPU box): [PERF_LIB=path/to/variant.so] python tools/perf_transforms.py [B ...]
+PERF_LIB points the loader at an experimental build of the same C ABI (build_variants/, not committed)."""
+import ctypes as C
 import os
 import sys
 
@@ -7,6 +9,10 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import pyspeedy_amd._lib as _L  # noqa: E402
+
+if os.environ.get("PERF_LIB"):
+    _L.LIB_PATH = os.path.abspath(os.environ["PERF_LIB"])
 import pyspeedy_amd  # noqa: E402
 
 S, F, G = 15872, 23808, 36864
@@ -27,31 +33,29 @@ def timeit(fn, iters=50, warm=5):
 
 def main():
     sizes = [int(x) for x in sys.argv[1:]] or [64, 512, 728, 4096, 5824, 16384]
-    for fpw in (1, 2):
-        os.environ["PYSPEEDY_AMD_FPW"] = str(fpw)
-        sp = pyspeedy_amd.ModSpectral()
-        for B in sizes:
-            spec = torch.view_as_complex(torch.randn((B, 32, 31, 2), dtype=torch.float64, device="cuda"))
-            grid = torch.randn((B, 48, 96), dtype=torch.float64, device="cuda")
-            four = torch.randn((B, 48, 62), dtype=torch.float64, device="cuda")
-            og, osp, of = torch.empty_like(grid), torch.empty_like(spec), torch.empty_like(four)
-            L = sp._lib
-            import ctypes as C
-            h, st = sp.handle, C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            p = lambda t: C.c_void_p(t.data_ptr())
-            rows = [
-                ("spec2grid", lambda: L.spd_spec2grid(h, p(spec), p(og), 1, B, st), S + G),
-                ("grid2spec", lambda: L.spd_grid2spec(h, p(grid), p(osp), B, st), S + G),
-                ("legendre_inv", lambda: L.spd_legendre_inv(h, p(spec), p(of), B, st), S + F),
-                ("legendre", lambda: L.spd_legendre(h, p(four), p(osp), B, st), S + F),
-                ("fourier_inv", lambda: L.spd_fourier_inv(h, p(four), p(og), 1, B, st), F + G),
-                ("fourier", lambda: L.spd_fourier(h, p(grid), p(of), B, st), F + G),
-            ]
-            for name, fn, bytes_per in rows:
-                t = timeit(fn)
-                print("fpw=%d B=%6d %-13s %9.2f us  %8.1f GB/s  %6.2f ns/field" %
-                      (fpw, B, name, t * 1e6, bytes_per * B / t / 1e9, t / B * 1e9), flush=True)
-        sp.close()
+    tag = os.path.basename(os.environ.get("PERF_LIB", "default"))
+    sp = pyspeedy_amd.ModSpectral()
+    L = sp._lib
+    for B in sizes:
+        spec = torch.view_as_complex(torch.randn((B, 32, 31, 2), dtype=torch.float64, device="cuda"))
+        grid = torch.randn((B, 48, 96), dtype=torch.float64, device="cuda")
+        four = torch.randn((B, 48, 62), dtype=torch.float64, device="cuda")
+        og, osp, of = torch.empty_like(grid), torch.empty_like(spec), torch.empty_like(four)
+        h, st = sp.handle, C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        rows = [
+            ("spec2grid", lambda: L.spd_spec2grid(h, p(spec), p(og), 1, B, st), S + G),
+            ("grid2spec", lambda: L.spd_grid2spec(h, p(grid), p(osp), B, st), S + G),
+            ("legendre_inv", lambda: L.spd_legendre_inv(h, p(spec), p(of), B, st), S + F),
+            ("legendre", lambda: L.spd_legendre(h, p(four), p(osp), B, st), S + F),
+            ("fourier_inv", lambda: L.spd_fourier_inv(h, p(four), p(og), 1, B, st), F + G),
+            ("fourier", lambda: L.spd_fourier(h, p(grid), p(of), B, st), F + G),
+        ]
+        for name, fn, bytes_per in rows:
+            t = timeit(fn)
+            print("%s B=%6d %-13s %9.2f us  %8.1f GB/s  %6.2f ns/field" %
+                  (tag, B, name, t * 1e6, bytes_per * B / t / 1e9, t / B * 1e9), flush=True)
+    sp.close()
     # device copy bandwidth for reference
     n = 1 << 28
     x = torch.empty(n, dtype=torch.uint8, device="cuda")
