@@ -45,7 +45,7 @@ def parse():
 
 
 def load_bc():
-    return np.load(os.path.join(ROOT, "tests", "golden", "example_bc.npz"))
+    return np.load(os.path.join(ROOT, "pyspeedy_amd", "data", "example_bc.npz"))
 
 
 def build_ensemble(M, device, seed):

@@ -169,6 +169,17 @@ int spd_model_profile_read(spd_model_handle m, double *mean_ms, int *launches, i
 /* registry scalars land_coupling_flag, sst_anomaly_coupling_flag, increase_co2 (model_state_def.py:305-418) */
 int spd_model_set_flags(spd_model_handle m, int land_coupling_flag, int sst_anomaly_coupling_flag, int increase_co2);
 
+/* Grid-space views of the prognostic state in output units, members [first, first + count)
+ * (prognostics.f90:125-219; `transform_spectral2grid`, `transform_grid2spectral`, `apply_grid_filter` of
+ * speedy_driver.f90.j2:94-125).  Variables u_grid, v_grid, t_grid, q_grid (kg/kg), phi_grid (m), ps_grid (Pa). */
+int spd_model_spectral2grid(spd_model_handle m, int first, int count, void *stream);
+int spd_model_grid2spectral(spd_model_handle m, int first, int count, void *stream);
+int spd_model_grid_filter(spd_model_handle m, int first, int count, void *stream);
+/* modelstate_init_sst_anom (speedy_driver.f90.j2:225-237): sst_anom(ix, il, 0:n_months+1) per member, zero-filled */
+int spd_model_init_sst_anom(spd_model_handle m, int n_months);
+/* device-to-device copy of every registered variable of one member into a member of another model on the same GPU */
+int spd_model_copy_member(spd_model_handle dst, int dst_member, spd_model_handle src, int src_member, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

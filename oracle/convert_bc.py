@@ -6,7 +6,7 @@ conda interpreter (the only one that has h5py):
     /opt/conda/bin/python3.9 oracle/convert_bc.py
 
 Input : /root/reference/pyspeedy/data/example_bc.nc   (HDF5 / NetCDF4, data only)
-Output: tests/golden/example_bc.npz  -- the 12 fields read by the reference's
+Output: pyspeedy_amd/data/example_bc.npz  -- the 12 fields read by the reference's
         Speedy.set_bc (pyspeedy/speedy.py:277-296), float32, dims (lon, lat[, month]),
         latitude south -> north, exactly as stored.
 """
@@ -17,7 +17,7 @@ import h5py
 import numpy as np
 
 SRC = "/root/reference/pyspeedy/data/example_bc.nc"
-DST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "example_bc.npz")
+DST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pyspeedy_amd", "data", "example_bc.npz")
 
 FIELDS = ["alb", "icec", "lsm", "orog", "snowd", "sst", "stl", "swl1", "swl2", "swl3", "vegh", "vegl"]
 

@@ -32,7 +32,7 @@ def cz():
 
 
 def new_model():
-    bc = np.load(os.path.join(GOLD, "example_bc.npz"))
+    bc = np.load(os.path.join(GOLD, "..", "..", "pyspeedy_amd", "data", "example_bc.npz"))
     m = R.RefModel()
     m.set_bc(bc)
     return m

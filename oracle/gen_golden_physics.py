@@ -70,7 +70,7 @@ def snapshot(m, compute_shortwave, seed):
 
 
 def gen_physics():
-    bc = np.load(os.path.join(GOLD, "example_bc.npz"))
+    bc = np.load(os.path.join(GOLD, "..", "..", "pyspeedy_amd", "data", "example_bc.npz"))
     m = R.RefModel()
     m.set_bc(bc)
     for _ in range(39):  # into day 2: step 39 is a shortwave step (mod(39,3)==0), moist processes active
@@ -102,7 +102,7 @@ def implicit_arrays(m):
 def gen_steps():
     """step.npz: the model state of the example_bc run before step 42 (a shortwave step) and after steps 42 and 43, as the
     reference's do_single_step produces them, plus the dt-dependent tables of ModImplicit_t for dt = 2*delt."""
-    bc = np.load(os.path.join(GOLD, "example_bc.npz"))
+    bc = np.load(os.path.join(GOLD, "..", "..", "pyspeedy_amd", "data", "example_bc.npz"))
     m = R.RefModel()
     m.set_bc(bc)
     for _ in range(42):
@@ -140,7 +140,7 @@ def gen_run():
     """run.npz: the reference model right after init (pyspeedy.Speedy.set_bc: rest atmosphere + first_step) and after 36
     and 108 calls of step (1 and 3 simulated days from 1982-01-01, example_bc, zero SST anomaly) -- the same run the
     reference's own test_speedy_run checks against its NetCDF fixtures."""
-    bc = np.load(os.path.join(GOLD, "example_bc.npz"))
+    bc = np.load(os.path.join(GOLD, "..", "..", "pyspeedy_amd", "data", "example_bc.npz"))
     m = R.RefModel()
     m.set_bc(bc)
     d = {}

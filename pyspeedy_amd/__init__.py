@@ -2,11 +2,13 @@
 
 Spectral transforms (Legendre + zonal FFT), spectral-space operators and the fused column physics run as
 hand-written HIP kernels behind the C ABI in include/pyspeedy_amd.h; this package is the Python host side that
-mirrors the reference's operator interface (ModSpectral_t procedures, get_physical_tendencies).
+mirrors the reference's interfaces: the operator level (ModSpectral_t procedures, get_physical_tendencies), the f2py
+driver function set (speedy_driver) and the user-facing Speedy / SpeedyEns classes with their callbacks.
 """
 from ._lib import (IL, IX, IY, KX, MX, NX, TRUNC, SpeedyHipError, build, lib)  # noqa: F401
 
-__all__ = ["ModSpectral", "ColumnPhysics", "SpeedyHipError", "build", "lib"]
+__all__ = ["ModSpectral", "ColumnPhysics", "Speedy", "SpeedyEns", "example_bc_file", "DEFAULT_OUTPUT_VARS", "SpeedyHipError",
+           "build", "lib"]
 
 
 def __getattr__(name):
@@ -17,4 +19,10 @@ def __getattr__(name):
     if name == "ColumnPhysics":
         from .physics import ColumnPhysics
         return ColumnPhysics
+    if name in ("Speedy", "SpeedyEns", "example_bc_file"):
+        from . import speedy
+        return getattr(speedy, name)
+    if name == "DEFAULT_OUTPUT_VARS":
+        from .registry import DEFAULT_OUTPUT_VARS
+        return DEFAULT_OUTPUT_VARS
     raise AttributeError(name)

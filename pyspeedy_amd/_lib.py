@@ -87,6 +87,11 @@ _SIGNATURES = {
     "spd_model_get_date": (C.c_int, [C.c_void_p, C.c_void_p]),
     "spd_model_mark_initialized": (C.c_int, [C.c_void_p] + [C.c_int] * 6),
     "spd_model_set_flags": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "spd_model_spectral2grid": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "spd_model_grid2spectral": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "spd_model_grid_filter": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "spd_model_init_sst_anom": (C.c_int, [C.c_void_p, C.c_int]),
+    "spd_model_copy_member": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "spd_model_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "spd_model_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }

@@ -38,6 +38,13 @@ hipError_t run_grid2spec(const DeviceTables &T, int stage, const double *src, do
 hipError_t run_spec2grid(const DeviceTables &T, int stage, const double *src, double *dst, int kcos, int nfields,
                          hipStream_t stream, int fpw);
 hipError_t run_scale(const double *in, double *out, const double *table, double sign, int nfields, hipStream_t s);
+hipError_t run_export_units(double *q, double *phi, double *ps, long n2d, hipStream_t s);
+hipError_t run_log_ps(const double *ps_grid, double *out, long n2d, hipStream_t s);
+hipError_t run_vort2vel(const DeviceTables &T, const double *vor, const double *div, double *ucos, double *vcos, int nfields,
+                        hipStream_t s);
+hipError_t run_vel2vort(const DeviceTables &T, const double *ucos, const double *vcos, double *vor, double *div, int nfields,
+                        hipStream_t s);
+hipError_t run_export_spec_units(double *tr, double *phi, long ncomplex, hipStream_t s);
 }  // namespace spd
 
 using namespace spd;
@@ -81,6 +88,9 @@ struct spd_model {
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     size_t prof_used = 0;
+    // grid-space copies of the prognostic variables in output units (prognostics.f90:125-219) and their transform tables
+    double *u_grid = nullptr, *v_grid = nullptr, *t_grid = nullptr, *q_grid = nullptr, *phi_grid = nullptr, *ps_grid = nullptr;
+    FieldDesc *exp_inv_table = nullptr, *exp_fwd_table = nullptr;  // 41 / 40 entries per member, member-major
     double *d_dmp1 = nullptr, *d_dmp1d = nullptr, *d_dmp1s = nullptr, *d_elz = nullptr, *d_xj = nullptr, *d_xc = nullptr,
            *d_xd = nullptr;
 };
@@ -170,6 +180,35 @@ static int build_tables(spd_model *m) {
     m->allocs.push_back(d);
     M_HIP(hipMemcpy(d, t.data(), t.size() * sizeof(FieldDesc), hipMemcpyHostToDevice));
     m->fwd_table = static_cast<FieldDesc *>(d);
+    // export tables (prognostics.f90:125-219), time level 1.  sv holds ucos | vcos in the [M][2][8] layout of vor / div.
+    {
+        std::vector<FieldDesc> ti, tf;
+        const size_t half = static_cast<size_t>(M) * 16;  // fields in the ucos block of sv
+        for (int i = 0; i < M; ++i) {
+            const size_t w = static_cast<size_t>(i) * 8, s1 = static_cast<size_t>(i) * 16;
+            for (int k = 0; k < 8; ++k) {
+                ti.push_back({spec(P.sv, s1 + k), grid(m->u_grid, w + k), 2, 0});
+                ti.push_back({spec(P.sv, half + s1 + k), grid(m->v_grid, w + k), 2, 0});
+                ti.push_back({spec(P.t, s1 + k), grid(m->t_grid, w + k), 1, 0});
+                ti.push_back({spec(P.tr, s1 + k), grid(m->q_grid, w + k), 1, 0});
+                ti.push_back({spec(P.phi, w + k), grid(m->phi_grid, w + k), 1, 0});
+                tf.push_back({grid(m->u_grid, w + k), spec(P.sv, s1 + k), 1, 0});  // kcos = 2: rows times cosgr
+                tf.push_back({grid(m->v_grid, w + k), spec(P.sv, half + s1 + k), 1, 0});
+                tf.push_back({grid(m->t_grid, w + k), spec(P.t, s1 + k), 0, 0});
+                tf.push_back({grid(m->q_grid, w + k), spec(P.tr, s1 + k), 0, 0});
+                tf.push_back({grid(m->phi_grid, w + k), spec(P.phi, w + k), 0, 0});
+            }
+            ti.push_back({spec(P.ps, static_cast<size_t>(i) * 2), grid(m->ps_grid, i), 1, 0});
+        }
+        for (int pass = 0; pass < 2; ++pass) {
+            const std::vector<FieldDesc> &t = pass ? tf : ti;
+            void *dd = nullptr;
+            M_HIP(hipMalloc(&dd, t.size() * sizeof(FieldDesc)));
+            m->allocs.push_back(dd);
+            M_HIP(hipMemcpy(dd, t.data(), t.size() * sizeof(FieldDesc), hipMemcpyHostToDevice));
+            (pass ? m->exp_fwd_table : m->exp_inv_table) = static_cast<FieldDesc *>(dd);
+        }
+    }
     return SPD_OK;
 }
 
@@ -249,6 +288,8 @@ int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
     A(m->orog, M * NG, "orog", NG); A(m->phi0, M * NG, "phi0", NG); A(m->fmask_orig, M * NG, "fmask_orig", NG);
     A(m->veg_high, M * NG, "veg_high", NG); A(m->veg_low, M * NG, "veg_low", NG);
     A(m->bmask_land, M * NG, "bmask_land", NG); A(m->bmask_sea, M * NG, "bmask_sea", NG);
+    A(m->u_grid, M * G3, "u_grid", G3); A(m->v_grid, M * G3, "v_grid", G3); A(m->t_grid, M * G3, "t_grid", G3);
+    A(m->q_grid, M * G3, "q_grid", G3); A(m->phi_grid, M * G3, "phi_grid", G3); A(m->ps_grid, M * NG, "ps_grid", NG);
     A(m->corh_t, M * NG, nullptr, 0); A(m->corh_q, M * NG, nullptr, 0); A(m->scratch_spec, 2 * M * S, nullptr, 0);
     SF.land_temp = const_cast<double *>(pa.land_temp); SF.soil_avail_water = const_cast<double *>(pa.soil_avail_water);
     SF.sst_am = const_cast<double *>(pa.sst_am); SF.hfluxn = pa.hfluxn; SF.shf = pa.shf; SF.evap = pa.evap; SF.ssrd = pa.ssrd;
@@ -608,6 +649,7 @@ int spd_model_mark_initialized(spd_model_handle m, int current_step, int year, i
     if (!m) return m_fail(SPD_E_ARG, "spd_model_mark_initialized: null model");
     m->cal.set(year, month, day, hour, minute);
     m->current_step = current_step;
+    m->ablco2_ref = m->air_absortivity_co2;  // set_forcing(imode = 0), forcing.f90:40
     m->initialized = true;
     return SPD_OK;
 }
@@ -623,6 +665,98 @@ int spd_model_set_flags(spd_model_handle m, int land_coupling_flag, int sst_anom
     m->land_coupling_flag = land_coupling_flag ? 1 : 0;
     m->sst_anomaly_flag = sst_anomaly_coupling_flag ? 1 : 0;
     m->increase_co2 = increase_co2 ? 1 : 0;
+    return SPD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// grid-space views of the prognostic state (prognostics.f90:125-219) for members [first, first + count)
+// ---------------------------------------------------------------------------------------------------------------
+static int member_range(spd_model_handle m, int first, int count, const char *who) {
+    if (!m) return m_fail(SPD_E_ARG, std::string(who) + ": null model");
+    if (first < 0 || count < 0 || first + count > m->M) return m_fail(SPD_E_ARG, std::string(who) + ": member range out of bounds");
+    return SPD_OK;
+}
+
+// spectral2grid: u, v from vorticity / divergence; q in kg/kg; phi in m; ps in Pa
+int spd_model_spectral2grid(spd_model_handle m, int first, int count, void *stream) {
+    if (int rc = member_range(m, first, count, "spd_model_spectral2grid")) return rc;
+    if (count == 0) return SPD_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const DeviceTables &T = m->ctx->dev;
+    const size_t S = NSPEC * C, half = static_cast<size_t>(m->M) * 16, off = static_cast<size_t>(first) * 16;
+    // vort2vel over both time levels of the members (contiguous); only level 1 is transformed
+    hipError_t e = run_vort2vel(T, m->P.vor + off * S, m->P.div + off * S, m->P.sv + off * S, m->P.sv + (half + off) * S,
+                                count * 16, s);
+    if (e == hipSuccess) e = run_spec2grid_table(T, m->exp_inv_table + static_cast<size_t>(first) * 41, count * 41, s);
+    if (e == hipSuccess)
+        e = run_export_units(m->q_grid + static_cast<size_t>(first) * 8 * NG, m->phi_grid + static_cast<size_t>(first) * 8 * NG,
+                             m->ps_grid + static_cast<size_t>(first) * NG, static_cast<long>(count) * NG, s);
+    if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_spectral2grid: ") + hipGetErrorString(e));
+    return SPD_OK;
+}
+
+// grid2spectral: the inverse mapping into time level 1 (ps_grid is not modified; its logarithm goes through scratch)
+int spd_model_grid2spectral(spd_model_handle m, int first, int count, void *stream) {
+    if (int rc = member_range(m, first, count, "spd_model_grid2spectral")) return rc;
+    if (count == 0) return SPD_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const DeviceTables &T = m->ctx->dev;
+    const size_t S = NSPEC * C, half = static_cast<size_t>(m->M) * 16;
+    hipError_t e = run_grid2spec_table(T, m->exp_fwd_table + static_cast<size_t>(first) * 40, count * 40, s);
+    for (int i = first; i < first + count && e == hipSuccess; ++i) {
+        const size_t s1 = static_cast<size_t>(i) * 16;
+        e = run_vel2vort(T, m->P.sv + s1 * S, m->P.sv + (half + s1) * S, m->P.vor + s1 * S, m->P.div + s1 * S, 8, s);
+        if (e == hipSuccess) e = run_export_spec_units(m->P.tr + s1 * S, m->P.phi + static_cast<size_t>(i) * 8 * S, 8 * NSPEC, s);
+    }
+    if (e == hipSuccess)
+        e = run_log_ps(m->ps_grid + static_cast<size_t>(first) * NG, m->corh_t + static_cast<size_t>(first) * NG,
+                       static_cast<long>(count) * NG, s);
+    for (int i = first; i < first + count && e == hipSuccess; ++i)
+        e = run_grid2spec(T, 0, m->corh_t + static_cast<size_t>(i) * NG, m->P.ps + static_cast<size_t>(i) * 2 * S, 0, 1, s, 0);
+    if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_grid2spectral: ") + hipGetErrorString(e));
+    return SPD_OK;
+}
+
+// grid_filter: spectral truncation of the six grid-space variables, in place
+int spd_model_grid_filter(spd_model_handle m, int first, int count, void *stream) {
+    if (int rc = member_range(m, first, count, "spd_model_grid_filter")) return rc;
+    if (count == 0) return SPD_OK;
+    double *v3[5] = {m->u_grid, m->v_grid, m->t_grid, m->q_grid, m->phi_grid};
+    for (double *v : v3) {
+        double *p = v + static_cast<size_t>(first) * 8 * NG;
+        if (int rc = spd_grid_filter(m->ctx, p, p, count * 8, stream)) return rc;
+    }
+    double *p = m->ps_grid + static_cast<size_t>(first) * NG;
+    return spd_grid_filter(m->ctx, p, p, count, stream);
+}
+
+// sst_anom(ix, il, 0:n_months+1) for every member (modelstate_init_sst_anom, speedy_driver.f90.j2:225-237); zero-filled
+int spd_model_init_sst_anom(spd_model_handle m, int n_months) {
+    if (!m) return m_fail(SPD_E_ARG, "spd_model_init_sst_anom: null model");
+    if (n_months < 1) return m_fail(SPD_E_ARG, "spd_model_init_sst_anom: n_months must be at least 1");
+    M_HIP(hipSetDevice(m->ctx->device));
+    const size_t planes = static_cast<size_t>(n_months) + 2;
+    double *p = nullptr;
+    if (int rc = dalloc(m, static_cast<size_t>(m->M) * planes * NG, &p, "sst_anom", planes * NG * sizeof(double))) return rc;
+    m->S.sst_anom = p;  // the previous array stays allocated until spd_model_destroy
+    m->anom_planes = static_cast<int>(planes);
+    return SPD_OK;
+}
+
+// copy every registered variable of member `si` of `src` into member `di` of `dst` (same device, same variable sizes)
+int spd_model_copy_member(spd_model_handle dst, int di, spd_model_handle src, int si, void *stream) {
+    if (!dst || !src) return m_fail(SPD_E_ARG, "spd_model_copy_member: null model");
+    if (di < 0 || di >= dst->M || si < 0 || si >= src->M) return m_fail(SPD_E_ARG, "spd_model_copy_member: member index out of range");
+    if (dst->ctx->device != src->ctx->device) return m_fail(SPD_E_ARG, "spd_model_copy_member: models live on different devices");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (const auto &kv : src->reg) {
+        auto it = dst->reg.find(kv.first);
+        if (it == dst->reg.end() || it->second.bytes_member != kv.second.bytes_member)
+            return m_fail(SPD_E_SIZE, "spd_model_copy_member: variable '" + kv.first + "' differs between the models");
+        const size_t b = kv.second.bytes_member;
+        M_HIP(hipMemcpyAsync(static_cast<char *>(it->second.ptr) + b * di, static_cast<const char *>(kv.second.ptr) + b * si, b,
+                             hipMemcpyDeviceToDevice, s));
+    }
     return SPD_OK;
 }
 

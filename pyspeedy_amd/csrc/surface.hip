@@ -248,4 +248,41 @@ hipError_t run_rest_state(const RestPtrs &R, int M, const RestConsts &c, hipStre
     return hipGetLastError();
 }
 
+// Output units of the grid-space prognostic variables (prognostics.f90:143-150): q kg/kg, phi m, ps Pa; and back (:166-171).
+__global__ __launch_bounds__(kT) void export_units_kernel(double *q, double *phi, double *ps, long n2d) {
+    const long i = static_cast<long>(blockIdx.x) * kT + threadIdx.x;
+    if (i < 8 * n2d) {
+        q[i] = q[i] * static_cast<double>(1.0e-3f);
+        phi[i] = phi[i] / static_cast<double>(9.81f);
+    }
+    if (i < n2d) ps[i] = static_cast<double>(1.e+5f) * exp(ps[i]);
+}
+
+__global__ __launch_bounds__(kT) void log_ps_kernel(const double *ps_grid, double *out, long n2d) {
+    const long i = static_cast<long>(blockIdx.x) * kT + threadIdx.x;
+    if (i < n2d) out[i] = log(ps_grid[i] / static_cast<double>(1.e+5f));
+}
+
+__global__ __launch_bounds__(kT) void export_spec_units_kernel(double *tr, double *phi, long ndoubles) {
+    const long i = static_cast<long>(blockIdx.x) * kT + threadIdx.x;
+    if (i < ndoubles) {
+        tr[i] = tr[i] / static_cast<double>(1.0e-3f);
+        phi[i] = phi[i] * static_cast<double>(9.81f);
+    }
+}
+
+hipError_t run_export_units(double *q, double *phi, double *ps, long n2d, hipStream_t s) {
+    hipLaunchKernelGGL(export_units_kernel, dim3((8 * n2d + kT - 1) / kT), dim3(kT), 0, s, q, phi, ps, n2d);
+    return hipGetLastError();
+}
+hipError_t run_log_ps(const double *ps_grid, double *out, long n2d, hipStream_t s) {
+    hipLaunchKernelGGL(log_ps_kernel, dim3((n2d + kT - 1) / kT), dim3(kT), 0, s, ps_grid, out, n2d);
+    return hipGetLastError();
+}
+hipError_t run_export_spec_units(double *tr, double *phi, long ncomplex, hipStream_t s) {
+    const long n = 2 * ncomplex;
+    hipLaunchKernelGGL(export_spec_units_kernel, dim3((n + kT - 1) / kT), dim3(kT), 0, s, tr, phi, n);
+    return hipGetLastError();
+}
+
 }  // namespace spd

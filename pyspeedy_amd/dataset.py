@@ -1,0 +1,179 @@
+"""A small labelled-array container with NetCDF-3 classic I/O (scipy.io.netcdf_file) for the model output.
+
+The reference exports through xarray + netCDF4 (pyspeedy/speedy.py:415-477, callbacks.py:169-255); neither is a dependency
+here, and its own test fixtures are NetCDF-3 classic files, so this module writes that format directly, with the same
+variable names, dimension order, dtypes and attributes: float32 data variables on (time, [ens,] lev, lat, lon), int32
+`time` ("<unit> since <first time>", proleptic_gregorian) and `ens`, float32 coordinates.
+"""
+from datetime import datetime, timedelta
+
+import numpy as np
+
+
+class Variable:
+    __slots__ = ("dims", "values", "attrs")
+
+    def __init__(self, dims, values, attrs=None):
+        self.dims = tuple(dims)
+        self.values = np.asarray(values)
+        if self.values.ndim != len(self.dims):
+            raise ValueError("dims %s do not match an array of shape %s" % (self.dims, self.values.shape))
+        self.attrs = dict(attrs or {})
+
+    @property
+    def shape(self):
+        return self.values.shape
+
+
+class Dataset:
+    """data_vars / coords: name -> Variable or (dims, values[, attrs])."""
+
+    def __init__(self, data_vars=None, coords=None, attrs=None):
+        as_var = lambda v: v if isinstance(v, Variable) else Variable(*v)
+        self.data_vars = {k: as_var(v) for k, v in (data_vars or {}).items()}
+        self.coords = {k: as_var(v) for k, v in (coords or {}).items()}
+        self.attrs = dict(attrs or {})
+
+    # ---- mapping-style access (what the reference's tests use of xarray) ----
+    def keys(self):
+        return self.data_vars.keys()
+
+    @property
+    def variables(self):
+        out = dict(self.coords)
+        out.update(self.data_vars)
+        return out
+
+    def __contains__(self, name):
+        return name in self.data_vars or name in self.coords
+
+    def __getitem__(self, name):
+        return self.data_vars[name] if name in self.data_vars else self.coords[name]
+
+    @property
+    def dims(self):
+        out = {}
+        for v in self.variables.values():
+            for d, n in zip(v.dims, v.shape):
+                out[d] = n
+        return out
+
+    # ---- selection / combination ----
+    def isel(self, **indexers):
+        """Integer selection along dimensions; the selected dimensions are dropped."""
+        def cut(v):
+            idx = tuple(indexers.get(d, slice(None)) for d in v.dims)
+            dims = tuple(d for d in v.dims if d not in indexers)
+            return Variable(dims, v.values[idx], v.attrs)
+        return Dataset({k: cut(v) for k, v in self.data_vars.items()},
+                       {k: cut(v) for k, v in self.coords.items() if k not in indexers}, self.attrs)
+
+    def sel(self, **labels):
+        idx = {}
+        for d, lab in labels.items():
+            hits = np.nonzero(self.coords[d].values == lab)[0]
+            if hits.size == 0:
+                raise KeyError("%s=%r not found" % (d, lab))
+            idx[d] = int(hits[0])
+        return self.isel(**idx)
+
+    def to_netcdf(self, path):
+        write_netcdf(self, path)
+
+
+def concat(datasets, dim):
+    """Join datasets that differ only along `dim` (an existing dimension of the data variables), ordered by its coordinate."""
+    datasets = list(datasets)
+    first = datasets[0]
+    labels = np.concatenate([d.coords[dim].values for d in datasets])
+    order = np.argsort(labels, kind="stable")
+    data = {}
+    for name, v in first.data_vars.items():
+        ax = v.dims.index(dim)
+        data[name] = Variable(v.dims, np.take(np.concatenate([d.data_vars[name].values for d in datasets], axis=ax), order, axis=ax),
+                              v.attrs)
+    coords = dict(first.coords)
+    coords[dim] = Variable((dim,), labels[order], first.coords[dim].attrs)
+    return Dataset(data, coords, first.attrs)
+
+
+def assert_allclose(a, b, rtol=1e-5, atol=0.0):
+    """xr.testing.assert_allclose for these datasets: same variables, dimensions and values within tolerance."""
+    if set(a.keys()) != set(b.keys()):
+        raise AssertionError("data variables differ: %s vs %s" % (sorted(a.keys()), sorted(b.keys())))
+    for name in list(a.keys()) + [c for c in a.coords if c in b.coords]:
+        va, vb = a[name], b[name]
+        if va.dims != vb.dims or va.shape != vb.shape:
+            raise AssertionError("%s: dims %s %s vs %s %s" % (name, va.dims, va.shape, vb.dims, vb.shape))
+        if va.values.dtype.kind == "M":
+            if not (va.values == vb.values).all():
+                raise AssertionError("%s: time coordinates differ" % name)
+            continue
+        np.testing.assert_allclose(va.values, vb.values, rtol=rtol, atol=atol, err_msg=name)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# NetCDF-3 classic
+# --------------------------------------------------------------------------------------------------------------------
+_EPOCH_FMT = "%Y-%m-%d %H:%M:%S"
+
+
+def _encode_time(values):
+    """datetime64 / datetime values -> (int32 offsets, units string): the coarsest unit that keeps the offsets integral."""
+    t = np.asarray(values, dtype="datetime64[s]")
+    ref = t.min()
+    secs = (t - ref).astype(np.int64)
+    for unit, n in (("days", 86400), ("hours", 3600), ("minutes", 60), ("seconds", 1)):
+        if (secs % n == 0).all():
+            break
+    ref_dt = ref.astype(datetime)
+    return (secs // n).astype(np.int32), "%s since %s" % (unit, ref_dt.strftime(_EPOCH_FMT))
+
+
+def _decode_time(offsets, units):
+    unit, _, ref = units.partition(" since ")
+    ref = ref.strip()
+    fmt = _EPOCH_FMT if len(ref) > 10 else "%Y-%m-%d"
+    ref_dt = datetime.strptime(ref, fmt)
+    step = {"days": 86400, "hours": 3600, "minutes": 60, "seconds": 1}[unit]
+    return np.array([np.datetime64(ref_dt + timedelta(seconds=int(o) * step), "s") for o in np.atleast_1d(offsets)])
+
+
+def write_netcdf(ds, path):
+    from scipy.io import netcdf_file
+    with netcdf_file(str(path), "w", version=1) as f:
+        for d, n in ds.dims.items():
+            f.createDimension(d, int(n))
+        for k, v in ds.attrs.items():
+            setattr(f, k, v)
+        for name, v in ds.variables.items():
+            vals, attrs = v.values, dict(v.attrs)
+            if vals.dtype.kind == "M" or (vals.dtype == object and len(vals) and isinstance(vals.flat[0], datetime)):
+                vals, units = _encode_time(vals)
+                attrs.update(units=units, calendar="proleptic_gregorian")
+            elif vals.dtype.kind in "iu":
+                vals = vals.astype(np.int32)
+            elif vals.dtype.kind == "f":
+                vals = vals.astype(np.float32)
+            nv = f.createVariable(name, vals.dtype.char, v.dims)
+            nv[...] = vals
+            for k, a in attrs.items():
+                if a is not None:
+                    setattr(nv, k, a)
+
+
+def open_dataset(path):
+    """Read a NetCDF-3 classic file (ours or the reference's fixtures) into a Dataset; `time` is decoded to datetime64."""
+    from scipy.io import netcdf_file
+    with netcdf_file(str(path), "r", mmap=False) as f:
+        coords, data = {}, {}
+        for name, nv in f.variables.items():
+            attrs = {k: (a.decode() if isinstance(a, bytes) else a) for k, a in nv._attributes.items() if k != "_FillValue"}
+            vals = np.array(nv.data).astype(nv.data.dtype.newbyteorder("="))
+            if name == "time" and "units" in attrs:
+                vals = _decode_time(vals, attrs.pop("units"))
+                attrs.pop("calendar", None)
+            var = Variable(nv.dimensions, vals, attrs)
+            (coords if nv.dimensions == (name,) else data)[name] = var
+        gattrs = {k: (a.decode() if isinstance(a, bytes) else a) for k, a in f._attributes.items()}
+    return Dataset(data, coords, gattrs)

@@ -11,30 +11,11 @@ import torch
 
 from . import _lib
 from ._lib import check
+from .registry import REGISTRY
 
-# registry shapes (registry/model_state_def.py:121-495) of the variables the model object holds
-_C, _F = np.complex128, np.float64
-SHAPES = {
-    "vor": (_C, (31, 32, 8, 2)), "div": (_C, (31, 32, 8, 2)), "t": (_C, (31, 32, 8, 2)), "tr": (_C, (31, 32, 8, 2)),
-    "ps": (_C, (31, 32, 2)), "phi": (_C, (31, 32, 8)), "phis": (_C, (31, 32)), "tcorh": (_C, (31, 32)), "qcorh": (_C, (31, 32)),
-    "rad_st4a": (_F, (96, 48, 8, 2)), "rad_flux": (_F, (96, 48, 4)), "tt_rsw": (_F, (96, 48, 8)),
-    "rad_tau2": (_F, (96, 48, 8, 4)), "rad_strat_corr": (_F, (96, 48, 2)),
-}
-for _n in ("fmask_land", "phis0", "forog", "sst_am", "alb_land", "alb_sea", "snowc", "land_temp", "soil_avail_water",
-           "flux_solar_in", "flux_ozone_upper", "flux_ozone_lower", "zenit_correction", "stratospheric_correction",
-           "alb_surface", "precnv", "precls", "cbmf", "slrd", "slr", "olr", "tsr", "ssrd", "ssr", "qcloud_equiv"):
-    SHAPES[_n] = (_F, (96, 48))
-for _n in ("slru", "ustr", "vstr", "shf", "evap", "hfluxn"):
-    SHAPES[_n] = (_F, (96, 48, 3))
-
-for _n in ("stl12", "snowd12", "soilw12", "sst12", "sea_ice_frac12", "soil_wc_l1", "soil_wc_l2", "soil_wc_l3"):
-    SHAPES[_n] = (_F, (96, 48, 12))
-SHAPES["sst_anom"] = (_F, (96, 48, 3))
-for _n in ("stlcl_obs", "snowdcl_obs", "soilwcl_obs", "stl_lm", "snow_depth", "cdland", "rhcapl", "sstcl_ob", "sicecl_ob",
-           "ticecl_ob", "sstan_ob", "sst_om", "tice_om", "sice_om", "sstan_am", "sice_am", "tice_am", "ssti_om", "cdsea",
-           "cdice", "rhcaps", "rhcapi", "hfseacl", "fmask_sea", "alb0", "orog", "phi0", "fmask_orig", "veg_high", "veg_low",
-           "bmask_land", "bmask_sea"):
-    SHAPES[_n] = (_F, (96, 48))
+# reference shapes of the device-resident registry variables (registry.py); sst_anom follows the model's allocation
+SHAPES = {n: (v.dtype, v.shape) for n, v in REGISTRY.items() if v.where == "device"}
+SHAPES["sst_anom"] = (np.float64, (96, 48, 3))  # right after creation: n_months = 1
 
 DELT = 86400.0 / 36  # params.f90:33
 
@@ -50,6 +31,7 @@ class EnsembleModel:
         self.nmembers = int(nmembers)
         self._lib = _lib.lib()
         self._m = C.c_void_p()
+        self.n_months = 1  # sst_anom holds n_months + 2 planes
         with torch.cuda.device(spectral.device):
             check(self._lib.spd_model_create(spectral.handle, self.nmembers, C.byref(self._m)), "spd_model_create")
 
@@ -65,9 +47,13 @@ class EnsembleModel:
             pass
 
     # ---- registry access (speedy_driver.f90.j2:250-334) --------------------------------------------------
+    def shape(self, name):
+        dtype, shape = SHAPES[name]
+        return (dtype, (96, 48, self.n_months + 2)) if name == "sst_anom" else (dtype, shape)
+
     def set(self, name, value, member=-1):
         """Copy a host array (reference shape) into one member, or into every member when member == -1."""
-        dtype, shape = SHAPES[name]
+        dtype, shape = self.shape(name)
         a = np.asarray(value, dtype=dtype)
         if a.shape != shape:
             raise ValueError("Array shape missmatch: %s expects %s, got %s" % (name, shape, a.shape))  # speedy.py:153
@@ -76,7 +62,7 @@ class EnsembleModel:
               "spd_model_set(%s)" % name)
 
     def get(self, name, member=0):
-        dtype, shape = SHAPES[name]
+        dtype, shape = self.shape(name)
         flat = np.empty(int(np.prod(shape)), dtype=dtype)
         check(self._lib.spd_model_get(self._m, name.encode(), int(member), flat.ctypes.data_as(C.c_void_p), flat.nbytes),
               "spd_model_get(%s)" % name)
@@ -92,8 +78,47 @@ class EnsembleModel:
         `sst_anom` was set before."""
         for state_name, bc_name in BC_MAP:
             self.set(state_name, np.asarray(bc[bc_name], dtype=np.float64), member)
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(self._lib.spd_model_init(self._m, *[int(v) for v in start_date], stream), "spd_model_init")
+        self.init(start_date)
+
+    def init(self, start_date=(1982, 1, 1, 0, 0)):
+        """The reference's `init` (initialize_state) for every member, from the boundary fields stored with set()."""
+        check(self._lib.spd_model_init(self._m, *[int(v) for v in start_date], self._stream()), "spd_model_init")
+
+    def init_sst_anom(self, n_months):
+        """modelstate_init_sst_anom: (re)allocate sst_anom with n_months + 2 zero-filled planes per member."""
+        check(self._lib.spd_model_init_sst_anom(self._m, int(n_months)), "spd_model_init_sst_anom")
+        self.n_months = int(n_months)
+
+    def mark_initialized(self, current_step, date):
+        """Declare a state loaded through set() / copy_member_from() as initialised at `date` = (y, m, d, h, mi)."""
+        check(self._lib.spd_model_mark_initialized(self._m, int(current_step), *[int(v) for v in date]),
+              "spd_model_mark_initialized")
+        self.set_time_step(2 * DELT)
+
+    def copy_member_from(self, src, src_member, dst_member):
+        """Device-to-device copy of every registry variable of one member of `src` into one of this model's members."""
+        check(self._lib.spd_model_copy_member(self._m, int(dst_member), src._m, int(src_member), self._stream()),
+              "spd_model_copy_member")
+
+    def sync(self):
+        torch.cuda.current_stream().synchronize()
+
+    @staticmethod
+    def _stream():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # ---- grid-space views of the prognostic variables (prognostics.f90:125-219) -------------------------
+    def _range(self, first, count):
+        return int(first), int(self.nmembers - first if count is None else count)
+
+    def spectral2grid(self, first=0, count=None):
+        check(self._lib.spd_model_spectral2grid(self._m, *self._range(first, count), self._stream()), "spd_model_spectral2grid")
+
+    def grid2spectral(self, first=0, count=None):
+        check(self._lib.spd_model_grid2spectral(self._m, *self._range(first, count), self._stream()), "spd_model_grid2spectral")
+
+    def grid_filter(self, first=0, count=None):
+        check(self._lib.spd_model_grid_filter(self._m, *self._range(first, count), self._stream()), "spd_model_grid_filter")
 
     def run(self, nsteps):
         """`nsteps` model steps (40 simulated minutes each) for every member; asynchronous."""

@@ -1,0 +1,300 @@
+"""`Speedy` and `SpeedyEns`: the user-facing model objects of pySPEEDY (pyspeedy/speedy.py:41-597) over the MI355X backend.
+
+Same constructor arguments, properties and methods as the reference classes -- set_params, set_bc, run(callbacks),
+state access with model["var"], get_shape, spectral2grid / grid2spectral, check, to_dataframe, get_current_step -- written
+against `speedy_driver` (the `_speedy` function set) exactly as the reference is.  Differences, all on the host side:
+
+* to_dataframe() returns a `pyspeedy_amd.dataset.Dataset` (xarray is not a dependency); it carries the same variables,
+  dimension order (time, [ens,] lev, lat, lon; lev top-down reversed), float32 dtype and attributes, and writes NetCDF-3.
+* Boundary conditions: the packaged example_bc (converted from the reference's example_bc.nc), an .npz / NetCDF-3 file,
+  or a mapping of arrays.  The reference's default SST-anomaly file is not distributed with it (.MISSING_LARGE_BLOBS),
+  so `sst_anomaly=None` means zero anomalies; a mapping / file with `ssta` (lon, lat, time) and `time` works as upstream.
+* SpeedyEns members are slots of ONE batched device model (speedy_driver.modelstate_init_ensemble): `SpeedyEns.run`
+  advances all members with one set of kernel launches per step.  A member of an ensemble cannot `run()` on its own.
+"""
+import os
+from datetime import datetime, timedelta
+
+import numpy as np
+
+from . import speedy_driver as _speedy
+from .dataset import Dataset, Variable, concat, open_dataset
+from .registry import DEFAULT_OUTPUT_VARS, REGISTRY
+from .speedy_driver import ERROR_CODES
+
+PACKAGE_DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+# boundary-condition file variable -> state variable (pyspeedy/speedy.py:279-296)
+_BC_FIELDS = (("orog", "orog"), ("fmask_orig", "lsm"), ("alb0", "alb"), ("veg_high", "vegh"), ("veg_low", "vegl"),
+              ("stl12", "stl"), ("snowd12", "snowd"), ("soil_wc_l1", "swl1"), ("soil_wc_l2", "swl2"), ("soil_wc_l3", "swl3"),
+              ("sst12", "sst"), ("sea_ice_frac12", "icec"))
+
+_DT_STEP = timedelta(seconds=3600 * 24 / 36)
+
+
+def example_bc_file():
+    """Path of the packaged example boundary conditions (ERA-interim 1979-2008 climatology of the original SPEEDY)."""
+    return os.path.join(PACKAGE_DATA_DIR, "example_bc.npz")
+
+
+def _add_months(date, months):
+    y, m = divmod(date.year * 12 + date.month - 1 + months, 12)
+    return date.replace(year=y, month=m + 1)
+
+
+def _load_fields(source):
+    """Mapping name -> array from an .npz file, a NetCDF-3 file, a Dataset or a plain mapping."""
+    if isinstance(source, (str, os.PathLike)):
+        if not os.path.isfile(source):
+            raise RuntimeError("The boundary conditions file does not exist.\nFile: %s" % source)
+        if str(source).endswith(".npz"):
+            with np.load(source) as z:
+                return {k: z[k] for k in z.files}
+        source = open_dataset(source)
+    if isinstance(source, Dataset):
+        return {k: v.values for k, v in source.variables.items()}
+    return dict(source)
+
+
+class Speedy:
+    """One SPEEDY model instance."""
+
+    def __init__(self, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 2), member=None, _state_cnt=None):
+        self._start_date = None
+        self._end_date = None
+        self._model_date = None
+        self._control_cnt = None
+        self.member_id = member
+        self.is_ensemble_member = self.member_id is not None
+        self._state_cnt = _speedy.modelstate_init() if _state_cnt is None else _state_cnt
+        self.set_params(start_date=start_date, end_date=end_date)
+        self._initialized_bc = False
+        self._initialized_ssta = False
+        self.current_date = self.start_date
+
+    def __del__(self):
+        try:
+            _speedy.modelstate_close(self._state_cnt)
+            if self._control_cnt is not None:
+                _speedy.controlparams_close(self._control_cnt)
+            for cnt in (self._start_date, self._end_date, self._model_date):
+                self._dealloc_date(cnt)
+        except Exception:
+            pass
+
+    def set_params(self, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 2)):
+        """Set the control parameters (start and end date of the simulation)."""
+        self.start_date = start_date
+        self.end_date = end_date
+        if self.start_date > self.end_date:
+            raise ValueError("The start date should be lower than the en date.")
+        if self._control_cnt is not None:
+            _speedy.controlparams_close(self._control_cnt)
+        self._control_cnt = _speedy.controlparams_init(self._start_date, self._end_date)
+        self.current_date = start_date
+        self.n_months = ((self.end_date.year - self.start_date.year) * 12 + (self.end_date.month - self.start_date.month) + 1)
+
+    # ---- dates ---------------------------------------------------------------------------------------------
+    @staticmethod
+    def _dealloc_date(container):
+        if container is not None:
+            _speedy.close_datetime(container)
+
+    @staticmethod
+    def _get_date(container):
+        return datetime(*_speedy.get_datetime(container))
+
+    @staticmethod
+    def _set_date(container, value):
+        Speedy._dealloc_date(container)
+        if not isinstance(value, datetime):
+            raise TypeError("The input value is not a datetime object.")
+        return _speedy.create_datetime(value.year, value.month, value.day, value.hour, value.minute)
+
+    start_date = property(lambda self: self._get_date(self._start_date),
+                          lambda self, v: setattr(self, "_start_date", self._set_date(self._start_date, v)))
+    end_date = property(lambda self: self._get_date(self._end_date),
+                        lambda self, v: setattr(self, "_end_date", self._set_date(self._end_date, v)))
+    current_date = property(lambda self: self._get_date(self._model_date),
+                            lambda self, v: setattr(self, "_model_date", self._set_date(self._model_date, v)))
+
+    # ---- state access --------------------------------------------------------------------------------------
+    def __getitem__(self, var_name):
+        getter = getattr(_speedy, "get_%s" % var_name, None)
+        if getter is None:
+            raise AttributeError("The state variable '%s' does not exist." % var_name)
+        if var_name == "sst_anom":
+            return getter(self._state_cnt, self.n_months)
+        return getter(self._state_cnt)
+
+    def get_shape(self, var_name):
+        getter = getattr(_speedy, "get_%s_shape" % var_name, None)
+        if getter is None:
+            raise AttributeError("The 'get-shape' method for the state variable '%s' does not exist." % var_name)
+        return tuple(getter(self._state_cnt))
+
+    def __setitem__(self, var_name, value):
+        setter = getattr(_speedy, "set_%s" % var_name, None)
+        if setter is None:
+            raise AttributeError("The setter for the state variable '%s' does not exist." % var_name)
+        if getattr(_speedy, "is_array_%s" % var_name)():
+            value = np.asarray(value)
+            if self.get_shape(var_name) != value.shape:
+                raise ValueError("Array shape missmatch")
+            if var_name == "sst_anom":
+                return setter(self._state_cnt, value, self.n_months)
+        return setter(self._state_cnt, value)
+
+    def get_current_step(self):
+        return self["current_step"]
+
+    # ---- boundary conditions and initialisation ----------------------------------------------------------
+    def set_bc(self, bc_file=None, sst_anomaly=None):
+        """Load the boundary conditions and initialise the model (the reference's set_bc, speedy.py:217-301).
+
+        bc_file: None (packaged example), a path (.npz or NetCDF-3) or a mapping with `orog, lsm, alb, vegh, vegl`
+        (lon, lat) and `stl, snowd, swl1, swl2, swl3, sst, icec` (lon, lat, month).
+        sst_anomaly: None (zero anomalies) or a path / mapping with `ssta` (lon, lat, time) and `time` (datetime64,
+        first day of each month) covering one month before the start to one month after the end of the run."""
+        if self._initialized_bc:
+            raise RuntimeError("The model was already initialized. Create a new instance if you need different boundary conditions.")
+        self._set_sst_anomalies(sst_anomaly)
+        fields = _load_fields(example_bc_file() if bc_file is None else bc_file)
+        for state_name, file_name in _BC_FIELDS:
+            self[state_name] = np.asarray(fields[file_name], dtype=np.float64)
+        code = _speedy.init(self._state_cnt, self._control_cnt)
+        if code < 0:
+            raise RuntimeError(ERROR_CODES[code])
+        self.spectral2grid()
+        self._initialized_bc = True
+
+    def _set_sst_anomalies(self, sst_anomaly=None):
+        if self._initialized_ssta:
+            raise RuntimeError("The SST anomaly was already initialized. Create a new instance if you need different boundary conditions.")
+        # the model interpolates in a 3-month window: months from (start - 1 month) to (end + 1 month), speedy.py:338-372
+        first = _add_months(self.start_date.replace(day=1, hour=0, minute=0, second=0, microsecond=0), -1)
+        last = _add_months(self.end_date.replace(day=1, hour=0, minute=0, second=0, microsecond=0), 1)
+        expected_months = (last.year - first.year) * 12 + (last.month - first.month) + 1
+        _speedy.modelstate_init_sst_anom(self._state_cnt, expected_months - 2)
+        self.n_months = expected_months - 2
+        if sst_anomaly is not None:
+            fields = _load_fields(sst_anomaly)
+            times = np.asarray(fields["time"], dtype="datetime64[s]")
+            keep = (times >= np.datetime64(first, "s")) & (times <= np.datetime64(last + timedelta(days=1), "s"))
+            missing = expected_months - int(keep.sum())
+            if missing > 0:
+                raise RuntimeError("%d months are missing in the SST anomalies for the period: %s , %s.\n"
+                                   % (missing, first.strftime("%Y/%m/%d"), last.strftime("%Y/%m/%d")))
+            self["sst_anom"] = np.asarray(fields["ssta"], dtype=np.float64)[:, :, keep][:, :, :expected_months]
+        self._initialized_ssta = True
+
+    # ---- run -------------------------------------------------------------------------------------------------
+    def run(self, callbacks=None):
+        """Run from `start_date` to `end_date`, calling every callback after each 40-minute step."""
+        callbacks = list(callbacks or [])
+        if not self._initialized_bc:
+            raise RuntimeError("The SPEEDY model was not initialized. Call the `set_bc` method to initialize the model.")
+        self.current_date = self.start_date
+        while self.current_date < self.end_date:
+            code = _speedy.step(self._state_cnt, self._control_cnt)
+            if code < 0:
+                raise RuntimeError(ERROR_CODES[code])
+            self.current_date += _DT_STEP
+            for callback in callbacks:
+                callback(self)
+
+    def grid2spectral(self):
+        """Transform the grid u, v, t, q, ps and phi fields to the spectral domain."""
+        _speedy.transform_grid2spectral(self._state_cnt)
+
+    def spectral2grid(self):
+        """Transform the spectral prognostic fields to u, v, t, q, phi and ps on the grid."""
+        _speedy.transform_spectral2grid(self._state_cnt)
+
+    def check(self):
+        code = _speedy.check(self._state_cnt)
+        if code < 0:
+            raise RuntimeError(ERROR_CODES[code])
+
+    # ---- export ----------------------------------------------------------------------------------------------
+    def to_dataframe(self, variables=None):
+        """Current model state as a Dataset following the export conventions of the reference (speedy.py:415-477)."""
+        variables = DEFAULT_OUTPUT_VARS if variables is None else variables
+        self.spectral2grid()
+        lead = ("time", "ens") if self.is_ensemble_member else ("time",)
+        data = {}
+        for var in variables:
+            meta = REGISTRY[var]
+            if meta.nc_dims is None or meta.where != "device":
+                raise ValueError("'%s' cannot be exported: not a grid-space array" % var)
+            values = self[var].astype(np.float32)
+            dims = tuple(reversed(meta.nc_dims))  # (lon, lat[, lev]) -> ([lev,] lat, lon)
+            values = values.transpose(*range(values.ndim - 1, -1, -1))
+            if "lev" in dims:
+                values = values[::-1]  # vertical levels increasing with height (lev coordinate reversed)
+            values = values[(None,) * len(lead)]
+            attrs = {"long_name": meta.long_name, "standard_name": var}
+            if meta.units is not None:
+                attrs["units"] = meta.units
+            data[meta.alt_name] = Variable(lead + dims, np.ascontiguousarray(values), attrs)
+        coords = {}
+        for c, axis in (("lon", "X"), ("lat", "Y"), ("lev", None)):
+            meta = REGISTRY[c]
+            vals = self[c][::-1] if c == "lev" else self[c]
+            attrs = {"long_name": meta.long_name, "standard_name": c}
+            if meta.units is not None:
+                attrs["units"] = meta.units
+            if axis:
+                attrs["axis"] = axis
+            coords[c] = Variable((c,), np.ascontiguousarray(vals, dtype=np.float32), attrs)
+        coords["time"] = Variable(("time",), np.array([np.datetime64(self.current_date, "s")]),
+                                  {"axis": "T", "standard_name": "time"})
+        if self.is_ensemble_member:
+            coords["ens"] = Variable(("ens",), np.array([self.member_id], dtype=np.int32))
+        return Dataset(data, coords)
+
+
+class SpeedyEns:
+    """Ensemble of Speedy members that live in one batched device model."""
+
+    def __init__(self, num_of_members, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 2)):
+        self.n_members = int(num_of_members)
+        cnts = _speedy.modelstate_init_ensemble(self.n_members)
+        self.members = [Speedy(start_date=start_date, end_date=end_date, member=i, _state_cnt=c) for i, c in enumerate(cnts)]
+        self.current_date = self.members[0].current_date
+
+    def __iter__(self):
+        return iter(self.members)
+
+    def __len__(self):
+        return self.n_members
+
+    def set_params(self, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 2)):
+        for member in self:
+            member.set_params(start_date=start_date, end_date=end_date)
+        self.current_date = start_date
+
+    def to_dataframe(self, variables=None):
+        return concat([member.to_dataframe(variables=variables) for member in self], "ens")
+
+    def run(self, callbacks=None):
+        """Advance every member from the start to the end date; all members step together (parallel_step)."""
+        callbacks = list(callbacks or [])
+        end_date = self.members[0].end_date
+        state_cnts = np.array([m._state_cnt for m in self], dtype=np.int64)
+        control_cnts = np.array([m._control_cnt for m in self], dtype=np.int64)
+        for member in self:
+            if not member._initialized_bc:
+                raise RuntimeError("The SPEEDY model was not initialized. Call the `set_bc` method of every member.")
+        while self.current_date < end_date:
+            codes = _speedy.parallel_step(state_cnts, control_cnts)
+            self.current_date += _DT_STEP
+            if (codes < 0).any():
+                raise RuntimeError("".join("Member%d: %s\n" % (n, ERROR_CODES[int(c)]) for n, c in enumerate(codes)))
+            for member in self:
+                member.current_date = self.current_date
+            for callback in callbacks:
+                callback(self)
+
+    def get_current_step(self):
+        return self.members[0]["current_step"]

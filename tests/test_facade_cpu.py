@@ -1,0 +1,121 @@
+"""Host-side pieces of the pySPEEDY-compatible facade that need no GPU: registry, the `_speedy` function-name surface,
+date containers, the NetCDF-3 dataset layer (checked against the reference's own fixture file) and callback gating."""
+import os
+import tempfile
+from datetime import datetime
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_registry_covers_the_reference_state():
+    from pyspeedy_amd import registry as R
+    # ModelState_t holds 112 entries (registry/model_state_def.py:121-495); the three polymorphic module instances
+    # (mod_geometry, mod_spectral, mod_implicit) have no getters in the reference either
+    assert len(R.REGISTRY) == 109 + 2  # + tcorh, qcorh: spectral corrections kept in the state by this implementation
+    for name in ("vor", "div", "t", "tr", "ps", "phi", "phis", "u_grid", "ps_grid", "sst_anom", "current_step", "lon", "fband",
+                 "snowcv", "sstom12", "rad_tau2", "hfluxn", "increase_co2"):
+        assert name in R.REGISTRY, name
+    assert R.shape_of("vor") == (31, 32, 8, 2) and R.REGISTRY["vor"].dtype == np.complex128
+    assert R.shape_of("sst_anom", n_months=4) == (96, 48, 6)
+    assert R.shape_of("current_step") == () and not R.is_array("current_step")
+    assert R.REGISTRY["lat"].dtype == np.float32
+    assert [R.REGISTRY[v].alt_name for v in R.DEFAULT_OUTPUT_VARS] == ["u", "v", "t", "q", "phi", "ps"]
+
+
+def test_driver_function_names():
+    from pyspeedy_amd import registry as R
+    from pyspeedy_amd import speedy_driver as drv
+    for fn in ("modelstate_init", "modelstate_init_sst_anom", "modelstate_close", "create_datetime", "get_datetime",
+               "close_datetime", "controlparams_init", "controlparams_close", "init", "step", "parallel_step", "check",
+               "transform_spectral2grid", "transform_grid2spectral", "apply_grid_filter"):
+        assert callable(getattr(drv, fn)), fn
+    for name in R.REGISTRY:
+        for pat in ("get_%s", "set_%s", "get_%s_shape", "is_array_%s"):
+            assert callable(getattr(drv, pat % name)), pat % name
+    assert drv.is_array_t() and not drv.is_array_air_absortivity_co2()
+    with pytest.raises(AttributeError):
+        drv.get_no_such_variable
+    assert getattr(drv, "get_no_such_variable", None) is None  # what Speedy.__getitem__ relies on
+
+
+def test_date_and_control_containers():
+    from pyspeedy_amd import speedy_driver as drv
+    a = drv.create_datetime(1982, 1, 1, 0, 0)
+    b = drv.create_datetime(1982, 3, 5, 12, 40)
+    assert drv.get_datetime(b) == (1982, 3, 5, 12, 40)
+    c = drv.controlparams_init(a, b)
+    assert c not in (a, b)
+    drv.controlparams_close(c)
+    drv.close_datetime(a)
+    with pytest.raises(ValueError):
+        drv.get_datetime(a)
+    with pytest.raises(ValueError):
+        drv.step(12345678, 1)  # unknown state container
+
+
+def test_month_window_of_the_sst_anomalies():
+    from pyspeedy_amd.speedy import _add_months
+    assert _add_months(datetime(1982, 1, 1), -1) == datetime(1981, 12, 1)
+    assert _add_months(datetime(1982, 12, 1), 1) == datetime(1983, 1, 1)
+    assert _add_months(datetime(1982, 6, 1), 7) == datetime(1983, 1, 1)
+
+
+def test_dataset_roundtrip_and_reference_fixture():
+    from pyspeedy_amd.dataset import Dataset, Variable, assert_allclose, concat, open_dataset
+    ref = open_dataset(os.path.join(GOLD, "reference_fixtures", "1982-01-02_0000.nc"))
+    assert set(ref.keys()) == {"u", "v", "t", "q", "phi", "ps"}
+    assert ref["u"].dims == ("time", "lev", "lat", "lon") and ref["ps"].dims == ("time", "lat", "lon")
+    assert ref["time"].values[0] == np.datetime64("1982-01-02T00:00:00")
+    assert ref["u"].attrs == {"units": "m/s", "long_name": "eastward_wind", "standard_name": "u_grid"}
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "copy.nc")
+        ref.to_netcdf(path)
+        back = open_dataset(path)
+    assert_allclose(back, ref, rtol=0, atol=0)
+    for name in ref.variables:
+        assert back[name].attrs == ref[name].attrs, name
+    # ensemble / time concatenation
+    def member(i, when):
+        return Dataset({"x": Variable(("time", "ens", "lat"), np.full((1, 1, 3), float(i)))},
+                       {"ens": Variable(("ens",), np.array([i], dtype=np.int32)),
+                        "time": Variable(("time",), np.array([np.datetime64(when, "s")])),
+                        "lat": Variable(("lat",), np.arange(3, dtype=np.float32))})
+    ens = concat([member(2, "1982-01-02"), member(0, "1982-01-02"), member(1, "1982-01-02")], "ens")
+    assert ens["x"].shape == (1, 3, 3) and list(ens["ens"].values) == [0, 1, 2]
+    assert float(ens.sel(ens=2)["x"].values[0, 0]) == 2.0
+    series = concat([member(0, "1982-01-02T00:40:00"), member(0, "1982-01-02T00:00:00")], "time")
+    with tempfile.TemporaryDirectory() as tmp:
+        series.to_netcdf(os.path.join(tmp, "s.nc"))
+        s2 = open_dataset(os.path.join(tmp, "s.nc"))
+    assert list(s2["time"].values) == [np.datetime64("1982-01-02T00:00:00"), np.datetime64("1982-01-02T00:40:00")]
+    with pytest.raises(AssertionError):
+        assert_allclose(ens, series)
+
+
+def test_callback_gating():
+    from pyspeedy_amd.callbacks import BaseCallback, ModelCheckpoint, XarrayExporter
+
+    class Fake:
+        def __init__(self, step, date):
+            self.step, self.current_date = step, date
+
+        def get_current_step(self):
+            return self.step
+
+    cb = BaseCallback(interval=36, spinup_date=datetime(1982, 1, 3))
+    assert cb.skip_flag(Fake(36, datetime(1982, 1, 2)))        # still spinning up
+    assert cb.skip_flag(Fake(73, datetime(1982, 1, 3, 0, 40)))  # not a multiple of the interval
+    assert not cb.skip_flag(Fake(72, datetime(1982, 1, 3)))
+    assert BaseCallback().interval == 1 and cb.copy() is not cb
+    assert XarrayExporter().variables == ("u_grid", "v_grid", "t_grid", "q_grid", "phi_grid", "ps_grid")
+    assert ModelCheckpoint(interval=4).history_interval == 4
+
+
+def test_example_bc_is_packaged():
+    import pyspeedy_amd
+    with np.load(pyspeedy_amd.example_bc_file()) as z:
+        assert z["orog"].shape == (96, 48) and z["sst"].shape == (96, 48, 12)
+        assert {"orog", "lsm", "alb", "vegh", "vegl", "stl", "snowd", "swl1", "swl2", "swl3", "sst", "icec"} <= set(z.files)

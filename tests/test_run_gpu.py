@@ -24,7 +24,7 @@ def run(golden_dir):
 
 @pytest.fixture(scope="module")
 def bc(golden_dir):
-    return np.load(golden_dir + "/example_bc.npz")
+    return np.load(golden_dir + "/../../pyspeedy_amd/data/example_bc.npz")
 
 
 def compare(model, run, tag, tol, member=0):

@@ -1,0 +1,208 @@
+"""The reference's own integration tests (pyspeedy/tests/test_speedy.py) against the MI355X backend, through the same
+user-facing classes.  Expected values: tests/golden/export.npz, generated from the reference Fortran on the same inputs
+(zero SST anomalies; oracle/gen_golden_export.py); the reference's NetCDF fixture pins the file format.
+
+Tolerances: the reference compares float32 exports with rtol=1e-6, atol=0; the same here (both sides cast fp64 -> fp32).
+The fp64 comparisons of the grid <-> spectral conversions use 1e-12 of the field's max norm.
+"""
+import os
+import tempfile
+from datetime import datetime, timedelta
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+VARS = ("u", "v", "t", "q", "phi", "ps")
+
+start_dates = (
+    # twice the same date: state must not leak between instances
+    (datetime(1982, 1, 1), datetime(1982, 1, 2)),
+    (datetime(1982, 1, 1), datetime(1982, 1, 2)),
+    (datetime(1982, 1, 1), datetime(1982, 1, 4)),
+)
+export_variables = (["u_grid", "v_grid"], ["t_grid", "q_grid"], ["phi_grid", "ps_grid"], ["precnv", "precls"])
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLD, "export.npz"))
+
+
+def expected(gold, day):
+    """The golden grid fields arranged as the exporter writes them: float32, (time, lev reversed, lat, lon)."""
+    out = {}
+    for v in VARS:
+        a = np.asarray(gold["d%d_%s_grid" % (day, v)], dtype=np.float32)
+        a = a.transpose(*range(a.ndim - 1, -1, -1))
+        out[v] = (a[::-1] if a.ndim == 3 else a)[None]
+    return out
+
+
+def assert_matches(ds, exp, rtol=1e-6):
+    assert set(ds.keys()) == set(exp)
+    for v, e in exp.items():
+        np.testing.assert_allclose(ds[v].values, e, rtol=rtol, atol=0, err_msg=v)
+
+
+@pytest.mark.parametrize("start_date, end_date", start_dates)
+def test_speedy_run(gold, start_date, end_date):
+    from pyspeedy_amd.callbacks import XarrayExporter
+    from pyspeedy_amd.dataset import open_dataset
+    from pyspeedy_amd.speedy import Speedy
+    file_name = end_date.strftime("%Y-%m-%d_%H%M.nc")
+    with tempfile.TemporaryDirectory() as tmp:
+        model = Speedy(start_date=start_date, end_date=end_date)
+        model.set_bc()
+        model.run(callbacks=[XarrayExporter(output_dir=tmp)])
+        ds = open_dataset(os.path.join(tmp, file_name))
+    assert_matches(ds, expected(gold, (end_date - start_date).days))
+    assert ds["time"].values[0] == np.datetime64(end_date, "s")
+    np.testing.assert_array_equal(ds["lat"].values, gold["lat"])
+    np.testing.assert_array_equal(ds["lon"].values, gold["lon"])
+    np.testing.assert_array_equal(ds["lev"].values, gold["lev"][::-1])
+
+
+def test_speedy_concurrent(gold):
+    """Two instances advanced alternately, one day at a time: both must equal the 3-day result."""
+    from pyspeedy_amd.callbacks import XarrayExporter
+    from pyspeedy_amd.dataset import open_dataset
+    from pyspeedy_amd.speedy import Speedy
+    start, end = datetime(1982, 1, 1), datetime(1982, 1, 4)
+    file_name = end.strftime("%Y-%m-%d_%H%M.nc")
+    with tempfile.TemporaryDirectory() as tmp:
+        dirs = [os.path.join(tmp, "run1"), os.path.join(tmp, "run2")]
+        models = [Speedy(start_date=start, end_date=end) for _ in dirs]
+        for m in models:
+            m.set_bc()
+        for day in range(3):
+            for m, d in zip(models, dirs):
+                m.start_date = start + timedelta(days=day)
+                m.end_date = start + timedelta(days=day + 1)
+                m.run(callbacks=[XarrayExporter(output_dir=d)])
+        for d in dirs:
+            assert_matches(open_dataset(os.path.join(d, file_name)), expected(gold, 3))
+
+
+def test_ens_speedy(gold):
+    from pyspeedy_amd.callbacks import XarrayExporter
+    from pyspeedy_amd.dataset import open_dataset
+    from pyspeedy_amd.speedy import SpeedyEns
+    start, end = datetime(1982, 1, 1), datetime(1982, 1, 2)
+    file_name = end.strftime("%Y-%m-%d_%H%M.nc")
+    ens = SpeedyEns(3, start_date=start, end_date=end)
+    for member in ens:
+        member.set_bc()
+    exp = expected(gold, 1)
+    with tempfile.TemporaryDirectory() as tmp:
+        ens.run(callbacks=[XarrayExporter(output_dir=tmp)])
+        ens_ds = open_dataset(os.path.join(tmp, file_name))
+    assert ens_ds["u"].dims == ("time", "ens", "lev", "lat", "lon")
+    for m, member in enumerate(ens):
+        assert_matches(member.to_dataframe().isel(ens=0), exp)
+        assert_matches(ens_ds.sel(ens=m), exp)
+
+
+def test_ens_members_are_independent(gold):
+    """A perturbed member diverges, its neighbours still reproduce the unperturbed run (members never exchange data)."""
+    from pyspeedy_amd.speedy import SpeedyEns
+    ens = SpeedyEns(3, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 2))
+    for member in ens:
+        member.set_bc()
+    rng = np.random.default_rng(1)
+    t = ens.members[1]["t_grid"]
+    ens.members[1]["t_grid"] = t + rng.normal(0.0, 0.01, t.shape)  # examples/Ensemble_forecast.ipynb
+    ens.members[1].grid2spectral()
+    ens.run()
+    exp = expected(gold, 1)
+    assert_matches(ens.members[0].to_dataframe().isel(ens=0), exp)
+    assert_matches(ens.members[2].to_dataframe().isel(ens=0), exp)
+    d = ens.members[1].to_dataframe().isel(ens=0)["t"].values - exp["t"]
+    assert 1e-4 < np.abs(d).max() < 5.0
+
+
+def test_exceptions(gold):
+    from pyspeedy_amd.speedy import Speedy
+    model = Speedy(start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 2))
+    with pytest.raises(RuntimeError):
+        model.run()  # not initialised
+    model.set_bc()
+    with pytest.raises(RuntimeError):
+        model.set_bc()
+    model.run()
+    model.check()
+    t = model["t"]
+    t[:] = 0
+    model["t"] = t
+    assert int(gold["chk_zero_t"]) == -2
+    with pytest.raises(RuntimeError):
+        model.check()
+    with pytest.raises(ValueError):
+        model["t"] = np.zeros((3, 3))
+    with pytest.raises(AttributeError):
+        model["no_such_variable"]
+
+
+@pytest.mark.parametrize("variables", export_variables)
+def test_speedy_variable_export(variables):
+    from pyspeedy_amd.callbacks import XarrayExporter
+    from pyspeedy_amd.dataset import open_dataset
+    from pyspeedy_amd.speedy import Speedy
+    end = datetime(1982, 1, 2)
+    with tempfile.TemporaryDirectory() as tmp:
+        model = Speedy(start_date=datetime(1982, 1, 1), end_date=end)
+        model.set_bc()
+        model.run(callbacks=[XarrayExporter(output_dir=tmp, variables=variables)])
+        ds = open_dataset(os.path.join(tmp, end.strftime("%Y-%m-%d_%H%M.nc")))
+    assert set(v.replace("_grid", "") for v in variables) == set(ds.keys())
+
+
+def test_grid2spectral_and_filter(gold):
+    """transform_grid2spectral / apply_grid_filter (prognostics.f90:158-219) on perturbed grid fields vs the reference."""
+    from pyspeedy_amd.speedy import Speedy
+    model = Speedy(start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 2))
+    model.set_bc()
+    rng = np.random.default_rng(20260101)
+    for v in ("u_grid", "v_grid", "t_grid", "q_grid", "phi_grid", "ps_grid"):
+        g = gold["d1_" + v]
+        model[v] = g * (1.0 + 1e-3 * rng.standard_normal(g.shape))
+    model.grid2spectral()
+
+    def close(got, ref, name, tol=1e-12):
+        err = np.abs(got - ref).max() / np.abs(ref).max()
+        assert err <= tol, "%s: scaled max error %.3e" % (name, err)
+
+    for v in ("vor", "div", "t", "tr", "ps"):
+        close(model[v][..., 0], gold["rt_" + v], v)
+    close(model["phi"], gold["rt_phi"], "phi")
+    from pyspeedy_amd import speedy_driver
+    speedy_driver.apply_grid_filter(model._state_cnt)
+    for v in ("u_grid", "t_grid", "ps_grid"):
+        close(model[v], gold["gf_" + v], "filtered " + v)
+
+
+def test_reference_fixture_format_and_envelope():
+    """The reference's own 1-day fixture: identical file layout; values inside the SST-anomaly envelope (it was produced
+    with the observed anomalies, which are not distributed; SURVEY 8c measured rms 0.15 m/s, 0.12 K, 40 Pa)."""
+    from pyspeedy_amd.callbacks import XarrayExporter
+    from pyspeedy_amd.dataset import open_dataset
+    from pyspeedy_amd.speedy import Speedy
+    ref = open_dataset(os.path.join(GOLD, "reference_fixtures", "1982-01-02_0000.nc"))
+    end = datetime(1982, 1, 2)
+    with tempfile.TemporaryDirectory() as tmp:
+        model = Speedy(start_date=datetime(1982, 1, 1), end_date=end)
+        model.set_bc()
+        model.run(callbacks=[XarrayExporter(output_dir=tmp)])
+        ds = open_dataset(os.path.join(tmp, "1982-01-02_0000.nc"))
+    assert set(ds.keys()) == set(ref.keys())
+    for name in list(ref.keys()) + ["lon", "lat", "lev", "time"]:
+        assert ds[name].dims == ref[name].dims, name
+        assert ds[name].shape == ref[name].shape, name
+        assert ds[name].values.dtype == ref[name].values.dtype, name
+        assert ds[name].attrs == ref[name].attrs, (name, ds[name].attrs, ref[name].attrs)
+    for c in ("lon", "lat", "lev", "time"):
+        np.testing.assert_array_equal(ds[c].values, ref[c].values)
+    rms = lambda v: float(np.sqrt(np.mean((ds[v].values.astype(np.float64) - ref[v].values) ** 2)))
+    assert rms("u") < 0.4 and rms("v") < 0.4 and rms("t") < 0.3 and rms("ps") < 100.0
