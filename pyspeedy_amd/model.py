@@ -68,6 +68,19 @@ class EnsembleModel:
               "spd_model_get(%s)" % name)
         return flat.reshape(shape, order="F")
 
+    def device_view(self, name):
+        """Zero-copy torch view [nmembers, *reversed reference shape] of a registry variable in HBM (C order == the
+        reference's Fortran order inside a member).  For on-device post-processing such as ensemble statistics."""
+        dtype, shape = self.shape(name)
+        ptr = self._lib.spd_model_device_ptr(self._m, name.encode())
+        if not ptr:
+            raise KeyError(name)
+
+        class _Blob:  # CUDA array interface v2 (understood by torch.as_tensor on ROCm builds as well)
+            __cuda_array_interface__ = {"shape": (self.nmembers,) + tuple(reversed(shape)),
+                                        "typestr": np.dtype(dtype).str, "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(_Blob(), device=self.sp.device)
+
     def set_co2(self, value):
         check(self._lib.spd_model_set_co2(self._m, float(value)), "spd_model_set_co2")
 

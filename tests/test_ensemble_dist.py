@@ -1,4 +1,5 @@
-"""CPU tier: the N>1 path (member sharding + barrier + max-over-ranks timing) with world_size 2 on gloo."""
+"""CPU tier: the N>1 path (member sharding, barrier, max-over-ranks timing, boundary broadcast, ensemble statistics)
+with world_size 2 on gloo."""
 import os
 import socket
 import subprocess
@@ -46,6 +47,24 @@ WORKER = textwrap.dedent("""
     total = E.sum_over_ranks(count, dist)
     assert abs(slowest - 0.020) < 1e-12, slowest
     assert total == 65, total
+    # start-up broadcast of the shared boundary fields (rank 0 "reads the file") ...
+    import numpy as np, torch
+    bc = None
+    if rank == 0:
+        g = np.random.default_rng(5)
+        bc = {"orog": g.standard_normal((96, 48)), "sst": g.standard_normal((96, 48, 12)), "lsm": g.random((96, 48))}
+    got = E.broadcast_boundary_conditions(bc, dist, "cpu")
+    g = np.random.default_rng(5)
+    for k, shape in (("orog", (96, 48)), ("sst", (96, 48, 12))):
+        ref = g.standard_normal(shape)
+        assert got[k].shape == shape and (got[k] == ref).all(), k
+    assert sorted(got) == ["lsm", "orog", "sst"]
+    # ... and ensemble statistics over the members of both ranks (3 on rank 0, 2 on rank 1)
+    allv = np.random.default_rng(9).standard_normal((5, 4, 6))
+    mine = torch.from_numpy(allv[:3] if rank == 0 else allv[3:])
+    mean, spread = E.ensemble_mean_spread(mine, dist)
+    assert np.allclose(mean.numpy(), allv.mean(axis=0), rtol=0, atol=1e-15)
+    assert np.allclose(spread.numpy(), allv.std(axis=0, ddof=1), rtol=1e-14, atol=0)
     if rank == 0:
         print("RESULT", first, count, E.simulated_years_per_day(total, slowest))
     dist.barrier()

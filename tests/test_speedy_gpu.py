@@ -206,3 +206,27 @@ def test_reference_fixture_format_and_envelope():
         np.testing.assert_array_equal(ds[c].values, ref[c].values)
     rms = lambda v: float(np.sqrt(np.mean((ds[v].values.astype(np.float64) - ref[v].values) ** 2)))
     assert rms("u") < 0.4 and rms("v") < 0.4 and rms("t") < 0.3 and rms("ps") < 100.0
+
+
+def test_ensemble_statistics_on_device():
+    """Ensemble mean / spread computed on the GPU from the zero-copy state view (N = 1: no collective) vs numpy."""
+    from pyspeedy_amd import ensemble as E
+    from pyspeedy_amd import speedy_driver as drv
+    from pyspeedy_amd.speedy import SpeedyEns
+    ens = SpeedyEns(4, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 1, 4, 0))
+    rng = np.random.default_rng(3)
+    for member in ens:
+        member.set_bc()
+        t = member["t_grid"]
+        member["t_grid"] = t + rng.normal(0.0, 0.01, t.shape)
+        member.grid2spectral()
+    ens.run()
+    model = drv._lookup(ens.members[0]._state_cnt, drv._State).batch.model
+    model.spectral2grid()
+    view = model.device_view("t_grid")
+    assert tuple(view.shape) == (4, 8, 48, 96) and view.is_cuda
+    mean, spread = E.ensemble_mean_spread(view, None)
+    host = np.stack([m["t_grid"] for m in ens])  # [member, lon, lat, lev]
+    np.testing.assert_allclose(mean.cpu().numpy().transpose(2, 1, 0), host.mean(axis=0), rtol=1e-14)
+    np.testing.assert_allclose(spread.cpu().numpy().transpose(2, 1, 0), host.std(axis=0, ddof=1), rtol=1e-9, atol=1e-14)
+    assert float(spread.max()) > 1e-4
