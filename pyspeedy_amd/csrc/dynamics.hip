@@ -12,7 +12,7 @@
 // Layouts (member-major, the reference's Fortran order inside a member):
 //   vor, div, t, tr  complex [M][2 time levels][8][32][31] ; ps [M][2][32][31] ; phi [M][8][32][31] ; phis [M][32][31]
 //   grid fields      [M][8][48][96] or [M][48][96]
-// One lane per spectral coefficient (all 8 levels in registers) or per grid column; all accesses unit-stride over lanes.
+// One lane per spectral coefficient or grid column (spectral_step_kernel: per coefficient and level); unit-stride accesses.
 #include <hip/hip_runtime.h>
 
 #include "device_tables.hpp"
@@ -28,7 +28,7 @@ constexpr int kT = 256;
 __device__ constexpr double CPd = 1004.0f;
 __device__ constexpr double AKAPd = 2.0f / 7.0f;
 __device__ constexpr double RGASd = AKAPd * CPd;
-__device__ constexpr double ROBd = 0.05f, WILd = 0.53f, TDRSd = 24.0f * 30.0f;
+__device__ constexpr double WILd = 0.53f, TDRSd = 24.0f * 30.0f;
 
 __device__ inline d2 times_i(d2 z) { return d2{-z.y, z.x}; }
 __device__ inline d2 operator_scale(double c, d2 z) { return d2{c * z.x, c * z.y}; }
@@ -222,123 +222,150 @@ __global__ __launch_bounds__(kT) void dyn_grid_kernel(ModelPtrs P, DynDeviceTabl
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// everything in spectral space after the forward transforms, for one coefficient (m, n) and all 8 levels
+// everything in spectral space after the forward transforms.
+// One lane per (coefficient, level): a wavefront owns 8 consecutive coefficients x 8 levels of one member
+// (lane = 8 * level + coefficient-in-block, so each level's 8 coefficients are one 128-byte line).  What couples the
+// levels -- the mass-weighted divergence sum, the sigma-dot prefix sum and the three 8x8 matrix products of the
+// semi-implicit scheme -- gathers the 8 level values of a coefficient from the other lanes (ds_bpermute) and then runs
+// the reference's loops in the reference's order on them, so the arithmetic is the same as with all levels in one lane
+// while the kernel has 8x the lanes to hide memory latency with (the one-lane-per-coefficient form needed 255 VGPRs and
+// took 45 us for 8 members / 72 us for 64: profiles/).
 // ---------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kCoefBlocks = NSPEC / 8;  // 124 blocks of 8 coefficients
+static_assert(NSPEC % 8 == 0, "coefficient blocks");
+
+__device__ inline void gather_levels(d2 v, int kk, d2 (&out)[KX]) {
+#pragma unroll
+    for (int l = 0; l < KX; ++l) out[l] = d2{__shfl(v.x, 8 * l + kk), __shfl(v.y, 8 * l + kk)};
+}
+template <int N>
+__device__ inline double pick(const double (&a)[N], int l) {
+    double r = a[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) r = (l == i) ? a[i] : r;
+    return r;
+}
+template <int N>
+__device__ inline d2 pick(const d2 (&a)[N], int l) {
+    d2 r = a[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) r = (l == i) ? a[i] : r;
+    return r;
+}
+}  // namespace
+
 __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTables T, DynDeviceTables D, int M, int j1,
                                                            double dt, double eps) {
     const int gid = blockIdx.x * kT + threadIdx.x;
-    if (gid >= M * NSPEC) return;
-    const int mem = gid / NSPEC, k = gid - mem * NSPEC, n = k / MX, m = k - n * MX;
+    const int w = gid >> 6, lane = gid & 63;
+    if (w >= M * kCoefBlocks) return;  // whole wavefronts only: the gathers below need all 64 lanes
+    const int l = lane >> 3, kk = lane & 7;
+    const int mem = w / kCoefBlocks, k = (w - mem * kCoefBlocks) * 8 + kk, n = k / MX, m = k - n * MX;
     const size_t f8 = static_cast<size_t>(mem) * 8 * NSPEC;        // [M][8] work arrays
     const size_t pair = static_cast<size_t>(M) * 8 * NSPEC;        // stride between the three (u,v)-pair outputs
-    const d2 *su = reinterpret_cast<const d2 *>(P.specu) + f8, *sv = reinterpret_cast<const d2 *>(P.specv) + f8;
-    d2 vordt[KX], divdt[KX], tdt[KX], trdt[KX];
+    const size_t fo = static_cast<size_t>(l) * NSPEC;
+    const d2 *su = reinterpret_cast<const d2 *>(P.specu) + f8 + fo, *sv = reinterpret_cast<const d2 *>(P.specv) + f8 + fo;
     const double el2 = T.el2[k];
-#pragma unroll
-    for (int l = 0; l < KX; ++l) {
-        const size_t fo = static_cast<size_t>(l) * NSPEC;
-        d2 dump;
-        uv_stencil<1>(su + fo, sv + fo, k, m, n, T, vordt[l], divdt[l]);                    // grid_vel2vort(utend, vtend)
+    d2 vordt, divdt, tdt, trdt, dump;
+    uv_stencil<1>(su, sv, k, m, n, T, vordt, divdt);                                     // grid_vel2vort(utend, vtend)
+    {
         const d2 ke = reinterpret_cast<const d2 *>(P.spec_ke)[f8 + fo + k];
-        const d2 lap = d2{-ke.x * el2, -ke.y * el2};                                         // laplacian(grid2spec(KE))
-        divdt[l] = d2{divdt[l].x - lap.x, divdt[l].y - lap.y};
-        uv_stencil<1>(su + pair + fo, sv + pair + fo, k, m, n, T, dump, tdt[l]);             // div of (-uT', -vT')
+        const d2 lap = d2{-ke.x * el2, -ke.y * el2};                                     // laplacian(grid2spec(KE))
+        divdt = d2{divdt.x - lap.x, divdt.y - lap.y};
+        uv_stencil<1>(su + pair, sv + pair, k, m, n, T, dump, tdt);                      // div of (-uT', -vT')
         const d2 stt = reinterpret_cast<const d2 *>(P.spec_tt)[f8 + fo + k];
-        tdt[l] = d2{tdt[l].x + stt.x, tdt[l].y + stt.y};
-        uv_stencil<1>(su + 2 * pair + fo, sv + 2 * pair + fo, k, m, n, T, dump, trdt[l]);   // div of (-uq, -vq)
+        tdt = d2{tdt.x + stt.x, tdt.y + stt.y};
+        uv_stencil<1>(su + 2 * pair, sv + 2 * pair, k, m, n, T, dump, trdt);             // div of (-uq, -vq)
         const d2 str = reinterpret_cast<const d2 *>(P.spec_tr)[f8 + fo + k];
-        trdt[l] = d2{trdt[l].x + str.x, trdt[l].y + str.y};
+        trdt = d2{trdt.x + str.x, trdt.y + str.y};
     }
     d2 psdt = reinterpret_cast<const d2 *>(P.spec_ps)[static_cast<size_t>(mem) * NSPEC + k];
     if (k == 0) psdt = d2{0.0, 0.0};
 
-    // ---- state at time level 1 (index 0) ----
-    const size_t s0 = static_cast<size_t>(mem) * 2 * 8 * NSPEC + k;  // level index 0, vertical level 0
+    // ---- state at time level 1 (index 0), this lane's level ----
+    const size_t s0 = static_cast<size_t>(mem) * 2 * 8 * NSPEC + fo + k;
     const size_t lvl = static_cast<size_t>(8) * NSPEC;               // distance between the two time levels
     d2 *vorS = reinterpret_cast<d2 *>(P.vor) + s0, *divS = reinterpret_cast<d2 *>(P.div) + s0;
     d2 *tS = reinterpret_cast<d2 *>(P.t) + s0, *trS = reinterpret_cast<d2 *>(P.tr) + s0;
     d2 *psS = reinterpret_cast<d2 *>(P.ps) + static_cast<size_t>(mem) * 2 * NSPEC + k;
-    d2 div1[KX];
-#pragma unroll
-    for (int l = 0; l < KX; ++l) div1[l] = divS[static_cast<size_t>(l) * NSPEC];
+    const d2 div1 = divS[0];
     const d2 ps1 = psS[0];
+    const double tref_l = pick(D.tref, l);
 
     // ---- spectral tendencies (tendencies.f90:283-352, called with time level 1 because alph = 0.5) ----
     d2 dmeanc{0.0, 0.0};
+    {
+        d2 dall[KX];
+        gather_levels(div1, kk, dall);
 #pragma unroll
-    for (int l = 0; l < KX; ++l) dmeanc = d2{dmeanc.x + div1[l].x * D.dhs[l], dmeanc.y + div1[l].y * D.dhs[l]};
-    psdt = d2{psdt.x - dmeanc.x, psdt.y - dmeanc.y};
-    if (k == 0) psdt = d2{0.0, 0.0};
-    d2 sig[KX + 1], dumk[KX + 1];
-    sig[0] = d2{0.0, 0.0};
-    sig[KX] = d2{0.0, 0.0};
+        for (int j = 0; j < KX; ++j) dmeanc = d2{dmeanc.x + dall[j].x * D.dhs[j], dmeanc.y + dall[j].y * D.dhs[j]};
+        psdt = d2{psdt.x - dmeanc.x, psdt.y - dmeanc.y};
+        if (k == 0) psdt = d2{0.0, 0.0};
+        // sigma-dot at the half levels below (l) and above (l + 1) this level: the reference's running sum
+        // sig(j+1) = sig(j) - dhs(j) (div(j) - dmeanc), sig(1) = sig(kx+1) = 0, accumulated in the same order
+        d2 sig_l{0.0, 0.0}, sig_l1{0.0, 0.0};
 #pragma unroll
-    for (int l = 0; l < KX - 1; ++l)
-        sig[l + 1] = d2{sig[l].x - D.dhs[l] * (div1[l].x - dmeanc.x), sig[l].y - D.dhs[l] * (div1[l].y - dmeanc.y)};
-    dumk[0] = d2{0.0, 0.0};
-    dumk[KX] = d2{0.0, 0.0};
+        for (int j = 0; j < KX - 1; ++j) {
+            const d2 term = d2{D.dhs[j] * (dall[j].x - dmeanc.x), D.dhs[j] * (dall[j].y - dmeanc.y)};
+            if (j < l) sig_l = d2{sig_l.x - term.x, sig_l.y - term.y};
+            if (j <= l) sig_l1 = d2{sig_l1.x - term.x, sig_l1.y - term.y};
+        }
+        if (l == KX - 1) sig_l1 = d2{0.0, 0.0};
+        // tref(l) - tref(l-1); zero at both ends (dumk(1) = dumk(kx+1) = 0)
+        double dtr_l = 0.0, dtr_l1 = 0.0;
 #pragma unroll
-    for (int l = 1; l < KX; ++l) {
-        const double dtr = D.tref[l] - D.tref[l - 1];
-        dumk[l] = d2{sig[l].x * dtr, sig[l].y * dtr};
-    }
-#pragma unroll
-    for (int l = 0; l < KX; ++l) {
-        tdt[l].x = tdt[l].x - (dumk[l + 1].x + dumk[l].x) * D.dhsr[l] + D.tref3[l] * (sig[l + 1].x + sig[l].x) - D.tref2[l] * dmeanc.x;
-        tdt[l].y = tdt[l].y - (dumk[l + 1].y + dumk[l].y) * D.dhsr[l] + D.tref3[l] * (sig[l + 1].y + sig[l].y) - D.tref2[l] * dmeanc.y;
+        for (int j = 1; j < KX; ++j) {
+            const double d = D.tref[j] - D.tref[j - 1];
+            dtr_l = (l == j) ? d : dtr_l;
+            dtr_l1 = (l + 1 == j) ? d : dtr_l1;
+        }
+        const d2 dumk_l = d2{sig_l.x * dtr_l, sig_l.y * dtr_l}, dumk_l1 = d2{sig_l1.x * dtr_l1, sig_l1.y * dtr_l1};
+        const double dhsr_l = pick(D.dhsr, l), tref3_l = pick(D.tref3, l), tref2_l = pick(D.tref2, l);
+        tdt.x = tdt.x - (dumk_l1.x + dumk_l.x) * dhsr_l + tref3_l * (sig_l1.x + sig_l.x) - tref2_l * dmeanc.x;
+        tdt.y = tdt.y - (dumk_l1.y + dumk_l.y) * dhsr_l + tref3_l * (sig_l1.y + sig_l.y) - tref2_l * dmeanc.y;
     }
     {   // geopotential (already valid for time level 1: geopotential_kernel ran before the physics) and its Laplacian
-        const d2 *phi = reinterpret_cast<const d2 *>(P.phi) + f8 + k;
-#pragma unroll
-        for (int l = 0; l < KX; ++l) {
-            const d2 ph = phi[static_cast<size_t>(l) * NSPEC];
-            const double c = RGASd * D.tref[l];
-            const d2 x = d2{ph.x + c * ps1.x, ph.y + c * ps1.y};
-            const d2 lap = d2{-x.x * el2, -x.y * el2};
-            divdt[l] = d2{divdt[l].x - lap.x, divdt[l].y - lap.y};
-        }
+        const d2 ph = reinterpret_cast<const d2 *>(P.phi)[f8 + fo + k];
+        const double c = RGASd * tref_l;
+        const d2 x = d2{ph.x + c * ps1.x, ph.y + c * ps1.y};
+        const d2 lap = d2{-x.x * el2, -x.y * el2};
+        divdt = d2{divdt.x - lap.x, divdt.y - lap.y};
     }
 
     // ---- semi-implicit correction (implicit.f90:234-289) ----
     {
-        d2 ye[KX], yf[KX];
+        d2 all[KX];
+        gather_levels(tdt, kk, all);
+        d2 ye{0.0, 0.0};
 #pragma unroll
-        for (int l = 0; l < KX; ++l) ye[l] = d2{0.0, 0.0};
-#pragma unroll
-        for (int k1 = 0; k1 < KX; ++k1)
-#pragma unroll
-            for (int l = 0; l < KX; ++l) {
-                const double x = D.xd[l + KX * k1];
-                ye[l] = d2{ye[l].x + x * tdt[k1].x, ye[l].y + x * tdt[k1].y};
-            }
-        const double elz = D.elz[k];
-#pragma unroll
-        for (int l = 0; l < KX; ++l) {
-            const double c = RGASd * D.tref[l];
-            ye[l] = d2{ye[l].x + c * psdt.x, ye[l].y + c * psdt.y};
-            yf[l] = d2{divdt[l].x + elz * ye[l].x, divdt[l].y + elz * ye[l].y};
-            divdt[l] = d2{0.0, 0.0};
+        for (int k1 = 0; k1 < KX; ++k1) {
+            const double x = D.xd[l + KX * k1];
+            ye = d2{ye.x + x * all[k1].x, ye.y + x * all[k1].y};
         }
+        const double elz = D.elz[k];
+        const double c = RGASd * tref_l;
+        ye = d2{ye.x + c * psdt.x, ye.y + c * psdt.y};
+        const d2 yf = d2{divdt.x + elz * ye.x, divdt.y + elz * ye.y};
+        divdt = d2{0.0, 0.0};
         const int l_tot = m + n;  // total wavenumber; xj(:, :, l_tot) with 1-based third index
+        gather_levels(yf, kk, all);
         if (l_tot != 0) {
             const double *xj = D.xj + static_cast<size_t>(KX) * KX * (l_tot - 1);
 #pragma unroll
-            for (int k1 = 0; k1 < KX; ++k1)
-#pragma unroll
-                for (int l = 0; l < KX; ++l) {
-                    const double x = xj[l + KX * k1];
-                    divdt[l] = d2{divdt[l].x + x * yf[k1].x, divdt[l].y + x * yf[k1].y};
-                }
-        }
-#pragma unroll
-        for (int l = 0; l < KX; ++l) psdt = d2{psdt.x - divdt[l].x * D.dhsx[l], psdt.y - divdt[l].y * D.dhsx[l]};
-#pragma unroll
-        for (int l = 0; l < KX; ++l)
-#pragma unroll
             for (int k1 = 0; k1 < KX; ++k1) {
-                const double x = D.xc[l + KX * k1];
-                tdt[l] = d2{tdt[l].x + x * divdt[k1].x, tdt[l].y + x * divdt[k1].y};
+                const double x = xj[l + KX * k1];
+                divdt = d2{divdt.x + x * all[k1].x, divdt.y + x * all[k1].y};
             }
+        }
+        gather_levels(divdt, kk, all);
+#pragma unroll
+        for (int j = 0; j < KX; ++j) psdt = d2{psdt.x - all[j].x * D.dhsx[j], psdt.y - all[j].y * D.dhsx[j]};
+#pragma unroll
+        for (int k1 = 0; k1 < KX; ++k1) {
+            const double x = D.xc[l + KX * k1];
+            tdt = d2{tdt.x + x * all[k1].x, tdt.y + x * all[k1].y};
+        }
     }
 
     // ---- horizontal diffusion (time_stepping.f90:78-122) and time integration (:130-188) ----
@@ -348,8 +375,8 @@ __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTa
     const d2 qcorh = reinterpret_cast<const d2 *>(P.qcorh)[static_cast<size_t>(mem) * NSPEC + k];
     const double sdrag = 1.0f / (TDRSd * 3600.0f);
     auto diffuse = [](d2 field, d2 fdt, double a, double b) { return d2{(fdt.x - a * field.x) * b, (fdt.y - a * field.y) * b}; };
-    auto advance = [&](d2 *base, size_t off, d2 fdt) {  // step_field_2d, time_stepping.f90:164-188
-        const d2 o1 = base[off], o2 = base[off + lvl];
+    auto advance = [&](d2 *base, size_t stride, d2 fdt) {  // step_field_2d, time_stepping.f90:164-188
+        const d2 o1 = base[0], o2 = base[stride];
         fdt = d2{fdt.x * trf, fdt.y * trf};
         const d2 oj = (j1 == 0) ? o1 : o2;
         const d2 fnew = d2{o1.x + dt * fdt.x, o1.y + dt * fdt.y};
@@ -358,42 +385,31 @@ __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTa
         const d2 oja = (j1 == 0) ? n1 : oj;
         const double we2 = (1.0f - WILd) * eps;
         const d2 n2 = d2{fnew.x - we2 * (n1.x - 2.0f * oja.x + fnew.x), fnew.y - we2 * (n1.y - 2.0f * oja.y + fnew.y)};
-        base[off] = n1;
-        base[off + lvl] = n2;
+        base[0] = n1;
+        base[stride] = n2;
     };
-#pragma unroll
-    for (int l = 0; l < KX; ++l) {
-        const size_t off = static_cast<size_t>(l) * NSPEC;
-        const d2 vor1 = vorS[off], t1 = tS[off], tr1 = trS[off];
-        d2 vd = diffuse(vor1, vordt[l], dmp, dmp1);
-        d2 dd = diffuse(div1[l], divdt[l], dmpd, dmp1d);
-        const d2 ct = d2{t1.x + tcorh.x * D.tcorv[l], t1.y + tcorh.y * D.tcorv[l]};
-        d2 td = diffuse(ct, tdt[l], dmp, dmp1);
+    {
+        const d2 vor1 = vorS[0], t1 = tS[0], tr1 = trS[0];
+        d2 vd = diffuse(vor1, vordt, dmp, dmp1);
+        d2 dd = diffuse(div1, divdt, dmpd, dmp1d);
+        const double tcorv_l = pick(D.tcorv, l), qcorv_l = pick(D.qcorv, l);
+        const d2 ct = d2{t1.x + tcorh.x * tcorv_l, t1.y + tcorh.y * tcorv_l};
+        d2 td = diffuse(ct, tdt, dmp, dmp1);
         if (l == 0 && m == 0) {  // stratospheric zonal-wind drag on the zonal-mean flow of the top level
             vd = d2{vd.x - sdrag * vor1.x, vd.y - sdrag * vor1.y};
-            dd = d2{dd.x - sdrag * div1[l].x, dd.y - sdrag * div1[l].y};
+            dd = d2{dd.x - sdrag * div1.x, dd.y - sdrag * div1.y};
         }
         vd = diffuse(vor1, vd, dmps, dmp1s);
-        dd = diffuse(div1[l], dd, dmps, dmp1s);
+        dd = diffuse(div1, dd, dmps, dmp1s);
         td = diffuse(ct, td, dmps, dmp1s);
-        const d2 cq = d2{tr1.x + qcorh.x * D.qcorv[l], tr1.y + qcorh.y * D.qcorv[l]};
-        const d2 qd = diffuse(cq, trdt[l], dmpd, dmp1d);
-        advance(vorS, off, vd);
-        advance(divS, off, dd);
-        advance(tS, off, td);
-        advance(trS, off, qd);
+        const d2 cq = d2{tr1.x + qcorh.x * qcorv_l, tr1.y + qcorh.y * qcorv_l};
+        const d2 qd = diffuse(cq, trdt, dmpd, dmp1d);
+        advance(vorS, lvl, vd);
+        advance(divS, lvl, dd);
+        advance(tS, lvl, td);
+        advance(trS, lvl, qd);
     }
-    {   // ln ps has no vertical index: the two time levels are NSPEC apart
-        const d2 o1 = psS[0], o2 = psS[NSPEC];
-        const d2 fdt = d2{psdt.x * trf, psdt.y * trf};
-        const d2 oj = (j1 == 0) ? o1 : o2;
-        const d2 fnew = d2{o1.x + dt * fdt.x, o1.y + dt * fdt.y};
-        const double we = WILd * eps, we2 = (1.0f - WILd) * eps;
-        const d2 n1 = d2{oj.x + we * (o1.x - 2 * oj.x + fnew.x), oj.y + we * (o1.y - 2 * oj.y + fnew.y)};
-        const d2 oja = (j1 == 0) ? n1 : oj;
-        psS[0] = n1;
-        psS[NSPEC] = d2{fnew.x - we2 * (n1.x - 2.0f * oja.x + fnew.x), fnew.y - we2 * (n1.y - 2.0f * oja.y + fnew.y)};
-    }
+    if (l == 0) advance(psS, NSPEC, psdt);  // ln ps has no vertical index: the two time levels are NSPEC apart
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -446,7 +462,7 @@ hipError_t run_dyn_grid(const ModelPtrs &P, const DynDeviceTables &D, int M, hip
 }
 hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const DynDeviceTables &D, int M, int j1, double dt,
                              double eps, hipStream_t s) {
-    hipLaunchKernelGGL(spectral_step_kernel, dim3((M * NSPEC + kT - 1) / kT), dim3(kT), 0, s, P, T, D, M, j1, dt, eps);
+    hipLaunchKernelGGL(spectral_step_kernel, dim3((M * NSPEC * KX + kT - 1) / kT), dim3(kT), 0, s, P, T, D, M, j1, dt, eps);
     return hipGetLastError();
 }
 hipError_t run_diagnostics(const ModelPtrs &P, const DeviceTables &T, int M, int tl, int *err, double *diag, hipStream_t s) {
