@@ -67,9 +67,12 @@ struct Col {  // per-column pointers resolved once
 // (PYSPEEDY_AMD_PHYS_WAVES) so the occupancy / spill trade-off can be measured on the same binary.
 template <int W>
 __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_args a, DeviceTables T, int nmembers) {
+    // rad_tau2 of this lane's column while the two longwave sweeps run: [band * 8 + level][lane], 16 KB per wavefront
+    __shared__ double tau_s[4 * KX][kPhysThreads];
     const int gid = blockIdx.x * kPhysThreads + threadIdx.x;
     if (gid >= nmembers * NG) return;
     const int mem = gid / NG, p = gid - mem * NG, j = p / IX;
+    const int lane = threadIdx.x;
     const size_t o2 = static_cast<size_t>(mem) * NG + p;              // (ix,il)
     const size_t o3 = static_cast<size_t>(mem) * NG * KX + p;         // (ix,il,kx), + NG*k
     const size_t oa = static_cast<size_t>(mem) * NG * 3 + p;          // (ix,il,3),  + NG*c
@@ -316,8 +319,8 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
     const double qtend_kx = qtend[KX - 1];
 
     // ------------------------------------------------------------------ clouds + shortwave (every nstrad-th step)
-    // rad_tau2(k, band) lives in HBM between shortwave steps (physics.f90 keeps it in the model state); the longwave sweeps
-    // below re-load one band at a time instead of holding all 32 transmissivities in registers.
+    // rad_tau2(k, band) lives in HBM between shortwave steps (physics.f90 keeps it in the model state); while the two
+    // longwave sweeps run it sits in LDS (tau_s), read one band at a time instead of holding all 32 values in registers.
     double ssrd, strat1, strat2;
     int icltop = 0;
     double cloudc = 0.0, clstr = 0.0;
@@ -430,8 +433,10 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         // longwave transmissivities, shortwave_radiation.f90:170-208
         const double co2 = a.air_absortivity_co2;
         const size_t NGs = static_cast<size_t>(NG);
-        a.rad_tau2[ot + NGs * (0 + KX * 0)] = exp(-psa * T.dhs[0] * ablwin);
-        a.rad_tau2[ot + NGs * (0 + KX * 1)] = exp(-psa * T.dhs[0] * co2);
+        tau_s[0][lane] = exp(-psa * T.dhs[0] * ablwin);
+        tau_s[KX][lane] = exp(-psa * T.dhs[0] * co2);
+        a.rad_tau2[ot + NGs * (0 + KX * 0)] = tau_s[0][lane];
+        a.rad_tau2[ot + NGs * (0 + KX * 1)] = tau_s[KX][lane];
         a.rad_tau2[ot + NGs * (0 + KX * 2)] = 1.0;
         a.rad_tau2[ot + NGs * (0 + KX * 3)] = 1.0;
         acloud = cloudc * ablcl2;
@@ -455,6 +460,10 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
             a.rad_tau2[ot + NGs * (k - 1 + KX * 1)] = t1;
             a.rad_tau2[ot + NGs * (k - 1 + KX * 2)] = t2;
             a.rad_tau2[ot + NGs * (k - 1 + KX * 3)] = t3;
+            tau_s[k - 1 + KX * 0][lane] = t0;
+            tau_s[k - 1 + KX * 1][lane] = t1;
+            tau_s[k - 1 + KX * 2][lane] = t2;
+            tau_s[k - 1 + KX * 3][lane] = t3;
         }
         const double eps1 = EPSLW / (T.dhs[0] + T.dhs[1]);
         strat1 = a.stratospheric_correction[o2] * psa;
@@ -464,6 +473,11 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
     } else {
 #pragma unroll
         for (int k = 0; k < KX; ++k) ttend[k] = ttend[k] + a.tt_rsw[o3 + NG * k];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int k = (b < 2 ? 0 : 1); k < KX; ++k)  // bands 3-4 do not use the top level
+                tau_s[k + KX * b][lane] = a.rad_tau2[ot + static_cast<size_t>(NG) * (k + KX * b)];
         ssrd = a.ssrd[o2];
         strat1 = a.rad_strat_corr[oc];
         strat2 = a.rad_strat_corr[oc + NG];
@@ -499,13 +513,11 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
             int it = static_cast<int>(round(ta[k]));
             itab[k] = (it < 100 ? 100 : (it > 400 ? 400 : it)) - 100;
         }
-        const double *tau_col = a.rad_tau2 + ot;  // tau_col[NG * (k + KX * b)]
-        const size_t NGt = static_cast<size_t>(NG);
         // Stratosphere (bands 1-2, :73-79) first for both bands, as the reference does: dfabs(1) sums in that order.
         double tau0[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            tau0[b] = tau_col[NGt * (KX * b)];
+            tau0[b] = tau_s[KX * b][lane];
             const double emis = 1.0f - tau0[b];
             const double brad = T.fband[itab[0] + 301 * b] * (st4a[0][0] + emis * st4a[0][1]);
             flux[b] = emis * brad;
@@ -516,7 +528,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         for (int b = 0; b < 4; ++b) {
             double tb[KX];
 #pragma unroll
-            for (int k = 2; k <= KX; ++k) tb[k - 1] = tau_col[NGt * (k - 1 + KX * b)];
+            for (int k = 2; k <= KX; ++k) tb[k - 1] = tau_s[k - 1 + KX * b][lane];
 #pragma unroll
             for (int k = 2; k <= KX; ++k) {
                 const double emis = 1.0f - tb[k - 1];
@@ -623,7 +635,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         for (int b = 0; b < 4; ++b) {
             double tb[KX];
 #pragma unroll
-            for (int k = 2; k <= KX; ++k) tb[k - 1] = tau_col[NGt * (k - 1 + KX * b)];
+            for (int k = 2; k <= KX; ++k) tb[k - 1] = tau_s[k - 1 + KX * b][lane];
 #pragma unroll
             for (int k = KX; k >= 2; --k) {
                 const double emis = 1.0f - tb[k - 1];
