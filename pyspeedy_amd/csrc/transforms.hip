@@ -49,6 +49,22 @@ __device__ inline int pos_im(int m) { return m == 0 ? 61 : 2 * m; }
 
 __device__ inline int wave_id() { return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6); }
 
+// Phase timing for kernel tuning (compiled only with -DSPD_TRACE, see tools/trace_transforms.py): thread 0 of every
+// workgroup adds the shader-clock time spent up to each phase boundary to a device-global table.
+#ifdef SPD_TRACE
+__device__ unsigned long long spd_trace_acc[2][8];
+__device__ unsigned long long spd_trace_cnt[2];
+#define TRACE_BEGIN() unsigned long long trace_t0 = (threadIdx.x == 0) ? wall_clock64() : 0ull
+#define TRACE_MARK(dir, i) \
+    do { if (threadIdx.x == 0) atomicAdd(&spd_trace_acc[dir][i], wall_clock64() - trace_t0); } while (0)
+#define TRACE_END(dir) \
+    do { if (threadIdx.x == 0) atomicAdd(&spd_trace_cnt[dir], 1ull); } while (0)
+#else
+#define TRACE_BEGIN()
+#define TRACE_MARK(dir, i)
+#define TRACE_END(dir)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // spec -> grid
 // ------------------------------------------------------------------------------------------------
@@ -63,11 +79,13 @@ __device__ __forceinline__ void spec2grid_body(const double *__restrict__ src, d
     const int tid = threadIdx.x;
     const int wave = wave_id(), lane = tid & 63;
 
+    TRACE_BEGIN();
     if (ST != Stage::FourierOnly) {
         // ---- stage spectral coefficients: 16 B per lane, fully coalesced ----
         const d2 *g = reinterpret_cast<const d2 *>(src);
         for (int idx = tid; idx < NSPEC; idx += kThreads) s[idx] = g[idx];
         __syncthreads();
+        TRACE_MARK(0, 0);
 
         // ---- inverse Legendre (legendre.f90:130-169): lane = (m, jq), latitude pairs 2jq, 2jq+1 ----
         if (tid < kInvLanes) {
@@ -102,6 +120,7 @@ __device__ __forceinline__ void spec2grid_body(const double *__restrict__ src, d
             }
         }
         __syncthreads();
+        TRACE_MARK(0, 1);
     } else {
         // ---- Fourier plane from memory: (62, 48) -> unpacked rows ----
         const double *g = src;
@@ -145,6 +164,7 @@ __device__ __forceinline__ void spec2grid_body(const double *__restrict__ src, d
         }
     }
     __syncthreads();
+    TRACE_MARK(0, 2);
     // ---- block stage (radb4 ido=3 + radb3), in place; wave = block ----
     {
         double o[4][3];
@@ -158,6 +178,7 @@ __device__ __forceinline__ void spec2grid_body(const double *__restrict__ src, d
         }
     }
     __syncthreads();
+    TRACE_MARK(0, 3);
 
     // ---- store grid rows: 16 B per lane, coalesced; optional 1/cos(lat) scaling (fourier.f90:87-91) ----
     d2 *g = reinterpret_cast<d2 *>(dst);
@@ -172,6 +193,8 @@ __device__ __forceinline__ void spec2grid_body(const double *__restrict__ src, d
         }
         g[idx] = v;
     }
+    TRACE_MARK(0, 4);
+    TRACE_END(0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -187,6 +210,7 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
     const int tid = threadIdx.x;
     const int wave = wave_id(), lane = tid & 63;
 
+    TRACE_BEGIN();
     if (ST != Stage::LegendreOnly) {
         // ---- load grid rows (16 B per lane, coalesced) ----
         const d2 *g = reinterpret_cast<const d2 *>(src);
@@ -203,6 +227,7 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
             a[1] = v.y;
         }
         __syncthreads();
+        TRACE_MARK(1, 0);
         double *row = rows + lane * kRowStride;
         const bool active = lane < kRows;
         // ---- forward FFT, block stage (radf3 + radf4 ido=3), in place; wave = block ----
@@ -216,6 +241,7 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
             }
         }
         __syncthreads();
+        TRACE_MARK(1, 1);
         // ---- group stage (radf4 ido=12 + radf2), scaled by fp32(1/96), retained wavenumbers only; wave = group ----
         {
             fft::Quad q[4];
@@ -244,6 +270,7 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
             }
         }
         __syncthreads();
+        TRACE_MARK(1, 2);
     } else {
         const double *g = src;
         for (int idx = tid; idx < NFOUR; idx += kThreads) {
@@ -276,6 +303,7 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
         rs[pi] = (ni - si) * w;
     }
     __syncthreads();
+    TRACE_MARK(1, 3);
     // step 2: lane = (m, parity, g): n = parity + 2g and n + 16; sum over the 24 latitude pairs in reference order
     if (tid < kDirLanes) {
         const int m = tid >> 4, par = (tid >> 3) & 1, gq = tid & 7;
@@ -297,8 +325,11 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
         s[(n0 + 16) * MX + m] = d2{acc[1][0], acc[1][1]};
     }
     __syncthreads();
+    TRACE_MARK(1, 4);
     d2 *g = reinterpret_cast<d2 *>(dst);
     for (int idx = tid; idx < NSPEC; idx += kThreads) g[idx] = s[idx];
+    TRACE_MARK(1, 5);
+    TRACE_END(1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -393,3 +424,19 @@ hipError_t run_grid2spec(const DeviceTables &T, int stage, const double *src, do
 }
 
 }  // namespace spd
+
+#ifdef SPD_TRACE
+// mean time (in 100 MHz wall-clock ticks = 10 ns) from kernel entry to each phase boundary; resets the counters
+extern "C" int spd_trace_read(double *out /* [2][8] */, double *count /* [2] */) {
+    unsigned long long acc[2][8], cnt[2], zero[2][8] = {};
+    if (hipMemcpyFromSymbol(acc, HIP_SYMBOL(spd::spd_trace_acc), sizeof(acc)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(cnt, HIP_SYMBOL(spd::spd_trace_cnt), sizeof(cnt)) != hipSuccess) return -1;
+    for (int d = 0; d < 2; ++d) {
+        count[d] = static_cast<double>(cnt[d]);
+        for (int i = 0; i < 8; ++i) out[d * 8 + i] = cnt[d] ? static_cast<double>(acc[d][i]) / cnt[d] : 0.0;
+    }
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(spd::spd_trace_acc), zero, sizeof(acc));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(spd::spd_trace_cnt), zero, sizeof(cnt));
+    return 0;
+}
+#endif
