@@ -69,20 +69,47 @@ static std::vector<double> make_pinv(const HostTables &h) {
     return p;
 }
 
-static std::vector<double> make_pdir(const HostTables &h) {
-    // [j = 24][lane = m*16 + parity*8 + g][2]: n = parity + 2g and n + 16; zero where the reference leaves the
-    // coefficient at 0 (n = 1..trunc+1 only and nsh2, legendre.f90:206-217)
-    std::vector<double> p(static_cast<size_t>(IY) * MX * 16 * 2, 0.0);
+// Direct-Legendre work list: one lane per (m, parity, two consecutive valid n of that parity), m-major.  Only the
+// coefficients the reference fills (n <= trunc, m + n <= trunc + 1: nsh2, legendre.f90:206-217) get a lane, so the
+// kernel streams 279 lanes x 24 latitude pairs x 16 B instead of the full 31 x 32 rectangle.
+struct DirLane {
+    int m, par, na, nb;  // nb = -1: the lane owns a single coefficient
+};
+static std::vector<DirLane> dir_lanes() {
+    std::vector<DirLane> lanes;
+    for (int m = 0; m < MX; ++m)
+        for (int par = 0; par < 2; ++par) {
+            std::vector<int> ns;
+            for (int n = par; n <= TRUNC && m + n <= TRUNC + 1; n += 2) ns.push_back(n);
+            for (size_t i = 0; i < ns.size(); i += 2) lanes.push_back({m, par, ns[i], i + 1 < ns.size() ? ns[i + 1] : -1});
+        }
+    return lanes;
+}
+
+static std::vector<double> make_pdir(const HostTables &h, const std::vector<DirLane> &lanes, int stride) {
+    // [j = 24][lane (stride)][2]: the polynomials of the lane's two coefficients at latitude pair j
+    std::vector<double> p(static_cast<size_t>(IY) * stride * 2, 0.0);
     for (int j = 0; j < IY; ++j)
-        for (int m = 0; m < MX; ++m)
-            for (int par = 0; par < 2; ++par)
-                for (int g = 0; g < 8; ++g)
-                    for (int hi = 0; hi < 2; ++hi) {
-                        const int n = par + 2 * g + 16 * hi;
-                        if (n <= TRUNC && m + n <= TRUNC + 1)
-                            p[((static_cast<size_t>(j) * MX + m) * 16 + par * 8 + g) * 2 + hi] = h.poly[m + MX * (n + NX * j)];
-                    }
+        for (size_t l = 0; l < lanes.size(); ++l) {
+            const DirLane &d = lanes[l];
+            p[(static_cast<size_t>(j) * stride + l) * 2] = h.poly[d.m + MX * (d.na + NX * j)];
+            if (d.nb >= 0) p[(static_cast<size_t>(j) * stride + l) * 2 + 1] = h.poly[d.m + MX * (d.nb + NX * j)];
+        }
     return p;
+}
+
+// per-lane metadata for the kernel: {LDS positions of re / im in a compact Fourier row, parity, output indices}
+static std::vector<int> make_dirmeta(const std::vector<DirLane> &lanes, int stride) {
+    std::vector<int> meta(static_cast<size_t>(stride) * 4, -1);
+    for (size_t l = 0; l < lanes.size(); ++l) {
+        const DirLane &d = lanes[l];
+        const int pr = d.m == 0 ? 0 : 2 * d.m - 1, pi = d.m == 0 ? 61 : 2 * d.m;  // pos_re / pos_im of transforms.hip
+        meta[4 * l + 0] = pr | (pi << 8);
+        meta[4 * l + 1] = d.par;
+        meta[4 * l + 2] = d.na * MX + d.m;
+        meta[4 * l + 3] = d.nb >= 0 ? d.nb * MX + d.m : -1;
+    }
+    return meta;
 }
 
 extern "C" {
@@ -107,9 +134,20 @@ int spd_create(spd_handle *out, int device) {
     auto up = [&](const double *src, size_t n, const double **dst) {
         if (rc == SPD_OK) rc = upload(c, src, n, dst);
     };
-    const std::vector<double> pinv = make_pinv(h), pdir = make_pdir(h);
+    const std::vector<DirLane> lanes = dir_lanes();
+    d.ndir = static_cast<int>(lanes.size());
+    d.dir_stride = (d.ndir + 63) / 64 * 64;
+    const std::vector<double> pinv = make_pinv(h), pdir = make_pdir(h, lanes, d.dir_stride);
+    const std::vector<int> dirmeta = make_dirmeta(lanes, d.dir_stride);
     up(pinv.data(), pinv.size(), &d.pinv);
     up(pdir.data(), pdir.size(), &d.pdir);
+    {   // int metadata travels through the same uploader, two ints per double slot
+        std::vector<double> raw(dirmeta.size() / 2);
+        std::memcpy(raw.data(), dirmeta.data(), dirmeta.size() * sizeof(int));
+        const double *dev = nullptr;
+        up(raw.data(), raw.size(), &dev);
+        d.dirmeta = reinterpret_cast<const int *>(dev);
+    }
     up(h.work.data(), 96, &d.work);
     up(h.cosgr.data(), 48, &d.cosgr);
     up(h.cosgr2.data(), 48, &d.cosgr2);

@@ -8,8 +8,11 @@ namespace spd {
 struct DeviceTables {
     // inverse-Legendre polynomials  [n=32][m*12+jq][2 lat pairs]      (zero where m + n > 31)
     const double *pinv;
-    // direct-Legendre polynomials   [j=24][m*16+parity*8+g][2 n]      (zero where n > min(30, 31-m))
+    // direct-Legendre polynomials   [j=24][lane (dir_stride)][2 n]    one lane per two valid coefficients of one
+    // (m, parity); dirmeta[lane] = {pos_re | pos_im << 8, parity, output index a, output index b or -1}
     const double *pdir;
+    const int *dirmeta;
+    int ndir, dir_stride;
     const double *work;    // FFTPACK twiddles, 96
     const double *cosgr;   // 48
     const double *cosgr2;  // 48

@@ -63,8 +63,8 @@ struct Col {  // per-column pointers resolved once
 
 }  // namespace
 
-// W = minimum waves per SIMD the register allocator must leave room for (launch-bounds hint); selected at run time
-// (PYSPEEDY_AMD_PHYS_WAVES) so the occupancy / spill trade-off can be measured on the same binary.
+// W = minimum waves per SIMD the register allocator must leave room for (launch-bounds hint): 2 by default (256 VGPRs, a
+// handful of spilled values), 1 with PYSPEEDY_AMD_PHYS_WAVES=1 for comparison; 3 and 4 spill heavily and were 1.5-2x slower.
 template <int W>
 __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_args a, DeviceTables T, int nmembers) {
     // rad_tau2 of this lane's column while the two longwave sweeps run: [band * 8 + level][lane], 16 KB per wavefront
@@ -692,10 +692,8 @@ hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nme
         return e ? atoi(e) : 2;
     }();
     switch (waves) {
-        case 2: hipLaunchKernelGGL(physics_kernel<2>, dim3(blocks), dim3(kPhysThreads), 0, s, a, T, nmembers); break;
-        case 3: hipLaunchKernelGGL(physics_kernel<3>, dim3(blocks), dim3(kPhysThreads), 0, s, a, T, nmembers); break;
-        case 4: hipLaunchKernelGGL(physics_kernel<4>, dim3(blocks), dim3(kPhysThreads), 0, s, a, T, nmembers); break;
-        default: hipLaunchKernelGGL(physics_kernel<1>, dim3(blocks), dim3(kPhysThreads), 0, s, a, T, nmembers); break;
+        case 1: hipLaunchKernelGGL(physics_kernel<1>, dim3(blocks), dim3(kPhysThreads), 0, s, a, T, nmembers); break;
+        default: hipLaunchKernelGGL(physics_kernel<2>, dim3(blocks), dim3(kPhysThreads), 0, s, a, T, nmembers); break;
     }
     return hipGetLastError();
 }

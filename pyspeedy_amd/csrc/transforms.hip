@@ -18,8 +18,9 @@
 //     wave diverges; lanes sit on different rows and the odd row stride makes every ds_read/write_b64
 //     bank-conflict free.
 //   * Legendre: a lane owns one zonal wavenumber m (re and im together, 16-byte LDS reads) and two latitude pairs
-//     (inverse) or two total wavenumbers (direct).  Lanes are ordered m-major so that a wavefront only loops over
-//     the total wavenumbers its smallest m needs (triangular truncation: 32 - m of them).  The associated-Legendre
+//     (inverse) or two total wavenumbers of one parity (direct).  Inverse lanes are ordered m-major so that a
+//     wavefront only loops over the total wavenumbers its smallest m needs (triangular truncation: 32 - m of them);
+//     direct lanes come from a work list that holds only the coefficients inside the truncation (279 lanes).  The associated-Legendre
 //     values stream from an L2-resident table laid out so that a wavefront reads 1 KiB contiguous per step.
 #include <hip/hip_runtime.h>
 
@@ -34,7 +35,6 @@ constexpr int kRows = IL;                       // 48 rows per field
 constexpr int kCStride = 63;                    // compact row: positions 0..60 + the parked Im(m=0) at 61
 constexpr int kCBufDoubles = kRows * kCStride;  // 3024 doubles = 24 192 B
 constexpr int kInvLanes = MX * 12;              // inverse Legendre tasks: (m, pair-of-latitude-pairs)
-constexpr int kDirLanes = MX * 16;              // direct  Legendre tasks: (m, parity, 8 groups of two n)
 constexpr size_t kLdsBytes = (kCBufDoubles + 2 * NSPEC) * sizeof(double);  // 40 064
 static_assert(kRows * kRowStride <= kCBufDoubles + 2 * NSPEC, "R must fit inside C + S");
 
@@ -290,7 +290,10 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
     }
 
     // ---- direct Legendre (legendre.f90:175-221) ----
-    // step 1, in place: north row <- symmetric part, south row <- antisymmetric part, both times the Gaussian weight
+    // step 1, in place: north row <- symmetric part, south row <- antisymmetric part, both times the Gaussian weight;
+    // the output staging area (free now: the FFT rows are dead) is cleared, step 2 only writes the coefficients the
+    // reference fills
+    for (int idx = tid; idx < NSPEC; idx += kThreads) s[idx] = d2{0.0, 0.0};
     for (int idx = tid; idx < MX * IY; idx += kThreads) {
         const int j = idx / MX, m = idx - j * MX;
         const int pr = pos_re(m), pi = pos_im(m);
@@ -304,25 +307,26 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
     }
     __syncthreads();
     TRACE_MARK(1, 3);
-    // step 2: lane = (m, parity, g): n = parity + 2g and n + 16; sum over the 24 latitude pairs in reference order
-    if (tid < kDirLanes) {
-        const int m = tid >> 4, par = (tid >> 3) & 1, gq = tid & 7;
-        const int pr = pos_re(m), pi = pos_im(m);
+    // step 2: lane = (m, parity, two valid n of that parity) from the work list of the context (capi.hip: dir_lanes);
+    // sum over the 24 latitude pairs in reference order
+    if (tid < T.ndir) {
+        const int4 meta = reinterpret_cast<const int4 *>(T.dirmeta)[tid];
+        const int pr = meta.x & 0xff, pi = meta.x >> 8, par = meta.y;
         double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-        const d2 *pol = reinterpret_cast<const d2 *>(T.pdir) + tid;  // [j][496] x {n0, n0+16}
+        const d2 *pol = reinterpret_cast<const d2 *>(T.pdir) + tid;  // [j][dir_stride] x {n_a, n_b}
+        const int pstride = T.dir_stride;
         const double *base = cbuf + (par ? 0 : (kRows - 1) * kCStride);
         const int rstep = par ? kCStride : -kCStride;
 #pragma unroll 4
         for (int j = 0; j < IY; ++j) {
-            const d2 p = pol[j * kDirLanes];
+            const d2 p = pol[j * pstride];
             const double *r = base + j * rstep;
             const double xr = r[pr], xi = r[pi];
             acc[0][0] += p.x * xr;  acc[0][1] += p.x * xi;
             acc[1][0] += p.y * xr;  acc[1][1] += p.y * xi;
         }
-        const int n0 = par + 2 * gq;
-        s[n0 * MX + m] = d2{acc[0][0], acc[0][1]};
-        s[(n0 + 16) * MX + m] = d2{acc[1][0], acc[1][1]};
+        s[meta.z] = d2{acc[0][0], acc[0][1]};
+        if (meta.w >= 0) s[meta.w] = d2{acc[1][0], acc[1][1]};
     }
     __syncthreads();
     TRACE_MARK(1, 4);
