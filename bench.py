@@ -145,14 +145,15 @@ def main():
         raise SystemExit("bench.py: %d members left the accepted range (diagnostics.f90)" % int((codes != 0).sum()))
 
     achieved = (S_BYTES + G_BYTES) * nfields / (kern_ms * 1e-3) / 1e9
-    # HBM bytes per launch from the committed PMC measurement of this kernel (rocprofv3 cannot run inside bench.py):
-    # bytes per field at 3648 fields/launch, FETCH_SIZE doubled as the gfx950 guide prescribes.
+    # HBM bytes per launch from the committed PMC measurement of this very kernel inside this bench (rocprofv3 cannot run
+    # inside bench.py): 5824 fields per launch at 64 members, FETCH_SIZE doubled as the gfx950 guide prescribes; scaled
+    # per field for other member counts.
     traffic, traffic_src = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
-            tj = json.load(fh)
-        traffic = tj["spec2grid_fused_hbm_bytes_per_field"] * nfields
-        traffic_src = "profiles/r01_pmc_transforms_v2.csv (per-field bytes measured at %d fields/launch)" % tj["fields_per_launch"]
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_model_step.json")) as fh:
+            tj = json.load(fh)["kernels"]["spd::spec2grid_table_kernel"]
+        traffic = tj["hbm_bytes_per_launch"] * nfields / 5824.0
+        traffic_src = "profiles/r01_pmc_model_step.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py, 5824 fields/launch)"
     except (OSError, KeyError, ValueError):
         pass
 
