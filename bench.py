@@ -49,14 +49,14 @@ def load_bc():
     return np.load(os.path.join(ROOT, "pyspeedy_amd", "data", "example_bc.npz"))
 
 
-def build_ensemble(M, device, seed, dist, rank):
+def build_ensemble(M, device, seed, dist, rank, coll_device):
     import pyspeedy_amd
     from pyspeedy_amd import ensemble as E
     from pyspeedy_amd.model import EnsembleModel
     sp = pyspeedy_amd.ModSpectral(device.index)
     model = EnsembleModel(sp, M)
     # rank 0 reads the boundary file; one RCCL broadcast (~3.4 MB over xGMI) hands it to the other GPUs
-    bc = E.broadcast_boundary_conditions(dict(load_bc()) if rank == 0 else None, dist, device)
+    bc = E.broadcast_boundary_conditions(dict(load_bc()) if rank == 0 else None, dist, coll_device)
     model.set_bc(bc, start_date=(1982, 1, 1, 0, 0))
     # member perturbations (examples/Ensemble_forecast.ipynb perturbs t_grid with N(0, 0.01) K): here a relative 1e-5
     # perturbation of the spectral temperature of both time levels, seed = global member id
@@ -121,16 +121,21 @@ def main():
     world, rank, local = E.dist_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
+    local = local % torch.cuda.device_count()  # (several ranks may share a GPU in a rehearsal on a one-GPU box)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    dist = E.init_process_group("nccl", device)  # RCCL; only used for the barrier and the max-over-ranks time
+    # RCCL ("nccl" on ROCm): barrier, max-over-ranks time and the start-up broadcast of the boundary fields.
+    # PYSPEEDY_AMD_BENCH_BACKEND=gloo rehearses the same control flow when the ranks cannot each have their own GPU.
+    backend = os.environ.get("PYSPEEDY_AMD_BENCH_BACKEND", "nccl")
+    dist = E.init_process_group(backend, device)
+    coll_device = device if backend == "nccl" else torch.device("cpu")
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    sp, model = build_ensemble(args.members, device, 1 + rank, dist, rank)
+    sp, model = build_ensemble(args.members, device, 1 + rank, dist, rank, coll_device)
     model.run(args.warmup)
     model.profile(True)
     barrier()
@@ -138,7 +143,7 @@ def main():
     model.run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = E.max_over_ranks(elapsed, dist, device)
+    elapsed = E.max_over_ranks(elapsed, dist, coll_device)
     kern_ms, launches, nfields = model.profile_read()
     codes = model.check(2)
     if (codes != 0).any():
