@@ -141,6 +141,8 @@ int spd_model_get(spd_model_handle m, const char *name, int member, void *host_b
 /* device base pointer of a registry array ([nmembers][...]), for zero-copy users */
 void *spd_model_device_ptr(spd_model_handle m, const char *name);
 int spd_model_set_co2(spd_model_handle m, double air_absortivity_co2);
+/* current value (the daily forcing raises it when increase_co2 is set, forcing.f90:52-57) */
+double spd_model_co2(spd_model_handle m);
 /* ModImplicit_set_time_step (implicit.f90:83-218): rebuilds the dt-dependent tables (8x8 inversions on the host) */
 int spd_model_set_time_step(spd_model_handle m, double dt);
 /* time_stepping.f90 `step(state, j1, j2, dt)` for all members; j1, j2 = 1 or 2 as in the reference */

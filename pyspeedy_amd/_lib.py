@@ -78,6 +78,7 @@ _SIGNATURES = {
     "spd_model_get": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]),
     "spd_model_device_ptr": (C.c_void_p, [C.c_void_p, C.c_char_p]),
     "spd_model_set_co2": (C.c_int, [C.c_void_p, C.c_double]),
+    "spd_model_co2": (C.c_double, [C.c_void_p]),
     "spd_model_set_time_step": (C.c_int, [C.c_void_p, C.c_double]),
     "spd_model_step_dynamics": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]),
     "spd_model_check": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

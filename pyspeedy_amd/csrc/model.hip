@@ -406,6 +406,8 @@ int spd_model_set_co2(spd_model_handle m, double air_absortivity_co2) {
     return SPD_OK;
 }
 
+double spd_model_co2(spd_model_handle m) { return m ? m->air_absortivity_co2 : 0.0; }
+
 int spd_model_set_time_step(spd_model_handle m, double dt) {
     if (!m) return m_fail(SPD_E_ARG, "spd_model_set_time_step: null model");
     M_HIP(hipSetDevice(m->ctx->device));

@@ -81,6 +81,10 @@ class EnsembleModel:
                                         "typestr": np.dtype(dtype).str, "data": (int(ptr), False), "version": 2}
         return torch.as_tensor(_Blob(), device=self.sp.device)
 
+    @property
+    def co2(self):
+        return float(self._lib.spd_model_co2(self._m))
+
     def set_co2(self, value):
         check(self._lib.spd_model_set_co2(self._m, float(value)), "spd_model_set_co2")
 

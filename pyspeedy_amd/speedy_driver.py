@@ -154,11 +154,12 @@ def controlparams_close(control_cnt):
 # --------------------------------------------------------------------------------------------------------------------
 # model control
 # --------------------------------------------------------------------------------------------------------------------
-def _push_flags(st):
+def _push_flags(st, co2=True):
     s = st.scalars
     m = st.batch.model
     m.set_flags(s["land_coupling_flag"], s["sst_anomaly_coupling_flag"], s["increase_co2"])
-    m.set_co2(s["air_absortivity_co2"])
+    if co2:  # (the model raises its own value daily when increase_co2 is set: do not overwrite it with the mirror)
+        m.set_co2(s["air_absortivity_co2"])
 
 
 def init(state_cnt, control_cnt):
@@ -288,6 +289,8 @@ def _get(name, state_cnt, n_months=None):
         return st.host.setdefault(name, np.zeros(R.shape_of(name), dtype=v.dtype, order="F")).copy(order="F")
     if name == "current_step":
         return b.model.current_step
+    if name == "air_absortivity_co2":
+        return b.model.co2
     return st.scalars[name]
 
 
@@ -308,7 +311,7 @@ def _set(name, state_cnt, value, n_months=None):
         raise ValueError("current_step is advanced by the model")
     else:
         st.scalars[name] = v.dtype(value).item()
-        _push_flags(st)
+        _push_flags(st, co2=(name == "air_absortivity_co2"))
 
 
 def _shape(name, state_cnt):

@@ -230,3 +230,37 @@ def test_ensemble_statistics_on_device():
     np.testing.assert_allclose(mean.cpu().numpy().transpose(2, 1, 0), host.mean(axis=0), rtol=1e-14)
     np.testing.assert_allclose(spread.cpu().numpy().transpose(2, 1, 0), host.std(axis=0, ddof=1), rtol=1e-9, atol=1e-14)
     assert float(spread.max()) > 1e-4
+
+
+def test_month_crossing_with_sst_anomaly_and_co2_trend():
+    """5 days across the January/February boundary with a synthetic SST anomaly (4 monthly planes) and increase_co2,
+    against the reference Fortran (oracle/gen_golden_anomaly.py).  Tolerance 1e-10 of each field's max norm (180 steps)."""
+    from pyspeedy_amd.speedy import Speedy
+    g = np.load(os.path.join(GOLD, "anomaly.npz"))
+    lat = g["lat"].astype(np.float64)
+    i = np.arange(96)[:, None, None]
+    t = np.arange(4)[None, None, :]
+    ssta = 1.5 * np.sin(2 * np.pi * i / 96 + 0.7 * t) * np.cos(np.deg2rad(lat))[None, :, None] + 0.3 * t - 0.4
+    times = np.array(["1981-12-01", "1982-01-01", "1982-02-01", "1982-03-01"], dtype="datetime64[s]")
+    model = Speedy(start_date=datetime(1982, 1, 29), end_date=datetime(1982, 2, 3))
+    model["increase_co2"] = True
+    model.set_bc(sst_anomaly={"ssta": ssta, "time": times})
+    assert model.get_shape("sst_anom") == (96, 48, 4)
+    np.testing.assert_array_equal(model["lat"], g["lat"])
+    model.run()
+    assert model.get_current_step() == int(g["current_step"]) == 180
+    assert abs(model["air_absortivity_co2"] - float(g["air_absortivity_co2"])) < 1e-13
+
+    def close(got, ref, name, tol=1e-10):
+        scale = np.abs(ref).max()
+        err = np.abs(got - ref).max() / (scale if scale > 0 else 1.0)
+        assert err <= tol, "%s: scaled max error %.3e" % (name, err)
+
+    for v in ("vor", "div", "t", "tr", "ps"):
+        close(model[v][..., 0], g[v], v)
+    close(model["phi"], g["phi"], "phi")
+    for v in ("sst_am", "sstan_am", "sice_am", "tice_am", "land_temp", "snow_depth", "soil_avail_water", "sst_om", "ssti_om",
+              "alb_surface", "snowc", "olr", "precnv"):
+        close(model[v], g[v], v)
+    with pytest.raises(RuntimeError):  # anomalies must cover the run (speedy.py:349-362)
+        Speedy(start_date=datetime(1982, 1, 29), end_date=datetime(1982, 4, 3)).set_bc(sst_anomaly={"ssta": ssta, "time": times})
