@@ -1,0 +1,103 @@
+// Grid-point dynamics of one column (tendencies.f90:125-224) and the products the forward transforms need (:242-266),
+// shared by the stand-alone kernel of dynamics.hip and the fused dynamics + physics kernel of physics.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "model.hpp"
+
+namespace spd {
+
+// Column p (0 .. ix*il-1, latitude row j) of member `mem`.  Stores utend / vtend above the lowest level, the kinetic energy
+// and flux products and the surface-pressure tendency; RETURNS the temperature / tracer tendencies of all levels and the
+// wind tendencies of the lowest level in registers (the physics adds to exactly those) -- or stores them too when STORE_ALL.
+template <bool STORE_ALL>
+__device__ __forceinline__ void dyn_column(const ModelPtrs &P, const DynDeviceTables &D, int mem, int p, int j,
+                                           double (&ttend)[KX], double (&trtend)[KX], double &utend_kx, double &vtend_kx) {
+    constexpr int NG = IX * IL;
+    constexpr double AKAPd = 2.0f / 7.0f, RGASd = AKAPd * static_cast<double>(1004.0f);
+    const size_t o3 = static_cast<size_t>(mem) * KX * NG + p, o2 = static_cast<size_t>(mem) * NG + p;
+    double ug[KX], vg[KX], tg[KX], trg[KX], vorg[KX], divg[KX];
+    const double cor = D.coriol[j];
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        ug[k] = P.ug2[o3 + NG * k];
+        vg[k] = P.vg2[o3 + NG * k];
+        tg[k] = P.tg2[o3 + NG * k];
+        trg[k] = P.trg2[o3 + NG * k];
+        vorg[k] = P.vorg[o3 + NG * k] + cor;
+        divg[k] = P.divg[o3 + NG * k];
+    }
+    const double px = P.px[o2], py = P.py[o2];
+    double umean = 0.0, vmean = 0.0, dmean = 0.0;
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        umean = umean + ug[k] * D.dhs[k];
+        vmean = vmean + vg[k] * D.dhs[k];
+        dmean = dmean + divg[k] * D.dhs[k];
+    }
+    P.psdtg[o2] = -umean * px - vmean * py;
+    double puv[KX], sigdt[KX + 1], sigm[KX + 1], tgg[KX], temp[KX + 1];
+    sigdt[0] = 0.0;
+    sigm[0] = 0.0;
+#pragma unroll
+    for (int k = 0; k < KX; ++k) puv[k] = (ug[k] - umean) * px + (vg[k] - vmean) * py;
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        sigdt[k + 1] = sigdt[k] - D.dhs[k] * (puv[k] + divg[k] - dmean);
+        sigm[k + 1] = sigm[k] - D.dhs[k] * puv[k];
+    }
+    // (tendencies.f90:153-156 zeroes level kx+1 BEFORE this loop; the loop's last iteration stores it again, so the
+    //  value used below is the accumulated one, ~1e-17, exactly as in the reference)
+#pragma unroll
+    for (int k = 0; k < KX; ++k) tgg[k] = tg[k] - D.tref[k];
+    temp[0] = 0.0;
+    temp[KX] = 0.0;
+    // zonal wind
+#pragma unroll
+    for (int k = 1; k < KX; ++k) temp[k] = sigdt[k] * (ug[k] - ug[k - 1]);
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        const double v = vg[k] * vorg[k] - tgg[k] * RGASd * px - (temp[k + 1] + temp[k]) * D.dhsr[k];
+        if (STORE_ALL || k < KX - 1) P.utend[o3 + NG * k] = v;
+        if (k == KX - 1) utend_kx = v;
+    }
+    // meridional wind
+#pragma unroll
+    for (int k = 1; k < KX; ++k) temp[k] = sigdt[k] * (vg[k] - vg[k - 1]);
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        const double v = -ug[k] * vorg[k] - tgg[k] * RGASd * py - (temp[k + 1] + temp[k]) * D.dhsr[k];
+        if (STORE_ALL || k < KX - 1) P.vtend[o3 + NG * k] = v;
+        if (k == KX - 1) vtend_kx = v;
+    }
+    // temperature
+#pragma unroll
+    for (int k = 1; k < KX; ++k) temp[k] = sigdt[k] * (tgg[k] - tgg[k - 1]) + sigm[k] * (D.tref[k] - D.tref[k - 1]);
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        ttend[k] = tgg[k] * divg[k] - (temp[k + 1] + temp[k]) * D.dhsr[k] + D.fsgr[k] * tgg[k] * (sigdt[k + 1] + sigdt[k]) +
+                   D.tref3[k] * (sigm[k + 1] + sigm[k]) + AKAPd * (tg[k] * puv[k] - tgg[k] * dmean);
+        if (STORE_ALL) P.ttend[o3 + NG * k] = ttend[k];
+    }
+    // tracer
+#pragma unroll
+    for (int k = 1; k < KX; ++k) temp[k] = sigdt[k] * (trg[k] - trg[k - 1]);
+    temp[1] = 0.0;
+    temp[2] = 0.0;
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        trtend[k] = trg[k] * divg[k] - (temp[k + 1] + temp[k]) * D.dhsr[k];
+        if (STORE_ALL) P.trtend[o3 + NG * k] = trtend[k];
+    }
+    // inputs of the forward transforms (tendencies.f90:247-266)
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        P.keg[o3 + NG * k] = 0.5f * (ug[k] * ug[k] + vg[k] * vg[k]);
+        P.utg[o3 + NG * k] = -ug[k] * tgg[k];
+        P.vtg[o3 + NG * k] = -vg[k] * tgg[k];
+        P.uqg[o3 + NG * k] = -ug[k] * trg[k];
+        P.vqg[o3 + NG * k] = -vg[k] * trg[k];
+    }
+}
+
+}  // namespace spd

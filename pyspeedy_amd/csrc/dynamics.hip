@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_tables.hpp"
+#include "dyn_column.hpp"
 #include "model.hpp"
 
 namespace spd {
@@ -140,85 +141,15 @@ __global__ __launch_bounds__(kT) void geopotential_kernel(ModelPtrs P, DynDevice
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// grid-point dynamics of one column (tendencies.f90:125-224) + the products the forward transforms need (:242-266)
+// grid-point dynamics of one column (dyn_column.hpp), stand-alone form.  The model step uses the fused dynamics +
+// physics kernel of physics.hip instead; this kernel serves spd_model_step_dynamics' split mode (parity tests).
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kT) void dyn_grid_kernel(ModelPtrs P, DynDeviceTables D, int M) {
     const int gid = blockIdx.x * kT + threadIdx.x;
     if (gid >= M * NG) return;
     const int mem = gid / NG, p = gid - mem * NG, j = p / IX;
-    const size_t o3 = static_cast<size_t>(mem) * KX * NG + p, o2 = static_cast<size_t>(mem) * NG + p;
-    double ug[KX], vg[KX], tg[KX], trg[KX], vorg[KX], divg[KX];
-    const double cor = D.coriol[j];
-#pragma unroll
-    for (int k = 0; k < KX; ++k) {
-        ug[k] = P.ug2[o3 + NG * k];
-        vg[k] = P.vg2[o3 + NG * k];
-        tg[k] = P.tg2[o3 + NG * k];
-        trg[k] = P.trg2[o3 + NG * k];
-        vorg[k] = P.vorg[o3 + NG * k] + cor;
-        divg[k] = P.divg[o3 + NG * k];
-    }
-    const double px = P.px[o2], py = P.py[o2];
-    double umean = 0.0, vmean = 0.0, dmean = 0.0;
-#pragma unroll
-    for (int k = 0; k < KX; ++k) {
-        umean = umean + ug[k] * D.dhs[k];
-        vmean = vmean + vg[k] * D.dhs[k];
-        dmean = dmean + divg[k] * D.dhs[k];
-    }
-    P.psdtg[o2] = -umean * px - vmean * py;
-    double puv[KX], sigdt[KX + 1], sigm[KX + 1], tgg[KX], temp[KX + 1];
-    sigdt[0] = 0.0;
-    sigm[0] = 0.0;
-#pragma unroll
-    for (int k = 0; k < KX; ++k) puv[k] = (ug[k] - umean) * px + (vg[k] - vmean) * py;
-#pragma unroll
-    for (int k = 0; k < KX; ++k) {
-        sigdt[k + 1] = sigdt[k] - D.dhs[k] * (puv[k] + divg[k] - dmean);
-        sigm[k + 1] = sigm[k] - D.dhs[k] * puv[k];
-    }
-    // (tendencies.f90:153-156 zeroes level kx+1 BEFORE this loop; the loop's last iteration stores it again, so the
-    //  value used below is the accumulated one, ~1e-17, exactly as in the reference)
-#pragma unroll
-    for (int k = 0; k < KX; ++k) tgg[k] = tg[k] - D.tref[k];
-    temp[0] = 0.0;
-    temp[KX] = 0.0;
-    // zonal wind
-#pragma unroll
-    for (int k = 1; k < KX; ++k) temp[k] = sigdt[k] * (ug[k] - ug[k - 1]);
-#pragma unroll
-    for (int k = 0; k < KX; ++k)
-        P.utend[o3 + NG * k] = vg[k] * vorg[k] - tgg[k] * RGASd * px - (temp[k + 1] + temp[k]) * D.dhsr[k];
-    // meridional wind
-#pragma unroll
-    for (int k = 1; k < KX; ++k) temp[k] = sigdt[k] * (vg[k] - vg[k - 1]);
-#pragma unroll
-    for (int k = 0; k < KX; ++k)
-        P.vtend[o3 + NG * k] = -ug[k] * vorg[k] - tgg[k] * RGASd * py - (temp[k + 1] + temp[k]) * D.dhsr[k];
-    // temperature
-#pragma unroll
-    for (int k = 1; k < KX; ++k) temp[k] = sigdt[k] * (tgg[k] - tgg[k - 1]) + sigm[k] * (D.tref[k] - D.tref[k - 1]);
-#pragma unroll
-    for (int k = 0; k < KX; ++k)
-        P.ttend[o3 + NG * k] = tgg[k] * divg[k] - (temp[k + 1] + temp[k]) * D.dhsr[k] +
-                               D.fsgr[k] * tgg[k] * (sigdt[k + 1] + sigdt[k]) + D.tref3[k] * (sigm[k + 1] + sigm[k]) +
-                               AKAPd * (tg[k] * puv[k] - tgg[k] * dmean);
-    // tracer
-#pragma unroll
-    for (int k = 1; k < KX; ++k) temp[k] = sigdt[k] * (trg[k] - trg[k - 1]);
-    temp[1] = 0.0;
-    temp[2] = 0.0;
-#pragma unroll
-    for (int k = 0; k < KX; ++k) P.trtend[o3 + NG * k] = trg[k] * divg[k] - (temp[k + 1] + temp[k]) * D.dhsr[k];
-    // inputs of the forward transforms (tendencies.f90:247-266)
-#pragma unroll
-    for (int k = 0; k < KX; ++k) {
-        P.keg[o3 + NG * k] = 0.5f * (ug[k] * ug[k] + vg[k] * vg[k]);
-        P.utg[o3 + NG * k] = -ug[k] * tgg[k];
-        P.vtg[o3 + NG * k] = -vg[k] * tgg[k];
-        P.uqg[o3 + NG * k] = -ug[k] * trg[k];
-        P.vqg[o3 + NG * k] = -vg[k] * trg[k];
-    }
+    double ttend[KX], trtend[KX], ut, vt;
+    dyn_column<true>(P, D, mem, p, j, ttend, trtend, ut, vt);
 }
 
 // ---------------------------------------------------------------------------------------------------------

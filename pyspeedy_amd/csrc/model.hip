@@ -19,6 +19,8 @@ namespace spd {
 hipError_t run_spec2grid_table(const DeviceTables &T, const FieldDesc *table, int nfields, hipStream_t st);
 hipError_t run_grid2spec_table(const DeviceTables &T, const FieldDesc *table, int nfields, hipStream_t st);
 hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nmembers, hipStream_t s);
+hipError_t run_dyn_physics(const ModelPtrs &P, const DynDeviceTables &D, const DeviceTables &T, const spd_physics_args &a,
+                           int nmembers, hipStream_t s);
 hipError_t run_model_uvgrad(const ModelPtrs &P, const DeviceTables &T, int M, int j2, hipStream_t s);
 hipError_t run_geopotential(const ModelPtrs &P, const DynDeviceTables &D, int M, int tl, hipStream_t s);
 hipError_t run_dyn_grid(const ModelPtrs &P, const DynDeviceTables &D, int M, hipStream_t s);
@@ -79,6 +81,7 @@ struct spd_model {
     Calendar cal;
     int current_step = 0;
     bool initialized = false;
+    bool split_dyn_physics = false;  // PYSPEEDY_AMD_SPLIT_DYN=1: separate dynamics and physics launches (for measurements)
     int land_coupling_flag = 1, sst_anomaly_flag = 1, increase_co2 = 0, anom_planes = 3;
     double ablco2_ref = 6.0;
     double *corh_t = nullptr, *corh_q = nullptr, *scratch_spec = nullptr;  // [M][NG], [M][NG], [2][M][992] complex
@@ -222,6 +225,7 @@ int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
     spd_model *m = new spd_model();
     m->ctx = h;
     m->M = nmembers;
+    if (const char *env = getenv("PYSPEEDY_AMD_SPLIT_DYN")) m->split_dyn_physics = atoi(env) != 0;
     const size_t M = nmembers, S = NSPEC * C, G3 = static_cast<size_t>(8) * NG;
     ModelPtrs &P = m->P;
     spd_physics_args &pa = m->pa;
@@ -450,11 +454,15 @@ int spd_model_step_dynamics(spd_model_handle m, int j1, int j2, double dt, int c
     }
     if (e == hipSuccess) e = run_spec2grid_table(T, m->inv_table[j2 - 1], 91 * M, s);     // :109-146, physics.f90:89-101
     if (ev1) (void)hipEventRecord(ev1, s);
-    if (e == hipSuccess) e = run_dyn_grid(m->P, m->D, M, s);                              // :151-224
     if (e == hipSuccess) {
         m->pa.compute_shortwave = compute_shortwave ? 1 : 0;
         m->pa.air_absortivity_co2 = m->air_absortivity_co2;
-        e = run_physics(T, m->pa, M, s);                                                  // :231
+        if (m->split_dyn_physics) {
+            e = run_dyn_grid(m->P, m->D, M, s);                                           // :151-224
+            if (e == hipSuccess) e = run_physics(T, m->pa, M, s);                         // :231
+        } else {
+            e = run_dyn_physics(m->P, m->D, T, m->pa, M, s);                              // both in one launch
+        }
     }
     if (e == hipSuccess) e = run_grid2spec_table(T, m->fwd_table, 73 * M, s);             // :238-268
     const double eps = (j1 == 1) ? 0.0 : static_cast<double>(0.05f);                      // rob, time_stepping.f90:130-134

@@ -23,6 +23,7 @@
 
 #include "../../include/pyspeedy_amd.h"
 #include "device_tables.hpp"
+#include "dyn_column.hpp"
 
 namespace spd {
 
@@ -65,8 +66,14 @@ struct Col {  // per-column pointers resolved once
 
 // W = minimum waves per SIMD the register allocator must leave room for (launch-bounds hint): 2 by default (256 VGPRs, a
 // handful of spilled values), 1 with PYSPEEDY_AMD_PHYS_WAVES=1 for comparison; 3 and 4 spill heavily and were 1.5-2x slower.
-template <int W>
-__global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_args a, DeviceTables T, int nmembers) {
+//
+// FUSED: the kernel first runs the grid-point dynamics of the column (dyn_column.hpp, tendencies.f90:125-224) and keeps the
+// temperature / humidity tendencies it produces in registers -- the physics adds to exactly those -- so they are written
+// once instead of written by one kernel and read and re-written by the next (the model step; 36 field moves per member
+// less).  Not FUSED: the tendencies are read from a.ttend / a.qtend / a.utend / a.vtend (the C ABI's spd_physics).
+template <int W, bool FUSED>
+__global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_args a, DeviceTables T, int nmembers, ModelPtrs MP,
+                                                                  DynDeviceTables MD) {
     // rad_tau2 of this lane's column while the two longwave sweeps run: [band * 8 + level][lane], 16 KB per wavefront
     __shared__ double tau_s[4 * KX][kPhysThreads];
     const int gid = blockIdx.x * kPhysThreads + threadIdx.x;
@@ -82,6 +89,21 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
     const size_t oc = static_cast<size_t>(mem) * NG * 2 + p;          // (ix,il,2)
     constexpr int nl1 = KX - 1;  // 1-based index of the level above the lowest; 0-based index nl1-1
 
+    // ------------------------------------------------------------------ tendencies so far (dynamics)
+    // FUSED: computed here and parked in LDS (the rows tau_s uses later) until the condensation scheme picks them up,
+    // so that they do not occupy 32 VGPRs through the convection scheme, the register peak of the kernel.
+    double utend_dyn = 0.0, vtend_dyn = 0.0;
+    if (FUSED) {
+        double tt[KX], qt[KX];
+        dyn_column<false>(MP, MD, mem, p, j, tt, qt, utend_dyn, vtend_dyn);
+#pragma unroll
+        for (int k = 0; k < KX; ++k) {
+            tau_s[k][lane] = tt[k];
+            tau_s[KX + k][lane] = qt[k];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the physics' loads below: the two phases must not add their registers
+    }
+
     // ------------------------------------------------------------------ thermodynamics, physics.f90:107-116
     double ta[KX], qa[KX], phi[KX], se[KX], qsat[KX], rh[KX];
     const double psa = exp(a.pslg[o2]);
@@ -95,13 +117,6 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         qsat[k] = qsat_point(ta[k], T.fsg[k] * psa);
         rh[k] = qa[k] / qsat[k];
     }
-    double ttend[KX], qtend[KX];
-#pragma unroll
-    for (int k = 0; k < KX; ++k) {
-        ttend[k] = a.ttend[o3 + NG * k];
-        qtend[k] = a.qtend[o3 + NG * k];
-    }
-
     // ------------------------------------------------------------------ deep convection, convection.f90
     const double psmin = 0.8f, trcnv = 6.0f, rhbl = 0.9f, rhil = 0.7f, entmax = 0.5f, smf = 0.8f;
     int itop = KX + 1;
@@ -215,6 +230,12 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
     int iptop = itop;
 
     // ------------------------------------------------------------------ large-scale condensation
+    double ttend[KX], qtend[KX];
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        ttend[k] = FUSED ? tau_s[k][lane] : a.ttend[o3 + NG * k];
+        qtend[k] = FUSED ? tau_s[KX + k][lane] : a.qtend[o3 + NG * k];
+    }
     double precls = 0.0;
     {
         const double trlsc = 4.0f, rhlsc = 0.9f, drhlsc = 0.1f, rhblsc = 0.95f, qsmax = 10.0f;
@@ -672,8 +693,8 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         const double vt_kx = 0.0 + vstr3 * rps * T.grdsig[KX - 1];
         ttend[KX - 1] = ttend[KX - 1] + shf3 * rps * T.grdscp[KX - 1];
         const size_t okx = o3 + static_cast<size_t>(NG) * (KX - 1);
-        a.utend[okx] = a.utend[okx] + ut_kx;  // ut_pbl, vt_pbl are zero above the lowest level
-        a.vtend[okx] = a.vtend[okx] + vt_kx;
+        a.utend[okx] = (FUSED ? utend_dyn : a.utend[okx]) + ut_kx;  // ut_pbl, vt_pbl are zero above the lowest level
+        a.vtend[okx] = (FUSED ? vtend_dyn : a.vtend[okx]) + vt_kx;
 #pragma unroll
         for (int k = 0; k < KX; ++k) a.ttend[o3 + NG * k] = ttend[k];
         a.qtend[okx] = qtend_kx + evap3 * rps * T.grdsig[KX - 1];
@@ -684,17 +705,36 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
     if (a.clstr) a.clstr[o2] = clstr;
 }
 
-hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nmembers, hipStream_t s) {
-    const long total = static_cast<long>(nmembers) * NG;
-    const unsigned blocks = static_cast<unsigned>((total + kPhysThreads - 1) / kPhysThreads);
+static int physics_waves() {
     static const int waves = [] {
         const char *e = getenv("PYSPEEDY_AMD_PHYS_WAVES");
         return e ? atoi(e) : 2;
     }();
-    switch (waves) {
-        case 1: hipLaunchKernelGGL(physics_kernel<1>, dim3(blocks), dim3(kPhysThreads), 0, s, a, T, nmembers); break;
-        default: hipLaunchKernelGGL(physics_kernel<2>, dim3(blocks), dim3(kPhysThreads), 0, s, a, T, nmembers); break;
-    }
+    return waves;
+}
+
+hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nmembers, hipStream_t s) {
+    const long total = static_cast<long>(nmembers) * NG;
+    const unsigned blocks = static_cast<unsigned>((total + kPhysThreads - 1) / kPhysThreads);
+    const ModelPtrs mp{};
+    const DynDeviceTables md{};
+    if (physics_waves() == 1)
+        hipLaunchKernelGGL((physics_kernel<1, false>), dim3(blocks), dim3(kPhysThreads), 0, s, a, T, nmembers, mp, md);
+    else
+        hipLaunchKernelGGL((physics_kernel<2, false>), dim3(blocks), dim3(kPhysThreads), 0, s, a, T, nmembers, mp, md);
+    return hipGetLastError();
+}
+
+// grid-point dynamics + physics of every column in one launch (the model step); a.ttend / a.qtend / a.utend / a.vtend must be
+// the dynamics' tendency arrays (P.ttend, P.trtend, P.utend, P.vtend)
+hipError_t run_dyn_physics(const ModelPtrs &P, const DynDeviceTables &D, const DeviceTables &T, const spd_physics_args &a,
+                           int nmembers, hipStream_t s) {
+    const long total = static_cast<long>(nmembers) * NG;
+    const unsigned blocks = static_cast<unsigned>((total + kPhysThreads - 1) / kPhysThreads);
+    if (physics_waves() == 1)
+        hipLaunchKernelGGL((physics_kernel<1, true>), dim3(blocks), dim3(kPhysThreads), 0, s, a, T, nmembers, P, D);
+    else
+        hipLaunchKernelGGL((physics_kernel<2, true>), dim3(blocks), dim3(kPhysThreads), 0, s, a, T, nmembers, P, D);
     return hipGetLastError();
 }
 
