@@ -34,6 +34,8 @@ constexpr int kRowStride = 97;
 constexpr int kRows = IL;                       // 48 rows per field
 constexpr int kCStride = 63;                    // compact row: positions 0..60 + the parked Im(m=0) at 61
 constexpr int kCBufDoubles = kRows * kCStride;  // 3024 doubles = 24 192 B
+constexpr int kSpecPerLane = (NSPEC + kThreads - 1) / kThreads;      // 2 x 16 B per lane stage a spectral field
+constexpr int kGridPerLane = (NGRID / 2 + kThreads - 1) / kThreads;  // 5 x 16 B per lane stage a grid field
 constexpr int kInvLanes = MX * 12;              // inverse Legendre tasks: (m, pair-of-latitude-pairs)
 constexpr size_t kLdsBytes = (kCBufDoubles + 2 * NSPEC) * sizeof(double);  // 40 064
 static_assert(kRows * kRowStride <= kCBufDoubles + 2 * NSPEC, "R must fit inside C + S");
@@ -41,6 +43,10 @@ static_assert(kRows * kRowStride <= kCBufDoubles + 2 * NSPEC, "R must fit inside
 enum class Stage { Fused, LegendreOnly, FourierOnly };
 
 using d2 = double __attribute__((ext_vector_type(2)));
+// field pointers handed to the kernels always point to global memory; saying so in the type gives global_load / global_store
+// instead of flat accesses where the pointer comes out of a descriptor table
+using gd2_in = const __attribute__((address_space(1))) d2 *;
+using gd2_out = __attribute__((address_space(1))) d2 *;
 
 // position of coefficient (m, re|im) in an unpacked FFT row (fourier.f90:74-81): re(m) -> 2m-1, im(m) -> 2m,
 // re(0) -> 0.  im(0) has no slot in the transform; it is parked at position 61 where a stage needs it.
@@ -82,8 +88,15 @@ __device__ __forceinline__ void spec2grid_body(const double *__restrict__ src, d
     TRACE_BEGIN();
     if (ST != Stage::FourierOnly) {
         // ---- stage spectral coefficients: 16 B per lane, fully coalesced ----
-        const d2 *g = reinterpret_cast<const d2 *>(src);
-        for (int idx = tid; idx < NSPEC; idx += kThreads) s[idx] = g[idx];
+        // (all loads of a lane are issued before the first LDS store: a rolled loop would wait for each one in turn)
+        gd2_in g = (gd2_in)src;
+        d2 sv[kSpecPerLane];
+#pragma unroll
+        for (int it = 0; it < kSpecPerLane; ++it)
+            if (tid + it * kThreads < NSPEC) sv[it] = g[tid + it * kThreads];
+#pragma unroll
+        for (int it = 0; it < kSpecPerLane; ++it)
+            if (tid + it * kThreads < NSPEC) s[tid + it * kThreads] = sv[it];
         __syncthreads();
         TRACE_MARK(0, 0);
 
@@ -181,17 +194,27 @@ __device__ __forceinline__ void spec2grid_body(const double *__restrict__ src, d
     TRACE_MARK(0, 3);
 
     // ---- store grid rows: 16 B per lane, coalesced; optional 1/cos(lat) scaling (fourier.f90:87-91) ----
-    d2 *g = reinterpret_cast<d2 *>(dst);
-    for (int idx = tid; idx < NGRID / 2; idx += kThreads) {
-        const int r = idx / (IX / 2), ip = idx - r * (IX / 2);
-        const double *a = rows + r * kRowStride + 2 * ip;
-        d2 v{a[0], a[1]};
-        if (kcos != 1) {
-            const double c = T.cosgr[r];
-            v.x *= c;
-            v.y *= c;
+    // (the scale factors are fetched first: on this ISA a wait for a load also waits for the stores issued before it)
+    gd2_out g = (gd2_out)dst;
+    double cs[kGridPerLane];
+#pragma unroll
+    for (int it = 0; it < kGridPerLane; ++it) {
+        const int idx = tid + it * kThreads;
+        cs[it] = (kcos != 1 && idx < NGRID / 2) ? T.cosgr[idx / (IX / 2)] : 1.0;
+    }
+#pragma unroll
+    for (int it = 0; it < kGridPerLane; ++it) {
+        const int idx = tid + it * kThreads;
+        if (idx < NGRID / 2) {
+            const int r = idx / (IX / 2), ip = idx - r * (IX / 2);
+            const double *a = rows + r * kRowStride + 2 * ip;
+            d2 v{a[0], a[1]};
+            if (kcos != 1) {
+                v.x *= cs[it];
+                v.y *= cs[it];
+            }
+            g[idx] = v;
         }
-        g[idx] = v;
     }
     TRACE_MARK(0, 4);
     TRACE_END(0);
@@ -213,18 +236,31 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
     TRACE_BEGIN();
     if (ST != Stage::LegendreOnly) {
         // ---- load grid rows (16 B per lane, coalesced) ----
-        const d2 *g = reinterpret_cast<const d2 *>(src);
-        for (int idx = tid; idx < NGRID / 2; idx += kThreads) {
-            const int r = idx / (IX / 2), ip = idx - r * (IX / 2);
-            d2 v = g[idx];
-            if (prescale != 0) {
-                const double c = (prescale == 1) ? T.cosgr[r] : T.cosgr2[r];
-                v.x *= c;
-                v.y *= c;
+        // (all loads of a lane are issued before the first LDS store: a rolled loop would wait for each one in turn)
+        gd2_in g = (gd2_in)src;
+        d2 gv[kGridPerLane];
+        double cs[kGridPerLane];
+        const double *ctab = (prescale == 1) ? T.cosgr : T.cosgr2;
+#pragma unroll
+        for (int it = 0; it < kGridPerLane; ++it) {
+            const int idx = tid + it * kThreads;
+            if (idx < NGRID / 2) gv[it] = g[idx];
+            cs[it] = (prescale != 0 && idx < NGRID / 2) ? ctab[idx / (IX / 2)] : 1.0;
+        }
+#pragma unroll
+        for (int it = 0; it < kGridPerLane; ++it) {
+            const int idx = tid + it * kThreads;
+            if (idx < NGRID / 2) {
+                const int r = idx / (IX / 2), ip = idx - r * (IX / 2);
+                d2 v = gv[it];
+                if (prescale != 0) {
+                    v.x *= cs[it];
+                    v.y *= cs[it];
+                }
+                double *a = rows + r * kRowStride + 2 * ip;
+                a[0] = v.x;
+                a[1] = v.y;
             }
-            double *a = rows + r * kRowStride + 2 * ip;
-            a[0] = v.x;
-            a[1] = v.y;
         }
         __syncthreads();
         TRACE_MARK(1, 0);
@@ -330,7 +366,7 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
     }
     __syncthreads();
     TRACE_MARK(1, 4);
-    d2 *g = reinterpret_cast<d2 *>(dst);
+    gd2_out g = (gd2_out)dst;
     for (int idx = tid; idx < NSPEC; idx += kThreads) g[idx] = s[idx];
     TRACE_MARK(1, 5);
     TRACE_END(1);
