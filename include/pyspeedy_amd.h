@@ -115,6 +115,8 @@ typedef struct spd_physics_args {
     double air_absortivity_co2; /* state%air_absortivity_co2 */
     int32_t compute_shortwave;  /* state%compute_shortwave (speedy.f90:53) */
     int32_t reserved;
+    /* SPPT pattern (ix,il,kx), values outside [-1, 1] are clipped; NULL = off (physics.f90:234-248, sppt_on = .false.) */
+    const double *sppt_pattern;
 } spd_physics_args;
 
 int spd_physics(spd_handle h, const spd_physics_args *args, int nmembers, void *stream);
@@ -179,6 +181,10 @@ int spd_model_grid2spectral(spd_model_handle m, int first, int count, void *stre
 int spd_model_grid_filter(spd_model_handle m, int first, int count, void *stream);
 /* modelstate_init_sst_anom (speedy_driver.f90.j2:225-237): sst_anom(ix, il, 0:n_months+1) per member, zero-filled */
 int spd_model_init_sst_anom(spd_model_handle m, int n_months);
+/* Stochastically perturbed parametrisation tendencies (sppt.f90; compile-time off and non-functional in the reference:
+ * PARITY UNPINNED, see csrc/sppt.hip).  Deterministic: the noise is a function of (seed, first_member_id + member, step,
+ * level, coefficient).  While on, every step advances the AR(1) spectral pattern (registry names sppt_spec, sppt_pattern). */
+int spd_model_set_sppt(spd_model_handle m, int on, uint64_t seed, int64_t first_member_id);
 /* device-to-device copy of every registered variable of one member into a member of another model on the same GPU */
 int spd_model_copy_member(spd_model_handle dst, int dst_member, spd_model_handle src, int src_member, void *stream);
 

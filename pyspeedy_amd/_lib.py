@@ -46,7 +46,8 @@ _PHYS_PTR_FIELDS = [
 class PhysicsArgs(C.Structure):
     """Mirror of spd_physics_args (include/pyspeedy_amd.h)."""
     _fields_ = [(n, C.c_void_p) for n in _PHYS_PTR_FIELDS] + [
-        ("air_absortivity_co2", C.c_double), ("compute_shortwave", C.c_int32), ("reserved", C.c_int32)]
+        ("air_absortivity_co2", C.c_double), ("compute_shortwave", C.c_int32), ("reserved", C.c_int32),
+        ("sppt_pattern", C.c_void_p)]
 
 
 _SIGNATURES = {
@@ -92,6 +93,7 @@ _SIGNATURES = {
     "spd_model_grid2spectral": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "spd_model_grid_filter": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "spd_model_init_sst_anom": (C.c_int, [C.c_void_p, C.c_int]),
+    "spd_model_set_sppt": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_int64]),
     "spd_model_copy_member": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "spd_model_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "spd_model_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

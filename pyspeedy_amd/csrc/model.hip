@@ -40,6 +40,8 @@ hipError_t run_grid2spec(const DeviceTables &T, int stage, const double *src, do
 hipError_t run_spec2grid(const DeviceTables &T, int stage, const double *src, double *dst, int kcos, int nfields,
                          hipStream_t stream, int fpw);
 hipError_t run_scale(const double *in, double *out, const double *table, double sign, int nfields, hipStream_t s);
+hipError_t run_sppt_update(double *spec, const DeviceTables &T, int M, unsigned long long seed, long long member_base,
+                           long long step, int first, hipStream_t s);
 hipError_t run_export_units(double *q, double *phi, double *ps, long n2d, hipStream_t s);
 hipError_t run_log_ps(const double *ps_grid, double *out, long n2d, hipStream_t s);
 hipError_t run_vort2vel(const DeviceTables &T, const double *vor, const double *div, double *ucos, double *vcos, int nfields,
@@ -81,6 +83,11 @@ struct spd_model {
     Calendar cal;
     int current_step = 0;
     bool initialized = false;
+    // SPPT (csrc/sppt.hip): AR(1) spectral pattern [M][8][992] complex, its grid-space image [M][8][NG]
+    bool sppt_on = false, sppt_first = true;
+    unsigned long long sppt_seed = 0;
+    long long sppt_member_base = 0, sppt_step = 0;
+    double *sppt_spec = nullptr, *sppt_grid = nullptr;
     bool split_dyn_physics = false;  // PYSPEEDY_AMD_SPLIT_DYN=1: separate dynamics and physics launches (for measurements)
     int land_coupling_flag = 1, sst_anomaly_flag = 1, increase_co2 = 0, anom_planes = 3;
     double ablco2_ref = 6.0;
@@ -457,7 +464,17 @@ int spd_model_step_dynamics(spd_model_handle m, int j1, int j2, double dt, int c
     if (e == hipSuccess) {
         m->pa.compute_shortwave = compute_shortwave ? 1 : 0;
         m->pa.air_absortivity_co2 = m->air_absortivity_co2;
-        if (m->split_dyn_physics) {
+        m->pa.sppt_pattern = nullptr;
+        if (m->sppt_on) {  // physics.f90:234-236: a new pattern for every call of the physics
+            e = run_sppt_update(m->sppt_spec, T, M, m->sppt_seed, m->sppt_member_base, m->sppt_step, m->sppt_first ? 1 : 0, s);
+            if (e == hipSuccess) e = run_spec2grid(T, 0, m->sppt_spec, m->sppt_grid, 1, 8 * M, s, 0);
+            m->sppt_first = false;
+            m->sppt_step += 1;
+            m->pa.sppt_pattern = m->sppt_grid;
+        }
+    }
+    if (e == hipSuccess) {
+        if (m->split_dyn_physics || m->sppt_on) {  // (SPPT needs the dynamics-only tendencies in memory)
             e = run_dyn_grid(m->P, m->D, M, s);                                           // :151-224
             if (e == hipSuccess) e = run_physics(T, m->pa, M, s);                         // :231
         } else {
@@ -738,6 +755,23 @@ int spd_model_grid_filter(spd_model_handle m, int first, int count, void *stream
     }
     double *p = m->ps_grid + static_cast<size_t>(first) * NG;
     return spd_grid_filter(m->ctx, p, p, count, stream);
+}
+
+int spd_model_set_sppt(spd_model_handle m, int on, uint64_t seed, int64_t first_member_id) {
+    if (!m) return m_fail(SPD_E_ARG, "spd_model_set_sppt: null model");
+    if (first_member_id < 0 || first_member_id + m->M >= (1ll << 24)) return m_fail(SPD_E_ARG, "spd_model_set_sppt: member id out of range");
+    M_HIP(hipSetDevice(m->ctx->device));
+    if (on && !m->sppt_spec) {
+        const size_t M = m->M;
+        if (int rc = dalloc(m, M * 8 * NSPEC * C, &m->sppt_spec, "sppt_spec", 8 * NSPEC * C * sizeof(double))) return rc;
+        if (int rc = dalloc(m, M * 8 * NG, &m->sppt_grid, "sppt_pattern", static_cast<size_t>(8) * NG * sizeof(double))) return rc;
+    }
+    m->sppt_on = on != 0;
+    m->sppt_seed = seed;
+    m->sppt_member_base = first_member_id;
+    m->sppt_first = true;
+    m->sppt_step = 0;
+    return SPD_OK;
 }
 
 // sst_anom(ix, il, 0:n_months+1) for every member (modelstate_init_sst_anom, speedy_driver.f90.j2:225-237); zero-filled

@@ -335,8 +335,16 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         ttend[k] = ttend[k] + ttv[k];
         qtend[k] = qtend[k] + qtv[k];
     }
+    // SPPT (physics.f90:234-248, csrc/sppt.hip): tend = (1 + r mu(k)) (tend - tend_dyn) + tend_dyn with mu = 1; the
+    // dynamics-only tendency is still in memory because this kernel writes each output once, here or at its end
+    const bool sppt = !FUSED && a.sppt_pattern != nullptr;
+    auto perturb = [&](double tend, double tend_dyn, int k) {
+        const double r = a.sppt_pattern[o3 + NG * k];
+        const double rc = dmin(1.0, fabs(r)) * (r < 0.0 ? -1.0 : 1.0);  // sppt.f90:112
+        return (1.0 + rc) * (tend - tend_dyn) + tend_dyn;
+    };
 #pragma unroll
-    for (int k = 0; k < KX - 1; ++k) a.qtend[o3 + NG * k] = qtend[k];
+    for (int k = 0; k < KX - 1; ++k) a.qtend[o3 + NG * k] = sppt ? perturb(qtend[k], a.qtend[o3 + NG * k], k) : qtend[k];
     const double qtend_kx = qtend[KX - 1];
 
     // ------------------------------------------------------------------ clouds + shortwave (every nstrad-th step)
@@ -693,11 +701,21 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         const double vt_kx = 0.0 + vstr3 * rps * T.grdsig[KX - 1];
         ttend[KX - 1] = ttend[KX - 1] + shf3 * rps * T.grdscp[KX - 1];
         const size_t okx = o3 + static_cast<size_t>(NG) * (KX - 1);
-        a.utend[okx] = (FUSED ? utend_dyn : a.utend[okx]) + ut_kx;  // ut_pbl, vt_pbl are zero above the lowest level
-        a.vtend[okx] = (FUSED ? vtend_dyn : a.vtend[okx]) + vt_kx;
+        const double ud = FUSED ? utend_dyn : a.utend[okx], vd = FUSED ? vtend_dyn : a.vtend[okx];
+        const double qkx = qtend_kx + evap3 * rps * T.grdsig[KX - 1];
+        if (sppt) {  // (above the lowest level the physics leaves the wind tendencies alone: nothing to perturb there)
+            a.utend[okx] = perturb(ud + ut_kx, ud, KX - 1);
+            a.vtend[okx] = perturb(vd + vt_kx, vd, KX - 1);
 #pragma unroll
-        for (int k = 0; k < KX; ++k) a.ttend[o3 + NG * k] = ttend[k];
-        a.qtend[okx] = qtend_kx + evap3 * rps * T.grdsig[KX - 1];
+            for (int k = 0; k < KX; ++k) a.ttend[o3 + NG * k] = perturb(ttend[k], a.ttend[o3 + NG * k], k);
+            a.qtend[okx] = perturb(qkx, a.qtend[okx], KX - 1);
+        } else {
+            a.utend[okx] = ud + ut_kx;  // ut_pbl, vt_pbl are zero above the lowest level
+            a.vtend[okx] = vd + vt_kx;
+#pragma unroll
+            for (int k = 0; k < KX; ++k) a.ttend[o3 + NG * k] = ttend[k];
+            a.qtend[okx] = qkx;
+        }
     }
     if (a.iptop) a.iptop[o2] = iptop;
     if (a.icltop) a.icltop[o2] = icltop;

@@ -81,6 +81,14 @@ class EnsembleModel:
                                         "typestr": np.dtype(dtype).str, "data": (int(ptr), False), "version": 2}
         return torch.as_tensor(_Blob(), device=self.sp.device)
 
+    def set_sppt(self, on=True, seed=0, first_member_id=0):
+        """Switch the deterministic SPPT scheme (csrc/sppt.hip) on or off; `first_member_id` = global id of member 0 of
+        this shard, so that an ensemble gives the same noise however it is split over GPUs."""
+        check(self._lib.spd_model_set_sppt(self._m, int(bool(on)), int(seed), int(first_member_id)), "spd_model_set_sppt")
+        if on:
+            SHAPES.setdefault("sppt_spec", (np.complex128, (31, 32, 8)))
+            SHAPES.setdefault("sppt_pattern", (np.float64, (96, 48, 8)))
+
     @property
     def co2(self):
         return float(self._lib.spd_model_co2(self._m))

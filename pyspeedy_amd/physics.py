@@ -42,6 +42,7 @@ def shapes(M):
     s["rad_flux"] = (M, 4, IL, IX)
     s["rad_tau2"] = (M, 4, KX, IL, IX)
     s["rad_strat_corr"] = (M, 2, IL, IX)
+    s["sppt_pattern"] = (M, KX, IL, IX)
     return s
 
 
@@ -80,13 +81,15 @@ class ColumnPhysics:
         pslg = self.sp.spec2grid(ps, 1)
         return dict(ug=uv[0], vg=uv[1], tg=tqp[0], qg=tqp[1], phig=tqp[2], pslg=pslg)
 
-    def __call__(self, fields, tend, forcing, state, compute_shortwave, air_absortivity_co2):
+    def __call__(self, fields, tend, forcing, state, compute_shortwave, air_absortivity_co2, sppt_pattern=None):
         """Run the fused column kernel.
 
         fields : dict ug, vg, tg, qg, phig [M,8,48,96], pslg [M,48,96]
         tend   : dict utend, vtend, ttend, qtend [M,8,48,96] -- updated IN PLACE like the reference's arguments
         forcing: dict with SURFACE_IN (always) and SHORTWAVE_IN (needed on shortwave steps) [M,48,96]
         state  : PhysicsState (outputs and persisted radiation fields, updated in place)
+        sppt_pattern : optional [M,8,48,96] multiplicative noise r; the physical part of every tendency is scaled by
+                 1 + clip(r, -1, 1) (physics.f90:234-248; off in the reference)
         """
         M = state.nmembers
         shp = shapes(M)
@@ -119,6 +122,7 @@ class ColumnPhysics:
             put(n, getattr(state, n, None) if state.diagnostics else None)
         for n in DIAG_I:
             put(n, getattr(state, n, None) if state.diagnostics else None, torch.int32)
+        put("sppt_pattern", sppt_pattern)
         args.air_absortivity_co2 = float(air_absortivity_co2)
         args.compute_shortwave = 1 if compute_shortwave else 0
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
