@@ -18,7 +18,7 @@ from datetime import datetime, timedelta
 import numpy as np
 
 from . import speedy_driver as _speedy
-from .dataset import Dataset, Variable, concat, open_dataset
+from .dataset import Dataset, Variable, open_dataset
 from .registry import DEFAULT_OUTPUT_VARS, REGISTRY
 from .speedy_driver import ERROR_CODES
 
@@ -221,37 +221,51 @@ class Speedy:
         """Current model state as a Dataset following the export conventions of the reference (speedy.py:415-477)."""
         variables = DEFAULT_OUTPUT_VARS if variables is None else variables
         self.spectral2grid()
-        lead = ("time", "ens") if self.is_ensemble_member else ("time",)
-        data = {}
+        arrays = {}
         for var in variables:
-            meta = REGISTRY[var]
-            if meta.nc_dims is None or meta.where != "device":
-                raise ValueError("'%s' cannot be exported: not a grid-space array" % var)
-            values = self[var].astype(np.float32)
-            dims = tuple(reversed(meta.nc_dims))  # (lon, lat[, lev]) -> ([lev,] lat, lon)
-            values = values.transpose(*range(values.ndim - 1, -1, -1))
-            if "lev" in dims:
-                values = values[::-1]  # vertical levels increasing with height (lev coordinate reversed)
-            values = values[(None,) * len(lead)]
-            attrs = {"long_name": meta.long_name, "standard_name": var}
-            if meta.units is not None:
-                attrs["units"] = meta.units
-            data[meta.alt_name] = Variable(lead + dims, np.ascontiguousarray(values), attrs)
-        coords = {}
-        for c, axis in (("lon", "X"), ("lat", "Y"), ("lev", None)):
-            meta = REGISTRY[c]
-            vals = self[c][::-1] if c == "lev" else self[c]
-            attrs = {"long_name": meta.long_name, "standard_name": c}
-            if meta.units is not None:
-                attrs["units"] = meta.units
-            if axis:
-                attrs["axis"] = axis
-            coords[c] = Variable((c,), np.ascontiguousarray(vals, dtype=np.float32), attrs)
-        coords["time"] = Variable(("time",), np.array([np.datetime64(self.current_date, "s")]),
-                                  {"axis": "T", "standard_name": "time"})
-        if self.is_ensemble_member:
-            coords["ens"] = Variable(("ens",), np.array([self.member_id], dtype=np.int32))
-        return Dataset(data, coords)
+            _exportable(var)
+            values = self[var]  # (lon, lat[, lev]) -> ([lev,] lat, lon)
+            arrays[var] = values.transpose(*range(values.ndim - 1, -1, -1))[None]
+        members = [self.member_id] if self.is_ensemble_member else None
+        return _build_dataset(self, arrays, members, self.current_date)
+
+
+def _exportable(var):
+    meta = REGISTRY[var]
+    if meta.nc_dims is None or meta.where != "device":
+        raise ValueError("'%s' cannot be exported: not a grid-space array" % var)
+    return meta
+
+
+def _build_dataset(model, arrays, members, date):
+    """arrays: var -> [member, (lev,) lat, lon] float64 in model level order; members: list of ids or None (single run)."""
+    lead = ("time", "ens") if members is not None else ("time",)
+    data = {}
+    for var, values in arrays.items():
+        meta = _exportable(var)
+        dims = tuple(reversed(meta.nc_dims))
+        values = values.astype(np.float32)
+        if "lev" in dims:
+            values = values[:, ::-1]  # vertical levels increasing with height (lev coordinate reversed)
+        values = values[None] if members is not None else values  # -> (time, ens, ...) or (time, ...)
+        attrs = {"long_name": meta.long_name, "standard_name": var}
+        if meta.units is not None:
+            attrs["units"] = meta.units
+        data[meta.alt_name] = Variable(lead + dims, np.ascontiguousarray(values), attrs)
+    coords = {}
+    for c, axis in (("lon", "X"), ("lat", "Y"), ("lev", None)):
+        meta = REGISTRY[c]
+        vals = model[c][::-1] if c == "lev" else model[c]
+        attrs = {"long_name": meta.long_name, "standard_name": c}
+        if meta.units is not None:
+            attrs["units"] = meta.units
+        if axis:
+            attrs["axis"] = axis
+        coords[c] = Variable((c,), np.ascontiguousarray(vals, dtype=np.float32), attrs)
+    coords["time"] = Variable(("time",), np.array([np.datetime64(date, "s")]), {"axis": "T", "standard_name": "time"})
+    if members is not None:
+        coords["ens"] = Variable(("ens",), np.array(members, dtype=np.int32))
+    return Dataset(data, coords)
 
 
 class SpeedyEns:
@@ -275,7 +289,13 @@ class SpeedyEns:
         self.current_date = start_date
 
     def to_dataframe(self, variables=None):
-        return concat([member.to_dataframe(variables=variables) for member in self], "ens")
+        """All members along the `ens` dimension: one batched spectral -> grid conversion and one device-to-host copy per
+        variable (the device layout [member][lev][lat][lon] is already the export order)."""
+        variables = DEFAULT_OUTPUT_VARS if variables is None else variables
+        for var in variables:
+            _exportable(var)
+        arrays = _speedy.ensemble_grid_arrays(self.members[0]._state_cnt, list(variables))
+        return _build_dataset(self.members[0], arrays, [m.member_id for m in self], self.current_date)
 
     def run(self, callbacks=None):
         """Advance every member from the start to the end date; all members step together (parallel_step)."""

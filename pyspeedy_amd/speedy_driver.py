@@ -246,6 +246,14 @@ def transform_grid2spectral(state_cnt):
     st.batch.model.grid2spectral(st.member, 1)
 
 
+def ensemble_grid_arrays(state_cnt, names):
+    """Extension: the grid-space variables `names` of ALL members of the batched model `state_cnt` belongs to, after one
+    batched spectral2grid: dict name -> float64 array [member, (lev,) lat, lon] (one device-to-host copy per variable)."""
+    b = _lookup(state_cnt, _State).batch
+    b.model.spectral2grid()
+    return {n: b.model.device_view(n).cpu().numpy() for n in names}
+
+
 def apply_grid_filter(state_cnt):
     st = _lookup(state_cnt, _State)
     st.batch.model.grid_filter(st.member, 1)
