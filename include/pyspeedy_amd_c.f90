@@ -1,0 +1,141 @@
+!> ISO_C_BINDING interface to libpyspeedy_amd.so (include/pyspeedy_amd.h) for a Fortran host: what a maintainer of
+!! speedy.f90 adds to call the MI355X backend.  The outer boundary (spd_model_*) takes HOST arrays in the reference's own
+!! shapes and order, so a Fortran program drives whole model runs without any HIP call of its own; the operator-level entry
+!! points (spd_spec2grid ...) take device pointers (type(c_ptr) from hipMalloc) and a stream.
+!!
+!! Replaces, call for call, the procedures of registry/templates/speedy_driver.f90.j2:
+!!   modelstate_init -> spd_create + spd_model_create     set_<v> / get_<v> -> spd_model_set / spd_model_get
+!!   init            -> spd_model_init                    step / parallel_step -> spd_model_step
+!!   check           -> spd_model_check                   transform_spectral2grid ... -> spd_model_spectral2grid ...
+module pyspeedy_amd_c
+    use iso_c_binding
+    implicit none
+
+    integer(c_int), parameter :: SPD_OK = 0, SPD_E_ARG = -1, SPD_E_DEVICE = -2, SPD_E_SIZE = -3
+
+    interface
+        ! ---- context ------------------------------------------------------------------------------------------
+        integer(c_int) function spd_create(handle, device) bind(C, name="spd_create")
+            import :: c_ptr, c_int
+            type(c_ptr), intent(out) :: handle
+            integer(c_int), value :: device
+        end function
+        integer(c_int) function spd_destroy(handle) bind(C, name="spd_destroy")
+            import :: c_ptr, c_int
+            type(c_ptr), value :: handle
+        end function
+        type(c_ptr) function spd_last_error() bind(C, name="spd_last_error")
+            import :: c_ptr
+        end function
+        integer(c_long) function spd_get_table_host(handle, name, buf, buf_elems) bind(C, name="spd_get_table_host")
+            import :: c_ptr, c_long, c_char, c_double, c_size_t
+            type(c_ptr), value :: handle
+            character(kind=c_char), intent(in) :: name(*)
+            real(c_double), intent(out) :: buf(*)
+            integer(c_size_t), value :: buf_elems
+        end function
+
+        ! ---- operator level: device pointers, explicit batch count, stream ------------------------------------------
+        integer(c_int) function spd_spec2grid(handle, spec, grid, kcos, nfields, stream) bind(C, name="spd_spec2grid")
+            import :: c_ptr, c_int
+            type(c_ptr), value :: handle, spec, grid, stream
+            integer(c_int), value :: kcos, nfields
+        end function
+        integer(c_int) function spd_grid2spec(handle, grid, spec, nfields, stream) bind(C, name="spd_grid2spec")
+            import :: c_ptr, c_int
+            type(c_ptr), value :: handle, grid, spec, stream
+            integer(c_int), value :: nfields
+        end function
+        integer(c_int) function spd_vort2vel(handle, vor, div, ucos, vcos, nfields, stream) bind(C, name="spd_vort2vel")
+            import :: c_ptr, c_int
+            type(c_ptr), value :: handle, vor, div, ucos, vcos, stream
+            integer(c_int), value :: nfields
+        end function
+        integer(c_int) function spd_grid_vel2vort(handle, ug, vg, vor, div, kcos, nfields, stream) &
+                bind(C, name="spd_grid_vel2vort")
+            import :: c_ptr, c_int
+            type(c_ptr), value :: handle, ug, vg, vor, div, stream
+            integer(c_int), value :: kcos, nfields
+        end function
+
+        ! ---- ensemble model: host arrays in the reference's shapes ---------------------------------------------------
+        integer(c_int) function spd_model_create(handle, nmembers, model) bind(C, name="spd_model_create")
+            import :: c_ptr, c_int
+            type(c_ptr), value :: handle
+            integer(c_int), value :: nmembers
+            type(c_ptr), intent(out) :: model
+        end function
+        integer(c_int) function spd_model_destroy(model) bind(C, name="spd_model_destroy")
+            import :: c_ptr, c_int
+            type(c_ptr), value :: model
+        end function
+        integer(c_int) function spd_model_set(model, name, member, host_buf, bytes) bind(C, name="spd_model_set")
+            import :: c_ptr, c_int, c_char, c_size_t
+            type(c_ptr), value :: model
+            character(kind=c_char), intent(in) :: name(*)
+            integer(c_int), value :: member          ! 0-based; -1 = every member
+            type(*), intent(in) :: host_buf(*)
+            integer(c_size_t), value :: bytes
+        end function
+        integer(c_int) function spd_model_get(model, name, member, host_buf, bytes) bind(C, name="spd_model_get")
+            import :: c_ptr, c_int, c_char, c_size_t
+            type(c_ptr), value :: model
+            character(kind=c_char), intent(in) :: name(*)
+            integer(c_int), value :: member
+            type(*) :: host_buf(*)
+            integer(c_size_t), value :: bytes
+        end function
+        integer(c_int) function spd_model_init_sst_anom(model, n_months) bind(C, name="spd_model_init_sst_anom")
+            import :: c_ptr, c_int
+            type(c_ptr), value :: model
+            integer(c_int), value :: n_months
+        end function
+        integer(c_int) function spd_model_init(model, year, month, day, hour, minute, stream) bind(C, name="spd_model_init")
+            import :: c_ptr, c_int
+            type(c_ptr), value :: model, stream
+            integer(c_int), value :: year, month, day, hour, minute
+        end function
+        integer(c_int) function spd_model_step(model, nsteps, stream) bind(C, name="spd_model_step")
+            import :: c_ptr, c_int
+            type(c_ptr), value :: model, stream
+            integer(c_int), value :: nsteps
+        end function
+        integer(c_int) function spd_model_check(model, time_level, error_codes, diag, stream) bind(C, name="spd_model_check")
+            import :: c_ptr, c_int, c_int32_t
+            type(c_ptr), value :: model, diag, stream   ! diag: c_null_ptr or c_loc of real(c_double) (kx, 3, nmembers)
+            integer(c_int), value :: time_level
+            integer(c_int32_t), intent(out) :: error_codes(*)
+        end function
+        integer(c_int) function spd_model_spectral2grid(model, first, count, stream) bind(C, name="spd_model_spectral2grid")
+            import :: c_ptr, c_int
+            type(c_ptr), value :: model, stream
+            integer(c_int), value :: first, count
+        end function
+        integer(c_int) function spd_model_grid2spectral(model, first, count, stream) bind(C, name="spd_model_grid2spectral")
+            import :: c_ptr, c_int
+            type(c_ptr), value :: model, stream
+            integer(c_int), value :: first, count
+        end function
+        integer(c_int) function spd_model_grid_filter(model, first, count, stream) bind(C, name="spd_model_grid_filter")
+            import :: c_ptr, c_int
+            type(c_ptr), value :: model, stream
+            integer(c_int), value :: first, count
+        end function
+        integer(c_int) function spd_model_current_step(model) bind(C, name="spd_model_current_step")
+            import :: c_ptr, c_int
+            type(c_ptr), value :: model
+        end function
+        integer(c_int) function spd_model_set_flags(model, land_coupling, sst_anomaly_coupling, increase_co2) &
+                bind(C, name="spd_model_set_flags")
+            import :: c_ptr, c_int
+            type(c_ptr), value :: model
+            integer(c_int), value :: land_coupling, sst_anomaly_coupling, increase_co2
+        end function
+        integer(c_int) function spd_model_set_sppt(model, on, seed, first_member_id) bind(C, name="spd_model_set_sppt")
+            import :: c_ptr, c_int, c_int64_t
+            type(c_ptr), value :: model
+            integer(c_int), value :: on
+            integer(c_int64_t), value :: seed, first_member_id
+        end function
+    end interface
+end module pyspeedy_amd_c
