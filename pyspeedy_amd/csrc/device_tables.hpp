@@ -27,12 +27,16 @@ struct DeviceTables {
 };
 
 // One transform of a descriptor-table launch: a spectral->grid entry carries kcos in `flag`, a grid->spectral entry the
-// pre-scale mode (0 none, 1 cosgr, 2 cosgr2).
+// pre-scale mode (0 none, 1 cosgr, 2 cosgr2).  Spectral->grid entries can ask for the spectral-space operator that feeds the
+// transform to be applied while the coefficients are staged (`mode`), so that u, v and grad ln ps never exist as spectral
+// arrays in memory: 0 = transform src as it is; 1 / 2 = ucos / vcos of vort2vel(vor = src, div = src2)
+// (spectral.f90:190-214); 3 / 4 = x / y component of gradient(src) (spectral.f90:275-296).
 struct FieldDesc {
     const double *src;
     double *dst;
     int flag;
-    int reserved;
+    int mode;
+    const double *src2;
 };
 
 }  // namespace spd

@@ -1,7 +1,7 @@
 // The callers of the hot path, on the device (SURVEY.md section 8f "next #1"): everything do_single_step does between
 // the spectral transforms and the column physics, so that a model step never leaves HBM.
 //
-//   model_uvgrad_kernel     vort2vel at two time levels + gradient(ln ps)       spectral.f90:190-214, 275-296
+//   (vort2vel at two time levels and gradient(ln ps) run inside the spectral->grid kernel: FieldDesc::mode)
 //   geopotential_kernel     hydrostatic integration in spectral space           geopotential.f90:49-77
 //   dyn_grid_kernel         grid-point dynamics tendencies of one column        tendencies.f90:125-224
 //   spectral_step_kernel    vel2vort + spectral tendencies + semi-implicit correction + horizontal diffusion +
@@ -58,57 +58,6 @@ __device__ inline void uv_stencil(const d2 *a, const d2 *b, int k, int m, int n,
     }
 }
 }  // namespace
-
-// ---------------------------------------------------------------------------------------------------------
-// u, v (cos-weighted) from vor, div at time levels j2 (dynamics) and j1 = 1 (physics); grad ln ps at level j2
-// grid: x = coefficient, y = member*8 + level (plus one extra "level" 8 per member for the gradient)
-// ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kT) void model_uvgrad_kernel(ModelPtrs P, DeviceTables T, int M, int j2) {
-    const int k = blockIdx.x * kT + threadIdx.x;
-    if (k >= NSPEC) return;
-    const int n = k / MX, m = k - n * MX;
-    const int mem = blockIdx.y / 9, lev = blockIdx.y - mem * 9;
-    if (lev == 8) {  // gradient of ln ps (tendencies.f90:144)
-        const d2 *psi = reinterpret_cast<const d2 *>(P.ps) + (static_cast<size_t>(mem) * 2 + j2) * NSPEC;
-        d2 *dx = reinterpret_cast<d2 *>(P.gps) + static_cast<size_t>(mem) * NSPEC;
-        d2 *dy = dx + static_cast<size_t>(M) * NSPEC;
-        const d2 z = psi[k];
-        const double g = T.gradx[m];
-        dx[k] = times_i(d2{g * z.x, g * z.y});
-        d2 r;
-        if (n == 0) {
-            const d2 zn = psi[k + MX];
-            r = d2{T.gradyp[k] * zn.x, T.gradyp[k] * zn.y};
-        } else if (n == NX - 1) {
-            const d2 zp = psi[k - MX];
-            r = d2{-T.gradym[k] * zp.x, -T.gradym[k] * zp.y};
-        } else {
-            const d2 zp = psi[k - MX], zn = psi[k + MX];
-            r = d2{-T.gradym[k] * zp.x + T.gradyp[k] * zn.x, -T.gradym[k] * zp.y + T.gradyp[k] * zn.y};
-        }
-        dy[k] = r;
-        return;
-    }
-    const size_t fl = (static_cast<size_t>(mem) * 8 + lev) * NSPEC;  // field offset inside an [M][8] work array
-#pragma unroll
-    for (int which = 0; which < 2; ++which) {  // 0: level j2, 1: level 0 (= reference time level 1)
-        const int tl = which == 0 ? j2 : 0;
-        if (which == 1 && j2 == 0) {  // same level: copy instead of recomputing
-            d2 *u0 = reinterpret_cast<d2 *>(P.sv) + fl, *v0 = u0 + static_cast<size_t>(M) * 8 * NSPEC;
-            d2 *u1 = v0 + static_cast<size_t>(M) * 8 * NSPEC, *v1 = u1 + static_cast<size_t>(M) * 8 * NSPEC;
-            u1[k] = u0[k];
-            v1[k] = v0[k];
-            break;
-        }
-        const size_t so = ((static_cast<size_t>(mem) * 2 + tl) * 8 + lev) * NSPEC;
-        const d2 *vor = reinterpret_cast<const d2 *>(P.vor) + so, *div = reinterpret_cast<const d2 *>(P.div) + so;
-        d2 u, v;
-        uv_stencil<0>(vor, div, k, m, n, T, u, v);
-        d2 *ud = reinterpret_cast<d2 *>(P.sv) + static_cast<size_t>(which) * 2 * M * 8 * NSPEC + fl;
-        ud[k] = u;
-        ud[static_cast<size_t>(M) * 8 * NSPEC + k] = v;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // geopotential from temperature at time level `tl` (geopotential.f90:49-77)
@@ -379,10 +328,6 @@ __global__ __launch_bounds__(64) void diagnostics_kernel(ModelPtrs P, DeviceTabl
 // ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
-hipError_t run_model_uvgrad(const ModelPtrs &P, const DeviceTables &T, int M, int j2, hipStream_t s) {
-    hipLaunchKernelGGL(model_uvgrad_kernel, dim3((NSPEC + kT - 1) / kT, M * 9), dim3(kT), 0, s, P, T, M, j2);
-    return hipGetLastError();
-}
 hipError_t run_geopotential(const ModelPtrs &P, const DynDeviceTables &D, int M, int tl, hipStream_t s) {
     hipLaunchKernelGGL(geopotential_kernel, dim3((M * NSPEC + kT - 1) / kT), dim3(kT), 0, s, P, D, M, tl);
     return hipGetLastError();

@@ -21,7 +21,6 @@ hipError_t run_grid2spec_table(const DeviceTables &T, const FieldDesc *table, in
 hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nmembers, hipStream_t s);
 hipError_t run_dyn_physics(const ModelPtrs &P, const DynDeviceTables &D, const DeviceTables &T, const spd_physics_args &a,
                            int nmembers, hipStream_t s);
-hipError_t run_model_uvgrad(const ModelPtrs &P, const DeviceTables &T, int M, int j2, hipStream_t s);
 hipError_t run_geopotential(const ModelPtrs &P, const DynDeviceTables &D, int M, int tl, hipStream_t s);
 hipError_t run_dyn_grid(const ModelPtrs &P, const DynDeviceTables &D, int M, hipStream_t s);
 hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const DynDeviceTables &D, int M, int j1, double dt,
@@ -142,22 +141,24 @@ static int build_tables(spd_model *m) {
         t.reserve(static_cast<size_t>(M) * 91);
         for (int i = 0; i < M; ++i) {
             const size_t w = static_cast<size_t>(i) * 8, st = (static_cast<size_t>(i) * 2 + j2) * 8, s1 = static_cast<size_t>(i) * 2 * 8;
-            const size_t quad = static_cast<size_t>(M) * 8;  // fields per [M][8] block inside sv
             for (int k = 0; k < 8; ++k) {
                 t.push_back({spec(P.vor, st + k), grid(P.vorg, w + k), 1, 0});
                 t.push_back({spec(P.div, st + k), grid(P.divg, w + k), 1, 0});
                 t.push_back({spec(P.t, st + k), grid(P.tg2, w + k), 1, 0});
                 t.push_back({spec(P.tr, st + k), grid(P.trg2, w + k), 1, 0});
-                t.push_back({spec(P.sv, w + k), grid(P.ug2, w + k), 2, 0});
-                t.push_back({spec(P.sv, quad + w + k), grid(P.vg2, w + k), 2, 0});
-                t.push_back({spec(P.sv, 2 * quad + w + k), grid(const_cast<double *>(pa.ug), w + k), 2, 0});
-                t.push_back({spec(P.sv, 3 * quad + w + k), grid(const_cast<double *>(pa.vg), w + k), 2, 0});
+                // u, v: vort2vel applied while the coefficients are staged (FieldDesc::mode 1 / 2), at the dynamics' time
+                // level and at time level 1 for the physics (tendencies.f90:109-118, physics.f90:89-94)
+                t.push_back({spec(P.vor, st + k), grid(P.ug2, w + k), 2, 1, spec(P.div, st + k)});
+                t.push_back({spec(P.vor, st + k), grid(P.vg2, w + k), 2, 2, spec(P.div, st + k)});
+                t.push_back({spec(P.vor, s1 + k), grid(const_cast<double *>(pa.ug), w + k), 2, 1, spec(P.div, s1 + k)});
+                t.push_back({spec(P.vor, s1 + k), grid(const_cast<double *>(pa.vg), w + k), 2, 2, spec(P.div, s1 + k)});
                 t.push_back({spec(P.t, s1 + k), grid(const_cast<double *>(pa.tg), w + k), 1, 0});
                 t.push_back({spec(P.tr, s1 + k), grid(const_cast<double *>(pa.qg), w + k), 1, 0});
                 t.push_back({spec(P.phi, w + k), grid(const_cast<double *>(pa.phig), w + k), 1, 0});
             }
-            t.push_back({spec(P.gps, i), grid(P.px, i), 2, 0});
-            t.push_back({spec(P.gps, static_cast<size_t>(M) + i), grid(P.py, i), 2, 0});
+            // grad ln ps at the dynamics' time level (tendencies.f90:144-146): gradient applied while staging (mode 3 / 4)
+            t.push_back({spec(P.ps, static_cast<size_t>(i) * 2 + j2), grid(P.px, i), 2, 3, nullptr});
+            t.push_back({spec(P.ps, static_cast<size_t>(i) * 2 + j2), grid(P.py, i), 2, 4, nullptr});
             t.push_back({spec(P.ps, static_cast<size_t>(i) * 2), grid(const_cast<double *>(pa.pslg), i), 1, 0});
         }
         void *d = nullptr;
@@ -250,7 +251,6 @@ int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
     A(P.tcorh, M * S, "tcorh", S);
     A(P.qcorh, M * S, "qcorh", S);
     A(P.sv, 4 * M * 8 * S, nullptr, 0);
-    A(P.gps, 2 * M * S, nullptr, 0);
     A(P.vorg, M * G3, nullptr, 0); A(P.divg, M * G3, nullptr, 0); A(P.tg2, M * G3, nullptr, 0);
     A(P.trg2, M * G3, nullptr, 0); A(P.ug2, M * G3, nullptr, 0); A(P.vg2, M * G3, nullptr, 0);
     A(P.px, M * NG, nullptr, 0); A(P.py, M * NG, nullptr, 0);
@@ -444,8 +444,7 @@ int spd_model_step_dynamics(spd_model_handle m, int j1, int j2, double dt, int c
     hipStream_t s = static_cast<hipStream_t>(stream);
     const DeviceTables &T = m->ctx->dev;
     const int M = m->M;
-    hipError_t e = run_model_uvgrad(m->P, T, M, j2 - 1, s);
-    if (e == hipSuccess) e = run_geopotential(m->P, m->D, M, 0, s);                       // tendencies.f90:229
+    hipError_t e = run_geopotential(m->P, m->D, M, 0, s);                                 // tendencies.f90:229
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (m->profile && e == hipSuccess) {
         if (m->prof_used == m->prof_events.size()) {

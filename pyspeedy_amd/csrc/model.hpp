@@ -12,8 +12,8 @@ struct ModelPtrs {
     double *phi;                 // [M][8][992]
     double *phis;                // [M][992]
     double *tcorh, *qcorh;       // [M][992]   horizontal parts of the orographic diffusion corrections
-    // spectral work: u,v at time levels j2 and 1: [2][2][M][8][992]; grad ln ps: [2][M][992]
-    double *sv, *gps;
+    // spectral work of the grid <-> spectral export routines (ucos | vcos in the [M][2][8] layout of vor / div)
+    double *sv;
     // grid fields of the dynamics (time level j2)
     double *vorg, *divg, *tg2, *trg2, *ug2, *vg2;  // [M][8][NG]
     double *px, *py;                               // [M][NG]

@@ -71,13 +71,66 @@ __device__ unsigned long long spd_trace_cnt[2];
 #define TRACE_END(dir)
 #endif
 
+// Coefficient k = m + 31 n of the spectral field a descriptor-table entry asks for (device_tables.hpp: FieldDesc::mode),
+// computed from the model's prognostic fields with the arithmetic of specops.hip / spectral.f90:190-214, 275-296.
+__device__ inline d2 times_i(d2 z) { return d2{-z.y, z.x}; }
+
+__device__ __forceinline__ d2 staged_coefficient(int mode, gd2_in a, gd2_in b, int k, const DeviceTables &T) {
+    const int n = k / MX, m = k - n * MX;
+    if (mode <= 2) {  // vort2vel: a = vorticity, b = divergence
+        const double dx = T.uvdx[k], cm = T.uvdym[k], cp = T.uvdyp[k];
+        if (mode == 1) {  // ucos
+            const d2 zb = b[k];
+            const d2 zc = times_i(d2{dx * zb.x, dx * zb.y});
+            if (n == 0) {
+                const d2 an = a[k + MX];
+                return d2{zc.x - cp * an.x, zc.y - cp * an.y};
+            }
+            if (n == NX - 1) {
+                const d2 ap = a[k - MX];
+                return d2{cm * ap.x, cm * ap.y};
+            }
+            const d2 ap = a[k - MX], an = a[k + MX];
+            return d2{cm * ap.x - cp * an.x + zc.x, cm * ap.y - cp * an.y + zc.y};
+        }
+        const d2 za = a[k];  // vcos
+        const d2 zp = times_i(d2{dx * za.x, dx * za.y});
+        if (n == 0) {
+            const d2 bn = b[k + MX];
+            return d2{zp.x + cp * bn.x, zp.y + cp * bn.y};
+        }
+        if (n == NX - 1) {
+            const d2 bp = b[k - MX];
+            return d2{-cm * bp.x, -cm * bp.y};
+        }
+        const d2 bp = b[k - MX], bn = b[k + MX];
+        return d2{-cm * bp.x + cp * bn.x + zp.x, -cm * bp.y + cp * bn.y + zp.y};
+    }
+    if (mode == 3) {  // d/dx
+        const d2 z = a[k];
+        const double g = T.gradx[m];
+        return times_i(d2{g * z.x, g * z.y});
+    }
+    if (n == 0) {  // d/dy
+        const d2 zn = a[k + MX];
+        return d2{T.gradyp[k] * zn.x, T.gradyp[k] * zn.y};
+    }
+    if (n == NX - 1) {
+        const d2 zp = a[k - MX];
+        return d2{-T.gradym[k] * zp.x, -T.gradym[k] * zp.y};
+    }
+    const d2 zp = a[k - MX], zn = a[k + MX];
+    return d2{-T.gradym[k] * zp.x + T.gradyp[k] * zn.x, -T.gradym[k] * zp.y + T.gradyp[k] * zn.y};
+}
+
 // ------------------------------------------------------------------------------------------------
 // spec -> grid
 // ------------------------------------------------------------------------------------------------
 // src / dst point at ONE field (spectral field or Fourier plane in, Fourier plane or grid field out)
 template <Stage ST>
 __device__ __forceinline__ void spec2grid_body(const double *__restrict__ src, double *__restrict__ dst,
-                                               const DeviceTables &T, int kcos) {
+                                               const DeviceTables &T, int kcos, int mode = 0,
+                                               const double *__restrict__ src2 = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *cbuf = lds;                                        // C[48][63]
     double *rows = lds;                                        // R[48][97], aliases C and S (see header)
@@ -91,9 +144,15 @@ __device__ __forceinline__ void spec2grid_body(const double *__restrict__ src, d
         // (all loads of a lane are issued before the first LDS store: a rolled loop would wait for each one in turn)
         gd2_in g = (gd2_in)src;
         d2 sv[kSpecPerLane];
+        if (mode == 0) {
 #pragma unroll
-        for (int it = 0; it < kSpecPerLane; ++it)
-            if (tid + it * kThreads < NSPEC) sv[it] = g[tid + it * kThreads];
+            for (int it = 0; it < kSpecPerLane; ++it)
+                if (tid + it * kThreads < NSPEC) sv[it] = g[tid + it * kThreads];
+        } else {  // the spectral operator in front of the transform, applied on the fly (FieldDesc::mode)
+#pragma unroll
+            for (int it = 0; it < kSpecPerLane; ++it)
+                if (tid + it * kThreads < NSPEC) sv[it] = staged_coefficient(mode, g, (gd2_in)src2, tid + it * kThreads, T);
+        }
 #pragma unroll
         for (int it = 0; it < kSpecPerLane; ++it)
             if (tid + it * kThreads < NSPEC) s[tid + it * kThreads] = sv[it];
@@ -393,7 +452,7 @@ __global__ __launch_bounds__(kThreads) void grid2spec_kernel(const double *__res
 
 __global__ __launch_bounds__(kThreads) void spec2grid_table_kernel(const FieldDesc *__restrict__ table, DeviceTables T) {
     const FieldDesc e = table[blockIdx.x];
-    spec2grid_body<Stage::Fused>(e.src, e.dst, T, e.flag);
+    spec2grid_body<Stage::Fused>(e.src, e.dst, T, e.flag, e.mode, e.src2);
 }
 
 __global__ __launch_bounds__(kThreads) void grid2spec_table_kernel(const FieldDesc *__restrict__ table, DeviceTables T) {
