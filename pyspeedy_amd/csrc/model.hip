@@ -141,21 +141,27 @@ static int build_tables(spd_model *m) {
         t.reserve(static_cast<size_t>(M) * 91);
         for (int i = 0; i < M; ++i) {
             const size_t w = static_cast<size_t>(i) * 8, st = (static_cast<size_t>(i) * 2 + j2) * 8, s1 = static_cast<size_t>(i) * 2 * 8;
+            // Entry order inside a member is variable-major, level-minor: workgroups are handed to the 8 XCDs round-robin by
+            // workgroup id, so all entries of level k of a member land on the same XCD and the four transforms that read
+            // vor_k / div_k (vorticity, divergence, u, v) share them through that XCD's L2 instead of fetching them four times.
+            FieldDesc e[11][8];
             for (int k = 0; k < 8; ++k) {
-                t.push_back({spec(P.vor, st + k), grid(P.vorg, w + k), 1, 0});
-                t.push_back({spec(P.div, st + k), grid(P.divg, w + k), 1, 0});
-                t.push_back({spec(P.t, st + k), grid(P.tg2, w + k), 1, 0});
-                t.push_back({spec(P.tr, st + k), grid(P.trg2, w + k), 1, 0});
+                e[0][k] = {spec(P.vor, st + k), grid(P.vorg, w + k), 1, 0};
+                e[1][k] = {spec(P.div, st + k), grid(P.divg, w + k), 1, 0};
                 // u, v: vort2vel applied while the coefficients are staged (FieldDesc::mode 1 / 2), at the dynamics' time
                 // level and at time level 1 for the physics (tendencies.f90:109-118, physics.f90:89-94)
-                t.push_back({spec(P.vor, st + k), grid(P.ug2, w + k), 2, 1, spec(P.div, st + k)});
-                t.push_back({spec(P.vor, st + k), grid(P.vg2, w + k), 2, 2, spec(P.div, st + k)});
-                t.push_back({spec(P.vor, s1 + k), grid(const_cast<double *>(pa.ug), w + k), 2, 1, spec(P.div, s1 + k)});
-                t.push_back({spec(P.vor, s1 + k), grid(const_cast<double *>(pa.vg), w + k), 2, 2, spec(P.div, s1 + k)});
-                t.push_back({spec(P.t, s1 + k), grid(const_cast<double *>(pa.tg), w + k), 1, 0});
-                t.push_back({spec(P.tr, s1 + k), grid(const_cast<double *>(pa.qg), w + k), 1, 0});
-                t.push_back({spec(P.phi, w + k), grid(const_cast<double *>(pa.phig), w + k), 1, 0});
+                e[2][k] = {spec(P.vor, st + k), grid(P.ug2, w + k), 2, 1, spec(P.div, st + k)};
+                e[3][k] = {spec(P.vor, st + k), grid(P.vg2, w + k), 2, 2, spec(P.div, st + k)};
+                e[4][k] = {spec(P.vor, s1 + k), grid(const_cast<double *>(pa.ug), w + k), 2, 1, spec(P.div, s1 + k)};
+                e[5][k] = {spec(P.vor, s1 + k), grid(const_cast<double *>(pa.vg), w + k), 2, 2, spec(P.div, s1 + k)};
+                e[6][k] = {spec(P.t, st + k), grid(P.tg2, w + k), 1, 0};
+                e[7][k] = {spec(P.tr, st + k), grid(P.trg2, w + k), 1, 0};
+                e[8][k] = {spec(P.t, s1 + k), grid(const_cast<double *>(pa.tg), w + k), 1, 0};
+                e[9][k] = {spec(P.tr, s1 + k), grid(const_cast<double *>(pa.qg), w + k), 1, 0};
+                e[10][k] = {spec(P.phi, w + k), grid(const_cast<double *>(pa.phig), w + k), 1, 0};
             }
+            for (int v = 0; v < 11; ++v)
+                for (int k = 0; k < 8; ++k) t.push_back(e[v][k]);
             // grad ln ps at the dynamics' time level (tendencies.f90:144-146): gradient applied while staging (mode 3 / 4)
             t.push_back({spec(P.ps, static_cast<size_t>(i) * 2 + j2), grid(P.px, i), 2, 3, nullptr});
             t.push_back({spec(P.ps, static_cast<size_t>(i) * 2 + j2), grid(P.py, i), 2, 4, nullptr});
