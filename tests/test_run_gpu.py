@@ -80,3 +80,33 @@ def test_exceptions_like_reference(spectral, bc):
     model.set("t", np.zeros((31, 32, 8, 2), dtype=np.complex128))
     assert model.check(1).tolist() == [-2]
     model.close()
+
+
+def test_members_of_a_large_batch_equal_single_member_runs(spectral, bc):
+    """27 members (not a multiple of the 8 XCDs) with different initial perturbations, 15 steps (5 shortwave steps): every
+    sampled member is bitwise identical to a one-member model started from the same state -- batching, the descriptor-table
+    order and the position inside a launch do not enter the arithmetic."""
+    from pyspeedy_amd.model import EnsembleModel
+    M = 27
+    ens = EnsembleModel(spectral, M)
+    ens.set_bc(bc)
+    t0 = ens.get("t", 0)
+    perturbed = {}
+    for i in range(1, M):
+        rng = np.random.default_rng(100 + i)
+        t = t0 * (1.0 + 1e-4 * rng.standard_normal((31, 32, 8, 1)))
+        t[0] = t[0].real
+        perturbed[i] = t
+        ens.set("t", t, member=i)
+    ens.run(15)
+    assert (ens.check(2) == 0).all()
+    for i in (0, 1, 7, 8, 13, 26):
+        single = EnsembleModel(spectral, 1)
+        single.set_bc(bc)
+        if i:
+            single.set("t", perturbed[i])
+        single.run(15)
+        for n in SPEC + ("phi", "land_temp", "sst_am", "olr", "precnv", "hfluxn", "rad_tau2"):
+            assert np.array_equal(ens.get(n, i), single.get(n, 0)), (i, n)
+        single.close()
+    assert not np.array_equal(ens.get("t", 1), ens.get("t", 2))
