@@ -6,7 +6,7 @@
 One "step" = one call of the reference's do_single_step (speedy.f90:20-74) for EVERY one of the M ensemble members
 resident on each GPU: daily forcing when due, shortwave every third step, the leapfrog step (91 spectral->grid transforms,
 grid-point dynamics, fused column physics, 73 grid->spectral transforms, spectral tendencies, semi-implicit correction,
-horizontal diffusion, Robert-Asselin-Williams filter), date advance and the land / sea-ice coupling.  Nothing crosses
+horizontal diffusion, Robert-Asselin-Williams filter), date advance and the land / sea-ice coupling -- 6 kernel launches.  Nothing crosses
 PCIe inside a step; the state of all members stays in HBM.  The hot path of BASELINE.json (transforms + column physics)
 is what dominates it (profiles/).
 
@@ -182,7 +182,8 @@ def main():
                 "parallelism": "ensemble members sharded per GPU, no collective",
             },
             "roofline": {
-                "kernel": "spec2grid_table_kernel (fused inverse Legendre + inverse FFT-96), %d fields/launch" % nfields,
+                "kernel": "spec2grid_table_kernel (inverse Legendre + inverse FFT-96, with vort2vel / gradient applied while staging "
+                          "the 34 wind and pressure-gradient fields of each member), %d fields/launch" % nfields,
                 "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "algorithmic_bytes_per_field": S_BYTES + G_BYTES, "avg_launch_ms": kern_ms, "launches_timed": launches,
                 "traffic": traffic, "traffic_source": traffic_src,
