@@ -14,9 +14,9 @@
 
 namespace spd {
 hipError_t run_spec2grid(const DeviceTables &T, int stage, const double *src, double *dst, int kcos, int nfields,
-                         hipStream_t stream, int fpw);
+                         hipStream_t stream);
 hipError_t run_grid2spec(const DeviceTables &T, int stage, const double *src, double *dst, int prescale, int nfields,
-                         hipStream_t stream, int fpw);
+                         hipStream_t stream);
 hipError_t run_vort2vel(const DeviceTables &T, const double *vor, const double *div, double *ucos, double *vcos,
                         int nfields, hipStream_t s);
 hipError_t run_vel2vort(const DeviceTables &T, const double *ucos, const double *vcos, double *vor, double *div,
@@ -127,7 +127,6 @@ int spd_create(spd_handle *out, int device) {
     SPD_HIP(hipSetDevice(device));
     spd_context *c = new spd_context();
     c->device = device;
-    if (const char *env = getenv("PYSPEEDY_AMD_FPW")) c->fpw = atoi(env);
     const HostTables &h = c->host;
     DeviceTables &d = c->dev;
     int rc = SPD_OK;
@@ -261,32 +260,32 @@ extern "C" {
 
 int spd_spec2grid(spd_handle h, const double *spec, double *grid, int kcos, int nfields, void *stream) {
     if (int rc = check(h, nfields, "spd_spec2grid", {spec, grid})) return rc;
-    return done(run_spec2grid(h->dev, 0, spec, grid, kcos, nfields, static_cast<hipStream_t>(stream), h->fpw), "spd_spec2grid");
+    return done(run_spec2grid(h->dev, 0, spec, grid, kcos, nfields, static_cast<hipStream_t>(stream)), "spd_spec2grid");
 }
 
 int spd_grid2spec(spd_handle h, const double *grid, double *spec, int nfields, void *stream) {
     if (int rc = check(h, nfields, "spd_grid2spec", {grid, spec})) return rc;
-    return done(run_grid2spec(h->dev, 0, grid, spec, 0, nfields, static_cast<hipStream_t>(stream), h->fpw), "spd_grid2spec");
+    return done(run_grid2spec(h->dev, 0, grid, spec, 0, nfields, static_cast<hipStream_t>(stream)), "spd_grid2spec");
 }
 
 int spd_legendre_inv(spd_handle h, const double *spec, double *four, int nfields, void *stream) {
     if (int rc = check(h, nfields, "spd_legendre_inv", {spec, four})) return rc;
-    return done(run_spec2grid(h->dev, 1, spec, four, 1, nfields, static_cast<hipStream_t>(stream), h->fpw), "spd_legendre_inv");
+    return done(run_spec2grid(h->dev, 1, spec, four, 1, nfields, static_cast<hipStream_t>(stream)), "spd_legendre_inv");
 }
 
 int spd_legendre(spd_handle h, const double *four, double *spec, int nfields, void *stream) {
     if (int rc = check(h, nfields, "spd_legendre", {four, spec})) return rc;
-    return done(run_grid2spec(h->dev, 1, four, spec, 0, nfields, static_cast<hipStream_t>(stream), h->fpw), "spd_legendre");
+    return done(run_grid2spec(h->dev, 1, four, spec, 0, nfields, static_cast<hipStream_t>(stream)), "spd_legendre");
 }
 
 int spd_fourier_inv(spd_handle h, const double *four, double *grid, int kcos, int nfields, void *stream) {
     if (int rc = check(h, nfields, "spd_fourier_inv", {four, grid})) return rc;
-    return done(run_spec2grid(h->dev, 2, four, grid, kcos, nfields, static_cast<hipStream_t>(stream), h->fpw), "spd_fourier_inv");
+    return done(run_spec2grid(h->dev, 2, four, grid, kcos, nfields, static_cast<hipStream_t>(stream)), "spd_fourier_inv");
 }
 
 int spd_fourier(spd_handle h, const double *grid, double *four, int nfields, void *stream) {
     if (int rc = check(h, nfields, "spd_fourier", {grid, four})) return rc;
-    return done(run_grid2spec(h->dev, 2, grid, four, 0, nfields, static_cast<hipStream_t>(stream), h->fpw), "spd_fourier");
+    return done(run_grid2spec(h->dev, 2, grid, four, 0, nfields, static_cast<hipStream_t>(stream)), "spd_fourier");
 }
 
 int spd_vort2vel(spd_handle h, const double *vor, const double *div, double *ucos, double *vcos, int nfields, void *stream) {
@@ -308,8 +307,8 @@ int spd_grid_vel2vort(spd_handle h, const double *ug, const double *vg, double *
     if (int rc = get_scratch(h, 2 * per * sizeof(double), &tmp)) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int prescale = (kcos == 2) ? 1 : 2;  // spectral.f90:229-243
-    hipError_t e = run_grid2spec(h->dev, 0, ug, tmp, prescale, nfields, s, h->fpw);
-    if (e == hipSuccess) e = run_grid2spec(h->dev, 0, vg, tmp + per, prescale, nfields, s, h->fpw);
+    hipError_t e = run_grid2spec(h->dev, 0, ug, tmp, prescale, nfields, s);
+    if (e == hipSuccess) e = run_grid2spec(h->dev, 0, vg, tmp + per, prescale, nfields, s);
     if (e == hipSuccess) e = run_vel2vort(h->dev, tmp, tmp + per, vor, div, nfields, s);
     return done(e, "spd_grid_vel2vort");
 }
@@ -337,9 +336,9 @@ int spd_grid_filter(spd_handle h, const double *fg1, double *fg2, int nfields, v
     const size_t per = static_cast<size_t>(nfields) * 2 * NSPEC;
     if (int rc = get_scratch(h, per * sizeof(double), &tmp)) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = run_grid2spec(h->dev, 0, fg1, tmp, 0, nfields, s, h->fpw);
+    hipError_t e = run_grid2spec(h->dev, 0, fg1, tmp, 0, nfields, s);
     if (e == hipSuccess) e = run_scale(tmp, tmp, h->dev.trfilt, 1.0, nfields, s);  // spectral.f90:308-313
-    if (e == hipSuccess) e = run_spec2grid(h->dev, 0, tmp, fg2, 1, nfields, s, h->fpw);
+    if (e == hipSuccess) e = run_spec2grid(h->dev, 0, tmp, fg2, 1, nfields, s);
     return done(e, "spd_grid_filter");
 }
 

@@ -15,7 +15,6 @@ struct spd_context {
     double *scratch = nullptr;
     size_t scratch_bytes = 0;
     std::mutex scratch_mutex;
-    int fpw = 0;  // fields per workgroup override (0 = automatic), env PYSPEEDY_AMD_FPW
 };
 
 // records the message returned by spd_last_error() (thread-local) and returns `code`

@@ -35,9 +35,9 @@ hipError_t run_scale_orog(const double *orog, double *phi0, long n, hipStream_t 
 hipError_t run_rest_surface(const double *phis0, double *forog, double *surf_ps, double *surf_q, const RestConsts &c, long n,
                             hipStream_t s);
 hipError_t run_grid2spec(const DeviceTables &T, int stage, const double *src, double *dst, int prescale, int nfields,
-                         hipStream_t stream, int fpw);
+                         hipStream_t stream);
 hipError_t run_spec2grid(const DeviceTables &T, int stage, const double *src, double *dst, int kcos, int nfields,
-                         hipStream_t stream, int fpw);
+                         hipStream_t stream);
 hipError_t run_scale(const double *in, double *out, const double *table, double sign, int nfields, hipStream_t s);
 hipError_t run_sppt_update(double *spec, const DeviceTables &T, int M, unsigned long long seed, long long member_base,
                            long long step, int first, hipStream_t s);
@@ -256,7 +256,7 @@ int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
     A(P.phis, M * S, "phis", S);
     A(P.tcorh, M * S, "tcorh", S);
     A(P.qcorh, M * S, "qcorh", S);
-    A(P.sv, 4 * M * 8 * S, nullptr, 0);
+    A(P.sv, 4 * M * 8 * S, nullptr, 0);  // ucos | vcos, [M][2][8] each: work space of spectral2grid / grid2spectral
     A(P.vorg, M * G3, nullptr, 0); A(P.divg, M * G3, nullptr, 0); A(P.tg2, M * G3, nullptr, 0);
     A(P.trg2, M * G3, nullptr, 0); A(P.ug2, M * G3, nullptr, 0); A(P.vg2, M * G3, nullptr, 0);
     A(P.px, M * NG, nullptr, 0); A(P.py, M * NG, nullptr, 0);
@@ -472,7 +472,7 @@ int spd_model_step_dynamics(spd_model_handle m, int j1, int j2, double dt, int c
         m->pa.sppt_pattern = nullptr;
         if (m->sppt_on) {  // physics.f90:234-236: a new pattern for every call of the physics
             e = run_sppt_update(m->sppt_spec, T, M, m->sppt_seed, m->sppt_member_base, m->sppt_step, m->sppt_first ? 1 : 0, s);
-            if (e == hipSuccess) e = run_spec2grid(T, 0, m->sppt_spec, m->sppt_grid, 1, 8 * M, s, 0);
+            if (e == hipSuccess) e = run_spec2grid(T, 0, m->sppt_spec, m->sppt_grid, 1, 8 * M, s);
             m->sppt_first = false;
             m->sppt_step += 1;
             m->pa.sppt_pattern = m->sppt_grid;
@@ -526,8 +526,8 @@ static int set_forcing(spd_model *m, int imode, hipStream_t s) {  // forcing.f90
     }
     const double gamlat = static_cast<double>(6.0f) / (1000.f * static_cast<double>(9.81f));  // setgam, forcing.f90:105-117
     hipError_t e = run_forcing(m->S, M, zd, gamlat, m->corh_t, m->corh_q, s);
-    if (e == hipSuccess) e = run_grid2spec(m->ctx->dev, 0, m->corh_t, m->P.tcorh, 0, M, s, 0);
-    if (e == hipSuccess) e = run_grid2spec(m->ctx->dev, 0, m->corh_q, m->P.qcorh, 0, M, s, 0);
+    if (e == hipSuccess) e = run_grid2spec(m->ctx->dev, 0, m->corh_t, m->P.tcorh, 0, M, s);
+    if (e == hipSuccess) e = run_grid2spec(m->ctx->dev, 0, m->corh_q, m->P.qcorh, 0, M, s);
     if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("set_forcing: ") + hipGetErrorString(e));
     return SPD_OK;
 }
@@ -584,9 +584,9 @@ int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, i
     // ---- initialize_boundaries (boundaries.f90:22-37): phi0 = g * orog, phis0 = spectrally truncated phi0
     double *phis0 = const_cast<double *>(m->pa.phis0);
     hipError_t e = run_scale_orog(m->orog, m->phi0, static_cast<long>(M) * NG, s);
-    if (e == hipSuccess) e = run_grid2spec(T, 0, m->phi0, m->scratch_spec, 0, M, s, 0);
+    if (e == hipSuccess) e = run_grid2spec(T, 0, m->phi0, m->scratch_spec, 0, M, s);
     if (e == hipSuccess) e = run_scale(m->scratch_spec, m->scratch_spec, T.trfilt, 1.0, M, s);
-    if (e == hipSuccess) e = run_spec2grid(T, 0, m->scratch_spec, phis0, 1, M, s, 0);
+    if (e == hipSuccess) e = run_spec2grid(T, 0, m->scratch_spec, phis0, 1, M, s);
     // ---- initialize_from_rest_state (prognostics.f90:29-120)
     RestConsts rc{};
     const DynHostTables &dh = *m->dynh;
@@ -602,11 +602,11 @@ int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, i
         }
     }
     (void)dh;
-    if (e == hipSuccess) e = run_grid2spec(T, 0, phis0, m->P.phis, 0, M, s, 0);
+    if (e == hipSuccess) e = run_grid2spec(T, 0, phis0, m->P.phis, 0, M, s);
     if (e == hipSuccess)
         e = run_rest_surface(phis0, const_cast<double *>(m->pa.forog), m->corh_t, m->corh_q, rc, static_cast<long>(M) * NG, s);
-    if (e == hipSuccess) e = run_grid2spec(T, 0, m->corh_t, m->scratch_spec, 0, M, s, 0);                       // ln ps
-    if (e == hipSuccess) e = run_grid2spec(T, 0, m->corh_q, m->scratch_spec + static_cast<size_t>(M) * NSPEC * C, 0, M, s, 0);  // q_sfc
+    if (e == hipSuccess) e = run_grid2spec(T, 0, m->corh_t, m->scratch_spec, 0, M, s);                       // ln ps
+    if (e == hipSuccess) e = run_grid2spec(T, 0, m->corh_q, m->scratch_spec + static_cast<size_t>(M) * NSPEC * C, 0, M, s);  // q_sfc
     if (e == hipSuccess) {
         M_HIP(hipMemsetAsync(m->P.vor, 0, static_cast<size_t>(M) * 16 * NSPEC * C * sizeof(double), s));
         M_HIP(hipMemsetAsync(m->P.div, 0, static_cast<size_t>(M) * 16 * NSPEC * C * sizeof(double), s));
@@ -744,7 +744,7 @@ int spd_model_grid2spectral(spd_model_handle m, int first, int count, void *stre
         e = run_log_ps(m->ps_grid + static_cast<size_t>(first) * NG, m->corh_t + static_cast<size_t>(first) * NG,
                        static_cast<long>(count) * NG, s);
     for (int i = first; i < first + count && e == hipSuccess; ++i)
-        e = run_grid2spec(T, 0, m->corh_t + static_cast<size_t>(i) * NG, m->P.ps + static_cast<size_t>(i) * 2 * S, 0, 1, s, 0);
+        e = run_grid2spec(T, 0, m->corh_t + static_cast<size_t>(i) * NG, m->P.ps + static_cast<size_t>(i) * 2 * S, 0, 1, s);
     if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_grid2spectral: ") + hipGetErrorString(e));
     return SPD_OK;
 }

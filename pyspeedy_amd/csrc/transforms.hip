@@ -503,7 +503,7 @@ hipError_t run_grid2spec_table(const DeviceTables &T, const FieldDesc *table, in
 }
 
 hipError_t run_spec2grid(const DeviceTables &T, int stage, const double *src, double *dst, int kcos, int nfields,
-                         hipStream_t stream, int /*fpw*/) {
+                         hipStream_t stream) {
     if (nfields == 0) return hipSuccess;
     switch (stage) {
         case 0: return launch_s2g<Stage::Fused>(src, dst, T, nfields, kcos, stream);
@@ -513,7 +513,7 @@ hipError_t run_spec2grid(const DeviceTables &T, int stage, const double *src, do
 }
 
 hipError_t run_grid2spec(const DeviceTables &T, int stage, const double *src, double *dst, int prescale, int nfields,
-                         hipStream_t stream, int /*fpw*/) {
+                         hipStream_t stream) {
     if (nfields == 0) return hipSuccess;
     switch (stage) {
         case 0: return launch_g2s<Stage::Fused>(src, dst, T, nfields, prescale, stream);
