@@ -120,6 +120,25 @@ class EnsembleModel:
               "spd_model_mark_initialized")
         self.set_time_step(2 * DELT)
 
+    # ---- checkpoint / resume: the registry arrays plus step counter, date and CO2 absorptivity are the whole state ---
+    def state_dict(self, member=0):
+        """Everything needed to continue a member's run elsewhere (numpy arrays in the reference's shapes)."""
+        out = {n: self.get(n, member) for n in SHAPES if n not in ("sppt_spec", "sppt_pattern")}
+        out["__current_step__"] = np.int64(self.current_step)
+        out["__date__"] = np.array(self.current_date, dtype=np.int64)
+        out["__air_absortivity_co2__"] = np.float64(self.co2)
+        return out
+
+    def load_state_dict(self, state, member=-1):
+        """Inverse of state_dict (member = -1: every member gets the same state); marks the model initialised."""
+        if state["sst_anom"].shape[2] != self.n_months + 2:
+            self.init_sst_anom(state["sst_anom"].shape[2] - 2)
+        for n in SHAPES:
+            if n in state:
+                self.set(n, state[n], member)
+        self.set_co2(float(state["__air_absortivity_co2__"]))
+        self.mark_initialized(int(state["__current_step__"]), tuple(int(v) for v in state["__date__"]))
+
     def copy_member_from(self, src, src_member, dst_member):
         """Device-to-device copy of every registry variable of one member of `src` into one of this model's members."""
         check(self._lib.spd_model_copy_member(self._m, int(dst_member), src._m, int(src_member), self._stream()),

@@ -5,6 +5,9 @@ upstream.
 
 Tolerances (scaled max norm, fp64): after init 1e-11, after 36 steps 1e-10, after 108 steps 1e-9.  SURVEY.md section 8c
 measured 1.2e-14 (36 steps) between two builds of the reference itself and no error growth during the first 10 days."""
+import os
+import tempfile
+
 import numpy as np
 import pytest
 
@@ -110,3 +113,24 @@ def test_members_of_a_large_batch_equal_single_member_runs(spectral, bc):
             assert np.array_equal(ens.get(n, i), single.get(n, 0)), (i, n)
         single.close()
     assert not np.array_equal(ens.get("t", 1), ens.get("t", 2))
+
+
+def test_restart_from_the_registry_is_bitwise(spectral, bc):
+    """The registry IS the model state: copying every registry array of a running model into a fresh one (plus step
+    counter and date, the two host-side scalars) and continuing gives bitwise the same trajectory as the uninterrupted run
+    -- across a day boundary (daily forcing) and shortwave / non-shortwave steps."""
+    from pyspeedy_amd.model import SHAPES, EnsembleModel
+    ref = EnsembleModel(spectral, 1)
+    ref.set_bc(bc)
+    ref.run(31)
+    snapshot = ref.state_dict(0)
+    with tempfile.TemporaryDirectory() as tmp:  # through a file, as a checkpoint would travel
+        np.savez(os.path.join(tmp, "ckpt.npz"), **snapshot)
+        snapshot = dict(np.load(os.path.join(tmp, "ckpt.npz")))
+    ref.run(17)  # crosses step 36 (new day: forcing) and several shortwave steps
+    resumed = EnsembleModel(spectral, 1)
+    resumed.load_state_dict(snapshot)
+    resumed.run(17)
+    assert resumed.current_step == ref.current_step == 48 and resumed.current_date == ref.current_date
+    for n in SHAPES:
+        assert np.array_equal(resumed.get(n, 0), ref.get(n, 0)), n
