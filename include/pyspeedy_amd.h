@@ -152,6 +152,10 @@ int spd_model_step_dynamics(spd_model_handle m, int j1, int j2, double dt, int c
 /* check_diagnostics (diagnostics.f90:16-76) for every member: error_codes_host[i] = 0 or -2; diag_host may be NULL or
  * receive [nmembers][3][kx] (eddy KE of vor, of div, global-mean T).  Synchronises `stream`. */
 int spd_model_check(spd_model_handle m, int time_level, int32_t *error_codes_host, double *diag_host, void *stream);
+/* The same check without stalling the launch pipeline: _begin enqueues it and returns a slot (0 or 1, at most two in flight),
+ * _end waits for that slot only.  Begin the check of step k, launch step k + 1, then end the check of step k. */
+int spd_model_check_begin(spd_model_handle m, int time_level, void *stream);
+int spd_model_check_end(spd_model_handle m, int slot, int32_t *error_codes_host);
 
 /* initialize_state (initialization.f90:13-91) for every member from the boundary fields stored beforehand with
  * spd_model_set (orog, fmask_orig, alb0, veg_high, veg_low, stl12, snowd12, soil_wc_l1, soil_wc_l2, sst12,

@@ -83,6 +83,8 @@ _SIGNATURES = {
     "spd_model_set_time_step": (C.c_int, [C.c_void_p, C.c_double]),
     "spd_model_step_dynamics": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]),
     "spd_model_check": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "spd_model_check_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "spd_model_check_end": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "spd_model_init": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
     "spd_model_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "spd_model_current_step": (C.c_int, [C.c_void_p]),

@@ -75,6 +75,11 @@ struct spd_model {
     FieldDesc *fwd_table = nullptr;
     int *d_err = nullptr;
     double *d_diag = nullptr;
+    // asynchronous range check (spd_model_check_begin / _end): two pinned result slots with their events
+    int *h_err[2] = {nullptr, nullptr};
+    int *d_err_slot[2] = {nullptr, nullptr};
+    hipEvent_t err_event[2] = {nullptr, nullptr};
+    int next_slot = 0;
     double air_absortivity_co2 = 6.0;  // model_state_def.py:320 default
     // device copies of the dt-dependent tables (re-uploaded by set_time_step)
     // surface / coupler state, calendar and run control (do_single_step, speedy.f90:20-74)
@@ -365,6 +370,10 @@ int spd_model_destroy(spd_model_handle m) {
     if (!m) return SPD_OK;
     (void)hipSetDevice(m->ctx->device);
     for (void *p : m->allocs) (void)hipFree(p);
+    for (int i = 0; i < 2; ++i) {
+        if (m->h_err[i]) (void)hipHostFree(m->h_err[i]);
+        if (m->err_event[i]) (void)hipEventDestroy(m->err_event[i]);
+    }
     for (auto &pr : m->prof_events) {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
@@ -504,6 +513,42 @@ int spd_model_check(spd_model_handle m, int time_level, int32_t *error_codes_hos
     M_HIP(hipMemcpyAsync(error_codes_host, m->d_err, sizeof(int) * m->M, hipMemcpyDeviceToHost, s));
     if (diag_host) M_HIP(hipMemcpyAsync(diag_host, m->d_diag, sizeof(double) * m->M * 24, hipMemcpyDeviceToHost, s));
     M_HIP(hipStreamSynchronize(s));
+    return SPD_OK;
+}
+
+
+// The same range check without stalling the launch pipeline: _begin enqueues the diagnostics of the current state and an
+// asynchronous copy of the codes into pinned memory and returns a slot (0 or 1; at most two checks may be in flight);
+// _end waits for that slot only and hands out the codes.  A host loop that begins the check of step k, launches step k + 1
+// and only then ends the check of step k keeps the GPU busy while still seeing every code (one step late).
+int spd_model_check_begin(spd_model_handle m, int time_level, void *stream) {
+    if (!m) return m_fail(SPD_E_ARG, "spd_model_check_begin: null model");
+    if (time_level < 1 || time_level > 2) return m_fail(SPD_E_ARG, "spd_model_check_begin: time level is 1 or 2");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int slot = m->next_slot;
+    if (!m->h_err[slot]) {
+        void *p = nullptr;
+        M_HIP(hipHostMalloc(&p, sizeof(int) * m->M, hipHostMallocDefault));
+        m->h_err[slot] = static_cast<int *>(p);
+        M_HIP(hipMalloc(&p, sizeof(int) * m->M));
+        m->allocs.push_back(p);
+        m->d_err_slot[slot] = static_cast<int *>(p);
+        M_HIP(hipEventCreateWithFlags(&m->err_event[slot], hipEventDisableTiming));
+    }
+    M_HIP(hipMemsetAsync(m->d_err_slot[slot], 0, sizeof(int) * m->M, s));
+    hipError_t e = run_diagnostics(m->P, m->ctx->dev, m->M, time_level - 1, m->d_err_slot[slot], m->d_diag, s);
+    if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_check_begin: ") + hipGetErrorString(e));
+    M_HIP(hipMemcpyAsync(m->h_err[slot], m->d_err_slot[slot], sizeof(int) * m->M, hipMemcpyDeviceToHost, s));
+    M_HIP(hipEventRecord(m->err_event[slot], s));
+    m->next_slot = 1 - slot;
+    return slot;
+}
+
+int spd_model_check_end(spd_model_handle m, int slot, int32_t *error_codes_host) {
+    if (!m || !error_codes_host) return m_fail(SPD_E_ARG, "spd_model_check_end: null argument");
+    if (slot < 0 || slot > 1 || !m->err_event[slot]) return m_fail(SPD_E_ARG, "spd_model_check_end: no check was begun in this slot");
+    M_HIP(hipEventSynchronize(m->err_event[slot]));
+    std::memcpy(error_codes_host, m->h_err[slot], sizeof(int) * m->M);
     return SPD_OK;
 }
 

@@ -201,6 +201,18 @@ class EnsembleModel:
         check(self._lib.spd_model_step_dynamics(self._m, int(j1), int(j2), float(dt), int(bool(compute_shortwave)), stream),
               "spd_model_step_dynamics")
 
+    def check_begin(self, time_level=2):
+        """Enqueue the range check of the current state; returns a token for check_end (at most two may be in flight)."""
+        slot = self._lib.spd_model_check_begin(self._m, int(time_level), self._stream())
+        if slot < 0:
+            check(slot, "spd_model_check_begin")
+        return slot
+
+    def check_end(self, token):
+        codes = np.zeros(self.nmembers, dtype=np.int32)
+        check(self._lib.spd_model_check_end(self._m, int(token), codes.ctypes.data_as(C.c_void_p)), "spd_model_check_end")
+        return codes
+
     def check(self, time_level=2, with_diag=False):
         """diagnostics.f90 range check; returns int32 codes per member (0 ok, -2 out of range) [and the diagnostics]."""
         codes = np.zeros(self.nmembers, dtype=np.int32)

@@ -190,18 +190,30 @@ class Speedy:
 
     # ---- run -------------------------------------------------------------------------------------------------
     def run(self, callbacks=None):
-        """Run from `start_date` to `end_date`, calling every callback after each 40-minute step."""
+        """Run from `start_date` to `end_date`, calling every callback after each 40-minute step.  The reference's range
+        check runs after every step as upstream, but its result is collected one step later so that the GPU is never left
+        waiting for the host: a RuntimeError for step k is raised once step k + 1 has been enqueued (or at the end)."""
         callbacks = list(callbacks or [])
         if not self._initialized_bc:
             raise RuntimeError("The SPEEDY model was not initialized. Call the `set_bc` method to initialize the model.")
         self.current_date = self.start_date
+        pending = None  # the range check of a step is collected after the next step has been enqueued (GPU never idles)
         while self.current_date < self.end_date:
-            code = _speedy.step(self._state_cnt, self._control_cnt)
-            if code < 0:
-                raise RuntimeError(ERROR_CODES[code])
+            token = _speedy.parallel_step_begin([self._state_cnt], [self._control_cnt])
+            self._collect(pending)
+            pending = token
             self.current_date += _DT_STEP
             for callback in callbacks:
                 callback(self)
+        self._collect(pending)
+
+    @staticmethod
+    def _collect(token):
+        if token is not None:
+            codes = _speedy.parallel_step_end(token)
+            if (codes < 0).any():
+                raise RuntimeError("".join("Member%d: %s\n" % (n, ERROR_CODES[int(c)]) for n, c in enumerate(codes))
+                                   if len(codes) > 1 else ERROR_CODES[int(codes[0])])
 
     def grid2spectral(self):
         """Transform the grid u, v, t, q, ps and phi fields to the spectral domain."""
@@ -306,15 +318,17 @@ class SpeedyEns:
         for member in self:
             if not member._initialized_bc:
                 raise RuntimeError("The SPEEDY model was not initialized. Call the `set_bc` method of every member.")
+        pending = None
         while self.current_date < end_date:
-            codes = _speedy.parallel_step(state_cnts, control_cnts)
+            token = _speedy.parallel_step_begin(state_cnts, control_cnts)
+            Speedy._collect(pending)
+            pending = token
             self.current_date += _DT_STEP
-            if (codes < 0).any():
-                raise RuntimeError("".join("Member%d: %s\n" % (n, ERROR_CODES[int(c)]) for n, c in enumerate(codes)))
             for member in self:
                 member.current_date = self.current_date
             for callback in callbacks:
                 callback(self)
+        Speedy._collect(pending)
 
     def get_current_step(self):
         return self.members[0]["current_step"]

@@ -139,6 +139,14 @@ def test_exceptions(gold):
     assert int(gold["chk_zero_t"]) == -2
     with pytest.raises(RuntimeError):
         model.check()
+    # a run that leaves the accepted range fails too: the per-step check is collected one step late, never dropped
+    hot = Speedy(start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 1, 2, 0))
+    hot.set_bc()
+    t = hot["t"]
+    t[0, 0] *= 2.0  # doubles the global-mean temperature (the (0,0) coefficient) at both time levels
+    hot["t"] = t
+    with pytest.raises(RuntimeError):
+        hot.run()
     with pytest.raises(ValueError):
         model["t"] = np.zeros((3, 3))
     with pytest.raises(AttributeError):
