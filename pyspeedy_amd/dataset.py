@@ -139,27 +139,79 @@ def _decode_time(offsets, units):
     return np.array([np.datetime64(ref_dt + timedelta(seconds=int(o) * step), "s") for o in np.atleast_1d(offsets)])
 
 
+def _prepare(ds):
+    """(dims, [(name, dim names, big-endian array, attrs)]) with times encoded and dtypes narrowed as the files carry them."""
+    out = []
+    for name, v in ds.variables.items():
+        vals, attrs = v.values, dict(v.attrs)
+        if vals.dtype.kind == "M" or (vals.dtype == object and len(vals) and isinstance(vals.flat[0], datetime)):
+            vals, units = _encode_time(vals)
+            attrs.update(units=units, calendar="proleptic_gregorian")
+        if vals.dtype.kind in "iu":
+            vals = vals.astype(">i4")
+        elif vals.dtype.kind == "f":
+            vals = vals.astype(">f4")
+        else:
+            raise TypeError("%s: dtype %s cannot be written" % (name, vals.dtype))
+        out.append((name, v.dims, vals, {k: a for k, a in attrs.items() if a is not None}))
+    return ds.dims, out
+
+
 def write_netcdf(ds, path):
-    from scipy.io import netcdf_file
-    with netcdf_file(str(path), "w", version=1) as f:
-        for d, n in ds.dims.items():
-            f.createDimension(d, int(n))
-        for k, v in ds.attrs.items():
-            setattr(f, k, v)
-        for name, v in ds.variables.items():
-            vals, attrs = v.values, dict(v.attrs)
-            if vals.dtype.kind == "M" or (vals.dtype == object and len(vals) and isinstance(vals.flat[0], datetime)):
-                vals, units = _encode_time(vals)
-                attrs.update(units=units, calendar="proleptic_gregorian")
-            elif vals.dtype.kind in "iu":
-                vals = vals.astype(np.int32)
-            elif vals.dtype.kind == "f":
-                vals = vals.astype(np.float32)
-            nv = f.createVariable(name, vals.dtype.char, v.dims)
-            nv[...] = vals
-            for k, a in attrs.items():
-                if a is not None:
-                    setattr(nv, k, a)
+    """NetCDF-3 classic (CDF-1) writer: header, then every variable as one contiguous big-endian block.  Written directly
+    (one tofile per variable) because it is on the path of every model output; files are read back by scipy / netCDF4 /
+    xarray like any other classic file (tests/test_facade_cpu.py compares with scipy.io.netcdf_file)."""
+    import struct
+
+    NC_DIMENSION, NC_VARIABLE, NC_ATTRIBUTE, NC_CHAR, NC_INT, NC_FLOAT, NC_DOUBLE = 10, 11, 12, 2, 4, 5, 6
+    pad = lambda b: b + b"\0" * (-len(b) % 4)
+    name = lambda s_: struct.pack(">i", len(s_.encode())) + pad(s_.encode())
+
+    def attributes(attrs):
+        if not attrs:
+            return struct.pack(">ii", 0, 0)
+        out = struct.pack(">ii", NC_ATTRIBUTE, len(attrs))
+        for k, a in attrs.items():
+            if isinstance(a, str):
+                raw = a.encode()
+                out += name(k) + struct.pack(">ii", NC_CHAR, len(raw)) + pad(raw)
+            else:
+                arr = np.atleast_1d(np.asarray(a))
+                if arr.dtype.kind in "iu":
+                    out += name(k) + struct.pack(">ii", NC_INT, arr.size) + arr.astype(">i4").tobytes()
+                elif arr.dtype == np.float32:
+                    out += name(k) + struct.pack(">ii", NC_FLOAT, arr.size) + arr.astype(">f4").tobytes()
+                else:
+                    out += name(k) + struct.pack(">ii", NC_DOUBLE, arr.size) + arr.astype(">f8").tobytes()
+        return out
+
+    dims, variables = _prepare(ds)
+    dim_ids = {d: i for i, d in enumerate(dims)}
+    head = b"CDF\x01" + struct.pack(">i", 0)
+    head += struct.pack(">ii", NC_DIMENSION, len(dims)) if dims else struct.pack(">ii", 0, 0)
+    for d, n in dims.items():
+        head += name(d) + struct.pack(">i", int(n))
+    head += attributes(ds.attrs)
+    # variable headers need the data offsets, which need the header size: build them with a placeholder first
+    def var_headers(begins):
+        out = struct.pack(">ii", NC_VARIABLE, len(variables))
+        for (vname, vdims, vals, attrs), begin in zip(variables, begins):
+            out += name(vname) + struct.pack(">i", len(vdims)) + b"".join(struct.pack(">i", dim_ids[d]) for d in vdims)
+            out += attributes(attrs)
+            out += struct.pack(">iii", NC_INT if vals.dtype.kind == "i" else NC_FLOAT, vals.nbytes + (-vals.nbytes % 4), begin)
+        return out
+    size = len(head) + len(var_headers([0] * len(variables)))
+    begins = []
+    for _, _, vals, _ in variables:
+        begins.append(size)
+        size += vals.nbytes + (-vals.nbytes % 4)
+    if size >= 2 ** 31:
+        raise ValueError("dataset too large for the NetCDF-3 classic format (2 GiB offsets)")
+    with open(str(path), "wb") as f:
+        f.write(head + var_headers(begins))
+        for _, _, vals, _ in variables:
+            np.ascontiguousarray(vals).tofile(f)
+            f.write(b"\0" * (-vals.nbytes % 4))
 
 
 def open_dataset(path):

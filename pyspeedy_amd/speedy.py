@@ -256,14 +256,14 @@ def _build_dataset(model, arrays, members, date):
     for var, values in arrays.items():
         meta = _exportable(var)
         dims = tuple(reversed(meta.nc_dims))
-        values = values.astype(np.float32)
         if "lev" in dims:
             values = values[:, ::-1]  # vertical levels increasing with height (lev coordinate reversed)
+        values = values.astype(np.float32)  # one pass: reversed view -> contiguous float32
         values = values[None] if members is not None else values  # -> (time, ens, ...) or (time, ...)
         attrs = {"long_name": meta.long_name, "standard_name": var}
         if meta.units is not None:
             attrs["units"] = meta.units
-        data[meta.alt_name] = Variable(lead + dims, np.ascontiguousarray(values), attrs)
+        data[meta.alt_name] = Variable(lead + dims, values, attrs)
     coords = {}
     for c, axis in (("lon", "X"), ("lat", "Y"), ("lev", None)):
         meta = REGISTRY[c]
