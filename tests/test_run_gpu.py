@@ -134,3 +134,26 @@ def test_restart_from_the_registry_is_bitwise(spectral, bc):
     assert resumed.current_step == ref.current_step == 48 and resumed.current_date == ref.current_date
     for n in SHAPES:
         assert np.array_equal(resumed.get(n, 0), ref.get(n, 0)), n
+
+
+def test_ten_day_forecast(spectral, bc, golden_dir):
+    """360 steps against the reference Fortran (tests/golden/run10.npz): still round-off level, no drift.
+    Tolerance 1e-9 of each field's max norm (observed ~1e-13); precipitation fields, which are sums of thresholded
+    column processes, 1e-6 of their maximum."""
+    from pyspeedy_amd.model import EnsembleModel
+    g = np.load(golden_dir + "/run10.npz")
+    model = EnsembleModel(spectral, 1)
+    model.set_bc(bc)
+    model.run(360)
+    assert (model.check(2) == 0).all() and model.current_date == (1982, 1, 11, 0, 0)
+    worst = 0.0
+    for n in ("vor", "div", "t", "tr", "ps"):
+        e = err(model.get(n, 0)[..., 0], g[n])
+        worst = max(worst, e)
+        assert e <= 1e-9, (n, e)
+    for n in ("land_temp", "sst_am", "tice_am", "snowc", "olr", "tsr"):
+        e = err(model.get(n, 0), g[n])
+        assert e <= 1e-9, (n, e)
+    for n in ("precnv", "precls"):
+        assert err(model.get(n, 0), g[n]) <= 1e-6, n
+    print("10-day scaled max error of the spectral state: %.2e" % worst)
