@@ -75,35 +75,23 @@ __device__ unsigned long long spd_trace_cnt[2];
 // computed from the model's prognostic fields with the arithmetic of specops.hip / spectral.f90:190-214, 275-296.
 __device__ inline d2 times_i(d2 z) { return d2{-z.y, z.x}; }
 
+// Branch-free: the reference treats the first and the last total wavenumber separately (no n-1 / n+1 neighbour, and no
+// x-derivative term at the last one); here the neighbour index is clamped and the missing terms vanish because the
+// reference's own coefficient tables are zero there (uvdym(:,1) = gradym(:,1) = 0, uvdyp(:,nx) = gradyp(:,nx) = 0) or are
+// selected away -- every lane issues the same loads at once instead of running three divergent paths one after the other.
 __device__ __forceinline__ d2 staged_coefficient(int mode, gd2_in a, gd2_in b, int k, const DeviceTables &T) {
     const int n = k / MX, m = k - n * MX;
+    const int km = n == 0 ? k : k - MX, kp = n == NX - 1 ? k : k + MX;
+    const bool last = n == NX - 1;
     if (mode <= 2) {  // vort2vel: a = vorticity, b = divergence
-        const double dx = T.uvdx[k], cm = T.uvdym[k], cp = T.uvdyp[k];
-        if (mode == 1) {  // ucos
-            const d2 zb = b[k];
+        const double dx = last ? 0.0 : T.uvdx[k], cm = T.uvdym[k], cp = T.uvdyp[k];
+        if (mode == 1) {  // ucos = uvdym vor(n-1) - uvdyp vor(n+1) + i uvdx div(n)
+            const d2 zb = b[k], ap = a[km], an = a[kp];
             const d2 zc = times_i(d2{dx * zb.x, dx * zb.y});
-            if (n == 0) {
-                const d2 an = a[k + MX];
-                return d2{zc.x - cp * an.x, zc.y - cp * an.y};
-            }
-            if (n == NX - 1) {
-                const d2 ap = a[k - MX];
-                return d2{cm * ap.x, cm * ap.y};
-            }
-            const d2 ap = a[k - MX], an = a[k + MX];
             return d2{cm * ap.x - cp * an.x + zc.x, cm * ap.y - cp * an.y + zc.y};
         }
-        const d2 za = a[k];  // vcos
+        const d2 za = a[k], bp = b[km], bn = b[kp];  // vcos = -uvdym div(n-1) + uvdyp div(n+1) + i uvdx vor(n)
         const d2 zp = times_i(d2{dx * za.x, dx * za.y});
-        if (n == 0) {
-            const d2 bn = b[k + MX];
-            return d2{zp.x + cp * bn.x, zp.y + cp * bn.y};
-        }
-        if (n == NX - 1) {
-            const d2 bp = b[k - MX];
-            return d2{-cm * bp.x, -cm * bp.y};
-        }
-        const d2 bp = b[k - MX], bn = b[k + MX];
         return d2{-cm * bp.x + cp * bn.x + zp.x, -cm * bp.y + cp * bn.y + zp.y};
     }
     if (mode == 3) {  // d/dx
@@ -111,16 +99,9 @@ __device__ __forceinline__ d2 staged_coefficient(int mode, gd2_in a, gd2_in b, i
         const double g = T.gradx[m];
         return times_i(d2{g * z.x, g * z.y});
     }
-    if (n == 0) {  // d/dy
-        const d2 zn = a[k + MX];
-        return d2{T.gradyp[k] * zn.x, T.gradyp[k] * zn.y};
-    }
-    if (n == NX - 1) {
-        const d2 zp = a[k - MX];
-        return d2{-T.gradym[k] * zp.x, -T.gradym[k] * zp.y};
-    }
-    const d2 zp = a[k - MX], zn = a[k + MX];
-    return d2{-T.gradym[k] * zp.x + T.gradyp[k] * zn.x, -T.gradym[k] * zp.y + T.gradyp[k] * zn.y};
+    const d2 zp = a[km], zn = a[kp];  // d/dy
+    const double gm = T.gradym[k], gp = T.gradyp[k];
+    return d2{-gm * zp.x + gp * zn.x, -gm * zp.y + gp * zn.y};
 }
 
 // ------------------------------------------------------------------------------------------------
