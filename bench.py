@@ -189,7 +189,7 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_src,
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the host baseline is measured on single-GPU runs only
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if dist is not None:
