@@ -20,8 +20,13 @@
 //   * Legendre: a lane owns one zonal wavenumber m (re and im together, 16-byte LDS reads) and two latitude pairs
 //     (inverse) or two total wavenumbers of one parity (direct).  Inverse lanes are ordered m-major so that a
 //     wavefront only loops over the total wavenumbers its smallest m needs (triangular truncation: 32 - m of them);
-//     direct lanes come from a work list that holds only the coefficients inside the truncation (279 lanes).  The associated-Legendre
-//     values stream from an L2-resident table laid out so that a wavefront reads 1 KiB contiguous per step.
+//     direct lanes come from a work list that holds only the coefficients inside the truncation (279 lanes).  The
+//     associated-Legendre values stream from an L2-resident table laid out so that a wavefront reads 1 KiB contiguous
+//     per step.
+//   * Staging: every lane issues all its global loads before the first dependent LDS store (and, on the way out, all
+//     scale-factor loads before the first global store).  In the model step the spectral -> grid kernel can apply the
+//     spectral operator in front of the transform while it stages the coefficients (FieldDesc::mode: vort2vel, gradient),
+//     so u, v and grad ln ps are never materialised as spectral fields.
 #include <hip/hip_runtime.h>
 
 #include "device_tables.hpp"
