@@ -137,7 +137,12 @@ __device__ inline d2 pick(const d2 (&a)[N], int l) {
 
 __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTables T, DynDeviceTables D, int M, int j1,
                                                            double dt, double eps) {
-    const int gid = blockIdx.x * kT + threadIdx.x;
+    // XCD-aware block order: workgroups are dealt to the 8 XCDs round-robin, and the n-1 / n+1 neighbours of the vel2vort
+    // stencils live one workgroup away (31 coefficients), so each XCD is given a CONTIGUOUS range of the work -- the halo
+    // lines are then found in that XCD's L2 instead of being fetched again by every neighbour's XCD.
+    const int xcd = blockIdx.x & 7, q = gridDim.x >> 3, r = gridDim.x & 7;  // XCD c owns q + (c < r) consecutive blocks
+    const int block = xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3);
+    const int gid = block * kT + threadIdx.x;
     const int w = gid >> 6, lane = gid & 63;
     if (w >= M * kCoefBlocks) return;  // whole wavefronts only: the gathers below need all 64 lanes
     const int l = lane >> 3, kk = lane & 7;
