@@ -62,10 +62,10 @@ __device__ inline void uv_stencil(const d2 *a, const d2 *b, int k, int m, int n,
 // ---------------------------------------------------------------------------------------------------------
 // geopotential from temperature at time level `tl` (geopotential.f90:49-77)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kT) void geopotential_kernel(ModelPtrs P, DynDeviceTables D, int M, int tl) {
+__global__ __launch_bounds__(kT) void geopotential_kernel(ModelPtrs P, DynDeviceTables D, int first, int count, int tl) {
     const int gid = blockIdx.x * kT + threadIdx.x;
-    if (gid >= M * NSPEC) return;
-    const int mem = gid / NSPEC, k = gid - mem * NSPEC, m = k % MX;
+    if (gid >= count * NSPEC) return;
+    const int lm = gid / NSPEC, mem = first + lm, k = gid - lm * NSPEC, m = k % MX;
     const d2 *t = reinterpret_cast<const d2 *>(P.t) + (static_cast<size_t>(mem) * 2 + tl) * 8 * NSPEC + k;
     d2 *phi = reinterpret_cast<d2 *>(P.phi) + static_cast<size_t>(mem) * 8 * NSPEC + k;
     d2 tt[KX], ph[KX];
@@ -135,8 +135,8 @@ __device__ inline d2 pick(const d2 (&a)[N], int l) {
 }
 }  // namespace
 
-__global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTables T, DynDeviceTables D, int M, int j1,
-                                                           double dt, double eps) {
+__global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTables T, DynDeviceTables D, int M, int first,
+                                                           int count, int j1, double dt, double eps) {
     // XCD-aware block order: workgroups are dealt to the 8 XCDs round-robin, and the n-1 / n+1 neighbours of the vel2vort
     // stencils live one workgroup away (31 coefficients), so each XCD is given a CONTIGUOUS range of the work -- the halo
     // lines are then found in that XCD's L2 instead of being fetched again by every neighbour's XCD.
@@ -144,9 +144,9 @@ __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTa
     const int block = xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3);
     const int gid = block * kT + threadIdx.x;
     const int w = gid >> 6, lane = gid & 63;
-    if (w >= M * kCoefBlocks) return;  // whole wavefronts only: the gathers below need all 64 lanes
+    if (w >= count * kCoefBlocks) return;  // whole wavefronts only: the gathers below need all 64 lanes
     const int l = lane >> 3, kk = lane & 7;
-    const int mem = w / kCoefBlocks, k = (w - mem * kCoefBlocks) * 8 + kk, n = k / MX, m = k - n * MX;
+    const int lm = w / kCoefBlocks, mem = first + lm, k = (w - lm * kCoefBlocks) * 8 + kk, n = k / MX, m = k - n * MX;
     const size_t f8 = static_cast<size_t>(mem) * 8 * NSPEC;        // [M][8] work arrays
     const size_t pair = static_cast<size_t>(M) * 8 * NSPEC;        // stride between the three (u,v)-pair outputs
     const size_t fo = static_cast<size_t>(l) * NSPEC;
@@ -333,17 +333,19 @@ __global__ __launch_bounds__(64) void diagnostics_kernel(ModelPtrs P, DeviceTabl
 // ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
-hipError_t run_geopotential(const ModelPtrs &P, const DynDeviceTables &D, int M, int tl, hipStream_t s) {
-    hipLaunchKernelGGL(geopotential_kernel, dim3((M * NSPEC + kT - 1) / kT), dim3(kT), 0, s, P, D, M, tl);
+// (first, count): the members the launch works on; M: members in the arrays (strides between the blocks of specu / specv)
+hipError_t run_geopotential(const ModelPtrs &P, const DynDeviceTables &D, int first, int count, int tl, hipStream_t s) {
+    hipLaunchKernelGGL(geopotential_kernel, dim3((count * NSPEC + kT - 1) / kT), dim3(kT), 0, s, P, D, first, count, tl);
     return hipGetLastError();
 }
 hipError_t run_dyn_grid(const ModelPtrs &P, const DynDeviceTables &D, int M, hipStream_t s) {
     hipLaunchKernelGGL(dyn_grid_kernel, dim3((M * NG + kT - 1) / kT), dim3(kT), 0, s, P, D, M);
     return hipGetLastError();
 }
-hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const DynDeviceTables &D, int M, int j1, double dt,
-                             double eps, hipStream_t s) {
-    hipLaunchKernelGGL(spectral_step_kernel, dim3((M * NSPEC * KX + kT - 1) / kT), dim3(kT), 0, s, P, T, D, M, j1, dt, eps);
+hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const DynDeviceTables &D, int M, int first, int count,
+                             int j1, double dt, double eps, hipStream_t s) {
+    hipLaunchKernelGGL(spectral_step_kernel, dim3((count * NSPEC * KX + kT - 1) / kT), dim3(kT), 0, s, P, T, D, M, first, count,
+                       j1, dt, eps);
     return hipGetLastError();
 }
 hipError_t run_diagnostics(const ModelPtrs &P, const DeviceTables &T, int M, int tl, int *err, double *diag, hipStream_t s) {

@@ -20,16 +20,16 @@ hipError_t run_spec2grid_table(const DeviceTables &T, const FieldDesc *table, in
 hipError_t run_grid2spec_table(const DeviceTables &T, const FieldDesc *table, int nfields, hipStream_t st);
 hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nmembers, hipStream_t s);
 hipError_t run_dyn_physics(const ModelPtrs &P, const DynDeviceTables &D, const DeviceTables &T, const spd_physics_args &a,
-                           int nmembers, hipStream_t s);
-hipError_t run_geopotential(const ModelPtrs &P, const DynDeviceTables &D, int M, int tl, hipStream_t s);
+                           int first, int nmembers, hipStream_t s);
+hipError_t run_geopotential(const ModelPtrs &P, const DynDeviceTables &D, int first, int count, int tl, hipStream_t s);
 hipError_t run_dyn_grid(const ModelPtrs &P, const DynDeviceTables &D, int M, hipStream_t s);
-hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const DynDeviceTables &D, int M, int j1, double dt,
-                             double eps, hipStream_t s);
+hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const DynDeviceTables &D, int M, int first, int count,
+                             int j1, double dt, double eps, hipStream_t s);
 hipError_t run_diagnostics(const ModelPtrs &P, const DeviceTables &T, int M, int tl, int *err, double *diag, hipStream_t s);
-hipError_t run_coupler(const SurfacePtrs &S, int M, const TimeInterp &w, int day, int land_coupling, int sst_anomaly,
-                       int anom_planes, hipStream_t s);
-hipError_t run_forcing(const SurfacePtrs &S, int M, const ZonalDevice &Z, double gamlat, double *corh_t, double *corh_q,
-                       hipStream_t s);
+hipError_t run_coupler(const SurfacePtrs &S, int first, int count, const TimeInterp &w, int day, int land_coupling,
+                       int sst_anomaly, int anom_planes, hipStream_t s);
+hipError_t run_forcing(const SurfacePtrs &S, int first, int count, const ZonalDevice &Z, double gamlat, double *corh_t,
+                       double *corh_q, hipStream_t s);
 hipError_t run_rest_state(const RestPtrs &R, int M, const RestConsts &c, hipStream_t s);
 hipError_t run_scale_orog(const double *orog, double *phi0, long n, hipStream_t s);
 hipError_t run_rest_surface(const double *phis0, double *forog, double *surf_ps, double *surf_q, const RestConsts &c, long n,
@@ -92,6 +92,11 @@ struct spd_model {
     unsigned long long sppt_seed = 0;
     long long sppt_member_base = 0, sppt_step = 0;
     double *sppt_spec = nullptr, *sppt_grid = nullptr;
+    // Members are stepped in `nchunks` groups on separate HIP streams (spd_model_step): a group's kernels overlap with
+    // the other groups' (different kernels, complementary resources, no idle tail between dependent launches).
+    int nchunks = 1;
+    hipStream_t cstream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t cev[4] = {nullptr, nullptr, nullptr, nullptr}, ev_start = nullptr;
     bool split_dyn_physics = false;  // PYSPEEDY_AMD_SPLIT_DYN=1: separate dynamics and physics launches (for measurements)
     int land_coupling_flag = 1, sst_anomaly_flag = 1, increase_co2 = 0, anom_planes = 3;
     double ablco2_ref = 6.0;
@@ -101,6 +106,7 @@ struct spd_model {
     // optional profiling of the dominant kernel (the spec2grid table launch): HIP events on the launch stream
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    std::vector<int> prof_fields;  // fields of each profiled launch
     size_t prof_used = 0;
     // grid-space copies of the prognostic variables in output units (prognostics.f90:125-219) and their transform tables
     double *u_grid = nullptr, *v_grid = nullptr, *t_grid = nullptr, *q_grid = nullptr, *phi_grid = nullptr, *ps_grid = nullptr;
@@ -245,6 +251,14 @@ int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
     m->ctx = h;
     m->M = nmembers;
     if (const char *env = getenv("PYSPEEDY_AMD_SPLIT_DYN")) m->split_dyn_physics = atoi(env) != 0;
+    // PYSPEEDY_AMD_CHUNKS = 2 or 3 steps the members in that many groups on separate streams: measured -6 % / -8 % per step
+    // at 64 members (4 groups: +7 %).  Off by default: with overlapping launches the duration of a single kernel -- what the
+    // roofline accounting of bench.py and the committed rocprof summaries are about -- is no longer attributable to it.
+    m->nchunks = 1;
+    if (const char *env = getenv("PYSPEEDY_AMD_CHUNKS")) m->nchunks = atoi(env);
+    if (m->nchunks < 1) m->nchunks = 1;
+    if (m->nchunks > 4) m->nchunks = 4;
+    if (m->nchunks > nmembers) m->nchunks = nmembers;
     const size_t M = nmembers, S = NSPEC * C, G3 = static_cast<size_t>(8) * NG;
     ModelPtrs &P = m->P;
     spd_physics_args &pa = m->pa;
@@ -370,6 +384,11 @@ int spd_model_destroy(spd_model_handle m) {
     if (!m) return SPD_OK;
     (void)hipSetDevice(m->ctx->device);
     for (void *p : m->allocs) (void)hipFree(p);
+    for (int i = 0; i < 4; ++i) {
+        if (m->cstream[i]) (void)hipStreamDestroy(m->cstream[i]);
+        if (m->cev[i]) (void)hipEventDestroy(m->cev[i]);
+    }
+    if (m->ev_start) (void)hipEventDestroy(m->ev_start);
     for (int i = 0; i < 2; ++i) {
         if (m->h_err[i]) (void)hipHostFree(m->h_err[i]);
         if (m->err_event[i]) (void)hipEventDestroy(m->err_event[i]);
@@ -451,53 +470,62 @@ int spd_model_set_time_step(spd_model_handle m, double dt) {
     return SPD_OK;
 }
 
+// one `step(state, j1, j2, dt)` of time_stepping.f90 for the members [first, first + count) on stream s
+static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int compute_shortwave, int first, int count, hipStream_t s) {
+    const DeviceTables &T = m->ctx->dev;
+    const int M = m->M;
+    hipError_t e = run_geopotential(m->P, m->D, first, count, 0, s);                      // tendencies.f90:229
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (m->profile && e == hipSuccess) {
+        if (m->prof_used == m->prof_events.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) {
+                m->prof_events.emplace_back(a, b);
+                m->prof_fields.push_back(0);
+            }
+        }
+        if (m->prof_used < m->prof_events.size()) {
+            ev0 = m->prof_events[m->prof_used].first;
+            ev1 = m->prof_events[m->prof_used].second;
+            m->prof_fields[m->prof_used] = 91 * count;
+            ++m->prof_used;
+            (void)hipEventRecord(ev0, s);
+        }
+    }
+    if (e == hipSuccess)                                                                  // :109-146, physics.f90:89-101
+        e = run_spec2grid_table(T, m->inv_table[j2 - 1] + static_cast<size_t>(first) * 91, 91 * count, s);
+    if (ev1) (void)hipEventRecord(ev1, s);
+    spd_physics_args pa = m->pa;
+    pa.compute_shortwave = compute_shortwave ? 1 : 0;
+    pa.air_absortivity_co2 = m->air_absortivity_co2;
+    pa.sppt_pattern = nullptr;
+    if (e == hipSuccess && m->sppt_on) {  // physics.f90:234-236: a new pattern for every call of the physics (whole model)
+        e = run_sppt_update(m->sppt_spec, T, M, m->sppt_seed, m->sppt_member_base, m->sppt_step, m->sppt_first ? 1 : 0, s);
+        if (e == hipSuccess) e = run_spec2grid(T, 0, m->sppt_spec, m->sppt_grid, 1, 8 * M, s);
+        m->sppt_first = false;
+        m->sppt_step += 1;
+        pa.sppt_pattern = m->sppt_grid;
+    }
+    if (e == hipSuccess) {
+        if (m->split_dyn_physics || m->sppt_on) {  // whole model only (SPPT needs the dynamics-only tendencies in memory)
+            e = run_dyn_grid(m->P, m->D, M, s);                                           // :151-224
+            if (e == hipSuccess) e = run_physics(T, pa, M, s);                            // :231
+        } else {
+            e = run_dyn_physics(m->P, m->D, T, pa, first, count, s);                      // both in one launch
+        }
+    }
+    if (e == hipSuccess) e = run_grid2spec_table(T, m->fwd_table + static_cast<size_t>(first) * 73, 73 * count, s);  // :238-268
+    const double eps = (j1 == 1) ? 0.0 : static_cast<double>(0.05f);                      // rob, time_stepping.f90:130-134
+    if (e == hipSuccess) e = run_spectral_step(m->P, T, m->D, M, first, count, j1 - 1, dt, eps, s);
+    return e;
+}
+
 // time_stepping.f90 `step(state, j1, j2, dt)`; j1, j2 are the reference's 1-based time-level indices.
 int spd_model_step_dynamics(spd_model_handle m, int j1, int j2, double dt, int compute_shortwave, void *stream) {
     if (!m) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: null model");
     if (j1 < 1 || j1 > 2 || j2 < 1 || j2 > 2) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: time levels are 1 or 2");
     if (m->dynh->dt == 0.0) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: call spd_model_set_time_step first");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const DeviceTables &T = m->ctx->dev;
-    const int M = m->M;
-    hipError_t e = run_geopotential(m->P, m->D, M, 0, s);                                 // tendencies.f90:229
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (m->profile && e == hipSuccess) {
-        if (m->prof_used == m->prof_events.size()) {
-            hipEvent_t a, b;
-            if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) m->prof_events.emplace_back(a, b);
-        }
-        if (m->prof_used < m->prof_events.size()) {
-            ev0 = m->prof_events[m->prof_used].first;
-            ev1 = m->prof_events[m->prof_used].second;
-            ++m->prof_used;
-            (void)hipEventRecord(ev0, s);
-        }
-    }
-    if (e == hipSuccess) e = run_spec2grid_table(T, m->inv_table[j2 - 1], 91 * M, s);     // :109-146, physics.f90:89-101
-    if (ev1) (void)hipEventRecord(ev1, s);
-    if (e == hipSuccess) {
-        m->pa.compute_shortwave = compute_shortwave ? 1 : 0;
-        m->pa.air_absortivity_co2 = m->air_absortivity_co2;
-        m->pa.sppt_pattern = nullptr;
-        if (m->sppt_on) {  // physics.f90:234-236: a new pattern for every call of the physics
-            e = run_sppt_update(m->sppt_spec, T, M, m->sppt_seed, m->sppt_member_base, m->sppt_step, m->sppt_first ? 1 : 0, s);
-            if (e == hipSuccess) e = run_spec2grid(T, 0, m->sppt_spec, m->sppt_grid, 1, 8 * M, s);
-            m->sppt_first = false;
-            m->sppt_step += 1;
-            m->pa.sppt_pattern = m->sppt_grid;
-        }
-    }
-    if (e == hipSuccess) {
-        if (m->split_dyn_physics || m->sppt_on) {  // (SPPT needs the dynamics-only tendencies in memory)
-            e = run_dyn_grid(m->P, m->D, M, s);                                           // :151-224
-            if (e == hipSuccess) e = run_physics(T, m->pa, M, s);                         // :231
-        } else {
-            e = run_dyn_physics(m->P, m->D, T, m->pa, M, s);                              // both in one launch
-        }
-    }
-    if (e == hipSuccess) e = run_grid2spec_table(T, m->fwd_table, 73 * M, s);             // :238-268
-    const double eps = (j1 == 1) ? 0.0 : static_cast<double>(0.05f);                      // rob, time_stepping.f90:130-134
-    if (e == hipSuccess) e = run_spectral_step(m->P, T, m->D, M, j1 - 1, dt, eps, s);
+    const hipError_t e = step_range(m, j1, j2, dt, compute_shortwave, 0, m->M, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_step_dynamics: ") + hipGetErrorString(e));
     return SPD_OK;
 }
@@ -556,8 +584,8 @@ int spd_model_check_end(spd_model_handle m, int slot, int32_t *error_codes_host)
 // ---------------------------------------------------------------------------------------------------------------
 // run control: initialize_state (initialization.f90:13-91) and do_single_step (speedy.f90:20-74)
 // ---------------------------------------------------------------------------------------------------------------
-static int set_forcing(spd_model *m, int imode, hipStream_t s) {  // forcing.f90:15-102
-    const int M = m->M;
+// set_forcing (forcing.f90:15-102): the host part (zonal forcing of the day, CO2 trend) ...
+static ZonalDevice forcing_host(spd_model *m, int imode) {
     if (imode == 0) m->ablco2_ref = m->air_absortivity_co2;  // radset / forog are handled at initialisation
     const ZonalForcing z = zonal_average_fields(m->ctx->host, m->cal.tyear);
     ZonalDevice zd;
@@ -569,22 +597,32 @@ static int set_forcing(spd_model *m, int imode, hipStream_t s) {  // forcing.f90
         const double del_co2 = 0.005f;
         m->air_absortivity_co2 = m->ablco2_ref * std::exp(del_co2 * (m->cal.year + m->cal.tyear - 1950));
     }
+    return zd;
+}
+
+// ... and the device part for the members [first, first + count)
+static int forcing_range(spd_model *m, const ZonalDevice &zd, int first, int count, hipStream_t s) {
     const double gamlat = static_cast<double>(6.0f) / (1000.f * static_cast<double>(9.81f));  // setgam, forcing.f90:105-117
-    hipError_t e = run_forcing(m->S, M, zd, gamlat, m->corh_t, m->corh_q, s);
-    if (e == hipSuccess) e = run_grid2spec(m->ctx->dev, 0, m->corh_t, m->P.tcorh, 0, M, s);
-    if (e == hipSuccess) e = run_grid2spec(m->ctx->dev, 0, m->corh_q, m->P.qcorh, 0, M, s);
+    const size_t og = static_cast<size_t>(first) * NG, os = static_cast<size_t>(first) * NSPEC * C;
+    hipError_t e = run_forcing(m->S, first, count, zd, gamlat, m->corh_t, m->corh_q, s);
+    if (e == hipSuccess) e = run_grid2spec(m->ctx->dev, 0, m->corh_t + og, m->P.tcorh + os, 0, count, s);
+    if (e == hipSuccess) e = run_grid2spec(m->ctx->dev, 0, m->corh_q + og, m->P.qcorh + os, 0, count, s);
     if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("set_forcing: ") + hipGetErrorString(e));
     return SPD_OK;
 }
 
-static int couple(spd_model *m, int day, hipStream_t s) {  // couple_sea_land, coupler.f90:35-48
+static int set_forcing(spd_model *m, int imode, hipStream_t s) { return forcing_range(m, forcing_host(m, imode), 0, m->M, s); }
+
+static int couple_range(spd_model *m, int day, int first, int count, hipStream_t s) {  // couple_sea_land, coupler.f90:35-48
     const TimeInterp w = time_interp(m->cal);
     if (m->sst_anomaly_flag && (w.a0 < 0 || w.a1 < 0 || w.a0 >= m->anom_planes || w.a1 >= m->anom_planes))
         return m_fail(SPD_E_ARG, "SST anomaly planes do not cover the simulated period (speedy.py:338-372)");
-    hipError_t e = run_coupler(m->S, m->M, w, day, m->land_coupling_flag, m->sst_anomaly_flag, m->anom_planes, s);
+    hipError_t e = run_coupler(m->S, first, count, w, day, m->land_coupling_flag, m->sst_anomaly_flag, m->anom_planes, s);
     if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("couple_sea_land: ") + hipGetErrorString(e));
     return SPD_OK;
 }
+
+static int couple(spd_model *m, int day, hipStream_t s) { return couple_range(m, day, 0, m->M, s); }
 
 // initialize_state for every member from the boundary fields previously stored with spd_model_set:
 // orog, fmask_orig, alb0, veg_high, veg_low, stl12, snowd12, soil_wc_l1, soil_wc_l2, sst12, sea_ice_frac12 [, sst_anom].
@@ -684,16 +722,55 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
     if (!m->initialized) return m_fail(SPD_E_ARG, "spd_model_step: model state not initialized (error code -1 of the reference)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double delt = 86400.0 / 36;
-    for (int it = 0; it < nsteps; ++it) {
-        if (m->current_step % 36 == 0)
-            if (int rc = set_forcing(m, 1, s)) return rc;
+    // Members never exchange data, so the step is issued group by group on separate streams: every group runs the same
+    // six launches on its own members, and the groups' kernels overlap on the GPU.  The caller's stream orders the whole call:
+    // the group streams start after everything already enqueued on it, and it continues after all of them.
+    const int G = (m->split_dyn_physics || m->sppt_on) ? 1 : m->nchunks;
+    hipStream_t gs[4] = {s, nullptr, nullptr, nullptr};
+    if (G > 1) {
+        M_HIP(hipSetDevice(m->ctx->device));
+        if (!m->ev_start) M_HIP(hipEventCreateWithFlags(&m->ev_start, hipEventDisableTiming));
+        M_HIP(hipEventRecord(m->ev_start, s));
+        for (int g = 0; g < G; ++g) {
+            if (!m->cstream[g]) {
+                M_HIP(hipStreamCreateWithFlags(&m->cstream[g], hipStreamNonBlocking));
+                M_HIP(hipEventCreateWithFlags(&m->cev[g], hipEventDisableTiming));
+            }
+            gs[g] = m->cstream[g];
+            M_HIP(hipStreamWaitEvent(gs[g], m->ev_start, 0));
+        }
+    }
+    const int base = m->M / G, extra = m->M % G;
+    int rc = SPD_OK;
+    for (int it = 0; it < nsteps && rc == SPD_OK; ++it) {
+        const bool new_day = m->current_step % 36 == 0;
+        ZonalDevice zd{};
+        if (new_day) zd = forcing_host(m, 1);
         const int sw = (m->current_step % 3 == 0) ? 1 : 0;
-        if (int rc = spd_model_step_dynamics(m, 2, 2, 2 * delt, sw, stream)) return rc;
+        for (int g = 0, first = 0; g < G && rc == SPD_OK; ++g) {
+            const int count = base + (g < extra ? 1 : 0);
+            if (new_day) rc = forcing_range(m, zd, first, count, gs[g]);
+            if (rc == SPD_OK) {
+                const hipError_t e = step_range(m, 2, 2, 2 * delt, sw, first, count, gs[g]);
+                if (e != hipSuccess) rc = m_fail(SPD_E_DEVICE, std::string("spd_model_step: ") + hipGetErrorString(e));
+            }
+            first += count;
+        }
+        if (rc != SPD_OK) break;
         m->current_step += 1;
         m->cal.advance();
-        if (int rc = couple(m, 1 + m->current_step / 36, s)) return rc;
+        for (int g = 0, first = 0; g < G && rc == SPD_OK; ++g) {
+            const int count = base + (g < extra ? 1 : 0);
+            rc = couple_range(m, 1 + m->current_step / 36, first, count, gs[g]);
+            first += count;
+        }
     }
-    return SPD_OK;
+    if (G > 1)
+        for (int g = 0; g < G; ++g) {
+            M_HIP(hipEventRecord(m->cev[g], gs[g]));
+            M_HIP(hipStreamWaitEvent(s, m->cev[g], 0));
+        }
+    return rc;
 }
 
 int spd_model_current_step(spd_model_handle m) { return m ? m->current_step : SPD_E_ARG; }
@@ -718,7 +795,7 @@ int spd_model_profile_read(spd_model_handle m, double *mean_ms, int *launches, i
     }
     *launches = static_cast<int>(m->prof_used);
     *mean_ms = m->prof_used ? sum / m->prof_used : 0.0;
-    *fields_per_launch = 91 * m->M;
+    *fields_per_launch = m->prof_used ? m->prof_fields[0] : 91 * m->M;
     return SPD_OK;
 }
 

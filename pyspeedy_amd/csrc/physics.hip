@@ -72,13 +72,13 @@ struct Col {  // per-column pointers resolved once
 // once instead of written by one kernel and read and re-written by the next (the model step; 36 field moves per member
 // less).  Not FUSED: the tendencies are read from a.ttend / a.qtend / a.utend / a.vtend (the C ABI's spd_physics).
 template <int W, bool FUSED>
-__global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_args a, DeviceTables T, int nmembers, ModelPtrs MP,
-                                                                  DynDeviceTables MD) {
+__global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_args a, DeviceTables T, int first, int nmembers,
+                                                                  ModelPtrs MP, DynDeviceTables MD) {
     // rad_tau2 of this lane's column while the two longwave sweeps run: [band * 8 + level][lane], 16 KB per wavefront
     __shared__ double tau_s[4 * KX][kPhysThreads];
     const int gid = blockIdx.x * kPhysThreads + threadIdx.x;
     if (gid >= nmembers * NG) return;
-    const int mem = gid / NG, p = gid - mem * NG, j = p / IX;
+    const int lmem = gid / NG, mem = first + lmem, p = gid - lmem * NG, j = p / IX;  // members [first, first + nmembers)
     const int lane = threadIdx.x;
     const size_t o2 = static_cast<size_t>(mem) * NG + p;              // (ix,il)
     const size_t o3 = static_cast<size_t>(mem) * NG * KX + p;         // (ix,il,kx), + NG*k
@@ -737,22 +737,22 @@ hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nme
     const ModelPtrs mp{};
     const DynDeviceTables md{};
     if (physics_waves() == 1)
-        hipLaunchKernelGGL((physics_kernel<1, false>), dim3(blocks), dim3(kPhysThreads), 0, s, a, T, nmembers, mp, md);
+        hipLaunchKernelGGL((physics_kernel<1, false>), dim3(blocks), dim3(kPhysThreads), 0, s, a, T, 0, nmembers, mp, md);
     else
-        hipLaunchKernelGGL((physics_kernel<2, false>), dim3(blocks), dim3(kPhysThreads), 0, s, a, T, nmembers, mp, md);
+        hipLaunchKernelGGL((physics_kernel<2, false>), dim3(blocks), dim3(kPhysThreads), 0, s, a, T, 0, nmembers, mp, md);
     return hipGetLastError();
 }
 
 // grid-point dynamics + physics of every column in one launch (the model step); a.ttend / a.qtend / a.utend / a.vtend must be
 // the dynamics' tendency arrays (P.ttend, P.trtend, P.utend, P.vtend)
 hipError_t run_dyn_physics(const ModelPtrs &P, const DynDeviceTables &D, const DeviceTables &T, const spd_physics_args &a,
-                           int nmembers, hipStream_t s) {
+                           int first, int nmembers, hipStream_t s) {
     const long total = static_cast<long>(nmembers) * NG;
     const unsigned blocks = static_cast<unsigned>((total + kPhysThreads - 1) / kPhysThreads);
     if (physics_waves() == 1)
-        hipLaunchKernelGGL((physics_kernel<1, true>), dim3(blocks), dim3(kPhysThreads), 0, s, a, T, nmembers, P, D);
+        hipLaunchKernelGGL((physics_kernel<1, true>), dim3(blocks), dim3(kPhysThreads), 0, s, a, T, first, nmembers, P, D);
     else
-        hipLaunchKernelGGL((physics_kernel<2, true>), dim3(blocks), dim3(kPhysThreads), 0, s, a, T, nmembers, P, D);
+        hipLaunchKernelGGL((physics_kernel<2, true>), dim3(blocks), dim3(kPhysThreads), 0, s, a, T, first, nmembers, P, D);
     return hipGetLastError();
 }
 

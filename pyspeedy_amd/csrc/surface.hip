@@ -32,11 +32,11 @@ __device__ inline double qsat_p(double ta, double pr) {  // humidity.f90:44-78 w
 }
 }  // namespace
 
-__global__ __launch_bounds__(kT) void coupler_kernel(SurfacePtrs S, int M, TimeInterp w, int day, int land_coupling,
+__global__ __launch_bounds__(kT) void coupler_kernel(SurfacePtrs S, int first, int count, TimeInterp w, int day, int land_coupling,
                                                      int sst_anomaly, int anom_planes) {
     const int gid = blockIdx.x * kT + threadIdx.x;
-    if (gid >= M * NG) return;
-    const int mem = gid / NG, p = gid - mem * NG;
+    if (gid >= count * NG) return;
+    const int lm = gid / NG, mem = first + lm, p = gid - lm * NG;
     const size_t o = static_cast<size_t>(mem) * NG + p, o12 = static_cast<size_t>(mem) * 12 * NG + p;
     // ---- land (land_model.f90:151-215)
     const double stlcl = forin5(S.stl12, o12, w);
@@ -123,11 +123,11 @@ __global__ __launch_bounds__(kT) void coupler_kernel(SurfacePtrs S, int M, TimeI
     S.ssti_om[o] = sst_om + sice_om * (tice_om - sst_om);
 }
 
-__global__ __launch_bounds__(kT) void forcing_kernel(SurfacePtrs S, int M, ZonalDevice Z, double gamlat, double *corh_t,
-                                                     double *corh_q) {
+__global__ __launch_bounds__(kT) void forcing_kernel(SurfacePtrs S, int first, int count, ZonalDevice Z, double gamlat,
+                                                     double *corh_t, double *corh_q) {
     const int gid = blockIdx.x * kT + threadIdx.x;
-    if (gid >= M * NG) return;
-    const int mem = gid / NG, p = gid - mem * NG, j = p / IX;
+    if (gid >= count * NG) return;
+    const int lm = gid / NG, mem = first + lm, p = gid - lm * NG, j = p / IX;
     const size_t o = static_cast<size_t>(mem) * NG + p;
     // zonally averaged radiation fields (shortwave_radiation.f90:256-274)
     S.flux_solar_in[o] = Z.v[0][j];
@@ -232,15 +232,17 @@ hipError_t run_rest_surface(const double *phis0, double *forog, double *surf_ps,
     return hipGetLastError();
 }
 
-hipError_t run_coupler(const SurfacePtrs &S, int M, const TimeInterp &w, int day, int land_coupling, int sst_anomaly,
-                       int anom_planes, hipStream_t s) {
-    hipLaunchKernelGGL(coupler_kernel, dim3((M * NG + kT - 1) / kT), dim3(kT), 0, s, S, M, w, day, land_coupling, sst_anomaly,
-                       anom_planes);
+// members [first, first + count)
+hipError_t run_coupler(const SurfacePtrs &S, int first, int count, const TimeInterp &w, int day, int land_coupling,
+                       int sst_anomaly, int anom_planes, hipStream_t s) {
+    hipLaunchKernelGGL(coupler_kernel, dim3((count * NG + kT - 1) / kT), dim3(kT), 0, s, S, first, count, w, day, land_coupling,
+                       sst_anomaly, anom_planes);
     return hipGetLastError();
 }
-hipError_t run_forcing(const SurfacePtrs &S, int M, const ZonalDevice &Z, double gamlat, double *corh_t, double *corh_q,
-                       hipStream_t s) {
-    hipLaunchKernelGGL(forcing_kernel, dim3((M * NG + kT - 1) / kT), dim3(kT), 0, s, S, M, Z, gamlat, corh_t, corh_q);
+hipError_t run_forcing(const SurfacePtrs &S, int first, int count, const ZonalDevice &Z, double gamlat, double *corh_t,
+                       double *corh_q, hipStream_t s) {
+    hipLaunchKernelGGL(forcing_kernel, dim3((count * NG + kT - 1) / kT), dim3(kT), 0, s, S, first, count, Z, gamlat, corh_t,
+                       corh_q);
     return hipGetLastError();
 }
 hipError_t run_rest_state(const RestPtrs &R, int M, const RestConsts &c, hipStream_t s) {

@@ -157,3 +157,26 @@ def test_ten_day_forecast(spectral, bc, golden_dir):
     for n in ("precnv", "precls"):
         assert err(model.get(n, 0), g[n]) <= 1e-6, n
     print("10-day scaled max error of the spectral state: %.2e" % worst)
+
+
+def test_member_groups_on_separate_streams_are_bitwise(spectral, bc, monkeypatch):
+    """PYSPEEDY_AMD_CHUNKS: stepping the members in 3 overlapping groups (uneven: 4 + 3 + 3) gives bitwise the same state
+    as the single-stream step, including across the daily forcing and with get / check right after an asynchronous run."""
+    from pyspeedy_amd.model import EnsembleModel
+    states = []
+    for chunks in ("1", "3"):
+        monkeypatch.setenv("PYSPEEDY_AMD_CHUNKS", chunks)
+        model = EnsembleModel(spectral, 10)
+        model.set_bc(bc)
+        t0 = model.get("t", 0)
+        for i in range(1, 10):
+            t = t0 * (1.0 + 1e-4 * np.random.default_rng(i).standard_normal((31, 32, 8, 1)))
+            t[0] = t[0].real
+            model.set("t", t, member=i)
+        model.run(40)
+        assert (model.check(2) == 0).all()
+        states.append({n: [model.get(n, i) for i in (0, 3, 4, 6, 9)] for n in SPEC + ("sst_am", "olr", "tcorh")})
+        model.close()
+    for n, per_member in states[0].items():
+        for a, b in zip(per_member, states[1][n]):
+            assert np.array_equal(a, b), n
