@@ -37,8 +37,8 @@ S_BYTES, G_BYTES = 15872, 36864  # one spectral / one grid field
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=72)
-    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=360)
+    ap.add_argument("--warmup", type=int, default=36)
     ap.add_argument("--members", type=int, default=64, help="ensemble members resident per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
