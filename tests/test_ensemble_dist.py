@@ -96,3 +96,27 @@ def test_two_ranks_gloo(tmp_path):
     line = [l for l in outs[0].splitlines() if l.startswith("RESULT")][0].split()
     assert int(line[1]) == 0 and int(line[2]) == 33
     assert abs(float(line[3]) - 65 * 86400.0 / (0.020 * 13140)) < 1e-6
+
+
+@pytest.mark.gpu
+def test_sharded_ensemble_forecast_is_independent_of_the_sharding(tmp_path):
+    """examples/ensemble_multi_gpu.py with 1 rank and with 2 ranks (gloo, both on the one GPU of the test box: the control
+    flow of the multi-GPU run -- boundary broadcast, block sharding, per-rank batched model, all-reduced statistics): the
+    ensemble mean and spread written by rank 0 agree (seeds are global member ids; only the reduction order differs)."""
+    import numpy as np
+    from pyspeedy_amd.dataset import open_dataset
+    script = os.path.join(ROOT, "examples", "ensemble_multi_gpu.py")
+    out1, out2 = str(tmp_path / "one"), str(tmp_path / "two")
+    run = subprocess.run([sys.executable, script, "--members", "5", "--days", "1", "--out", out1], capture_output=True,
+                         text=True, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    env = dict(os.environ, PYSPEEDY_AMD_BACKEND="gloo")
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(free_port()), script, "--members", "5", "--days", "1", "--out", out2],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert run.returncode == 0, run.stdout + run.stderr
+    a = open_dataset(os.path.join(out1, "tstat_1982-01-02_0000.nc"))
+    b = open_dataset(os.path.join(out2, "tstat_1982-01-02_0000.nc"))
+    for v in ("t_mean", "t_spread"):
+        np.testing.assert_allclose(a[v].values, b[v].values, rtol=1e-6, atol=1e-7)
+    assert float(a["t_spread"].values.max()) > 1e-3
