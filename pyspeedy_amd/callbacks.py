@@ -1,92 +1,98 @@
-"""Callbacks: objects called with the model instance after every time step (pyspeedy/callbacks.py:31-255).
+"""Per-step hooks for `Speedy.run` / `SpeedyEns.run`, API-compatible with the reference's pyspeedy/callbacks.py:31-255
+(BaseCallback, DiagnosticCheck, ModelCheckpoint, XarrayExporter; same constructor keywords, `interval` / `spinup_date` gating,
+`skip_flag`, `print_msg`, `copy`).
 
-BaseCallback (interval / spin-up gating), DiagnosticCheck, ModelCheckpoint (time series kept in memory) and
-XarrayExporter (one NetCDF file per output time).  Names and constructor arguments follow the reference; the files are
-NetCDF-3 classic written by pyspeedy_amd.dataset (the reference's own fixtures are in that format).
+Design: gating lives in ONE place.  `BaseCallback.__call__` decides whether the hook is due at this step and, if so, hands the
+model to `fire()`; the concrete hooks only implement `fire()`.  Output goes through pyspeedy_amd.dataset (NetCDF-3 classic,
+the format of the reference's own fixtures); for an ensemble one file holds all members along `ens`.
 """
-import copy
+import copy as _copy
 import os
 
-from .dataset import concat
+from . import dataset as _dataset
 from .registry import DEFAULT_OUTPUT_VARS
 from .speedy import Speedy
 
 
 class BaseCallback:
+    """interval: fire every `interval` model steps; spinup_date: stay silent before that date; verbose: print progress."""
+
     def __init__(self, *args, **kwargs):
-        """interval: apply every `interval` time steps; verbose: print progress; spinup_date: ignore calls before it."""
         self.verbose = kwargs.pop("verbose", False)
         self.interval = kwargs.pop("interval", 1)
         self.spinup_date = kwargs.pop("spinup_date", None)
 
+    # -- gating ------------------------------------------------------------------------------------------------
     def skip_flag(self, model_instance):
-        """True when this time step is skipped: still in the spin-up period, or not a multiple of `interval`."""
-        if self.spinup_date is not None and model_instance.current_date < self.spinup_date:
-            return True
-        return model_instance.get_current_step() % self.interval != 0
+        """True when nothing is due at this step: still spinning up, or not a multiple of `interval`."""
+        spinning_up = self.spinup_date is not None and model_instance.current_date < self.spinup_date
+        return spinning_up or model_instance.get_current_step() % self.interval != 0
 
+    def __call__(self, model_instance):
+        if not self.skip_flag(model_instance):
+            self.fire(model_instance)
+
+    def fire(self, model_instance):
+        """What the hook does when it is due (nothing in the base class)."""
+
+    # -- helpers -----------------------------------------------------------------------------------------------
     def print_msg(self, msg):
         if self.verbose:
             print(msg)
 
     def copy(self):
-        return copy.deepcopy(self)
-
-    def __call__(self, model_instance):
-        pass
+        return _copy.deepcopy(self)
 
 
 class DiagnosticCheck(BaseCallback):
-    """Check that the prognostic variables are inside their accepted ranges (diagnostics.f90) every `interval` steps."""
+    """Range check of the prognostic variables (diagnostics.f90) every `interval` steps; raises RuntimeError on failure."""
 
     def __init__(self, interval=36):
         super().__init__(interval=interval)
 
-    def __call__(self, model_instance):
-        if self.skip_flag(model_instance):
-            return
-        members = [model_instance] if isinstance(model_instance, Speedy) else model_instance
-        for member in members:
-            member.check()  # raises RuntimeError when a range test fails
+    def fire(self, model_instance):
+        for member in ([model_instance] if isinstance(model_instance, Speedy) else model_instance):
+            member.check()
 
 
-class ModelCheckpoint(BaseCallback):
-    """Keep a time series of selected grid-space variables in memory (`dataframe`), one entry every `interval` steps."""
+class _GridOutput(BaseCallback):
+    """Common part of the two output hooks: which variables, how often, where."""
 
-    def __init__(self, interval=36, verbose=False, spinup_date=None, variables=None, output_dir="./"):
+    def __init__(self, interval, verbose, spinup_date, variables, output_dir):
+        super().__init__(verbose=verbose, interval=interval, spinup_date=spinup_date)
         self.variables = DEFAULT_OUTPUT_VARS if variables is None else variables
         self.output_dir = output_dir
         self.history_interval = interval
-        super().__init__(verbose=verbose, interval=interval, spinup_date=spinup_date)
+
+    def snapshot(self, model_instance):
+        return model_instance.to_dataframe(variables=self.variables)
+
+
+class ModelCheckpoint(_GridOutput):
+    """Accumulates the selected grid-space variables as a time series in memory (`dataframe`)."""
+
+    def __init__(self, interval=36, verbose=False, spinup_date=None, variables=None, output_dir="./"):
+        super().__init__(interval, verbose, spinup_date, variables, output_dir)
         self.dataframe = None
 
-    def __call__(self, model_instance):
-        if self.skip_flag(model_instance):
-            return
-        snapshot = model_instance.to_dataframe(variables=self.variables)
-        self.dataframe = snapshot if self.dataframe is None else concat((self.dataframe, snapshot), "time")
+    def fire(self, model_instance):
+        now = self.snapshot(model_instance)
+        self.dataframe = now if self.dataframe is None else _dataset.concat((self.dataframe, now), "time")
 
 
-class XarrayExporter(BaseCallback):
-    """Write selected grid-space variables to `output_dir/<filename_fmt of the model date>` every `interval` steps.
-    For an ensemble the file holds all members along the `ens` dimension."""
+class XarrayExporter(_GridOutput):
+    """Writes the selected grid-space variables to `output_dir/<model date formatted with filename_fmt>`."""
 
     def __init__(self, interval=36, verbose=False, spinup_date=None, variables=None, output_dir="./",
                  filename_fmt="%Y-%m-%d_%H%M.nc"):
-        self.variables = DEFAULT_OUTPUT_VARS if variables is None else variables
-        self.output_dir = output_dir
+        super().__init__(interval, verbose, spinup_date, variables, output_dir)
         self.filename_fmt = filename_fmt
-        self.history_interval = interval
-        super().__init__(verbose=verbose, interval=interval, spinup_date=spinup_date)
 
-    def __call__(self, model_instance):
-        if self.skip_flag(model_instance):
-            return
-        snapshot = model_instance.to_dataframe(variables=self.variables)
+    def fire(self, model_instance):
+        target = os.path.join(self.output_dir, model_instance.current_date.strftime(self.filename_fmt))
         os.makedirs(self.output_dir, exist_ok=True)
-        path = os.path.join(self.output_dir, model_instance.current_date.strftime(self.filename_fmt))
-        self.print_msg("Saving model output at: %s." % path)
-        snapshot.to_netcdf(path)
+        self.print_msg("Saving model output at: %s." % target)
+        self.snapshot(model_instance).to_netcdf(target)
 
 
 NetcdfExporter = XarrayExporter
