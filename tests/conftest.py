@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Tests that start other programs (the Fortran host, torch.distributed.run ranks) run FIRST: the GPU box does not allow a
+# process that has initialised the GPU to exec another program (not even in a forked child), and the test process
+# initialises it as soon as the first device fixture is used.
+_SPAWNING_MODULES = ("test_fortran_host.py", "test_ensemble_dist.py")
+
+
+def pytest_collection_modifyitems(config, items):
+    items.sort(key=lambda item: 0 if os.path.basename(str(item.fspath)) in _SPAWNING_MODULES else 1)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
