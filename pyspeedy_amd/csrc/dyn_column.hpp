@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "model.hpp"
+#include "stream_store.hpp"
 
 namespace spd {
 
@@ -35,7 +36,7 @@ __device__ __forceinline__ void dyn_column(const ModelPtrs &P, const DynDeviceTa
         vmean = vmean + vg[k] * D.dhs[k];
         dmean = dmean + divg[k] * D.dhs[k];
     }
-    P.psdtg[o2] = -umean * px - vmean * py;
+    stream_store(&P.psdtg[o2], -umean * px - vmean * py);
     double puv[KX], sigdt[KX + 1], sigm[KX + 1], tgg[KX], temp[KX + 1];
     sigdt[0] = 0.0;
     sigm[0] = 0.0;
@@ -58,7 +59,7 @@ __device__ __forceinline__ void dyn_column(const ModelPtrs &P, const DynDeviceTa
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
         const double v = vg[k] * vorg[k] - tgg[k] * RGASd * px - (temp[k + 1] + temp[k]) * D.dhsr[k];
-        if (STORE_ALL || k < KX - 1) P.utend[o3 + NG * k] = v;
+        if (STORE_ALL || k < KX - 1) stream_store(&P.utend[o3 + NG * k], v);
         if (k == KX - 1) utend_kx = v;
     }
     // meridional wind
@@ -67,7 +68,7 @@ __device__ __forceinline__ void dyn_column(const ModelPtrs &P, const DynDeviceTa
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
         const double v = -ug[k] * vorg[k] - tgg[k] * RGASd * py - (temp[k + 1] + temp[k]) * D.dhsr[k];
-        if (STORE_ALL || k < KX - 1) P.vtend[o3 + NG * k] = v;
+        if (STORE_ALL || k < KX - 1) stream_store(&P.vtend[o3 + NG * k], v);
         if (k == KX - 1) vtend_kx = v;
     }
     // temperature
@@ -77,7 +78,7 @@ __device__ __forceinline__ void dyn_column(const ModelPtrs &P, const DynDeviceTa
     for (int k = 0; k < KX; ++k) {
         ttend[k] = tgg[k] * divg[k] - (temp[k + 1] + temp[k]) * D.dhsr[k] + D.fsgr[k] * tgg[k] * (sigdt[k + 1] + sigdt[k]) +
                    D.tref3[k] * (sigm[k + 1] + sigm[k]) + AKAPd * (tg[k] * puv[k] - tgg[k] * dmean);
-        if (STORE_ALL) P.ttend[o3 + NG * k] = ttend[k];
+        if (STORE_ALL) stream_store(&P.ttend[o3 + NG * k], ttend[k]);
     }
     // tracer
 #pragma unroll
@@ -87,16 +88,16 @@ __device__ __forceinline__ void dyn_column(const ModelPtrs &P, const DynDeviceTa
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
         trtend[k] = trg[k] * divg[k] - (temp[k + 1] + temp[k]) * D.dhsr[k];
-        if (STORE_ALL) P.trtend[o3 + NG * k] = trtend[k];
+        if (STORE_ALL) stream_store(&P.trtend[o3 + NG * k], trtend[k]);
     }
     // inputs of the forward transforms (tendencies.f90:247-266)
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
-        P.keg[o3 + NG * k] = 0.5f * (ug[k] * ug[k] + vg[k] * vg[k]);
-        P.utg[o3 + NG * k] = -ug[k] * tgg[k];
-        P.vtg[o3 + NG * k] = -vg[k] * tgg[k];
-        P.uqg[o3 + NG * k] = -ug[k] * trg[k];
-        P.vqg[o3 + NG * k] = -vg[k] * trg[k];
+        stream_store(&P.keg[o3 + NG * k], 0.5f * (ug[k] * ug[k] + vg[k] * vg[k]));
+        stream_store(&P.utg[o3 + NG * k], -ug[k] * tgg[k]);
+        stream_store(&P.vtg[o3 + NG * k], -vg[k] * tgg[k]);
+        stream_store(&P.uqg[o3 + NG * k], -ug[k] * trg[k]);
+        stream_store(&P.vqg[o3 + NG * k], -vg[k] * trg[k]);
     }
 }
 

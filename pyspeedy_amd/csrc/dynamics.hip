@@ -270,8 +270,8 @@ __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTa
         const d2 oja = (j1 == 0) ? n1 : oj;
         const double we2 = (1.0f - WILd) * eps;
         const d2 n2 = d2{fnew.x - we2 * (n1.x - 2.0f * oja.x + fnew.x), fnew.y - we2 * (n1.y - 2.0f * oja.y + fnew.y)};
-        base[0] = n1;
-        base[stride] = n2;
+        stream_store(&base[0], n1);
+        stream_store(&base[stride], n2);
     };
     {
         const d2 vor1 = vorS[0], t1 = tS[0], tr1 = trS[0];

@@ -24,6 +24,7 @@
 #include "../../include/pyspeedy_amd.h"
 #include "device_tables.hpp"
 #include "dyn_column.hpp"
+#include "stream_store.hpp"
 
 namespace spd {
 
@@ -224,8 +225,8 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
                 dfqa[k - 1] = fuq - fdq - precnv;
             }
     }
-    a.cbmf[o2] = cbmf;
-    a.precnv[o2] = precnv;
+    stream_store(&a.cbmf[o2], cbmf);
+    stream_store(&a.precnv[o2], precnv);
     const int icnv = KX - itop;  // physics.f90:132
     int iptop = itop;
 
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         qtend[0] = qtend[0] + dfqa[0] + 0.0;
         precls = precls * psa;
     }
-    a.precls[o2] = precls;
+    stream_store(&a.precls[o2], precls);
 
     const double gse = (se[nl1 - 1] - se[KX - 1]) / (phi[nl1 - 1] - phi[KX - 1]);  // physics.f90:152 (used on shortwave steps)
     const double phi_kx = phi[KX - 1];
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         cloudc = dmin(1.0f, wpcl * sqrt(pr1) + cq * cq);
         icltop = iptop < icltop ? iptop : icltop;
         const double qcloud = qa[nl1 - 1];
-        a.qcloud_equiv[o2] = qcloud;
+        stream_store(&a.qcloud_equiv[o2], qcloud);
         const double clfact = 1.2f, rgse = 1.0f / (gse_s1 - gse_s0);
         const double fstab = dmax(0.0f, dmin(1.0f, rgse * (gse - gse_s0)));
         clstr = fstab * dmax(clsmax - clfact * cloudc, 0.0f);
@@ -441,8 +442,8 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         }
         ssrd = f1 + f2;
         f1 = f1 * a.alb_surface[o2];
-        a.ssrd[o2] = ssrd;
-        a.ssr[o2] = ssrd - f1;
+        stream_store(&a.ssrd[o2], ssrd);
+        stream_store(&a.ssr[o2], ssrd - f1);
 #pragma unroll
         for (int k = KX; k >= 1; --k) {
             tt_rsw[k - 1] = tt_rsw[k - 1] + f1;
@@ -450,12 +451,12 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
             tt_rsw[k - 1] = tt_rsw[k - 1] - f1;
             f1 = f1 + refl[k - 1];
         }
-        a.tsr[o2] = tsr - f1;
+        stream_store(&a.tsr[o2], tsr - f1);
         // physics.f90:166-168
 #pragma unroll
         for (int k = 0; k < KX; ++k) {
             tt_rsw[k] = tt_rsw[k] * rps * T.grdscp[k];
-            a.tt_rsw[o3 + NG * k] = tt_rsw[k];
+            stream_store(&a.tt_rsw[o3 + NG * k], tt_rsw[k]);
             ttend[k] = ttend[k] + tt_rsw[k];
         }
 
@@ -464,10 +465,10 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         const size_t NGs = static_cast<size_t>(NG);
         tau_s[0][lane] = exp(-psa * T.dhs[0] * ablwin);
         tau_s[KX][lane] = exp(-psa * T.dhs[0] * co2);
-        a.rad_tau2[ot + NGs * (0 + KX * 0)] = tau_s[0][lane];
-        a.rad_tau2[ot + NGs * (0 + KX * 1)] = tau_s[KX][lane];
-        a.rad_tau2[ot + NGs * (0 + KX * 2)] = 1.0;
-        a.rad_tau2[ot + NGs * (0 + KX * 3)] = 1.0;
+        stream_store(&a.rad_tau2[ot + NGs * (0 + KX * 0)], tau_s[0][lane]);
+        stream_store(&a.rad_tau2[ot + NGs * (0 + KX * 1)], tau_s[KX][lane]);
+        stream_store(&a.rad_tau2[ot + NGs * (0 + KX * 2)], 1.0);
+        stream_store(&a.rad_tau2[ot + NGs * (0 + KX * 3)], 1.0);
         acloud = cloudc * ablcl2;
 #pragma unroll
         for (int k = 2; k <= KX; ++k) {
@@ -485,10 +486,10 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
                 t2 = exp(-deltap * dmax(ablwv1 * qa[k - 1], acloud));
                 t3 = exp(-deltap * dmax(ablwv2 * qa[k - 1], acloud));
             }
-            a.rad_tau2[ot + NGs * (k - 1 + KX * 0)] = t0;
-            a.rad_tau2[ot + NGs * (k - 1 + KX * 1)] = t1;
-            a.rad_tau2[ot + NGs * (k - 1 + KX * 2)] = t2;
-            a.rad_tau2[ot + NGs * (k - 1 + KX * 3)] = t3;
+            stream_store(&a.rad_tau2[ot + NGs * (k - 1 + KX * 0)], t0);
+            stream_store(&a.rad_tau2[ot + NGs * (k - 1 + KX * 1)], t1);
+            stream_store(&a.rad_tau2[ot + NGs * (k - 1 + KX * 2)], t2);
+            stream_store(&a.rad_tau2[ot + NGs * (k - 1 + KX * 3)], t3);
             tau_s[k - 1 + KX * 0][lane] = t0;
             tau_s[k - 1 + KX * 1][lane] = t1;
             tau_s[k - 1 + KX * 2][lane] = t2;
@@ -497,8 +498,8 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         const double eps1 = EPSLW / (T.dhs[0] + T.dhs[1]);
         strat1 = a.stratospheric_correction[o2] * psa;
         strat2 = eps1 * psa;
-        a.rad_strat_corr[oc] = strat1;
-        a.rad_strat_corr[oc + NG] = strat2;
+        stream_store(&a.rad_strat_corr[oc], strat1);
+        stream_store(&a.rad_strat_corr[oc + NG], strat2);
     } else {
 #pragma unroll
         for (int k = 0; k < KX; ++k) ttend[k] = ttend[k] + a.tt_rsw[o3 + NG * k];
@@ -573,11 +574,11 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         const double corlw = EPSLW * EMISFC * st4a[KX - 1][0];
         dfabs[KX - 1] = dfabs[KX - 1] - corlw;
         slrd = slrd + corlw;
-        a.slrd[o2] = slrd;
+        stream_store(&a.slrd[o2], slrd);
 #pragma unroll
         for (int k = 0; k < KX; ++k) {
-            a.rad_st4a[os + static_cast<size_t>(NG) * k] = st4a[k][0];
-            a.rad_st4a[os + static_cast<size_t>(NG) * (k + KX)] = st4a[k][1];
+            stream_store(&a.rad_st4a[os + static_cast<size_t>(NG) * k], st4a[k][0]);
+            stream_store(&a.rad_st4a[os + static_cast<size_t>(NG) * (k + KX)], st4a[k][1]);
         }
 
         // -------------------------------------------------------------- surface fluxes, surface_fluxes.f90:40-320
@@ -642,21 +643,21 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         const double slru3 = slru2 + fmask * (slru1 - slru2);
         const double tsfc = tsea + fmask * (land_temp - tsea);
         const double tskin_avg = tsea + fmask * (tskin - tsea);
-        a.ustr[oa] = ustr1; a.ustr[oa + NG] = ustr2; a.ustr[oa + 2 * NG] = ustr3;
-        a.vstr[oa] = vstr1; a.vstr[oa + NG] = vstr2; a.vstr[oa + 2 * NG] = vstr3;
-        a.shf[oa] = shf1;   a.shf[oa + NG] = shf2;   a.shf[oa + 2 * NG] = shf3;
-        a.evap[oa] = evap1; a.evap[oa + NG] = evap2; a.evap[oa + 2 * NG] = evap3;
-        a.slru[oa] = slru1; a.slru[oa + NG] = slru2; a.slru[oa + 2 * NG] = slru3;
-        a.hfluxn[oa] = hfl1; a.hfluxn[oa + NG] = hfl2;
-        if (a.ts) a.ts[o2] = tsfc;
-        if (a.tskin) a.tskin[o2] = tskin_avg;
-        if (a.u0) a.u0[o2] = u0;
-        if (a.v0) a.v0[o2] = v0;
-        if (a.t0) a.t0[o2] = t0;
+        stream_store(&a.ustr[oa], ustr1); a.ustr[oa + NG] = ustr2; a.ustr[oa + 2 * NG] = ustr3;
+        stream_store(&a.vstr[oa], vstr1); a.vstr[oa + NG] = vstr2; a.vstr[oa + 2 * NG] = vstr3;
+        stream_store(&a.shf[oa], shf1);   a.shf[oa + NG] = shf2;   a.shf[oa + 2 * NG] = shf3;
+        stream_store(&a.evap[oa], evap1); a.evap[oa + NG] = evap2; a.evap[oa + 2 * NG] = evap3;
+        stream_store(&a.slru[oa], slru1); a.slru[oa + NG] = slru2; a.slru[oa + 2 * NG] = slru3;
+        stream_store(&a.hfluxn[oa], hfl1); a.hfluxn[oa + NG] = hfl2;
+        if (a.ts) stream_store(&a.ts[o2], tsfc);
+        if (a.tskin) stream_store(&a.tskin[o2], tskin_avg);
+        if (a.u0) stream_store(&a.u0[o2], u0);
+        if (a.v0) stream_store(&a.v0[o2], v0);
+        if (a.t0) stream_store(&a.t0[o2], t0);
 
         // -------------------------------------------------------------- longwave, upward sweep (:124-205)
         const double refsfc = 1.0f - EMISFC;
-        a.slr[o2] = slru3 - slrd;
+        stream_store(&a.slr[o2], slru3 - slrd);
 #pragma unroll
         for (int b = 0; b < 4; ++b) flux[b] = fband_at(T.fband, tsfc, b) * slru3 + refsfc * flux[b];
         dfabs[KX - 1] = dfabs[KX - 1] + EPSLW * slru3;
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         double olr = corlw1 + corlw2;
 #pragma unroll
         for (int b = 0; b < 4; ++b) olr = olr + flux[b];
-        a.olr[o2] = olr;
+        stream_store(&a.olr[o2], olr);
 #pragma unroll
         for (int b = 0; b < 4; ++b) a.rad_flux[of4 + static_cast<size_t>(NG) * b] = flux[b];
         // physics.f90:207-211: ttend = ttend + tt_rsw + tt_rlw
@@ -704,23 +705,23 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         const double ud = FUSED ? utend_dyn : a.utend[okx], vd = FUSED ? vtend_dyn : a.vtend[okx];
         const double qkx = qtend_kx + evap3 * rps * T.grdsig[KX - 1];
         if (sppt) {  // (above the lowest level the physics leaves the wind tendencies alone: nothing to perturb there)
-            a.utend[okx] = perturb(ud + ut_kx, ud, KX - 1);
-            a.vtend[okx] = perturb(vd + vt_kx, vd, KX - 1);
+            stream_store(&a.utend[okx], perturb(ud + ut_kx, ud, KX - 1));
+            stream_store(&a.vtend[okx], perturb(vd + vt_kx, vd, KX - 1));
 #pragma unroll
             for (int k = 0; k < KX; ++k) a.ttend[o3 + NG * k] = perturb(ttend[k], a.ttend[o3 + NG * k], k);
-            a.qtend[okx] = perturb(qkx, a.qtend[okx], KX - 1);
+            stream_store(&a.qtend[okx], perturb(qkx, a.qtend[okx], KX - 1));
         } else {
-            a.utend[okx] = ud + ut_kx;  // ut_pbl, vt_pbl are zero above the lowest level
-            a.vtend[okx] = vd + vt_kx;
+            stream_store(&a.utend[okx], ud + ut_kx);  // ut_pbl, vt_pbl are zero above the lowest level
+            stream_store(&a.vtend[okx], vd + vt_kx);
 #pragma unroll
             for (int k = 0; k < KX; ++k) a.ttend[o3 + NG * k] = ttend[k];
-            a.qtend[okx] = qkx;
+            stream_store(&a.qtend[okx], qkx);
         }
     }
     if (a.iptop) a.iptop[o2] = iptop;
     if (a.icltop) a.icltop[o2] = icltop;
-    if (a.cloudc) a.cloudc[o2] = cloudc;
-    if (a.clstr) a.clstr[o2] = clstr;
+    if (a.cloudc) stream_store(&a.cloudc[o2], cloudc);
+    if (a.clstr) stream_store(&a.clstr[o2], clstr);
 }
 
 static int physics_waves() {

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include "surface.hpp"
+#include "stream_store.hpp"
 
 namespace spd {
 namespace {
@@ -42,23 +43,23 @@ __global__ __launch_bounds__(kT) void coupler_kernel(SurfacePtrs S, int first, i
     const double stlcl = forin5(S.stl12, o12, w);
     const double snowdcl = forint(S.snowd12, o12, w);
     const double soilwcl = forint(S.soilw12, o12, w);
-    S.stlcl_obs[o] = stlcl;
-    S.snowdcl_obs[o] = snowdcl;
-    S.soilwcl_obs[o] = soilwcl;
+    stream_store(&S.stlcl_obs[o], stlcl);
+    stream_store(&S.snowdcl_obs[o], snowdcl);
+    stream_store(&S.soilwcl_obs[o], soilwcl);
     if (day == 0) {
-        S.stl_lm[o] = stlcl;
-        S.land_temp[o] = stlcl;
+        stream_store(&S.stl_lm[o], stlcl);
+        stream_store(&S.land_temp[o], stlcl);
     } else if (land_coupling) {
         double tanom = S.stl_lm[o] - stlcl;
         tanom = S.cdland[o] * (tanom + S.rhcapl[o] * S.hfluxn[static_cast<size_t>(mem) * 3 * NG + p]);
         const double stl = tanom + stlcl;
-        S.stl_lm[o] = stl;
-        S.land_temp[o] = stl;
+        stream_store(&S.stl_lm[o], stl);
+        stream_store(&S.land_temp[o], stl);
     } else {
-        S.land_temp[o] = stlcl;
+        stream_store(&S.land_temp[o], stlcl);
     }
-    S.snow_depth[o] = snowdcl;
-    S.soil_avail_water[o] = soilwcl;
+    stream_store(&S.snow_depth[o], snowdcl);
+    stream_store(&S.soil_avail_water[o], soilwcl);
 
     // ---- sea (sea_model.f90:193-316)
     double sstcl = forin5(S.sst12, o12, w);
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(kT) void coupler_kernel(SurfacePtrs S, int first, i
         const size_t oa = static_cast<size_t>(mem) * anom_planes * NG + p;
         const double a = S.sst_anom[oa + static_cast<size_t>(NG) * w.a0];
         sstan_ob = a + w.wan * (S.sst_anom[oa + static_cast<size_t>(NG) * w.a1] - a);
-        S.sstan_ob[o] = sstan_ob;
+        stream_store(&S.sstan_ob[o], sstan_ob);
     }
     const double sstfr = 273.2f - 1.8f;  // single-precision subtraction, sea_model.f90:229
     double ticecl;
@@ -81,9 +82,9 @@ __global__ __launch_bounds__(kT) void coupler_kernel(SurfacePtrs S, int first, i
         ticecl = sstfr + (sstcl - sstfr) / sicecl;
         sstcl = sstfr;
     }
-    S.sstcl_ob[o] = sstcl;
-    S.sicecl_ob[o] = sicecl;
-    S.ticecl_ob[o] = ticecl;
+    stream_store(&S.sstcl_ob[o], sstcl);
+    stream_store(&S.sicecl_ob[o], sicecl);
+    stream_store(&S.ticecl_ob[o], ticecl);
     double sst_om, tice_om, sice_om;
     if (day == 0) {
         sst_om = 0.0;  // sea_coupling_flag <= 0 (sea_model.f90:261)
@@ -110,17 +111,17 @@ __global__ __launch_bounds__(kT) void coupler_kernel(SurfacePtrs S, int first, i
         tice_om = tanom + ticecl;
         sice_om = sicecl;
     }
-    S.sst_om[o] = sst_om;
-    S.tice_om[o] = tice_om;
-    S.sice_om[o] = sice_om;
+    stream_store(&S.sst_om[o], sst_om);
+    stream_store(&S.tice_om[o], tice_om);
+    stream_store(&S.sice_om[o], sice_om);
     const double sstan_am = sst_anomaly ? sstan_ob : 0.0;
-    S.sstan_am[o] = sstan_am;
+    stream_store(&S.sstan_am[o], sstan_am);
     double sst_am = sstcl + sstan_am;
-    S.sice_am[o] = sice_om;
-    S.tice_am[o] = tice_om;
+    stream_store(&S.sice_am[o], sice_om);
+    stream_store(&S.tice_am[o], tice_om);
     sst_am = sst_am + sice_om * (tice_om - sst_am);
-    S.sst_am[o] = sst_am;
-    S.ssti_om[o] = sst_om + sice_om * (tice_om - sst_om);
+    stream_store(&S.sst_am[o], sst_am);
+    stream_store(&S.ssti_om[o], sst_om + sice_om * (tice_om - sst_om));
 }
 
 __global__ __launch_bounds__(kT) void forcing_kernel(SurfacePtrs S, int first, int count, ZonalDevice Z, double gamlat,
