@@ -94,6 +94,10 @@ struct spd_model {
     double *sppt_spec = nullptr, *sppt_grid = nullptr;
     // Members are stepped in `nchunks` groups on separate HIP streams (spd_model_step): a group's kernels overlap with
     // the other groups' (different kernels, complementary resources, no idle tail between dependent launches).
+    // spectral -> grid transforms per member and step: 91 as in the reference, or 77 with PYSPEEDY_AMD_PRUNE_DEAD=1, which
+    // drops the 14 whose results nothing reads (u, v above the lowest level at the physics' time level: physics.f90:93-94
+    // computes them, get_surface_fluxes only uses level kx).  Off by default: the measured step is the reference's step.
+    int inv_per_member = 91;
     int nchunks = 1;
     hipStream_t cstream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t cev[4] = {nullptr, nullptr, nullptr, nullptr}, ev_start = nullptr;
@@ -171,8 +175,10 @@ static int build_tables(spd_model *m) {
                 e[9][k] = {spec(P.tr, s1 + k), grid(const_cast<double *>(pa.qg), w + k), 1, 0};
                 e[10][k] = {spec(P.phi, w + k), grid(const_cast<double *>(pa.phig), w + k), 1, 0};
             }
+            const bool prune = m->inv_per_member == 77;
             for (int v = 0; v < 11; ++v)
-                for (int k = 0; k < 8; ++k) t.push_back(e[v][k]);
+                for (int k = 0; k < 8; ++k)
+                    if (!(prune && (v == 4 || v == 5) && k < 7)) t.push_back(e[v][k]);
             // grad ln ps at the dynamics' time level (tendencies.f90:144-146): gradient applied while staging (mode 3 / 4)
             t.push_back({spec(P.ps, static_cast<size_t>(i) * 2 + j2), grid(P.px, i), 2, 3, nullptr});
             t.push_back({spec(P.ps, static_cast<size_t>(i) * 2 + j2), grid(P.py, i), 2, 4, nullptr});
@@ -251,6 +257,7 @@ int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
     m->ctx = h;
     m->M = nmembers;
     if (const char *env = getenv("PYSPEEDY_AMD_SPLIT_DYN")) m->split_dyn_physics = atoi(env) != 0;
+    if (const char *env = getenv("PYSPEEDY_AMD_PRUNE_DEAD")) m->inv_per_member = atoi(env) != 0 ? 77 : 91;
     // PYSPEEDY_AMD_CHUNKS = 2 or 3 steps the members in that many groups on separate streams: measured -6 % / -8 % per step
     // at 64 members (4 groups: +7 %).  Off by default: with overlapping launches the duration of a single kernel -- what the
     // roofline accounting of bench.py and the committed rocprof summaries are about -- is no longer attributable to it.
@@ -487,13 +494,13 @@ static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int comput
         if (m->prof_used < m->prof_events.size()) {
             ev0 = m->prof_events[m->prof_used].first;
             ev1 = m->prof_events[m->prof_used].second;
-            m->prof_fields[m->prof_used] = 91 * count;
+            m->prof_fields[m->prof_used] = m->inv_per_member * count;
             ++m->prof_used;
             (void)hipEventRecord(ev0, s);
         }
     }
     if (e == hipSuccess)                                                                  // :109-146, physics.f90:89-101
-        e = run_spec2grid_table(T, m->inv_table[j2 - 1] + static_cast<size_t>(first) * 91, 91 * count, s);
+        e = run_spec2grid_table(T, m->inv_table[j2 - 1] + static_cast<size_t>(first) * m->inv_per_member, m->inv_per_member * count, s);
     if (ev1) (void)hipEventRecord(ev1, s);
     spd_physics_args pa = m->pa;
     pa.compute_shortwave = compute_shortwave ? 1 : 0;
@@ -795,7 +802,7 @@ int spd_model_profile_read(spd_model_handle m, double *mean_ms, int *launches, i
     }
     *launches = static_cast<int>(m->prof_used);
     *mean_ms = m->prof_used ? sum / m->prof_used : 0.0;
-    *fields_per_launch = m->prof_used ? m->prof_fields[0] : 91 * m->M;
+    *fields_per_launch = m->prof_used ? m->prof_fields[0] : m->inv_per_member * m->M;
     return SPD_OK;
 }
 

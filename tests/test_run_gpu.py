@@ -180,3 +180,19 @@ def test_member_groups_on_separate_streams_are_bitwise(spectral, bc, monkeypatch
     for n, per_member in states[0].items():
         for a, b in zip(per_member, states[1][n]):
             assert np.array_equal(a, b), n
+
+
+def test_pruning_the_unused_transforms_changes_nothing(spectral, bc, monkeypatch):
+    """PYSPEEDY_AMD_PRUNE_DEAD=1 drops the 14 inverse transforms per member-step whose results nothing reads (u, v above the
+    lowest level at the physics' time level): every registry variable stays bitwise identical."""
+    from pyspeedy_amd.model import SHAPES, EnsembleModel
+    states = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("PYSPEEDY_AMD_PRUNE_DEAD", flag)
+        model = EnsembleModel(spectral, 3)
+        model.set_bc(bc)
+        model.run(40)
+        states.append({n: model.get(n, 2) for n in SHAPES})
+        model.close()
+    for n in SHAPES:
+        assert np.array_equal(states[0][n], states[1][n]), n
