@@ -21,14 +21,14 @@ __device__ __forceinline__ void dyn_column(const ModelPtrs &P, const DynDeviceTa
     const double cor = D.coriol[j];
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
-        ug[k] = P.ug2[o3 + NG * k];
-        vg[k] = P.vg2[o3 + NG * k];
-        tg[k] = P.tg2[o3 + NG * k];
-        trg[k] = P.trg2[o3 + NG * k];
-        vorg[k] = P.vorg[o3 + NG * k] + cor;
-        divg[k] = P.divg[o3 + NG * k];
+        ug[k] = stream_load(&P.ug2[o3 + NG * k]);
+        vg[k] = stream_load(&P.vg2[o3 + NG * k]);
+        tg[k] = stream_load(&P.tg2[o3 + NG * k]);
+        trg[k] = stream_load(&P.trg2[o3 + NG * k]);
+        vorg[k] = stream_load(&P.vorg[o3 + NG * k]) + cor;
+        divg[k] = stream_load(&P.divg[o3 + NG * k]);
     }
-    const double px = P.px[o2], py = P.py[o2];
+    const double px = stream_load(&P.px[o2]), py = stream_load(&P.py[o2]);
     double umean = 0.0, vmean = 0.0, dmean = 0.0;
 #pragma unroll
     for (int k = 0; k < KX; ++k) {

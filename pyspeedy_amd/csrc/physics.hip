@@ -111,9 +111,9 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
     const double rps = 1.0f / psa;
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
-        ta[k] = a.tg[o3 + NG * k];
-        qa[k] = dmax(a.qg[o3 + NG * k], 0.0f);
-        phi[k] = a.phig[o3 + NG * k];
+        ta[k] = stream_load(&a.tg[o3 + NG * k]);
+        qa[k] = dmax(stream_load(&a.qg[o3 + NG * k]), 0.0f);
+        phi[k] = stream_load(&a.phig[o3 + NG * k]);
         se[k] = CP * ta[k] + phi[k];
         qsat[k] = qsat_point(ta[k], T.fsg[k] * psa);
         rh[k] = qa[k] / qsat[k];

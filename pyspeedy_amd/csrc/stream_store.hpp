@@ -9,4 +9,10 @@ template <typename T, typename V>
 __device__ __forceinline__ void stream_store(T *p, V v) {
     __builtin_nontemporal_store(static_cast<T>(v), p);
 }
+// ... and loads of values this launch reads exactly once and nobody else in it reads (grid fields coming from the previous
+// kernel): the same hint on the way in (-0.6 % ... -0.9 % per step; NOT for inputs several workgroups share).
+template <typename T>
+__device__ __forceinline__ T stream_load(const T *p) {
+    return __builtin_nontemporal_load(p);
+}
 }  // namespace spd

@@ -291,7 +291,7 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
 #pragma unroll
         for (int it = 0; it < kGridPerLane; ++it) {
             const int idx = tid + it * kThreads;
-            if (idx < NGRID / 2) gv[it] = g[idx];
+            if (idx < NGRID / 2) gv[it] = __builtin_nontemporal_load(&g[idx]);  // read once, by this workgroup only
             cs[it] = (prescale != 0 && idx < NGRID / 2) ? ctab[idx / (IX / 2)] : 1.0;
         }
 #pragma unroll
