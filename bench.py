@@ -1,78 +1,147 @@
 #!/usr/bin/env python3
-"""Benchmark of pyspeedy_amd on MI355X: ensemble SPEEDY T30L8 (96x48x8, fp64), whole model step on the GPU.
+"""Benchmark of pyspeedy_amd on MI355X: ensemble SPEEDY T30L8 (96x48x8), whole model step on the GPU.
 
-    python bench.py --gpus N --steps K --warmup W [--members M]
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--config cfg4|cfg5] [--members M]
 
-One "step" = one call of the reference's do_single_step (speedy.f90:20-74) for EVERY one of the M ensemble members
-resident on each GPU: daily forcing when due, shortwave every third step, the leapfrog step (91 spectral->grid transforms,
-grid-point dynamics, fused column physics, 73 grid->spectral transforms, spectral tendencies, semi-implicit correction,
-horizontal diffusion, Robert-Asselin-Williams filter), date advance and the land / sea-ice coupling -- 6 kernel launches.  Nothing crosses
-PCIe inside a step; the state of all members stays in HBM.  The hot path of BASELINE.json (transforms + column physics)
-is what dominates it (profiles/).
+One "step" = one call of the reference's do_single_step (speedy.f90:20-74) for EVERY ensemble member resident on each
+GPU: daily forcing when due, shortwave every third step, the leapfrog step (91 spectral->grid transforms, grid-point
+dynamics, fused column physics, 73 grid->spectral transforms, spectral tendencies, semi-implicit correction, horizontal
+diffusion, Robert-Asselin-Williams filter), date advance and the land / sea-ice coupling.  Nothing crosses PCIe inside a
+step; the state of all members stays in HBM.
 
-Workload: BASELINE.json cfg 4's ensemble, 64 members per GPU by default (weak scaling: every rank owns its own M members,
-members never exchange data -- speedy_driver.f90.j2:71-77 -- so there is no data-path collective; the only collective is
-the start-up broadcast of the boundary fields from rank 0, outside the timed region).  Members start from the
-reference's own initial state (example boundary conditions, resting atmosphere, first_step) with a small temperature
-perturbation per member, spun up for `warmup` steps.
+Workloads (BASELINE.json):
+  --config cfg4 (default)  fp64 everywhere.  --scaling weak (default): 64 members PER GPU; --scaling strong: 64 members in
+                           total, block-sharded over the ranks (8 per GPU at N = 8, cfg 4 to the letter).
+  --config cfg5            SPPT on + fp32 arithmetic in the column physics.  weak: 32 members per GPU; strong: 256 in total.
+  --members M overrides the per-GPU (weak) or total (strong) member count.
+Members never exchange data (speedy_driver.f90.j2:71-77): no data-path collective; the one collective is the start-up
+broadcast of the boundary fields from rank 0 (RCCL, device buffers), outside the timed region.  Members start from the
+reference's own initial state (example boundary fields, resting atmosphere, first_step), are perturbed as
+examples/Ensemble_forecast.ipynb does (t_grid += N(0, 0.01 K), grid2spectral; seed = global member id) and spun up
+`warmup` steps.
 
+Launching: with N > 1 and no torchrun environment, this process only starts N rank processes (before touching the GPU),
+relays rank 0's JSON line and fails if any rank fails.  Under `python -m torch.distributed.run ... bench.py --gpus N` each
+process is one rank.  PYSPEEDY_AMD_BENCH_BACKEND=gloo rehearses the N-rank control flow when the ranks share one GPU.
+
+Timing: W warm-up steps, then regions of EXACTLY K steps, each bracketed by barrier + synchronize on both sides and reduced
+with MAX over ranks.  When one region is shorter than a second it is repeated (up to 100 regions) and `ms_per_step` is the
+MEDIAN region (minimum and count reported beside it), so that a 20-step run is not a 7 ms sample.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 STEPS_PER_YEAR = 36 * 365  # model_control.f90:57-60, params.f90:32
 S_BYTES, G_BYTES = 15872, 36864  # one spectral / one grid field
+MAX_STEPS = STEPS_PER_YEAR        # the run stays inside the 14 months of (zero) SST anomalies the bench allocates
+NG = 96 * 48
+
+# Algorithmic HBM bytes of each step kernel PER MEMBER, counted from the kernels' argument lists (DESIGN.md section 5 has
+# the itemised lists).  Transforms: SURVEY 8d's contract figure S + G per field.
+COLUMN_DOUBLES = {"column_sw": 254, "column": 243}  # doubles moved per column (dynamics 50 in / 55 out + physics)
+ALGO_BYTES = {
+    "geopotential": 17 * S_BYTES,
+    "spectral_step": 215 * S_BYTES,
+    "coupler": 55 * 8 * NG,
+    "forcing": 19 * 8 * NG + 2 * (S_BYTES + G_BYTES),
+    "dyn_grid": (50 + 55 + 18) * 8 * NG,
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=360)
     ap.add_argument("--warmup", type=int, default=36)
-    ap.add_argument("--members", type=int, default=64, help="ensemble members resident per GPU")
+    ap.add_argument("--config", choices=("cfg4", "cfg5"), default="cfg4")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--members", type=int, default=None, help="members per GPU (weak) or in total (strong)")
+    ap.add_argument("--regions", type=int, default=0, help="timed regions of `steps` steps (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-worker", type=float, nargs=2, default=None, metavar=("T_START", "SECONDS"), help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
 
 
 def load_bc():
+    import numpy as np
     return np.load(os.path.join(ROOT, "pyspeedy_amd", "data", "example_bc.npz"))
 
 
-def build_ensemble(M, device, seed, dist, rank, coll_device):
-    import pyspeedy_amd
-    from pyspeedy_amd import ensemble as E
-    from pyspeedy_amd.model import EnsembleModel
-    sp = pyspeedy_amd.ModSpectral(device.index)
-    model = EnsembleModel(sp, M)
-    # rank 0 reads the boundary file; one RCCL broadcast (~3.4 MB over xGMI) hands it to the other GPUs
-    bc = E.broadcast_boundary_conditions(dict(load_bc()) if rank == 0 else None, dist, coll_device)
-    model.set_bc(bc, start_date=(1982, 1, 1, 0, 0))
-    # member perturbations (examples/Ensemble_forecast.ipynb perturbs t_grid with N(0, 0.01) K): here a relative 1e-5
-    # perturbation of the spectral temperature of both time levels, seed = global member id
-    t0 = model.get("t", 0)
-    for i in range(1, M):
-        rng = np.random.default_rng(seed * 100003 + i)
-        t = t0 * (1.0 + 1e-5 * rng.standard_normal((31, 32, 8, 1)))
-        t[0] = t[0].real  # zonal-mean coefficients stay real
-        model.set("t", t, member=i)
-    return sp, model
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
-def cpu_baseline(seconds):
-    """The reference Fortran itself (flang-compiled, oracle/_ref/libspeedy_ref.so, built in the build container from
-    /root/reference) timed on one host core: the same do_single_step for ONE member.  Falls back to the C port
-    (oracle/liboracle.so) when the reference library did not travel."""
+# ----------------------------------------------------------------------------------------------------------------------
+# launcher: N rank processes, started before this process touches the GPU (it never does)
+# ----------------------------------------------------------------------------------------------------------------------
+def launch_ranks(args, argv):
+    port = str(free_port())
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, WORLD_SIZE=str(args.gpus), RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE,
+                                      text=True))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = r
+        time.sleep(0.05)
+    if failed is None:
+        failed = next((r for r, p in enumerate(procs) if p.returncode != 0), None)
+    if failed is not None:  # a dead rank leaves the others waiting in a collective: stop exactly the processes started here
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    outs = [p.stdout.read() for p in procs]
+    if failed is not None:
+        sys.stderr.write("bench.py: rank %d exited with code %s\n%s" % (failed, procs[failed].returncode, outs[failed]))
+        raise SystemExit(1)
+    lines = [ln for ln in outs[0].splitlines() if ln.startswith("{")]
+    if len(lines) != 1:
+        raise SystemExit("bench.py: rank 0 printed %d result lines" % len(lines))
+    print(lines[0], flush=True)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# host baseline: the reference Fortran itself (oracle/_ref), one member on one core and one member per core on all cores
+# ----------------------------------------------------------------------------------------------------------------------
+def host_cores():
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def _reference_member():
+    """(step function of one member, kind, description): the flang-compiled reference when it travelled, else the C port."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     bc = load_bc()
     try:
@@ -81,17 +150,10 @@ def cpu_baseline(seconds):
             raise OSError("no reference library")
         m = R.RefModel(end=(1983, 1, 1, 0, 0))
         m.set_bc(bc)
-        for _ in range(6):
-            m.step()
-        n, t0 = 0, time.perf_counter()
-        while True:
-            for _ in range(36):
-                assert m.step() == 0
-            n += 36
-            el = time.perf_counter() - t0
-            if el >= seconds:
-                break
-        kind, what = "reference", "reference Fortran (amdflang -O2) do_single_step"
+
+        def step():
+            assert m.step() == 0
+        return step, "reference", "reference Fortran (amdflang -O2) do_single_step"
     except (OSError, AttributeError):
         import oracle as orc
         orc.build()
@@ -100,25 +162,166 @@ def cpu_baseline(seconds):
         arr["tcorh"], arr["qcorh"] = g["tab_tcorh"], g["tab_qcorh"]
         st = orc.ModelState(arr, True, float(g["air_absortivity_co2"]))
         d = orc.dyn_tables(2 * 2400.0)
-        n, t0 = 0, time.perf_counter()
-        while True:
-            st.set_shortwave(n % 3 == 0)
+        count = [0]
+
+        def step():
+            st.set_shortwave(count[0] % 3 == 0)
             orc.step(st, d, 2, 2, 2 * 2400.0)
-            n += 1
-            el = time.perf_counter() - t0
-            if el >= seconds and n >= 3:
-                break
-        kind, what = "port", "C port (oracle/liboracle.so) of time_stepping.f90 step incl. transforms and physics"
-    ms = el / n * 1e3
-    return {"value": 86400.0 / (ms * 1e-3 * STEPS_PER_YEAR), "unit": "simulated-years/day (1 member)", "cores": 1,
-            "kind": kind, "ms_per_member_step": ms,
-            "sample": "%d model steps of one member with the %s in %.1f s on one host core" % (n, what, el)}
+            count[0] += 1
+        return step, "port", "C port (oracle/liboracle.so) of time_stepping.f90 step incl. transforms and physics"
 
 
-def main():
-    args = parse()
+def _time_member(step, seconds, t_start=None):
+    for _ in range(6):
+        step()
+    if t_start is not None:  # all workers of the all-core leg start their timed loop together
+        while time.time() < t_start:
+            time.sleep(0.001)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        for _ in range(12):
+            step()
+        n += 12
+        el = time.perf_counter() - t0
+        if el >= seconds:
+            return n, el
+
+
+def cpu_worker(t_start, seconds):
+    step, kind, _ = _reference_member()
+    n, el = _time_member(step, seconds, t_start)
+    print("CPUWORKER %s %d %.6f" % (kind, n, el), flush=True)
+
+
+def cpu_baseline(seconds):
+    """Runs BEFORE this process initialises the GPU (it starts child processes).  Leg 1: one member on one core.  Leg 2: one
+    member per host core, all cores at once (members are independent: the reference's own OpenMP loop,
+    speedy_driver.f90.j2:71-77, does exactly this), started together; throughput = sum over workers."""
+    step, kind, what = _reference_member()
+    n1, el1 = _time_member(step, seconds)
+    ms1 = el1 / n1 * 1e3
+    out = {"value": 86400.0 / (ms1 * 1e-3 * STEPS_PER_YEAR), "unit": "simulated-years/day", "cores": 1, "kind": kind,
+           "ms_per_member_step": ms1,
+           "sample": "%d model steps of one member with the %s in %.1f s on one host core" % (n1, what, el1)}
+    cores = host_cores()
+    t_start = time.time() + 6.0 + 0.02 * cores  # allowance for interpreter start-up, library load and model initialisation
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", repr(t_start), repr(seconds)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(cores)]
+    rate, steps, longest, ok = 0.0, 0, 0.0, 0
+    for p in procs:
+        o = p.communicate()[0]
+        for ln in o.splitlines():
+            if ln.startswith("CPUWORKER"):
+                _, _, n, el = ln.split()
+                rate += int(n) / float(el)
+                steps += int(n)
+                longest = max(longest, float(el))
+                ok += 1
+    if ok:
+        out["all_cores"] = {
+            "value": rate * 86400.0 / STEPS_PER_YEAR, "unit": "simulated-years/day", "cores": ok, "kind": kind,
+            "member_steps_per_second": rate, "ms_per_member_step_per_core": ok / rate * 1e3,
+            "sample": "%d member-steps: one member per core on %d cores at once (%d workers started), %.1f s each" % (
+                steps, ok, cores, longest)}
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# one rank
+# ----------------------------------------------------------------------------------------------------------------------
+def workload(args, world, rank):
+    """(members on this rank, global id of its first member, members in total)"""
     from pyspeedy_amd import ensemble as E
+    per_gpu_default, total_default = (64, 64) if args.config == "cfg4" else (32, 256)
+    if args.scaling == "weak":
+        m = args.members if args.members is not None else per_gpu_default
+        return m, rank * m, m * world
+    total = args.members if args.members is not None else total_default
+    first, count = E.shard_members(total, world, rank)
+    if count == 0:
+        raise SystemExit("bench.py: rank %d would own no member (%d members on %d ranks)" % (rank, total, world))
+    return count, first, total
+
+
+def build_ensemble(args, M, first_id, device, dist, rank, coll_device):
+    import numpy as np
+    import torch
+    import pyspeedy_amd
+    from pyspeedy_amd import ensemble as E
+    from pyspeedy_amd.model import EnsembleModel
+    sp = pyspeedy_amd.ModSpectral(device.index)
+    model = EnsembleModel(sp, M)
+    model.init_sst_anom(14)  # sst_anom(ix, il, 0:15), zero: December 1981 ... February 1983 (speedy.py:338-372)
+    # rank 0 reads the boundary file; one RCCL broadcast (~3.4 MB over xGMI) hands it to the other GPUs (SURVEY 8e)
+    bc = E.broadcast_boundary_conditions(dict(load_bc()) if rank == 0 else None, dist, coll_device)
+    model.set_bc(bc, start_date=(1982, 1, 1, 0, 0))
+    # cfg 4 perturbation (SURVEY 8d, examples/Ensemble_forecast.ipynb): t_grid += N(0, 0.01), then grid2spectral;
+    # the generator is seeded with the GLOBAL member id, so the ensemble does not depend on how it is sharded
+    model.spectral2grid()
+    t_grid = model.device_view("t_grid")  # [M, lev, lat, lon] in HBM
+    noise = np.stack([np.random.default_rng(first_id + i).normal(0.0, 0.01, (96, 48, 8)).transpose(2, 1, 0) for i in range(M)])
+    t_grid += torch.from_numpy(np.ascontiguousarray(noise)).to(device)
+    model.grid2spectral()
+    if args.config == "cfg5":
+        model.set_sppt(True, seed=2024, first_member_id=first_id)
+        model.set_physics_precision(True)
+    return sp, model
+
+
+def kernel_table(model, M, inv_per_member, sppt):
+    """roofline.kernels[]: every kernel of the step with its algorithmic bytes (argument lists), HIP-event time, fraction of
+    the 8 TB/s HBM peak.  Measured in a separate one-day pass with a bracket around every launch."""
+    from pyspeedy_amd.model import KERNEL_NAMES  # noqa: F401
+    model.profile(2)
+    model.run(36)
+    prof = model.profile_read_kernels()
+    model.profile(0)
+    extra = 8 if sppt else 0  # the column kernel also reads the SPPT pattern
+    rows = []
+    for name, (mean_ms, min_ms, n, units) in prof.items():
+        if name == "spec2grid" or name == "grid2spec":
+            algo = (S_BYTES + G_BYTES) * units
+        elif name in COLUMN_DOUBLES:
+            algo = (COLUMN_DOUBLES[name] + extra) * 8 * NG * units
+        elif name in ("physics_sw", "physics"):
+            algo = (COLUMN_DOUBLES["column_sw" if name == "physics_sw" else "column"] - 105 + 18 + extra) * 8 * NG * units
+        elif name == "sppt":
+            algo = 16 * S_BYTES * (units // 8) + (S_BYTES + G_BYTES) * units
+        else:
+            algo = ALGO_BYTES[name] * units
+        gbs = algo / (mean_ms * 1e-3) / 1e9
+        rows.append({"kernel": name, "launches_timed": n, "avg_launch_us": mean_ms * 1e3, "min_launch_us": min_ms * 1e3,
+                     "algorithmic_bytes_per_launch": algo, "achieved": gbs, "frac": gbs / 8000.0})
+    return rows
+
+
+def load_traffic(nfields):
+    """HBM bytes per spec2grid launch from the committed PMC measurement of this very kernel inside this bench (rocprofv3
+    cannot run inside bench.py): FETCH_SIZE doubled as the gfx950 guide prescribes, scaled per field."""
+    for name in ("r02_pmc_model_step.json", "r01_pmc_model_step.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                tj = json.load(fh)["kernels"]["spd::spec2grid_table_kernel"]
+            per_field = tj["hbm_bytes_per_launch"] / float(tj.get("fields_per_launch", 5824))
+            return per_field * nfields, "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py)" % name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+def run_rank(args):
+    baseline = None
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env == 1 and not args.no_cpu_baseline:
+        baseline = cpu_baseline(args.cpu_seconds)  # spawns processes: must come before the first GPU call
+
+    import torch
+    import pyspeedy_amd
+    from pyspeedy_amd import ensemble as E
+    pyspeedy_amd.lib()  # load (or fail loudly) before the GPU is initialised; there is no CPU fallback
     world, rank, local = E.dist_env()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
     local = local % torch.cuda.device_count()  # (several ranks may share a GPU in a rehearsal on a one-GPU box)
@@ -127,73 +330,93 @@ def main():
     # RCCL ("nccl" on ROCm): barrier, max-over-ranks time and the start-up broadcast of the boundary fields.
     # PYSPEEDY_AMD_BENCH_BACKEND=gloo rehearses the same control flow when the ranks cannot each have their own GPU.
     backend = os.environ.get("PYSPEEDY_AMD_BENCH_BACKEND", "nccl")
-    dist = E.init_process_group(backend, device)
+    # the process group is also created for an explicit one-rank world (WORLD_SIZE=1 in the environment): RCCL end to end
+    dist = E.init_process_group(backend, device, force="WORLD_SIZE" in os.environ)
     coll_device = device if backend == "nccl" else torch.device("cpu")
+    n_gpus = dist.get_world_size() if dist is not None else 1
+    assert n_gpus == args.gpus, (n_gpus, args.gpus)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    sp, model = build_ensemble(args.members, device, 1 + rank, dist, rank, coll_device)
+    M, first_id, total_members = workload(args, world, rank)
+    sp, model = build_ensemble(args, M, first_id, device, dist, rank, coll_device)
     model.run(args.warmup)
-    model.profile(True)
-    barrier()
-    t0 = time.perf_counter()
-    model.run(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = E.max_over_ranks(elapsed, dist, coll_device)
+    model.profile(1)
+    regions, region_s = max(args.regions, 1), []
+    r = 0
+    while r < regions:
+        barrier()
+        t0 = time.perf_counter()
+        model.run(args.steps)
+        barrier()
+        region_s.append(E.max_over_ranks(time.perf_counter() - t0, dist, coll_device))
+        if r == 0 and args.regions == 0 and region_s[0] < 1.0:  # identical on every rank: it is the all-reduced time
+            regions = min(100, int(math.ceil(1.0 / max(region_s[0], 1e-6))))
+        regions = max(1, min(regions, (MAX_STEPS - args.warmup - 36) // max(args.steps, 1)))
+        r += 1
     kern_ms, launches, nfields = model.profile_read()
     codes = model.check(2)
     if (codes != 0).any():
         raise SystemExit("bench.py: %d members left the accepted range (diagnostics.f90)" % int((codes != 0).sum()))
-
-    achieved = (S_BYTES + G_BYTES) * nfields / (kern_ms * 1e-3) / 1e9
-    # HBM bytes per launch from the committed PMC measurement of this very kernel inside this bench (rocprofv3 cannot run
-    # inside bench.py): 5824 fields per launch at 64 members, FETCH_SIZE doubled as the gfx950 guide prescribes; scaled
-    # per field for other member counts.
-    traffic, traffic_src = None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_model_step.json")) as fh:
-            tj = json.load(fh)["kernels"]["spd::spec2grid_table_kernel"]
-        traffic = tj["hbm_bytes_per_launch"] * nfields / 5824.0
-        traffic_src = "profiles/r01_pmc_model_step.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py, 5824 fields/launch)"
-    except (OSError, KeyError, ValueError):
-        pass
+    model.profile(0)
+    kernels = kernel_table(model, M, nfields // M, args.config == "cfg5") if rank == 0 or dist is None else None
 
     if rank == 0:
-        ms_step = elapsed / args.steps * 1e3
-        total_members = args.members * world
+        ordered = sorted(region_s)
+        median = ordered[len(ordered) // 2] if len(ordered) % 2 else 0.5 * (ordered[len(ordered) // 2 - 1] + ordered[len(ordered) // 2])
+        ms_step, ms_min = median / args.steps * 1e3, ordered[0] / args.steps * 1e3
         value = E.simulated_years_per_day(total_members, ms_step * 1e-3, STEPS_PER_YEAR)
+        achieved = (S_BYTES + G_BYTES) * nfields / (kern_ms * 1e-3) / 1e9
+        traffic, traffic_src = load_traffic(nfields)
+        physics = "fp64 column physics" if args.config == "cfg4" else "SPPT on, fp32 arithmetic in the column physics (fp64 state)"
         line = {
             "metric": "simulated-years/day (whole node), T30L8", "value": value, "unit": "simulated-years/day",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f64" if args.config == "cfg4" else "f64 state and dynamics, f32 column physics",
             "data": "reference example_bc boundary fields (committed fixture, no download); state generated by the model: "
-                    "resting atmosphere + first_step, per-member temperature perturbation, %d spin-up steps" % args.warmup,
+                    "resting atmosphere + first_step, members perturbed with t_grid += N(0, 0.01 K) (seed = global member "
+                    "id), %d spin-up steps" % args.warmup,
+            "ms_per_step_min": ms_min, "regions": len(region_s),
             "config": {
-                "workload": "BASELINE cfg 4 ensemble shard: %d members per GPU, T30L8 96x48x8 fp64, full do_single_step per "
-                            "member (91 spec2grid + grid-point dynamics + fused column physics + 73 grid2spec + spectral "
-                            "tendencies/semi-implicit/diffusion/RAW filter + coupler + daily forcing), all on the GPU"
-                            % args.members,
-                "members_per_gpu": args.members, "members_total": total_members,
-                "ms_per_member_step": ms_step / args.members, "simulated_days": args.steps / 36.0,
-                "parallelism": "ensemble members sharded per GPU, no collective",
+                "workload": "BASELINE %s ensemble (%s scaling): %d members per GPU, %d in total, T30L8 96x48x8, %s; full "
+                            "do_single_step per member (%d spec2grid + grid-point dynamics + fused column physics + 73 "
+                            "grid2spec + spectral tendencies/semi-implicit/diffusion/RAW filter + coupler + daily "
+                            "forcing), all on the GPU" % (args.config, args.scaling, M, total_members, physics, nfields // M),
+                "members_per_gpu": M, "members_total": total_members,
+                "ms_per_member_step": ms_step * n_gpus / total_members, "simulated_days_per_region": args.steps / 36.0,
+                "parallelism": "ensemble members sharded per GPU, no collective in the step",
+                "backend": backend if dist is not None else "none (single process)",
             },
             "roofline": {
-                "kernel": "spec2grid_table_kernel (inverse Legendre + inverse FFT-96, with vort2vel / gradient applied while staging "
-                          "the 34 wind and pressure-gradient fields of each member), %d fields/launch" % nfields,
+                "kernel": "spec2grid_table_kernel (inverse Legendre + inverse FFT-96, with vort2vel / gradient applied while "
+                          "staging the wind and pressure-gradient fields of each member), %d fields/launch" % nfields,
                 "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "algorithmic_bytes_per_field": S_BYTES + G_BYTES, "avg_launch_ms": kern_ms, "launches_timed": launches,
-                "traffic": traffic, "traffic_source": traffic_src,
+                "traffic": traffic, "traffic_source": traffic_src, "kernels": kernels,
             },
         }
-        if not args.no_cpu_baseline and world == 1:  # the host baseline is measured on single-GPU runs only
-            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        if baseline is not None:
+            line["cpu_baseline"] = baseline
         print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if args.cpu_worker is not None:
+        return cpu_worker(*args.cpu_worker)
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)  # this process never touches the GPU
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -114,7 +114,7 @@ typedef struct spd_physics_args {
     double *ts, *tskin, *u0, *v0, *t0, *cloudc, *clstr; /* (ix,il) */
     double air_absortivity_co2; /* state%air_absortivity_co2 */
     int32_t compute_shortwave;  /* state%compute_shortwave (speedy.f90:53) */
-    int32_t reserved;
+    int32_t fp32; /* != 0: column arithmetic in single precision (cfg 5); inputs / outputs stay double */
     /* SPPT pattern (ix,il,kx), values outside [-1, 1] are clipped; NULL = off (physics.f90:234-248, sppt_on = .false.) */
     const double *sppt_pattern;
 } spd_physics_args;
@@ -168,12 +168,55 @@ int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, i
 int spd_model_step(spd_model_handle m, int nsteps, void *stream);
 int spd_model_current_step(spd_model_handle m);
 int spd_model_get_date(spd_model_handle m, int *ymdhm /* 5 ints */);
-/* declare a state loaded through spd_model_set (e.g. a restart) as initialised, with its step counter and date */
+/* declare a state loaded through spd_model_set as initialised at the START of a run: step counter and date as given, month
+ * index 1, CO2 reference = the current absorptivity (what set_forcing(imode = 0) does, forcing.f90:40) */
 int spd_model_mark_initialized(spd_model_handle m, int current_step, int year, int month, int day, int hour, int minute);
-/* measurement hook: bracket the dominant kernel of every step (the 91*M-field spectral->grid launch) with HIP events on the
- * launch stream; _read synchronises them and returns the mean launch time in ms */
-int spd_model_profile(spd_model_handle m, int enable);
+/* Everything the model keeps on the host between steps (ControlParams_t / Datetime_t of model_control.f90:19-47, the
+ * registry scalars of model_state_def.py:305-423 and the SPPT generator position).  Together with the registry arrays
+ * (spd_model_get / _set) this IS the state of a run: _get + the arrays make a checkpoint, _set + the arrays resume it
+ * bit for bit at any step -- after a month boundary (month_idx selects the sst_anom planes), with the CO2 trend on
+ * (ablco2_ref is the untrended reference value) and with SPPT on (the AR(1) pattern sppt_spec continues at sppt_step).
+ * spd_model_set_control marks the model initialised and resets nothing. */
+typedef struct spd_model_control {
+    int32_t current_step;
+    int32_t year, month, day, hour, minute; /* model date */
+    int32_t month_idx;                      /* months started since the run began, + 1: plane of sst_anom */
+    int32_t land_coupling_flag, sst_anomaly_coupling_flag, increase_co2;
+    int32_t sppt_on, sppt_first, physics_fp32;
+    int32_t reserved;
+    int64_t sppt_step, sppt_first_member_id;
+    uint64_t sppt_seed;
+    double air_absortivity_co2, ablco2_ref;
+} spd_model_control;
+int spd_model_get_control(spd_model_handle m, spd_model_control *out);
+int spd_model_set_control(spd_model_handle m, const spd_model_control *in);
+/* measurement hook: HIP events recorded on the launch stream around the kernels of every step.  level 0 = off, 1 = the
+ * dominant kernel only (the 91*M-field spectral->grid launch; cheap enough for the timed region of bench.py), 2 = every
+ * kernel of the step (a separate measurement pass: each bracket adds a few microseconds between launches).
+ * _read synchronises the events of the spectral->grid launches and returns their mean time in ms;
+ * _read_kernels returns, per kernel id SPD_K_*, mean and minimum bracket time in ms, the number of brackets and the units
+ * (fields for the transforms, members otherwise) one bracket processed; all four arrays hold SPD_K_COUNT entries. */
+#define SPD_K_GEOPOTENTIAL 0  /* geopotential_kernel */
+#define SPD_K_SPEC2GRID 1     /* spec2grid_table_kernel, 91 (77 pruned) fields per member */
+#define SPD_K_COLUMN_SW 2     /* fused grid-point dynamics + column physics, shortwave step */
+#define SPD_K_COLUMN 3        /* the same on the two steps out of three without shortwave */
+#define SPD_K_GRID2SPEC 4     /* grid2spec_table_kernel, 73 fields per member */
+#define SPD_K_SPECTRAL_STEP 5 /* spectral_step_kernel */
+#define SPD_K_COUPLER 6       /* coupler_kernel */
+#define SPD_K_FORCING 7       /* daily: forcing_kernel + the two 1-field-per-member transforms of tcorh / qcorh */
+#define SPD_K_SPPT 8          /* SPPT on: AR(1) update + 8 fields per member spectral->grid */
+#define SPD_K_DYN_GRID 9      /* split mode: dyn_grid_kernel */
+#define SPD_K_PHYSICS_SW 10   /* split mode: physics_kernel, shortwave step */
+#define SPD_K_PHYSICS 11      /* split mode: physics_kernel, other steps */
+#define SPD_K_COUNT 12
+int spd_model_profile(spd_model_handle m, int level);
 int spd_model_profile_read(spd_model_handle m, double *mean_ms, int *launches, int *fields_per_launch);
+int spd_model_profile_read_kernels(spd_model_handle m, double *mean_ms, double *min_ms, int *launches, int *units);
+/* BASELINE cfg 5: fp32 != 0 runs the arithmetic of the column physics (physics.f90:107-256 and the schemes it calls) in
+ * single precision; the model state, the grid-point dynamics and the tendencies handed to the transforms stay fp64 (the
+ * physics increment is formed in fp32 and added to the fp64 dynamics tendency).  Not bitwise comparable with the reference:
+ * tests/test_cfg5_gpu.py states the error bounds.  Default 0. */
+int spd_model_set_physics_precision(spd_model_handle m, int fp32);
 /* registry scalars land_coupling_flag, sst_anomaly_coupling_flag, increase_co2 (model_state_def.py:305-418) */
 int spd_model_set_flags(spd_model_handle m, int land_coupling_flag, int sst_anomaly_coupling_flag, int increase_co2);
 

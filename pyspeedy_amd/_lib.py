@@ -46,8 +46,17 @@ _PHYS_PTR_FIELDS = [
 class PhysicsArgs(C.Structure):
     """Mirror of spd_physics_args (include/pyspeedy_amd.h)."""
     _fields_ = [(n, C.c_void_p) for n in _PHYS_PTR_FIELDS] + [
-        ("air_absortivity_co2", C.c_double), ("compute_shortwave", C.c_int32), ("reserved", C.c_int32),
+        ("air_absortivity_co2", C.c_double), ("compute_shortwave", C.c_int32), ("fp32", C.c_int32),
         ("sppt_pattern", C.c_void_p)]
+
+
+class ModelControl(C.Structure):
+    """Mirror of spd_model_control (include/pyspeedy_amd.h)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "current_step", "year", "month", "day", "hour", "minute", "month_idx", "land_coupling_flag",
+        "sst_anomaly_coupling_flag", "increase_co2", "sppt_on", "sppt_first", "physics_fp32", "reserved")] + [
+        ("sppt_step", C.c_int64), ("sppt_first_member_id", C.c_int64), ("sppt_seed", C.c_uint64),
+        ("air_absortivity_co2", C.c_double), ("ablco2_ref", C.c_double)]
 
 
 _SIGNATURES = {
@@ -90,6 +99,8 @@ _SIGNATURES = {
     "spd_model_current_step": (C.c_int, [C.c_void_p]),
     "spd_model_get_date": (C.c_int, [C.c_void_p, C.c_void_p]),
     "spd_model_mark_initialized": (C.c_int, [C.c_void_p] + [C.c_int] * 6),
+    "spd_model_get_control": (C.c_int, [C.c_void_p, C.POINTER(ModelControl)]),
+    "spd_model_set_control": (C.c_int, [C.c_void_p, C.POINTER(ModelControl)]),
     "spd_model_set_flags": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "spd_model_spectral2grid": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "spd_model_grid2spectral": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -99,6 +110,8 @@ _SIGNATURES = {
     "spd_model_copy_member": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "spd_model_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "spd_model_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "spd_model_profile_read_kernels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "spd_model_set_physics_precision": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -23,7 +23,7 @@ hipError_t run_vel2vort(const DeviceTables &T, const double *ucos, const double 
                         int nfields, hipStream_t s);
 hipError_t run_gradient(const DeviceTables &T, const double *psi, double *psdx, double *psdy, int nfields, hipStream_t s);
 hipError_t run_scale(const double *in, double *out, const double *table, double sign, int nfields, hipStream_t s);
-hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nmembers, hipStream_t s);
+hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nmembers, int fp32, hipStream_t s);
 }  // namespace spd
 
 using namespace spd;
@@ -164,6 +164,17 @@ int spd_create(spd_handle *out, int device) {
     up(h.vddyp.data(), NSPEC, &d.vddyp);
     up(h.fband.data(), h.fband.size(), &d.fband);
     up(h.coa.data(), 48, &d.coa);
+    {   // fp32 copies of the two physics tables (cfg 5), packed two floats per double slot of the same uploader
+        std::vector<float> f32(h.fband.size() + 48);
+        for (size_t i = 0; i < h.fband.size(); ++i) f32[i] = static_cast<float>(h.fband[i]);
+        for (int j = 0; j < 48; ++j) f32[h.fband.size() + j] = static_cast<float>(h.coa[j]);
+        std::vector<double> raw((f32.size() + 1) / 2);
+        std::memcpy(raw.data(), f32.data(), f32.size() * sizeof(float));
+        const double *dev = nullptr;
+        up(raw.data(), raw.size(), &dev);
+        d.fband32 = reinterpret_cast<const float *>(dev);
+        d.coa32 = d.fband32 ? d.fband32 + h.fband.size() : nullptr;
+    }
     if (rc != SPD_OK) {
         spd_destroy(c);
         return rc;
@@ -359,7 +370,7 @@ int spd_physics(spd_handle h, const spd_physics_args *a, int nmembers, void *str
         for (const void *p : sw)
             if (!p) return fail(SPD_E_ARG, "spd_physics: shortwave forcing pointer is null on a shortwave step");
     }
-    return done(run_physics(h->dev, *a, nmembers, static_cast<hipStream_t>(stream)), "spd_physics");
+    return done(run_physics(h->dev, *a, nmembers, a->fp32, static_cast<hipStream_t>(stream)), "spd_physics");
 }
 
 }  // extern "C"

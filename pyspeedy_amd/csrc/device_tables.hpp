@@ -23,6 +23,7 @@ struct DeviceTables {
     // physics
     const double *fband;   // (301,4)
     const double *coa;     // 48, cos(latitude)
+    const float *fband32, *coa32;  // the same two tables rounded to fp32, for the mixed-precision physics (cfg 5)
     double fsg[8], dhs[8], sigl[8], sigh[9], grdsig[8], grdscp[8], wvi[16];
 };
 

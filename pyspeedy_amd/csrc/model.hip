@@ -18,9 +18,9 @@
 namespace spd {
 hipError_t run_spec2grid_table(const DeviceTables &T, const FieldDesc *table, int nfields, hipStream_t st);
 hipError_t run_grid2spec_table(const DeviceTables &T, const FieldDesc *table, int nfields, hipStream_t st);
-hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nmembers, hipStream_t s);
+hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nmembers, int fp32, hipStream_t s);
 hipError_t run_dyn_physics(const ModelPtrs &P, const DynDeviceTables &D, const DeviceTables &T, const spd_physics_args &a,
-                           int first, int nmembers, hipStream_t s);
+                           int first, int nmembers, int fp32, hipStream_t s);
 hipError_t run_geopotential(const ModelPtrs &P, const DynDeviceTables &D, int first, int count, int tl, hipStream_t s);
 hipError_t run_dyn_grid(const ModelPtrs &P, const DynDeviceTables &D, int M, hipStream_t s);
 hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const DynDeviceTables &D, int M, int first, int count,
@@ -102,15 +102,18 @@ struct spd_model {
     hipStream_t cstream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t cev[4] = {nullptr, nullptr, nullptr, nullptr}, ev_start = nullptr;
     bool split_dyn_physics = false;  // PYSPEEDY_AMD_SPLIT_DYN=1: separate dynamics and physics launches (for measurements)
+    int phys_fp32 = 0;               // spd_model_set_physics_precision: column physics arithmetic in fp32 (BASELINE cfg 5)
     int land_coupling_flag = 1, sst_anomaly_flag = 1, increase_co2 = 0, anom_planes = 3;
     double ablco2_ref = 6.0;
     double *corh_t = nullptr, *corh_q = nullptr, *scratch_spec = nullptr;  // [M][NG], [M][NG], [2][M][992] complex
     double *orog = nullptr, *phi0 = nullptr, *fmask_orig = nullptr, *veg_high = nullptr, *veg_low = nullptr,
            *soil_wc_l1 = nullptr, *soil_wc_l2 = nullptr, *soil_wc_l3 = nullptr, *bmask_land = nullptr, *bmask_sea = nullptr;
-    // optional profiling of the dominant kernel (the spec2grid table launch): HIP events on the launch stream
-    bool profile = false;
+    // optional profiling with HIP events on the launch stream: level 1 brackets the dominant kernel (the spec2grid table
+    // launch) only, level 2 every kernel of the step (spd_model_profile; kernel ids SPD_K_* of pyspeedy_amd.h)
+    int profile = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     std::vector<int> prof_fields;  // fields of each profiled launch
+    std::vector<int> prof_kernel;  // kernel id of each profiled launch
     size_t prof_used = 0;
     // grid-space copies of the prognostic variables in output units (prognostics.f90:125-219) and their transform tables
     double *u_grid = nullptr, *v_grid = nullptr, *t_grid = nullptr, *q_grid = nullptr, *phi_grid = nullptr, *ps_grid = nullptr;
@@ -477,36 +480,50 @@ int spd_model_set_time_step(spd_model_handle m, double dt) {
     return SPD_OK;
 }
 
+// HIP-event bracket around one launch (or a short group of launches) of the step when profiling asks for it
+struct ProfScope {
+    spd_model *m;
+    hipStream_t s;
+    hipEvent_t stop = nullptr;
+    ProfScope(spd_model *m_, int kernel, int fields, hipStream_t s_) : m(m_), s(s_) {
+        if (m->profile == 0 || (m->profile == 1 && kernel != SPD_K_SPEC2GRID)) return;
+        if (m->prof_used == m->prof_events.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            m->prof_events.emplace_back(a, b);
+            m->prof_fields.push_back(0);
+            m->prof_kernel.push_back(0);
+        }
+        const size_t i = m->prof_used++;
+        m->prof_fields[i] = fields;
+        m->prof_kernel[i] = kernel;
+        (void)hipEventRecord(m->prof_events[i].first, s);
+        stop = m->prof_events[i].second;
+    }
+    ~ProfScope() {
+        if (stop) (void)hipEventRecord(stop, s);
+    }
+};
+
 // one `step(state, j1, j2, dt)` of time_stepping.f90 for the members [first, first + count) on stream s
 static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int compute_shortwave, int first, int count, hipStream_t s) {
     const DeviceTables &T = m->ctx->dev;
     const int M = m->M;
-    hipError_t e = run_geopotential(m->P, m->D, first, count, 0, s);                      // tendencies.f90:229
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (m->profile && e == hipSuccess) {
-        if (m->prof_used == m->prof_events.size()) {
-            hipEvent_t a, b;
-            if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) {
-                m->prof_events.emplace_back(a, b);
-                m->prof_fields.push_back(0);
-            }
-        }
-        if (m->prof_used < m->prof_events.size()) {
-            ev0 = m->prof_events[m->prof_used].first;
-            ev1 = m->prof_events[m->prof_used].second;
-            m->prof_fields[m->prof_used] = m->inv_per_member * count;
-            ++m->prof_used;
-            (void)hipEventRecord(ev0, s);
-        }
+    hipError_t e;
+    {
+        ProfScope ps(m, SPD_K_GEOPOTENTIAL, count, s);
+        e = run_geopotential(m->P, m->D, first, count, 0, s);                             // tendencies.f90:229
     }
-    if (e == hipSuccess)                                                                  // :109-146, physics.f90:89-101
+    if (e == hipSuccess) {                                                                // :109-146, physics.f90:89-101
+        ProfScope ps(m, SPD_K_SPEC2GRID, m->inv_per_member * count, s);
         e = run_spec2grid_table(T, m->inv_table[j2 - 1] + static_cast<size_t>(first) * m->inv_per_member, m->inv_per_member * count, s);
-    if (ev1) (void)hipEventRecord(ev1, s);
+    }
     spd_physics_args pa = m->pa;
     pa.compute_shortwave = compute_shortwave ? 1 : 0;
     pa.air_absortivity_co2 = m->air_absortivity_co2;
     pa.sppt_pattern = nullptr;
     if (e == hipSuccess && m->sppt_on) {  // physics.f90:234-236: a new pattern for every call of the physics (whole model)
+        ProfScope ps(m, SPD_K_SPPT, 8 * M, s);
         e = run_sppt_update(m->sppt_spec, T, M, m->sppt_seed, m->sppt_member_base, m->sppt_step, m->sppt_first ? 1 : 0, s);
         if (e == hipSuccess) e = run_spec2grid(T, 0, m->sppt_spec, m->sppt_grid, 1, 8 * M, s);
         m->sppt_first = false;
@@ -514,16 +531,29 @@ static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int comput
         pa.sppt_pattern = m->sppt_grid;
     }
     if (e == hipSuccess) {
-        if (m->split_dyn_physics || m->sppt_on) {  // whole model only (SPPT needs the dynamics-only tendencies in memory)
-            e = run_dyn_grid(m->P, m->D, M, s);                                           // :151-224
-            if (e == hipSuccess) e = run_physics(T, pa, M, s);                            // :231
+        if (m->split_dyn_physics) {  // whole model only; the default is the fused launch (with SPPT: its KEEP variant)
+            {
+                ProfScope ps(m, SPD_K_DYN_GRID, M, s);
+                e = run_dyn_grid(m->P, m->D, M, s);                                       // :151-224
+            }
+            if (e == hipSuccess) {
+                ProfScope ps(m, compute_shortwave ? SPD_K_PHYSICS_SW : SPD_K_PHYSICS, M, s);
+                e = run_physics(T, pa, M, m->phys_fp32, s);                               // :231
+            }
         } else {
-            e = run_dyn_physics(m->P, m->D, T, pa, first, count, s);                      // both in one launch
+            ProfScope ps(m, compute_shortwave ? SPD_K_COLUMN_SW : SPD_K_COLUMN, count, s);
+            e = run_dyn_physics(m->P, m->D, T, pa, first, count, m->phys_fp32, s);        // both in one launch
         }
     }
-    if (e == hipSuccess) e = run_grid2spec_table(T, m->fwd_table + static_cast<size_t>(first) * 73, 73 * count, s);  // :238-268
+    if (e == hipSuccess) {                                                                // :238-268
+        ProfScope ps(m, SPD_K_GRID2SPEC, 73 * count, s);
+        e = run_grid2spec_table(T, m->fwd_table + static_cast<size_t>(first) * 73, 73 * count, s);
+    }
     const double eps = (j1 == 1) ? 0.0 : static_cast<double>(0.05f);                      // rob, time_stepping.f90:130-134
-    if (e == hipSuccess) e = run_spectral_step(m->P, T, m->D, M, first, count, j1 - 1, dt, eps, s);
+    if (e == hipSuccess) {
+        ProfScope ps(m, SPD_K_SPECTRAL_STEP, count, s);
+        e = run_spectral_step(m->P, T, m->D, M, first, count, j1 - 1, dt, eps, s);
+    }
     return e;
 }
 
@@ -611,6 +641,7 @@ static ZonalDevice forcing_host(spd_model *m, int imode) {
 static int forcing_range(spd_model *m, const ZonalDevice &zd, int first, int count, hipStream_t s) {
     const double gamlat = static_cast<double>(6.0f) / (1000.f * static_cast<double>(9.81f));  // setgam, forcing.f90:105-117
     const size_t og = static_cast<size_t>(first) * NG, os = static_cast<size_t>(first) * NSPEC * C;
+    ProfScope ps(m, SPD_K_FORCING, count, s);
     hipError_t e = run_forcing(m->S, first, count, zd, gamlat, m->corh_t, m->corh_q, s);
     if (e == hipSuccess) e = run_grid2spec(m->ctx->dev, 0, m->corh_t + og, m->P.tcorh + os, 0, count, s);
     if (e == hipSuccess) e = run_grid2spec(m->ctx->dev, 0, m->corh_q + og, m->P.qcorh + os, 0, count, s);
@@ -624,7 +655,11 @@ static int couple_range(spd_model *m, int day, int first, int count, hipStream_t
     const TimeInterp w = time_interp(m->cal);
     if (m->sst_anomaly_flag && (w.a0 < 0 || w.a1 < 0 || w.a0 >= m->anom_planes || w.a1 >= m->anom_planes))
         return m_fail(SPD_E_ARG, "SST anomaly planes do not cover the simulated period (speedy.py:338-372)");
-    hipError_t e = run_coupler(m->S, first, count, w, day, m->land_coupling_flag, m->sst_anomaly_flag, m->anom_planes, s);
+    hipError_t e;
+    {
+        ProfScope ps(m, SPD_K_COUPLER, count, s);
+        e = run_coupler(m->S, first, count, w, day, m->land_coupling_flag, m->sst_anomaly_flag, m->anom_planes, s);
+    }
     if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("couple_sea_land: ") + hipGetErrorString(e));
     return SPD_OK;
 }
@@ -782,11 +817,13 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
 
 int spd_model_current_step(spd_model_handle m) { return m ? m->current_step : SPD_E_ARG; }
 
-// Profiling of the dominant kernel: when enabled, every step brackets its 91*M-field spec2grid launch with HIP events
-// on the launch stream.  spd_model_profile_read synchronises those events and returns the mean launch time.
-int spd_model_profile(spd_model_handle m, int enable) {
+// Profiling with HIP events on the launch stream.  Level 1: every step brackets its 91*M-field spec2grid launch (the
+// roofline kernel of bench.py); level 2: every kernel of the step is bracketed (the events serialise nothing, but each
+// bracket adds a few microseconds between launches, so level 2 is for a separate measurement pass, not for the timed region).
+int spd_model_profile(spd_model_handle m, int level) {
     if (!m) return m_fail(SPD_E_ARG, "spd_model_profile: null model");
-    m->profile = enable != 0;
+    if (level < 0 || level > 2) return m_fail(SPD_E_ARG, "spd_model_profile: level is 0, 1 or 2");
+    m->profile = level;
     m->prof_used = 0;
     return SPD_OK;
 }
@@ -794,15 +831,42 @@ int spd_model_profile(spd_model_handle m, int enable) {
 int spd_model_profile_read(spd_model_handle m, double *mean_ms, int *launches, int *fields_per_launch) {
     if (!m || !mean_ms || !launches || !fields_per_launch) return m_fail(SPD_E_ARG, "spd_model_profile_read: null argument");
     double sum = 0.0;
+    int n = 0, fields = m->inv_per_member * m->M;
     for (size_t i = 0; i < m->prof_used; ++i) {
+        if (m->prof_kernel[i] != SPD_K_SPEC2GRID) continue;
         float ms = 0.f;
         M_HIP(hipEventSynchronize(m->prof_events[i].second));
         M_HIP(hipEventElapsedTime(&ms, m->prof_events[i].first, m->prof_events[i].second));
         sum += ms;
+        if (n == 0) fields = m->prof_fields[i];
+        ++n;
     }
-    *launches = static_cast<int>(m->prof_used);
-    *mean_ms = m->prof_used ? sum / m->prof_used : 0.0;
-    *fields_per_launch = m->prof_used ? m->prof_fields[0] : m->inv_per_member * m->M;
+    *launches = n;
+    *mean_ms = n ? sum / n : 0.0;
+    *fields_per_launch = fields;
+    return SPD_OK;
+}
+
+// per kernel id (SPD_K_*): mean and minimum bracket time in ms, number of brackets, units (fields or members) per bracket
+int spd_model_profile_read_kernels(spd_model_handle m, double *mean_ms, double *min_ms, int *launches, int *units) {
+    if (!m || !mean_ms || !min_ms || !launches || !units) return m_fail(SPD_E_ARG, "spd_model_profile_read_kernels: null argument");
+    for (int k = 0; k < SPD_K_COUNT; ++k) {
+        mean_ms[k] = min_ms[k] = 0.0;
+        launches[k] = units[k] = 0;
+    }
+    for (size_t i = 0; i < m->prof_used; ++i) {
+        const int k = m->prof_kernel[i];
+        if (k < 0 || k >= SPD_K_COUNT) continue;
+        float ms = 0.f;
+        M_HIP(hipEventSynchronize(m->prof_events[i].second));
+        M_HIP(hipEventElapsedTime(&ms, m->prof_events[i].first, m->prof_events[i].second));
+        mean_ms[k] += ms;
+        if (launches[k] == 0 || ms < min_ms[k]) min_ms[k] = ms;
+        units[k] = m->prof_fields[i];
+        ++launches[k];
+    }
+    for (int k = 0; k < SPD_K_COUNT; ++k)
+        if (launches[k]) mean_ms[k] /= launches[k];
     return SPD_OK;
 }
 
@@ -815,9 +879,60 @@ int spd_model_mark_initialized(spd_model_handle m, int current_step, int year, i
     return SPD_OK;
 }
 
+int spd_model_get_control(spd_model_handle m, spd_model_control *out) {
+    if (!m || !out) return m_fail(SPD_E_ARG, "spd_model_get_control: null argument");
+    spd_model_control c{};
+    c.current_step = m->current_step;
+    c.year = m->cal.year; c.month = m->cal.month; c.day = m->cal.day; c.hour = m->cal.hour; c.minute = m->cal.minute;
+    c.month_idx = m->cal.month_idx;
+    c.land_coupling_flag = m->land_coupling_flag;
+    c.sst_anomaly_coupling_flag = m->sst_anomaly_flag;
+    c.increase_co2 = m->increase_co2;
+    c.sppt_on = m->sppt_on ? 1 : 0;
+    c.sppt_first = m->sppt_first ? 1 : 0;
+    c.physics_fp32 = m->phys_fp32;
+    c.sppt_step = m->sppt_step;
+    c.sppt_first_member_id = m->sppt_member_base;
+    c.sppt_seed = m->sppt_seed;
+    c.air_absortivity_co2 = m->air_absortivity_co2;
+    c.ablco2_ref = m->ablco2_ref;
+    *out = c;
+    return SPD_OK;
+}
+
+int spd_model_set_control(spd_model_handle m, const spd_model_control *in) {
+    if (!m || !in) return m_fail(SPD_E_ARG, "spd_model_set_control: null argument");
+    if (in->month < 1 || in->month > 12 || in->day < 1 || in->day > 31 || in->month_idx < 1 || in->current_step < 0)
+        return m_fail(SPD_E_ARG, "spd_model_set_control: bad date, month index or step counter");
+    if (in->sppt_on && !m->sppt_spec)
+        return m_fail(SPD_E_ARG, "spd_model_set_control: SPPT is on in the control block: call spd_model_set_sppt and load sppt_spec first");
+    m->cal.set(in->year, in->month, in->day, in->hour, in->minute);
+    m->cal.month_idx = in->month_idx;
+    m->current_step = in->current_step;
+    m->land_coupling_flag = in->land_coupling_flag ? 1 : 0;
+    m->sst_anomaly_flag = in->sst_anomaly_coupling_flag ? 1 : 0;
+    m->increase_co2 = in->increase_co2 ? 1 : 0;
+    m->sppt_on = in->sppt_on != 0;
+    m->sppt_first = in->sppt_first != 0;
+    m->phys_fp32 = in->physics_fp32 ? 1 : 0;
+    m->sppt_step = in->sppt_step;
+    m->sppt_member_base = in->sppt_first_member_id;
+    m->sppt_seed = in->sppt_seed;
+    m->air_absortivity_co2 = in->air_absortivity_co2;
+    m->ablco2_ref = in->ablco2_ref;
+    m->initialized = true;
+    return SPD_OK;
+}
+
 int spd_model_get_date(spd_model_handle m, int *ymdhm) {
     if (!m || !ymdhm) return m_fail(SPD_E_ARG, "spd_model_get_date: null argument");
     ymdhm[0] = m->cal.year; ymdhm[1] = m->cal.month; ymdhm[2] = m->cal.day; ymdhm[3] = m->cal.hour; ymdhm[4] = m->cal.minute;
+    return SPD_OK;
+}
+
+int spd_model_set_physics_precision(spd_model_handle m, int fp32) {
+    if (!m) return m_fail(SPD_E_ARG, "spd_model_set_physics_precision: null model");
+    m->phys_fp32 = fp32 ? 1 : 0;
     return SPD_OK;
 }
 

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "../../include/pyspeedy_amd.h"
 #include "device_tables.hpp"
@@ -33,35 +34,78 @@ namespace {
 constexpr int NG = IX * IL;  // columns per member
 constexpr int kPhysThreads = 64;
 
-// physical_constants.f90 / mod_radcon.f90
-__device__ constexpr double P0 = 1.e+5f, CP = 1004.0f, GRAV = 9.81f, ALHC = 2501.0f, SBC = 5.67e-8f;
-__device__ constexpr double AKAP = 2.0f / 7.0f;
-__device__ constexpr double RGAS = AKAP * CP;
-__device__ constexpr double EPSLW = 0.05f, EMISFC = 0.98f;
+// Arithmetic type of the column physics: R = double reproduces the reference (fp64 everywhere); R = float is BASELINE cfg 5's
+// mixed precision -- state, dynamics tendencies and every array in memory stay fp64, the column arithmetic runs in fp32 and
+// the physics increment is added to the fp64 dynamics tendency at the end.
+//
+// physical_constants.f90 / mod_radcon.f90: default-real literals, widened for R = double as the Fortran does
+template <typename R>
+struct PhysConst {
+    static constexpr R P0 = 1.e+5f, CP = 1004.0f, GRAV = 9.81f, ALHC = 2501.0f, SBC = 5.67e-8f;
+    static constexpr R AKAP = static_cast<R>(2.0f / 7.0f);
+    static constexpr R RGAS = AKAP * CP;
+    static constexpr R EPSLW = 0.05f, EMISFC = 0.98f;
+};
 
-__device__ inline double dmin(double a, double b) { return a < b ? a : b; }
-__device__ inline double dmax(double a, double b) { return a > b ? a : b; }
-__device__ inline double pow3(double x) { return (x * x) * x; }
-__device__ inline double pow4(double x) { const double x2 = x * x; return x2 * x2; }
+template <typename R> __device__ __forceinline__ R rmin(R a, R b) { return a < b ? a : b; }
+template <typename R> __device__ __forceinline__ R rmax(R a, R b) { return a > b ? a : b; }
+template <typename R> __device__ __forceinline__ R pow3(R x) { return (x * x) * x; }
+template <typename R> __device__ __forceinline__ R pow4(R x) { const R x2 = x * x; return x2 * x2; }
+__device__ __forceinline__ double rexp(double x) { return exp(x); }
+__device__ __forceinline__ float rexp(float x) { return expf(x); }
+__device__ __forceinline__ double rsqrt_(double x) { return sqrt(x); }
+__device__ __forceinline__ float rsqrt_(float x) { return sqrtf(x); }
+__device__ __forceinline__ int rnint(double x) { return static_cast<int>(round(x)); }
+__device__ __forceinline__ int rnint(float x) { return static_cast<int>(roundf(x)); }
 
 // humidity.f90:44-78 for one point, P = sig * ps
-__device__ inline double qsat_point(double ta, double p) {
-    const double e0 = 6.108e-3, c1 = 17.269f, c2 = 21.875f, t0 = 273.16f, t1 = 35.86f, t2 = 7.66f;
-    const double e = (ta >= t0) ? e0 * exp(c1 * (ta - t0) / (ta - t1)) : e0 * exp(c2 * (ta - t0) / (ta - t2));
-    return 622.0f * e / (p - 0.378f * e);
+template <typename R>
+__device__ __forceinline__ R qsat_point(R ta, R p) {
+    const R e0 = static_cast<R>(6.108e-3), c1 = 17.269f, c2 = 21.875f, t0 = 273.16f, t1 = 35.86f, t2 = 7.66f;
+    const R e = (ta >= t0) ? e0 * rexp(c1 * (ta - t0) / (ta - t1)) : e0 * rexp(c2 * (ta - t0) / (ta - t2));
+    return R(622.0f) * e / (p - R(0.378f) * e);
 }
 
 // fband(nint(T), band): the reference does not clamp (model_state_def.py:425-430 sizes the table 100:400);
 // the clamp below only matters where the reference would read out of bounds.
-__device__ inline double fband_at(const double *fband, double temp, int band /*0-based*/) {
-    int it = static_cast<int>(round(temp));
+template <typename R>
+__device__ __forceinline__ R fband_at(const R *fband, R temp, int band /*0-based*/) {
+    int it = rnint(temp);
     it = it < 100 ? 100 : (it > 400 ? 400 : it);
     return fband[(it - 100) + 301 * band];
 }
 
-struct Col {  // per-column pointers resolved once
-    size_t p2;  // offset of this column in a (ix,il) plane array of this member: m*NG + p
+// the vertical-structure tables of DeviceTables in the arithmetic type of the kernel (built per launch on the host)
+template <typename R>
+struct ColTables {
+    R fsg[8], dhs[8], sigl[8], sigh[9], grdsig[8], grdscp[8], wvi[16];
+    const R *fband;  // (301,4)
+    const R *coa;    // 48, cos(latitude)
 };
+
+template <typename R> struct TablePtrs;
+template <> struct TablePtrs<double> {
+    static const double *fband(const DeviceTables &T) { return T.fband; }
+    static const double *coa(const DeviceTables &T) { return T.coa; }
+};
+template <> struct TablePtrs<float> {
+    static const float *fband(const DeviceTables &T) { return T.fband32; }
+    static const float *coa(const DeviceTables &T) { return T.coa32; }
+};
+
+template <typename R>
+ColTables<R> col_tables(const DeviceTables &T) {
+    ColTables<R> c;
+    for (int k = 0; k < 8; ++k) {
+        c.fsg[k] = static_cast<R>(T.fsg[k]); c.dhs[k] = static_cast<R>(T.dhs[k]); c.sigl[k] = static_cast<R>(T.sigl[k]);
+        c.grdsig[k] = static_cast<R>(T.grdsig[k]); c.grdscp[k] = static_cast<R>(T.grdscp[k]);
+    }
+    for (int k = 0; k < 9; ++k) c.sigh[k] = static_cast<R>(T.sigh[k]);
+    for (int k = 0; k < 16; ++k) c.wvi[k] = static_cast<R>(T.wvi[k]);
+    c.fband = TablePtrs<R>::fband(T);
+    c.coa = TablePtrs<R>::coa(T);
+    return c;
+}
 
 }  // namespace
 
@@ -72,11 +116,26 @@ struct Col {  // per-column pointers resolved once
 // temperature / humidity tendencies it produces in registers -- the physics adds to exactly those -- so they are written
 // once instead of written by one kernel and read and re-written by the next (the model step; 36 field moves per member
 // less).  Not FUSED: the tendencies are read from a.ttend / a.qtend / a.utend / a.vtend (the C ABI's spd_physics).
-template <int W, bool FUSED>
-__global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_args a, DeviceTables T, int first, int nmembers,
+// KEEP (FUSED only): the dynamics' temperature tendencies stay in LDS until the end of the kernel -- needed when the result is
+// not simply "dynamics + physics summed in R": mixed precision (R = float) and SPPT both combine the fp64 dynamics
+// tendency with the physics increment at the end.
+template <int W, bool FUSED, bool KEEP, typename R>
+__global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_args a, ColTables<R> CT, int first, int nmembers,
                                                                   ModelPtrs MP, DynDeviceTables MD) {
-    // rad_tau2 of this lane's column while the two longwave sweeps run: [band * 8 + level][lane], 16 KB per wavefront
-    __shared__ double tau_s[4 * KX][kPhysThreads];
+    using C = PhysConst<R>;
+    constexpr bool MIXED = !std::is_same<R, double>::value;
+    static_assert(!KEEP || FUSED, "KEEP is a variant of the fused kernel");
+    static_assert(!(MIXED && FUSED) || KEEP, "the fused mixed-precision kernel keeps the fp64 dynamics tendencies");
+    // LDS of the wavefront.  tau: rad_tau2 of this lane's column while the two longwave sweeps run, [band * 8 + level][lane].
+    // park_t / park_q: the dynamics' T / q tendencies (fp64) from the end of the dynamics phase until the condensation
+    // scheme picks them up; they alias tau (dead by then) except for park_t under KEEP, which lives to the end.
+    constexpr int kRowD = kPhysThreads * sizeof(double);
+    constexpr int kTauBytes = 4 * KX * kPhysThreads * sizeof(R), kKeepBytes = KEEP ? KX * kRowD : 0;
+    constexpr int kAliasBytes = (KEEP ? 1 : 2) * KX * kRowD;  // parked tendencies that share the tau area
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kKeepBytes + (kTauBytes > kAliasBytes ? kTauBytes : kAliasBytes)];
+    R(*tau_s)[kPhysThreads] = reinterpret_cast<R(*)[kPhysThreads]>(smem + kKeepBytes);
+    double(*park_t)[kPhysThreads] = reinterpret_cast<double(*)[kPhysThreads]>(smem);
+    double(*park_q)[kPhysThreads] = reinterpret_cast<double(*)[kPhysThreads]>(smem + KX * kRowD);
     const int gid = blockIdx.x * kPhysThreads + threadIdx.x;
     if (gid >= nmembers * NG) return;
     const int lmem = gid / NG, mem = first + lmem, p = gid - lmem * NG, j = p / IX;  // members [first, first + nmembers)
@@ -91,52 +150,65 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
     constexpr int nl1 = KX - 1;  // 1-based index of the level above the lowest; 0-based index nl1-1
 
     // ------------------------------------------------------------------ tendencies so far (dynamics)
-    // FUSED: computed here and parked in LDS (the rows tau_s uses later) until the condensation scheme picks them up,
-    // so that they do not occupy 32 VGPRs through the convection scheme, the register peak of the kernel.
+    // FUSED: computed here and parked in LDS until the condensation scheme picks them up, so that they do not occupy 32
+    // VGPRs through the convection scheme, the register peak of the kernel.
     double utend_dyn = 0.0, vtend_dyn = 0.0;
     if (FUSED) {
         double tt[KX], qt[KX];
         dyn_column<false>(MP, MD, mem, p, j, tt, qt, utend_dyn, vtend_dyn);
 #pragma unroll
         for (int k = 0; k < KX; ++k) {
-            tau_s[k][lane] = tt[k];
-            tau_s[KX + k][lane] = qt[k];
+            park_t[k][lane] = tt[k];
+            park_q[k][lane] = qt[k];
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the physics' loads below: the two phases must not add their registers
     }
+    // SPPT (physics.f90:234-248, csrc/sppt.hip): tend = (1 + r mu(k)) (tend - tend_dyn) + tend_dyn with mu = 1, r clipped to
+    // [-1, 1] (sppt.f90:112).  `finish` turns what the physics accumulated for one (variable, level) into the value that is
+    // stored: acc is the full tendency (dynamics + physics) for R = double and the physics increment alone when MIXED.
+    const bool sppt = a.sppt_pattern != nullptr;
+    const bool need_dyn = MIXED || sppt;  // the dynamics-only tendency is needed again when the result is stored
+    auto finish = [&](R acc, double dyn, int k) -> double {
+        if (sppt) {
+            const double r = a.sppt_pattern[o3 + NG * k];
+            const double rc = (r < -1.0) ? -1.0 : (r > 1.0 ? 1.0 : r);
+            return MIXED ? dyn + (1.0 + rc) * static_cast<double>(acc) : (1.0 + rc) * (static_cast<double>(acc) - dyn) + dyn;
+        }
+        return MIXED ? dyn + static_cast<double>(acc) : static_cast<double>(acc);
+    };
 
     // ------------------------------------------------------------------ thermodynamics, physics.f90:107-116
-    double ta[KX], qa[KX], phi[KX], se[KX], qsat[KX], rh[KX];
-    const double psa = exp(a.pslg[o2]);
-    const double rps = 1.0f / psa;
+    R ta[KX], qa[KX], phi[KX], se[KX], qsat[KX], rh[KX];
+    const R psa = rexp(R(a.pslg[o2]));
+    const R rps = 1.0f / psa;
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
-        ta[k] = stream_load(&a.tg[o3 + NG * k]);
-        qa[k] = dmax(stream_load(&a.qg[o3 + NG * k]), 0.0f);
-        phi[k] = stream_load(&a.phig[o3 + NG * k]);
-        se[k] = CP * ta[k] + phi[k];
-        qsat[k] = qsat_point(ta[k], T.fsg[k] * psa);
+        ta[k] = R(stream_load(&a.tg[o3 + NG * k]));
+        qa[k] = rmax<R>(R(stream_load(&a.qg[o3 + NG * k])), 0.0f);
+        phi[k] = R(stream_load(&a.phig[o3 + NG * k]));
+        se[k] = C::CP * ta[k] + phi[k];
+        qsat[k] = qsat_point<R>(ta[k], CT.fsg[k] * psa);
         rh[k] = qa[k] / qsat[k];
     }
     // ------------------------------------------------------------------ deep convection, convection.f90
-    const double psmin = 0.8f, trcnv = 6.0f, rhbl = 0.9f, rhil = 0.7f, entmax = 0.5f, smf = 0.8f;
+    const R psmin = 0.8f, trcnv = 6.0f, rhbl = 0.9f, rhil = 0.7f, entmax = 0.5f, smf = 0.8f;
     int itop = KX + 1;
-    double qdif = 0.0, cbmf = 0.0, precnv = 0.0;
-    double dfse[KX], dfqa[KX];
+    R qdif = R(0.0f), cbmf = R(0.0f), precnv = R(0.0f);
+    R dfse[KX], dfqa[KX];
 #pragma unroll
-    for (int k = 0; k < KX; ++k) dfse[k] = dfqa[k] = 0.0;
+    for (int k = 0; k < KX; ++k) dfse[k] = dfqa[k] = R(0.0f);
     if (psa > psmin) {  // diagnose_convection, convection.f90:170-253
-        const double mse0 = se[KX - 1] + ALHC * qa[KX - 1];
-        double mse1 = se[nl1 - 1] + ALHC * qa[nl1 - 1];
-        mse1 = dmin(mse0, mse1);
-        const double mss_kx = se[KX - 1] + ALHC * qsat[KX - 1];
-        const double mss0 = dmax(mse0, mss_kx);
+        const R mse0 = se[KX - 1] + C::ALHC * qa[KX - 1];
+        R mse1 = se[nl1 - 1] + C::ALHC * qa[nl1 - 1];
+        mse1 = rmin<R>(mse0, mse1);
+        const R mss_kx = se[KX - 1] + C::ALHC * qsat[KX - 1];
+        const R mss0 = rmax<R>(mse0, mss_kx);
         int ktop1 = KX, ktop2 = KX;
-        double msthr = 0.0;
+        R msthr = R(0.0f);
 #pragma unroll
         for (int k = KX - 3; k >= 3; --k) {  // 1-based k
-            const double mss_k = se[k - 1] + ALHC * qsat[k - 1], mss_k1 = se[k] + ALHC * qsat[k];
-            const double mss2 = mss_k + T.wvi[8 + k - 1] * (mss_k1 - mss_k);
+            const R mss_k = se[k - 1] + C::ALHC * qsat[k - 1], mss_k1 = se[k] + C::ALHC * qsat[k];
+            const R mss2 = mss_k + CT.wvi[8 + k - 1] * (mss_k1 - mss_k);
             if (mss0 > mss2) ktop1 = k;
             if (mse1 > mss2) {
                 ktop2 = k;
@@ -144,11 +216,11 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
             }
         }
         if (ktop1 < KX) {
-            const double qthr0 = rhbl * qsat[KX - 1], qthr1 = rhbl * qsat[nl1 - 1];
+            const R qthr0 = rhbl * qsat[KX - 1], qthr1 = rhbl * qsat[nl1 - 1];
             const bool lqthr = (qa[KX - 1] > qthr0) && (qa[nl1 - 1] > qthr1);
             if (ktop2 < KX) {
                 itop = ktop1;
-                qdif = dmax(qa[KX - 1] - qthr0, (mse0 - msthr) * (1.0 / ALHC));
+                qdif = rmax<R>(qa[KX - 1] - qthr0, (mse0 - msthr) * (R(1.0f) / C::ALHC));
             } else if (lqthr) {
                 itop = ktop1;
                 qdif = qa[KX - 1] - qthr0;
@@ -156,14 +228,14 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         }
     }
     if (itop != KX + 1) {  // convection.f90:78-156
-        const double fqmax = 5.0f;
-        const double fm0 = P0 * T.dhs[KX - 1] / (GRAV * trcnv * 3600.0f);
-        const double rdps = 2.0f / (1.0f - psmin);
-        double entr[KX];  // entr(2:kx-1), 0-based index k-1
-        double sentr = 0.0;
+        const R fqmax = 5.0f;
+        const R fm0 = C::P0 * CT.dhs[KX - 1] / (C::GRAV * trcnv * 3600.0f);
+        const R rdps = 2.0f / (1.0f - psmin);
+        R entr[KX];  // entr(2:kx-1), 0-based index k-1
+        R sentr = R(0.0f);
 #pragma unroll
         for (int k = 2; k <= nl1; ++k) {
-            const double d = dmax(0.0f, T.fsg[k - 1] - 0.5f);
+            const R d = rmax<R>(0.0f, CT.fsg[k - 1] - 0.5f);
             entr[k - 1] = d * d;
             sentr = sentr + entr[k - 1];
         }
@@ -171,16 +243,16 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
 #pragma unroll
         for (int k = 2; k <= nl1; ++k) entr[k - 1] = entr[k - 1] * sentr;
 
-        const double wv_nl1 = T.wvi[8 + nl1 - 1];
-        const double qmax = dmax(1.01f * qa[KX - 1], qsat[KX - 1]);
-        double sb = se[nl1 - 1] + wv_nl1 * (se[KX - 1] - se[nl1 - 1]);
-        double qb = qa[nl1 - 1] + wv_nl1 * (qa[KX - 1] - qa[nl1 - 1]);
-        qb = dmin(qb, qa[KX - 1]);
-        const double fpsa = psa * dmin(1.0f, (psa - psmin) * rdps);
-        double fmass = fm0 * fpsa * dmin(fqmax, qdif / (qmax - qb));
+        const R wv_nl1 = CT.wvi[8 + nl1 - 1];
+        const R qmax = rmax<R>(1.01f * qa[KX - 1], qsat[KX - 1]);
+        R sb = se[nl1 - 1] + wv_nl1 * (se[KX - 1] - se[nl1 - 1]);
+        R qb = qa[nl1 - 1] + wv_nl1 * (qa[KX - 1] - qa[nl1 - 1]);
+        qb = rmin<R>(qb, qa[KX - 1]);
+        const R fpsa = psa * rmin<R>(1.0f, (psa - psmin) * rdps);
+        R fmass = fm0 * fpsa * rmin<R>(fqmax, qdif / (qmax - qb));
         cbmf = fmass;
-        double fus = fmass * se[KX - 1], fuq = fmass * qmax;
-        double fds = fmass * sb, fdq = fmass * qb;
+        R fus = fmass * se[KX - 1], fuq = fmass * qmax;
+        R fds = fmass * sb, fdq = fmass * qb;
         dfse[KX - 1] = fds - fus;
         dfqa[KX - 1] = fdq - fuq;
 #pragma unroll
@@ -188,40 +260,40 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
             if (k >= itop + 1) {
                 dfse[k - 1] = fus - fds;
                 dfqa[k - 1] = fuq - fdq;
-                const double enmass = entr[k - 1] * psa * cbmf;
+                const R enmass = entr[k - 1] * psa * cbmf;
                 fmass = fmass + enmass;
                 fus = fus + enmass * se[k - 1];
                 fuq = fuq + enmass * qa[k - 1];
-                const double wv = T.wvi[8 + k - 2];
+                const R wv = CT.wvi[8 + k - 2];
                 sb = se[k - 2] + wv * (se[k - 1] - se[k - 2]);
                 qb = qa[k - 2] + wv * (qa[k - 1] - qa[k - 2]);
                 fds = fmass * sb;
                 fdq = fmass * qb;
                 dfse[k - 1] = dfse[k - 1] + fds - fus;
                 dfqa[k - 1] = dfqa[k - 1] + fdq - fuq;
-                const double delq = rhil * qsat[k - 1] - qa[k - 1];
-                if (delq > 0.0) {
-                    const double fsq = smf * cbmf * delq;
+                const R delq = rhil * qsat[k - 1] - qa[k - 1];
+                if (delq > R(0.0f)) {
+                    const R fsq = smf * cbmf * delq;
                     dfqa[k - 1] = dfqa[k - 1] + fsq;
                     dfqa[KX - 1] = dfqa[KX - 1] - fsq;
                 }
             }
         }
         // top layer k = itop (3 <= itop <= kx-3): static indexing through a select chain keeps arrays in registers
-        double qs_t = 0.0, qs_t1 = 0.0, wv_t = 0.0;
+        R qs_t = R(0.0f), qs_t1 = R(0.0f), wv_t = R(0.0f);
 #pragma unroll
         for (int k = 3; k <= KX - 3; ++k)
             if (k == itop) {
                 qs_t = qsat[k - 1];
                 qs_t1 = qsat[k];
-                wv_t = T.wvi[8 + k - 1];
+                wv_t = CT.wvi[8 + k - 1];
             }
-        const double qsatb = qs_t + wv_t * (qs_t1 - qs_t);
-        precnv = dmax(fuq - fmass * qsatb, 0.0);
+        const R qsatb = qs_t + wv_t * (qs_t1 - qs_t);
+        precnv = rmax<R>(fuq - fmass * qsatb, R(0.0f));
 #pragma unroll
         for (int k = 3; k <= KX - 3; ++k)
             if (k == itop) {
-                dfse[k - 1] = fus - fds + ALHC * precnv;
+                dfse[k - 1] = fus - fds + C::ALHC * precnv;
                 dfqa[k - 1] = fuq - fdq - precnv;
             }
     }
@@ -231,98 +303,98 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
     int iptop = itop;
 
     // ------------------------------------------------------------------ large-scale condensation
-    double ttend[KX], qtend[KX];
+    R ttend[KX], qtend[KX];
 #pragma unroll
-    for (int k = 0; k < KX; ++k) {
-        ttend[k] = FUSED ? tau_s[k][lane] : a.ttend[o3 + NG * k];
-        qtend[k] = FUSED ? tau_s[KX + k][lane] : a.qtend[o3 + NG * k];
+    for (int k = 0; k < KX; ++k) {  // R = double: the physics adds to the dynamics' tendencies; MIXED: it starts from zero
+        ttend[k] = MIXED ? R(0.0f) : static_cast<R>(FUSED ? park_t[k][lane] : R(a.ttend[o3 + NG * k]));
+        qtend[k] = MIXED ? R(0.0f) : static_cast<R>(FUSED ? park_q[k][lane] : R(a.qtend[o3 + NG * k]));
     }
-    double precls = 0.0;
+    R precls = R(0.0f);
     {
-        const double trlsc = 4.0f, rhlsc = 0.9f, drhlsc = 0.1f, rhblsc = 0.95f, qsmax = 10.0f;
-        const double rtlsc = 1.0f / (trlsc * 3600.0f), tfact = ALHC / CP, prg = P0 / GRAV;
-        const double psa2 = psa * psa;
+        const R trlsc = 4.0f, rhlsc = 0.9f, drhlsc = 0.1f, rhblsc = 0.95f, qsmax = 10.0f;
+        const R rtlsc = 1.0f / (trlsc * 3600.0f), tfact = C::ALHC / C::CP, prg = C::P0 / C::GRAV;
+        const R psa2 = psa * psa;
 #pragma unroll
         for (int k = 2; k <= KX; ++k) {
-            const double sig2 = T.fsg[k - 1] * T.fsg[k - 1];
-            double rhref = rhlsc + drhlsc * (sig2 - 1.0f);
-            if (k == KX) rhref = dmax(rhref, rhblsc);
-            const double dqmax = qsmax * sig2 * rtlsc;
-            const double dqa = rhref * qsat[k - 1] - qa[k - 1];
-            double dq = 0.0, dt = 0.0;
-            if (dqa < 0.0) {
+            const R sig2 = CT.fsg[k - 1] * CT.fsg[k - 1];
+            R rhref = rhlsc + drhlsc * (sig2 - 1.0f);
+            if (k == KX) rhref = rmax<R>(rhref, rhblsc);
+            const R dqmax = qsmax * sig2 * rtlsc;
+            const R dqa = rhref * qsat[k - 1] - qa[k - 1];
+            R dq = R(0.0f), dt = R(0.0f);
+            if (dqa < R(0.0f)) {
                 iptop = k < iptop ? k : iptop;
                 dq = dqa * rtlsc;
-                dt = tfact * dmin(-dq, dqmax * psa2);
+                dt = tfact * rmin<R>(-dq, dqmax * psa2);
             }
             // physics.f90:127-130, 138-139: ttend = ttend + tt_cnv + tt_lsc
-            ttend[k - 1] = ttend[k - 1] + dfse[k - 1] * rps * T.grdscp[k - 1] + dt;
-            qtend[k - 1] = qtend[k - 1] + dfqa[k - 1] * rps * T.grdsig[k - 1] + dq;
-            precls = precls - (T.dhs[k - 1] * prg) * dq;
+            ttend[k - 1] = ttend[k - 1] + dfse[k - 1] * rps * CT.grdscp[k - 1] + dt;
+            qtend[k - 1] = qtend[k - 1] + dfqa[k - 1] * rps * CT.grdsig[k - 1] + dq;
+            precls = precls - (CT.dhs[k - 1] * prg) * dq;
         }
         // level 1: tt_cnv(1) = dfse(1) (unscaled, zero), tt_lsc(1) = 0
-        ttend[0] = ttend[0] + dfse[0] + 0.0;
-        qtend[0] = qtend[0] + dfqa[0] + 0.0;
+        ttend[0] = ttend[0] + dfse[0] + R(0.0f);
+        qtend[0] = qtend[0] + dfqa[0] + R(0.0f);
         precls = precls * psa;
     }
     stream_store(&a.precls[o2], precls);
 
-    const double gse = (se[nl1 - 1] - se[KX - 1]) / (phi[nl1 - 1] - phi[KX - 1]);  // physics.f90:152 (used on shortwave steps)
-    const double phi_kx = phi[KX - 1];
+    const R gse = (se[nl1 - 1] - se[KX - 1]) / (phi[nl1 - 1] - phi[KX - 1]);  // physics.f90:152 (used on shortwave steps)
+    const R phi_kx = phi[KX - 1];
     // ------------------------------------------------------------------ vertical diffusion (vertical_diffusion.f90)
     // Evaluated here, right after the moist schemes, although the reference calls it after the radiation: it only
     // depends on se, rh, qa, qsat, phi and icnv, and computing it now lets those 40 per-column values die before the
     // register-hungry radiation sweeps.  Its tendencies are ADDED in the reference's order at the end.
-    const double trshc = 6.0f, trvdi = 24.0f, trvds = 6.0f, redshc = 0.5f, rhgrad = 0.5f, segrad = 0.1f;
-    const double cshc = T.dhs[KX - 1] / 3600.0f;
-    const double cvdi = (T.sigh[nl1] - T.sigh[1]) / (static_cast<float>(nl1 - 1) * 3600.0f);
-    const double fshcq = cshc / trshc, fshcse = cshc / (trshc * CP);
-    const double fvdiq = cvdi / trvdi, fvdise = cvdi / (trvds * CP);
-    double ttv[KX], qtv[KX];
+    const R trshc = 6.0f, trvdi = 24.0f, trvds = 6.0f, redshc = 0.5f, rhgrad = 0.5f, segrad = 0.1f;
+    const R cshc = CT.dhs[KX - 1] / 3600.0f;
+    const R cvdi = (CT.sigh[nl1] - CT.sigh[1]) / (static_cast<float>(nl1 - 1) * 3600.0f);
+    const R fshcq = cshc / trshc, fshcse = cshc / (trshc * C::CP);
+    const R fvdiq = cvdi / trvdi, fvdise = cvdi / (trvds * C::CP);
+    R ttv[KX], qtv[KX];
 #pragma unroll
-    for (int k = 0; k < KX; ++k) ttv[k] = qtv[k] = 0.0;
+    for (int k = 0; k < KX; ++k) ttv[k] = qtv[k] = R(0.0f);
     {
-        const double rs_nl1 = 1.0f / T.dhs[nl1 - 1], rs_kx = 1.0f / T.dhs[KX - 1];
-        const double drh0 = rhgrad * (T.fsg[KX - 1] - T.fsg[nl1 - 1]);
-        const double fvdiq2 = fvdiq * T.sigh[nl1];
-        const double dmse = se[KX - 1] - se[nl1 - 1] + ALHC * (qa[KX - 1] - qsat[nl1 - 1]);
-        const double drh = rh[KX - 1] - rh[nl1 - 1];
-        if (dmse >= 0.0) {
-            const double fcnv = (icnv > 0) ? redshc : static_cast<double>(1.0f);
-            const double fluxse = fcnv * fshcse * dmse;
+        const R rs_nl1 = 1.0f / CT.dhs[nl1 - 1], rs_kx = 1.0f / CT.dhs[KX - 1];
+        const R drh0 = rhgrad * (CT.fsg[KX - 1] - CT.fsg[nl1 - 1]);
+        const R fvdiq2 = fvdiq * CT.sigh[nl1];
+        const R dmse = se[KX - 1] - se[nl1 - 1] + C::ALHC * (qa[KX - 1] - qsat[nl1 - 1]);
+        const R drh = rh[KX - 1] - rh[nl1 - 1];
+        if (dmse >= R(0.0f)) {
+            const R fcnv = (icnv > 0) ? redshc : static_cast<R>(1.0f);
+            const R fluxse = fcnv * fshcse * dmse;
             ttv[nl1 - 1] = fluxse * rs_nl1;
             ttv[KX - 1] = -fluxse * rs_kx;
-            if (drh >= 0.0) {
-                const double fluxq = fcnv * fshcq * qsat[KX - 1] * drh;
+            if (drh >= R(0.0f)) {
+                const R fluxq = fcnv * fshcq * qsat[KX - 1] * drh;
                 qtv[nl1 - 1] = fluxq * rs_nl1;
                 qtv[KX - 1] = -fluxq * rs_kx;
             }
         } else if (drh > drh0) {
-            const double fluxq = fvdiq2 * qsat[nl1 - 1] * drh;
+            const R fluxq = fvdiq2 * qsat[nl1 - 1] * drh;
             qtv[nl1 - 1] = fluxq * rs_nl1;
             qtv[KX - 1] = -fluxq * rs_kx;
         }
     }
 #pragma unroll
     for (int k = 3; k <= KX - 2; ++k) {
-        if (T.sigh[k] > 0.5f) {
-            const double drh0 = rhgrad * (T.fsg[k] - T.fsg[k - 1]);
-            const double fvdiq2 = fvdiq * T.sigh[k];
-            const double drh = rh[k] - rh[k - 1];
+        if (CT.sigh[k] > 0.5f) {
+            const R drh0 = rhgrad * (CT.fsg[k] - CT.fsg[k - 1]);
+            const R fvdiq2 = fvdiq * CT.sigh[k];
+            const R drh = rh[k] - rh[k - 1];
             if (drh >= drh0) {
-                const double fluxq = fvdiq2 * qsat[k - 1] * drh;
-                qtv[k - 1] = qtv[k - 1] + fluxq * (1.0f / T.dhs[k - 1]);
-                qtv[k] = qtv[k] - fluxq * (1.0f / T.dhs[k]);
+                const R fluxq = fvdiq2 * qsat[k - 1] * drh;
+                qtv[k - 1] = qtv[k - 1] + fluxq * (1.0f / CT.dhs[k - 1]);
+                qtv[k] = qtv[k] - fluxq * (1.0f / CT.dhs[k]);
             }
         }
     }
 #pragma unroll
     for (int k = 1; k <= nl1; ++k) {
-        const double se0 = se[k] + segrad * (phi[k - 1] - phi[k]);
+        const R se0 = se[k] + segrad * (phi[k - 1] - phi[k]);
         if (se[k - 1] < se0) {
-            const double fluxse = fvdise * (se0 - se[k - 1]);
-            ttv[k - 1] = ttv[k - 1] + fluxse * (1.0f / T.dhs[k - 1]);
-            const double r1 = 1.0f / (1.0f - T.sigh[k]);
+            const R fluxse = fvdise * (se0 - se[k - 1]);
+            ttv[k - 1] = ttv[k - 1] + fluxse * (1.0f / CT.dhs[k - 1]);
+            const R r1 = 1.0f / (1.0f - CT.sigh[k]);
 #pragma unroll
             for (int k1 = k + 1; k1 <= KX; ++k1) ttv[k1 - 1] = ttv[k1 - 1] - fluxse * r1;
         }
@@ -336,95 +408,95 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         ttend[k] = ttend[k] + ttv[k];
         qtend[k] = qtend[k] + qtv[k];
     }
-    // SPPT (physics.f90:234-248, csrc/sppt.hip): tend = (1 + r mu(k)) (tend - tend_dyn) + tend_dyn with mu = 1; the
-    // dynamics-only tendency is still in memory because this kernel writes each output once, here or at its end
-    const bool sppt = !FUSED && a.sppt_pattern != nullptr;
-    auto perturb = [&](double tend, double tend_dyn, int k) {
-        const double r = a.sppt_pattern[o3 + NG * k];
-        const double rc = dmin(1.0, fabs(r)) * (r < 0.0 ? -1.0 : 1.0);  // sppt.f90:112
-        return (1.0 + rc) * (tend - tend_dyn) + tend_dyn;
-    };
+    // (when the dynamics-only tendency is needed again -- SPPT, mixed precision -- it is still in LDS (FUSED) or in memory:
+    // this kernel writes each output exactly once, here or at its end)
+    double qdyn_kx = 0.0;
+    if (need_dyn) qdyn_kx = FUSED ? park_q[KX - 1][lane] : a.qtend[o3 + static_cast<size_t>(NG) * (KX - 1)];
 #pragma unroll
-    for (int k = 0; k < KX - 1; ++k) a.qtend[o3 + NG * k] = sppt ? perturb(qtend[k], a.qtend[o3 + NG * k], k) : qtend[k];
-    const double qtend_kx = qtend[KX - 1];
+    for (int k = 0; k < KX - 1; ++k) {
+        double qdyn = 0.0;
+        if (need_dyn) qdyn = FUSED ? park_q[k][lane] : a.qtend[o3 + NG * k];
+        a.qtend[o3 + NG * k] = finish(qtend[k], qdyn, k);
+    }
+    const R qtend_kx = qtend[KX - 1];
 
     // ------------------------------------------------------------------ clouds + shortwave (every nstrad-th step)
     // rad_tau2(k, band) lives in HBM between shortwave steps (physics.f90 keeps it in the model state); while the two
     // longwave sweeps run it sits in LDS (tau_s), read one band at a time instead of holding all 32 values in registers.
-    double ssrd, strat1, strat2;
+    R ssrd, strat1, strat2;
     int icltop = 0;
-    double cloudc = 0.0, clstr = 0.0;
+    R cloudc = R(0.0f), clstr = R(0.0f);
     if (a.compute_shortwave) {
-        const double rhcl1 = 0.30f, rhcl2 = 1.00f, qacl = 0.20f, wpcl = 0.2f, pmaxcl = 10.0f, clsmax = 0.60f,
+        const R rhcl1 = 0.30f, rhcl2 = 1.00f, qacl = 0.20f, wpcl = 0.2f, pmaxcl = 10.0f, clsmax = 0.60f,
                      clsminl = 0.15f, gse_s0 = 0.25f, gse_s1 = 0.40f, albcl = 0.43f, albcls = 0.50f, absdry = 0.033f,
                      absaer = 0.033f, abswv1 = 0.022f, abswv2 = 15.000f, abscl1 = 0.015f, abscl2 = 0.15f,
                      ablwin = 0.3f, ablwv1 = 0.7f, ablwv2 = 50.0f, ablcl1 = 12.0f, ablcl2 = 0.6f;
-        const double fmask = a.fmask_land[o2];
+        const R fmask = R(a.fmask_land[o2]);
         // clouds, shortwave_radiation.f90:325-404
-        const double rrcl = 1.f / (rhcl2 - rhcl1);
+        const R rrcl = 1.f / (rhcl2 - rhcl1);
         if (rh[nl1 - 1] > rhcl1) {
             cloudc = rh[nl1 - 1] - rhcl1;
             icltop = nl1;
         } else {
-            cloudc = 0.0;
+            cloudc = R(0.0f);
             icltop = KX + 1;
         }
 #pragma unroll
         for (int k = 3; k <= KX - 2; ++k) {
-            const double drh = rh[k - 1] - rhcl1;
+            const R drh = rh[k - 1] - rhcl1;
             if (drh > cloudc && qa[k - 1] > qacl) {
                 cloudc = drh;
                 icltop = k;
             }
         }
-        const double pr1 = dmin(pmaxcl, 86.4f * (precnv + precls));
-        const double cq = dmin(1.0f, cloudc * rrcl);
-        cloudc = dmin(1.0f, wpcl * sqrt(pr1) + cq * cq);
+        const R pr1 = rmin<R>(pmaxcl, 86.4f * (precnv + precls));
+        const R cq = rmin<R>(1.0f, cloudc * rrcl);
+        cloudc = rmin<R>(1.0f, wpcl * rsqrt_(pr1) + cq * cq);
         icltop = iptop < icltop ? iptop : icltop;
-        const double qcloud = qa[nl1 - 1];
+        const R qcloud = qa[nl1 - 1];
         stream_store(&a.qcloud_equiv[o2], qcloud);
-        const double clfact = 1.2f, rgse = 1.0f / (gse_s1 - gse_s0);
-        const double fstab = dmax(0.0f, dmin(1.0f, rgse * (gse - gse_s0)));
-        clstr = fstab * dmax(clsmax - clfact * cloudc, 0.0f);
-        const double clstrl = dmax(clstr, clsminl) * rh[KX - 1];
+        const R clfact = 1.2f, rgse = 1.0f / (gse_s1 - gse_s0);
+        const R fstab = rmax<R>(0.0f, rmin<R>(1.0f, rgse * (gse - gse_s0)));
+        clstr = fstab * rmax<R>(clsmax - clfact * cloudc, 0.0f);
+        const R clstrl = rmax<R>(clstr, clsminl) * rh[KX - 1];
         clstr = clstr + fmask * (clstrl - clstr);
 
         // shortwave, shortwave_radiation.f90:50-214
-        const double fband2 = 0.05f, fband1 = 1.0f - fband2;
-        double refl[KX];  // rad_tau2(:, 3) during the shortwave sweep: cloud reflectivities, then reflected fluxes
+        const R fband2 = 0.05f, fband1 = 1.0f - fband2;
+        R refl[KX];  // rad_tau2(:, 3) during the shortwave sweep: cloud reflectivities, then reflected fluxes
 #pragma unroll
-        for (int k = 0; k < KX; ++k) refl[k] = 0.0;
+        for (int k = 0; k < KX; ++k) refl[k] = R(0.0f);
 #pragma unroll
         for (int k = 1; k <= KX; ++k)
             if (k == icltop) refl[k - 1] = albcl * cloudc;
         refl[KX - 1] = albcls * clstr;
-        const double psaz = psa * a.zenit_correction[o2];
-        double acloud = cloudc * dmin(abscl1 * qcloud, abscl2);
-        double tsw1[KX], tsw2[KX];  // shortwave transmissivities, bands 1 and 2
-        tsw1[0] = exp(-psaz * T.dhs[0] * absdry);
-        tsw2[0] = 0.0;
+        const R psaz = psa * R(a.zenit_correction[o2]);
+        R acloud = cloudc * rmin<R>(abscl1 * qcloud, abscl2);
+        R tsw1[KX], tsw2[KX];  // shortwave transmissivities, bands 1 and 2
+        tsw1[0] = rexp(-psaz * CT.dhs[0] * absdry);
+        tsw2[0] = R(0.0f);
 #pragma unroll
         for (int k = 2; k <= nl1; ++k) {
-            const double abs1 = absdry + absaer * (T.fsg[k - 1] * T.fsg[k - 1]);
-            tsw1[k - 1] = (k >= icltop) ? exp(-psaz * T.dhs[k - 1] * (abs1 + abswv1 * qa[k - 1] + acloud))
-                                        : exp(-psaz * T.dhs[k - 1] * (abs1 + abswv1 * qa[k - 1]));
+            const R abs1 = absdry + absaer * (CT.fsg[k - 1] * CT.fsg[k - 1]);
+            tsw1[k - 1] = (k >= icltop) ? rexp(-psaz * CT.dhs[k - 1] * (abs1 + abswv1 * qa[k - 1] + acloud))
+                                        : rexp(-psaz * CT.dhs[k - 1] * (abs1 + abswv1 * qa[k - 1]));
         }
         {
-            const double abs1 = absdry + absaer * (T.fsg[KX - 1] * T.fsg[KX - 1]);
-            tsw1[KX - 1] = exp(-psaz * T.dhs[KX - 1] * (abs1 + abswv1 * qa[KX - 1]));
+            const R abs1 = absdry + absaer * (CT.fsg[KX - 1] * CT.fsg[KX - 1]);
+            tsw1[KX - 1] = rexp(-psaz * CT.dhs[KX - 1] * (abs1 + abswv1 * qa[KX - 1]));
         }
 #pragma unroll
-        for (int k = 2; k <= KX; ++k) tsw2[k - 1] = exp(-psaz * T.dhs[k - 1] * abswv2 * qa[k - 1]);
+        for (int k = 2; k <= KX; ++k) tsw2[k - 1] = rexp(-psaz * CT.dhs[k - 1] * abswv2 * qa[k - 1]);
 
-        const double solar = a.flux_solar_in[o2];
-        double tsr = solar;
-        double tt_rsw[KX];
-        double f1 = solar * fband1, f2 = solar * fband2;
+        const R solar = R(a.flux_solar_in[o2]);
+        R tsr = solar;
+        R tt_rsw[KX];
+        R f1 = solar * fband1, f2 = solar * fband2;
         tt_rsw[0] = f1;
-        f1 = tsw1[0] * (f1 - a.flux_ozone_upper[o2] * psa);
+        f1 = tsw1[0] * (f1 - R(a.flux_ozone_upper[o2]) * psa);
         tt_rsw[0] = tt_rsw[0] - f1;
         tt_rsw[1] = f1;
-        f1 = tsw1[1] * (f1 - a.flux_ozone_lower[o2] * psa);
+        f1 = tsw1[1] * (f1 - R(a.flux_ozone_lower[o2]) * psa);
         tt_rsw[1] = tt_rsw[1] - f1;
 #pragma unroll
         for (int k = 3; k <= KX; ++k) {
@@ -441,7 +513,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
             tt_rsw[k - 1] = tt_rsw[k - 1] - f2;
         }
         ssrd = f1 + f2;
-        f1 = f1 * a.alb_surface[o2];
+        f1 = f1 * R(a.alb_surface[o2]);
         stream_store(&a.ssrd[o2], ssrd);
         stream_store(&a.ssr[o2], ssrd - f1);
 #pragma unroll
@@ -455,36 +527,36 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         // physics.f90:166-168
 #pragma unroll
         for (int k = 0; k < KX; ++k) {
-            tt_rsw[k] = tt_rsw[k] * rps * T.grdscp[k];
+            tt_rsw[k] = tt_rsw[k] * rps * CT.grdscp[k];
             stream_store(&a.tt_rsw[o3 + NG * k], tt_rsw[k]);
             ttend[k] = ttend[k] + tt_rsw[k];
         }
 
         // longwave transmissivities, shortwave_radiation.f90:170-208
-        const double co2 = a.air_absortivity_co2;
+        const R co2 = a.air_absortivity_co2;
         const size_t NGs = static_cast<size_t>(NG);
-        tau_s[0][lane] = exp(-psa * T.dhs[0] * ablwin);
-        tau_s[KX][lane] = exp(-psa * T.dhs[0] * co2);
+        tau_s[0][lane] = rexp(-psa * CT.dhs[0] * ablwin);
+        tau_s[KX][lane] = rexp(-psa * CT.dhs[0] * co2);
         stream_store(&a.rad_tau2[ot + NGs * (0 + KX * 0)], tau_s[0][lane]);
         stream_store(&a.rad_tau2[ot + NGs * (0 + KX * 1)], tau_s[KX][lane]);
-        stream_store(&a.rad_tau2[ot + NGs * (0 + KX * 2)], 1.0);
-        stream_store(&a.rad_tau2[ot + NGs * (0 + KX * 3)], 1.0);
+        stream_store(&a.rad_tau2[ot + NGs * (0 + KX * 2)], R(1.0f));
+        stream_store(&a.rad_tau2[ot + NGs * (0 + KX * 3)], R(1.0f));
         acloud = cloudc * ablcl2;
 #pragma unroll
         for (int k = 2; k <= KX; ++k) {
-            double t0, t1, t2, t3;
+            R t0, t1, t2, t3;
             if (k == 2 || k == KX) {
-                t0 = exp(-psa * T.dhs[k - 1] * ablwin);
-                t1 = exp(-psa * T.dhs[k - 1] * co2);
-                t2 = exp(-psa * T.dhs[k - 1] * ablwv1 * qa[k - 1]);
-                t3 = exp(-psa * T.dhs[k - 1] * ablwv2 * qa[k - 1]);
+                t0 = rexp(-psa * CT.dhs[k - 1] * ablwin);
+                t1 = rexp(-psa * CT.dhs[k - 1] * co2);
+                t2 = rexp(-psa * CT.dhs[k - 1] * ablwv1 * qa[k - 1]);
+                t3 = rexp(-psa * CT.dhs[k - 1] * ablwv2 * qa[k - 1]);
             } else {
-                const double deltap = psa * T.dhs[k - 1];
-                const double acloud1 = (k < icltop) ? acloud : ablcl1 * cloudc;
-                t0 = exp(-deltap * (ablwin + acloud1));
-                t1 = exp(-deltap * co2);
-                t2 = exp(-deltap * dmax(ablwv1 * qa[k - 1], acloud));
-                t3 = exp(-deltap * dmax(ablwv2 * qa[k - 1], acloud));
+                const R deltap = psa * CT.dhs[k - 1];
+                const R acloud1 = (k < icltop) ? acloud : ablcl1 * cloudc;
+                t0 = rexp(-deltap * (ablwin + acloud1));
+                t1 = rexp(-deltap * co2);
+                t2 = rexp(-deltap * rmax<R>(ablwv1 * qa[k - 1], acloud));
+                t3 = rexp(-deltap * rmax<R>(ablwv2 * qa[k - 1], acloud));
             }
             stream_store(&a.rad_tau2[ot + NGs * (k - 1 + KX * 0)], t0);
             stream_store(&a.rad_tau2[ot + NGs * (k - 1 + KX * 1)], t1);
@@ -495,83 +567,83 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
             tau_s[k - 1 + KX * 2][lane] = t2;
             tau_s[k - 1 + KX * 3][lane] = t3;
         }
-        const double eps1 = EPSLW / (T.dhs[0] + T.dhs[1]);
-        strat1 = a.stratospheric_correction[o2] * psa;
+        const R eps1 = C::EPSLW / (CT.dhs[0] + CT.dhs[1]);
+        strat1 = R(a.stratospheric_correction[o2]) * psa;
         strat2 = eps1 * psa;
         stream_store(&a.rad_strat_corr[oc], strat1);
         stream_store(&a.rad_strat_corr[oc + NG], strat2);
     } else {
 #pragma unroll
-        for (int k = 0; k < KX; ++k) ttend[k] = ttend[k] + a.tt_rsw[o3 + NG * k];
+        for (int k = 0; k < KX; ++k) ttend[k] = ttend[k] + R(a.tt_rsw[o3 + NG * k]);
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int k = (b < 2 ? 0 : 1); k < KX; ++k)  // bands 3-4 do not use the top level
-                tau_s[k + KX * b][lane] = a.rad_tau2[ot + static_cast<size_t>(NG) * (k + KX * b)];
-        ssrd = a.ssrd[o2];
-        strat1 = a.rad_strat_corr[oc];
-        strat2 = a.rad_strat_corr[oc + NG];
+                tau_s[k + KX * b][lane] = R(a.rad_tau2[ot + static_cast<size_t>(NG) * (k + KX * b)]);
+        ssrd = R(a.ssrd[o2]);
+        strat1 = R(a.rad_strat_corr[oc]);
+        strat2 = R(a.rad_strat_corr[oc + NG]);
     }
 
     // ------------------------------------------------------------------ longwave, downward sweep
-    double st4a[KX][2], dfabs[KX], flux[4];
+    R st4a[KX][2], dfabs[KX], flux[4];
     {
-        const double anis = 1.0f;
+        const R anis = 1.0f;
 #pragma unroll
-        for (int k = 1; k <= nl1; ++k) st4a[k - 1][0] = ta[k - 1] + T.wvi[8 + k - 1] * (ta[k] - ta[k - 1]);
+        for (int k = 1; k <= nl1; ++k) st4a[k - 1][0] = ta[k - 1] + CT.wvi[8 + k - 1] * (ta[k] - ta[k - 1]);
         st4a[0][1] = 0.75f * ta[0] + 0.25f * st4a[0][0];
         st4a[1][1] = 0.50f * ta[1] + 0.25f * (st4a[0][0] + st4a[1][0]);
 #pragma unroll
-        for (int k = 3; k <= nl1; ++k) st4a[k - 1][1] = 0.5f * anis * dmax(st4a[k - 1][0] - st4a[k - 2][0], 0.0f);
-        st4a[KX - 1][1] = anis * dmax(ta[KX - 1] - st4a[nl1 - 1][0], 0.0f);
+        for (int k = 3; k <= nl1; ++k) st4a[k - 1][1] = 0.5f * anis * rmax<R>(st4a[k - 1][0] - st4a[k - 2][0], 0.0f);
+        st4a[KX - 1][1] = anis * rmax<R>(ta[KX - 1] - st4a[nl1 - 1][0], 0.0f);
 #pragma unroll
         for (int k = 1; k <= 2; ++k) {
-            st4a[k - 1][0] = SBC * pow4(st4a[k - 1][1]);
-            st4a[k - 1][1] = 0.0;
+            st4a[k - 1][0] = C::SBC * pow4<R>(st4a[k - 1][1]);
+            st4a[k - 1][1] = R(0.0f);
         }
 #pragma unroll
         for (int k = 3; k <= KX; ++k) {
-            const double st3a = SBC * pow3(ta[k - 1]);
+            const R st3a = C::SBC * pow3<R>(ta[k - 1]);
             st4a[k - 1][0] = st3a * ta[k - 1];
             st4a[k - 1][1] = 4.0f * st3a * st4a[k - 1][1];
         }
 #pragma unroll
-        for (int k = 0; k < KX; ++k) dfabs[k] = 0.0;
+        for (int k = 0; k < KX; ++k) dfabs[k] = R(0.0f);
         int itab[KX];  // nint(ta(k)) - 100, clamped: row of fband for level k (both sweeps)
 #pragma unroll
         for (int k = 0; k < KX; ++k) {
-            int it = static_cast<int>(round(ta[k]));
+            int it = rnint(ta[k]);
             itab[k] = (it < 100 ? 100 : (it > 400 ? 400 : it)) - 100;
         }
         // Stratosphere (bands 1-2, :73-79) first for both bands, as the reference does: dfabs(1) sums in that order.
-        double tau0[2];
+        R tau0[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             tau0[b] = tau_s[KX * b][lane];
-            const double emis = 1.0f - tau0[b];
-            const double brad = T.fband[itab[0] + 301 * b] * (st4a[0][0] + emis * st4a[0][1]);
+            const R emis = 1.0f - tau0[b];
+            const R brad = CT.fband[itab[0] + 301 * b] * (st4a[0][0] + emis * st4a[0][1]);
             flux[b] = emis * brad;
             dfabs[0] = dfabs[0] - flux[b];
         }
-        flux[2] = flux[3] = 0.0;
+        flux[2] = flux[3] = R(0.0f);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            double tb[KX];
+            R tb[KX];
 #pragma unroll
             for (int k = 2; k <= KX; ++k) tb[k - 1] = tau_s[k - 1 + KX * b][lane];
 #pragma unroll
             for (int k = 2; k <= KX; ++k) {
-                const double emis = 1.0f - tb[k - 1];
-                const double brad = T.fband[itab[k - 1] + 301 * b] * (st4a[k - 1][0] + emis * st4a[k - 1][1]);
+                const R emis = 1.0f - tb[k - 1];
+                const R brad = CT.fband[itab[k - 1] + 301 * b] * (st4a[k - 1][0] + emis * st4a[k - 1][1]);
                 dfabs[k - 1] = dfabs[k - 1] + flux[b];
                 flux[b] = tb[k - 1] * flux[b] + emis * brad;
                 dfabs[k - 1] = dfabs[k - 1] - flux[b];
             }
         }
-        double slrd = 0.0;
+        R slrd = R(0.0f);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) slrd = slrd + EMISFC * flux[b];
-        const double corlw = EPSLW * EMISFC * st4a[KX - 1][0];
+        for (int b = 0; b < 4; ++b) slrd = slrd + C::EMISFC * flux[b];
+        const R corlw = C::EPSLW * C::EMISFC * st4a[KX - 1][0];
         dfabs[KX - 1] = dfabs[KX - 1] - corlw;
         slrd = slrd + corlw;
         stream_store(&a.slrd[o2], slrd);
@@ -582,19 +654,19 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         }
 
         // -------------------------------------------------------------- surface fluxes, surface_fluxes.f90:40-320
-        const double fwind0 = 0.95f, ftemp0 = 1.0f, cdl = 2.4e-3f, cds = 1.0e-3f, chl = 1.2e-3f, chs = 0.9e-3f,
+        const R fwind0 = 0.95f, ftemp0 = 1.0f, cdl = 2.4e-3f, cds = 1.0e-3f, chl = 1.2e-3f, chs = 0.9e-3f,
                      vgust = 5.0f, ctday = 1.0e-2f, dtheta = 3.0f, fstab = 0.67f, clambda = 7.0f, clambsn = 7.0f;
-        const double esbc = EMISFC * SBC;
-        const double ua = a.ug[o3 + NG * (KX - 1)], va = a.vg[o3 + NG * (KX - 1)];
-        const double fmask = a.fmask_land[o2], phi0 = a.phis0[o2], tsea = a.sst_am[o2], land_temp = a.land_temp[o2];
-        const double alb_land = a.alb_land[o2], swav = a.soil_avail_water[o2];
-        const double u0 = fwind0 * ua, v0 = fwind0 * va;
-        const double gtemp0 = 1.0f - ftemp0, rcp = 1.0f / CP;
-        const double dt1 = T.wvi[8 + KX - 1] * (ta[KX - 1] - ta[nl1 - 1]);
-        double t1l = ta[KX - 1] + dt1;
-        double t1s = t1l - phi0 * dt1 / (RGAS * 288.0f * T.sigl[KX - 1]);
-        const double t2s = ta[KX - 1] + rcp * phi_kx;
-        const double t2l = t2s - rcp * phi0;
+        const R esbc = C::EMISFC * C::SBC;
+        const R ua = R(a.ug[o3 + NG * (KX - 1)]), va = R(a.vg[o3 + NG * (KX - 1)]);
+        const R fmask = R(a.fmask_land[o2]), phi0 = R(a.phis0[o2]), tsea = R(a.sst_am[o2]), land_temp = R(a.land_temp[o2]);
+        const R alb_land = R(a.alb_land[o2]), swav = R(a.soil_avail_water[o2]);
+        const R u0 = fwind0 * ua, v0 = fwind0 * va;
+        const R gtemp0 = 1.0f - ftemp0, rcp = 1.0f / C::CP;
+        const R dt1 = CT.wvi[8 + KX - 1] * (ta[KX - 1] - ta[nl1 - 1]);
+        R t1l = ta[KX - 1] + dt1;
+        R t1s = t1l - phi0 * dt1 / (C::RGAS * 288.0f * CT.sigl[KX - 1]);
+        const R t2s = ta[KX - 1] + rcp * phi_kx;
+        const R t2l = t2s - rcp * phi0;
         if (ta[KX - 1] > ta[nl1 - 1]) {
             t1l = ftemp0 * t1l + gtemp0 * t2l;
             t1s = ftemp0 * t1s + gtemp0 * t2s;
@@ -602,47 +674,47 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
             t1l = ta[KX - 1];
             t1s = ta[KX - 1];
         }
-        const double t0 = t1s + fmask * (t1l - t1s);
-        const double den0 = (P0 * psa / (RGAS * t0)) * sqrt(u0 * u0 + v0 * v0 + vgust * vgust);
-        double tskin = land_temp + ctday * sqrt(T.coa[j]) * ssrd * (1.0f - alb_land) * psa;
-        const double rdth = fstab / dtheta, astab = 0.5f;
-        const double dthl = (tskin > t2l) ? dmin(dtheta, tskin - t2l) : dmax(-dtheta, astab * (tskin - t2l));
-        const double den1 = den0 * (1.0f + dthl * rdth);
-        const double cdldv = cdl * den0 * a.forog[o2];
-        const double ustr1 = -cdldv * ua, vstr1 = -cdldv * va;
-        const double chlcp = chl * CP;
-        double shf1 = chlcp * den1 * (tskin - t1l);
-        const double q1 = qa[KX - 1];
-        const double qs0l = qsat_point(tskin, 1.0 * psa);
-        double evap1 = chl * den1 * dmax(0.0f, swav * qs0l - q1);
-        const double tsk3 = pow3(tskin);
-        const double dslr = 4.0f * esbc * tsk3;
-        double slru1 = esbc * tsk3 * tskin;
-        double hfl1 = ssrd * (1.0f - alb_land) + slrd - (slru1 + shf1 + ALHC * evap1);
-        const double clamb = clambda + a.snowc[o2] * (clambsn - clambda);
+        const R t0 = t1s + fmask * (t1l - t1s);
+        const R den0 = (C::P0 * psa / (C::RGAS * t0)) * rsqrt_(u0 * u0 + v0 * v0 + vgust * vgust);
+        R tskin = land_temp + ctday * rsqrt_(CT.coa[j]) * ssrd * (1.0f - alb_land) * psa;
+        const R rdth = fstab / dtheta, astab = 0.5f;
+        const R dthl = (tskin > t2l) ? rmin<R>(dtheta, tskin - t2l) : rmax<R>(-dtheta, astab * (tskin - t2l));
+        const R den1 = den0 * (1.0f + dthl * rdth);
+        const R cdldv = cdl * den0 * R(a.forog[o2]);
+        const R ustr1 = -cdldv * ua, vstr1 = -cdldv * va;
+        const R chlcp = chl * C::CP;
+        R shf1 = chlcp * den1 * (tskin - t1l);
+        const R q1 = qa[KX - 1];
+        const R qs0l = qsat_point<R>(tskin, R(1.0f) * psa);
+        R evap1 = chl * den1 * rmax<R>(0.0f, swav * qs0l - q1);
+        const R tsk3 = pow3<R>(tskin);
+        const R dslr = 4.0f * esbc * tsk3;
+        R slru1 = esbc * tsk3 * tskin;
+        R hfl1 = ssrd * (1.0f - alb_land) + slrd - (slru1 + shf1 + C::ALHC * evap1);
+        const R clamb = clambda + R(a.snowc[o2]) * (clambsn - clambda);
         hfl1 = hfl1 - clamb * (tskin - land_temp);
-        double dqs = qsat_point(tskin + 1.0f, 1.0 * psa);
-        dqs = (evap1 > 0.0) ? swav * (dqs - qs0l) : 0.0;
-        const double dtskin = hfl1 / (clamb + dslr + chl * den1 * (CP + ALHC * dqs));
+        R dqs = qsat_point<R>(tskin + 1.0f, R(1.0f) * psa);
+        dqs = (evap1 > R(0.0f)) ? swav * (dqs - qs0l) : R(0.0f);
+        const R dtskin = hfl1 / (clamb + dslr + chl * den1 * (C::CP + C::ALHC * dqs));
         tskin = tskin + dtskin;
         shf1 = shf1 + chlcp * den1 * dtskin;
         evap1 = evap1 + chl * den1 * dqs * dtskin;
         slru1 = slru1 + dslr * dtskin;
         hfl1 = clamb * (tskin - land_temp);
-        const double dths = (tsea > t2s) ? dmin(dtheta, tsea - t2s) : dmax(-dtheta, astab * (tsea - t2s));
-        const double den2 = den0 * (1.0f + dths * rdth);
-        const double cdsdv = cds * den2;
-        const double ustr2 = -cdsdv * ua, vstr2 = -cdsdv * va;
-        const double shf2 = chs * CP * den2 * (tsea - t1s);
-        const double qs0s = qsat_point(tsea, 1.0 * psa);
-        const double evap2 = chs * den2 * (qs0s - q1);
-        const double slru2 = esbc * pow4(tsea);
-        const double hfl2 = ssrd * (1.0f - a.alb_sea[o2]) + slrd - slru2 + shf2 + ALHC * evap2;
-        const double ustr3 = ustr2 + fmask * (ustr1 - ustr2), vstr3 = vstr2 + fmask * (vstr1 - vstr2);
-        const double shf3 = shf2 + fmask * (shf1 - shf2), evap3 = evap2 + fmask * (evap1 - evap2);
-        const double slru3 = slru2 + fmask * (slru1 - slru2);
-        const double tsfc = tsea + fmask * (land_temp - tsea);
-        const double tskin_avg = tsea + fmask * (tskin - tsea);
+        const R dths = (tsea > t2s) ? rmin<R>(dtheta, tsea - t2s) : rmax<R>(-dtheta, astab * (tsea - t2s));
+        const R den2 = den0 * (1.0f + dths * rdth);
+        const R cdsdv = cds * den2;
+        const R ustr2 = -cdsdv * ua, vstr2 = -cdsdv * va;
+        const R shf2 = chs * C::CP * den2 * (tsea - t1s);
+        const R qs0s = qsat_point<R>(tsea, R(1.0f) * psa);
+        const R evap2 = chs * den2 * (qs0s - q1);
+        const R slru2 = esbc * pow4<R>(tsea);
+        const R hfl2 = ssrd * (1.0f - R(a.alb_sea[o2])) + slrd - slru2 + shf2 + C::ALHC * evap2;
+        const R ustr3 = ustr2 + fmask * (ustr1 - ustr2), vstr3 = vstr2 + fmask * (vstr1 - vstr2);
+        const R shf3 = shf2 + fmask * (shf1 - shf2), evap3 = evap2 + fmask * (evap1 - evap2);
+        const R slru3 = slru2 + fmask * (slru1 - slru2);
+        const R tsfc = tsea + fmask * (land_temp - tsea);
+        const R tskin_avg = tsea + fmask * (tskin - tsea);
         stream_store(&a.ustr[oa], ustr1); a.ustr[oa + NG] = ustr2; a.ustr[oa + 2 * NG] = ustr3;
         stream_store(&a.vstr[oa], vstr1); a.vstr[oa + NG] = vstr2; a.vstr[oa + 2 * NG] = vstr3;
         stream_store(&a.shf[oa], shf1);   a.shf[oa + NG] = shf2;   a.shf[oa + 2 * NG] = shf3;
@@ -656,20 +728,20 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         if (a.t0) stream_store(&a.t0[o2], t0);
 
         // -------------------------------------------------------------- longwave, upward sweep (:124-205)
-        const double refsfc = 1.0f - EMISFC;
+        const R refsfc = 1.0f - C::EMISFC;
         stream_store(&a.slr[o2], slru3 - slrd);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) flux[b] = fband_at(T.fband, tsfc, b) * slru3 + refsfc * flux[b];
-        dfabs[KX - 1] = dfabs[KX - 1] + EPSLW * slru3;
+        for (int b = 0; b < 4; ++b) flux[b] = fband_at(CT.fband, tsfc, b) * slru3 + refsfc * flux[b];
+        dfabs[KX - 1] = dfabs[KX - 1] + C::EPSLW * slru3;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            double tb[KX];
+            R tb[KX];
 #pragma unroll
             for (int k = 2; k <= KX; ++k) tb[k - 1] = tau_s[k - 1 + KX * b][lane];
 #pragma unroll
             for (int k = KX; k >= 2; --k) {
-                const double emis = 1.0f - tb[k - 1];
-                const double brad = T.fband[itab[k - 1] + 301 * b] * (st4a[k - 1][0] - emis * st4a[k - 1][1]);
+                const R emis = 1.0f - tb[k - 1];
+                const R brad = CT.fband[itab[k - 1] + 301 * b] * (st4a[k - 1][0] - emis * st4a[k - 1][1]);
                 dfabs[k - 1] = dfabs[k - 1] + flux[b];
                 flux[b] = tb[k - 1] * flux[b] + emis * brad;
                 dfabs[k - 1] = dfabs[k - 1] - flux[b];
@@ -677,17 +749,17 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const double emis = 1.0f - tau0[b];
-            const double brad = T.fband[itab[0] + 301 * b] * (st4a[0][0] - emis * st4a[0][1]);
+            const R emis = 1.0f - tau0[b];
+            const R brad = CT.fband[itab[0] + 301 * b] * (st4a[0][0] - emis * st4a[0][1]);
             dfabs[0] = dfabs[0] + flux[b];
             flux[b] = tau0[b] * flux[b] + emis * brad;
             dfabs[0] = dfabs[0] - flux[b];
         }
-        const double corlw1 = T.dhs[0] * strat2 * st4a[0][0] + strat1;
-        const double corlw2 = T.dhs[1] * strat2 * st4a[1][0];
+        const R corlw1 = CT.dhs[0] * strat2 * st4a[0][0] + strat1;
+        const R corlw2 = CT.dhs[1] * strat2 * st4a[1][0];
         dfabs[0] = dfabs[0] - corlw1;
         dfabs[1] = dfabs[1] - corlw2;
-        double olr = corlw1 + corlw2;
+        R olr = corlw1 + corlw2;
 #pragma unroll
         for (int b = 0; b < 4; ++b) olr = olr + flux[b];
         stream_store(&a.olr[o2], olr);
@@ -695,28 +767,25 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         for (int b = 0; b < 4; ++b) a.rad_flux[of4 + static_cast<size_t>(NG) * b] = flux[b];
         // physics.f90:207-211: ttend = ttend + tt_rsw + tt_rlw
 #pragma unroll
-        for (int k = 0; k < KX; ++k) ttend[k] = ttend[k] + dfabs[k] * rps * T.grdscp[k];
+        for (int k = 0; k < KX; ++k) ttend[k] = ttend[k] + dfabs[k] * rps * CT.grdscp[k];
 
         // physics.f90:223-231: surface-flux tendencies at the lowest level, then accumulate
-        const double ut_kx = 0.0 + ustr3 * rps * T.grdsig[KX - 1];
-        const double vt_kx = 0.0 + vstr3 * rps * T.grdsig[KX - 1];
-        ttend[KX - 1] = ttend[KX - 1] + shf3 * rps * T.grdscp[KX - 1];
+        const R ut_kx = R(0.0f) + ustr3 * rps * CT.grdsig[KX - 1];
+        const R vt_kx = R(0.0f) + vstr3 * rps * CT.grdsig[KX - 1];
+        ttend[KX - 1] = ttend[KX - 1] + shf3 * rps * CT.grdscp[KX - 1];
         const size_t okx = o3 + static_cast<size_t>(NG) * (KX - 1);
         const double ud = FUSED ? utend_dyn : a.utend[okx], vd = FUSED ? vtend_dyn : a.vtend[okx];
-        const double qkx = qtend_kx + evap3 * rps * T.grdsig[KX - 1];
-        if (sppt) {  // (above the lowest level the physics leaves the wind tendencies alone: nothing to perturb there)
-            stream_store(&a.utend[okx], perturb(ud + ut_kx, ud, KX - 1));
-            stream_store(&a.vtend[okx], perturb(vd + vt_kx, vd, KX - 1));
+        const R qkx = qtend_kx + evap3 * rps * CT.grdsig[KX - 1];
+        // (above the lowest level the physics leaves the wind tendencies alone: ut_pbl, vt_pbl are zero there)
+        stream_store(&a.utend[okx], finish(MIXED ? ut_kx : static_cast<R>(ud) + ut_kx, ud, KX - 1));
+        stream_store(&a.vtend[okx], finish(MIXED ? vt_kx : static_cast<R>(vd) + vt_kx, vd, KX - 1));
 #pragma unroll
-            for (int k = 0; k < KX; ++k) a.ttend[o3 + NG * k] = perturb(ttend[k], a.ttend[o3 + NG * k], k);
-            stream_store(&a.qtend[okx], perturb(qkx, a.qtend[okx], KX - 1));
-        } else {
-            stream_store(&a.utend[okx], ud + ut_kx);  // ut_pbl, vt_pbl are zero above the lowest level
-            stream_store(&a.vtend[okx], vd + vt_kx);
-#pragma unroll
-            for (int k = 0; k < KX; ++k) a.ttend[o3 + NG * k] = ttend[k];
-            stream_store(&a.qtend[okx], qkx);
+        for (int k = 0; k < KX; ++k) {
+            double tdyn = 0.0;
+            if (need_dyn) tdyn = FUSED ? park_t[k][lane] : a.ttend[o3 + NG * k];
+            a.ttend[o3 + NG * k] = finish(ttend[k], tdyn, k);
         }
+        stream_store(&a.qtend[okx], finish(qkx, qdyn_kx, KX - 1));
     }
     if (a.iptop) a.iptop[o2] = iptop;
     if (a.icltop) a.icltop[o2] = icltop;
@@ -731,30 +800,54 @@ static int physics_waves() {
     }();
     return waves;
 }
+// launch-bounds variant of the fp32 kernels (waves per SIMD the register allocator leaves room for): profiles/ compares them
+static int physics_waves32() {
+    static const int waves = [] {
+        const char *e = getenv("PYSPEEDY_AMD_PHYS_WAVES32");
+        return e ? atoi(e) : 3;
+    }();
+    return waves;
+}
 
-hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nmembers, hipStream_t s) {
+template <int W, bool FUSED, bool KEEP, typename R>
+static hipError_t launch_physics(const DeviceTables &T, const spd_physics_args &a, int first, int nmembers, const ModelPtrs &P,
+                                 const DynDeviceTables &D, hipStream_t s) {
     const long total = static_cast<long>(nmembers) * NG;
     const unsigned blocks = static_cast<unsigned>((total + kPhysThreads - 1) / kPhysThreads);
+    hipLaunchKernelGGL((physics_kernel<W, FUSED, KEEP, R>), dim3(blocks), dim3(kPhysThreads), 0, s, a, col_tables<R>(T), first,
+                       nmembers, P, D);
+    return hipGetLastError();
+}
+
+// the C ABI's spd_physics: tendencies of the dynamics are read from / written to a.utend ... a.qtend
+hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nmembers, int fp32, hipStream_t s) {
     const ModelPtrs mp{};
     const DynDeviceTables md{};
-    if (physics_waves() == 1)
-        hipLaunchKernelGGL((physics_kernel<1, false>), dim3(blocks), dim3(kPhysThreads), 0, s, a, T, 0, nmembers, mp, md);
-    else
-        hipLaunchKernelGGL((physics_kernel<2, false>), dim3(blocks), dim3(kPhysThreads), 0, s, a, T, 0, nmembers, mp, md);
-    return hipGetLastError();
+    if (fp32) {
+        switch (physics_waves32()) {
+            case 2: return launch_physics<2, false, false, float>(T, a, 0, nmembers, mp, md, s);
+            case 3: return launch_physics<3, false, false, float>(T, a, 0, nmembers, mp, md, s);
+            default: return launch_physics<4, false, false, float>(T, a, 0, nmembers, mp, md, s);
+        }
+    }
+    if (physics_waves() == 1) return launch_physics<1, false, false, double>(T, a, 0, nmembers, mp, md, s);
+    return launch_physics<2, false, false, double>(T, a, 0, nmembers, mp, md, s);
 }
 
 // grid-point dynamics + physics of every column in one launch (the model step); a.ttend / a.qtend / a.utend / a.vtend must be
 // the dynamics' tendency arrays (P.ttend, P.trtend, P.utend, P.vtend)
 hipError_t run_dyn_physics(const ModelPtrs &P, const DynDeviceTables &D, const DeviceTables &T, const spd_physics_args &a,
-                           int first, int nmembers, hipStream_t s) {
-    const long total = static_cast<long>(nmembers) * NG;
-    const unsigned blocks = static_cast<unsigned>((total + kPhysThreads - 1) / kPhysThreads);
-    if (physics_waves() == 1)
-        hipLaunchKernelGGL((physics_kernel<1, true>), dim3(blocks), dim3(kPhysThreads), 0, s, a, T, first, nmembers, P, D);
-    else
-        hipLaunchKernelGGL((physics_kernel<2, true>), dim3(blocks), dim3(kPhysThreads), 0, s, a, T, first, nmembers, P, D);
-    return hipGetLastError();
+                           int first, int nmembers, int fp32, hipStream_t s) {
+    if (fp32) {
+        switch (physics_waves32()) {
+            case 2: return launch_physics<2, true, true, float>(T, a, first, nmembers, P, D, s);
+            case 3: return launch_physics<3, true, true, float>(T, a, first, nmembers, P, D, s);
+            default: return launch_physics<4, true, true, float>(T, a, first, nmembers, P, D, s);
+        }
+    }
+    if (a.sppt_pattern) return launch_physics<2, true, true, double>(T, a, first, nmembers, P, D, s);
+    if (physics_waves() == 1) return launch_physics<1, true, false, double>(T, a, first, nmembers, P, D, s);
+    return launch_physics<2, true, false, double>(T, a, first, nmembers, P, D, s);
 }
 
 }  // namespace spd

@@ -29,14 +29,25 @@ def dist_env():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def init_process_group(backend, device=None):
-    """Initialise torch.distributed when WORLD_SIZE > 1; returns the module or None."""
+def init_process_group(backend, device=None, force=False):
+    """Initialise torch.distributed when WORLD_SIZE > 1 (or when `force` asks for a one-rank group); returns the module or
+    None.  The rendezvous address comes from the launcher (torchrun, bench.py's own launcher: MASTER_ADDR / MASTER_PORT);
+    there is no built-in port: two jobs on one host must not meet on a hard-wired one."""
     world, _, _ = dist_env()
-    if world <= 1:
+    if world <= 1 and not force:
         return None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29511")
+    if "MASTER_PORT" not in os.environ:
+        if world > 1:
+            raise RuntimeError("MASTER_PORT is not set: start the ranks with torch.distributed.run or `bench.py --gpus N`")
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+        s.close()
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
     kwargs = {}
     if device is not None and backend == "nccl":
         kwargs["device_id"] = device

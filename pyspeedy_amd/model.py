@@ -19,6 +19,10 @@ SHAPES["sst_anom"] = (np.float64, (96, 48, 3))  # right after creation: n_months
 
 DELT = 86400.0 / 36  # params.f90:33
 
+# kernel ids of spd_model_profile_read_kernels (SPD_K_* of include/pyspeedy_amd.h)
+KERNEL_NAMES = ("geopotential", "spec2grid", "column_sw", "column", "grid2spec", "spectral_step", "coupler", "forcing",
+                "sppt", "dyn_grid", "physics_sw", "physics")
+
 # boundary-condition file variable -> registry variable (pyspeedy/speedy.py:279-296)
 BC_MAP = (("orog", "orog"), ("fmask_orig", "lsm"), ("alb0", "alb"), ("veg_high", "vegh"), ("veg_low", "vegl"),
           ("stl12", "stl"), ("snowd12", "snowd"), ("soil_wc_l1", "swl1"), ("soil_wc_l2", "swl2"), ("soil_wc_l3", "swl3"),
@@ -32,6 +36,7 @@ class EnsembleModel:
         self._lib = _lib.lib()
         self._m = C.c_void_p()
         self.n_months = 1  # sst_anom holds n_months + 2 planes
+        self._shapes = dict(SHAPES)  # per model: set_sppt adds the two SPPT arrays
         with torch.cuda.device(spectral.device):
             check(self._lib.spd_model_create(spectral.handle, self.nmembers, C.byref(self._m)), "spd_model_create")
 
@@ -47,8 +52,12 @@ class EnsembleModel:
             pass
 
     # ---- registry access (speedy_driver.f90.j2:250-334) --------------------------------------------------
+    def variables(self):
+        """Names of the registry arrays of this model (the reference's + tcorh / qcorh [+ the SPPT arrays when SPPT is on])."""
+        return tuple(self._shapes)
+
     def shape(self, name):
-        dtype, shape = SHAPES[name]
+        dtype, shape = self._shapes[name]
         return (dtype, (96, 48, self.n_months + 2)) if name == "sst_anom" else (dtype, shape)
 
     def set(self, name, value, member=-1):
@@ -86,8 +95,8 @@ class EnsembleModel:
         this shard, so that an ensemble gives the same noise however it is split over GPUs."""
         check(self._lib.spd_model_set_sppt(self._m, int(bool(on)), int(seed), int(first_member_id)), "spd_model_set_sppt")
         if on:
-            SHAPES.setdefault("sppt_spec", (np.complex128, (31, 32, 8)))
-            SHAPES.setdefault("sppt_pattern", (np.float64, (96, 48, 8)))
+            self._shapes.setdefault("sppt_spec", (np.complex128, (31, 32, 8)))
+            self._shapes.setdefault("sppt_pattern", (np.float64, (96, 48, 8)))
 
     @property
     def co2(self):
@@ -120,24 +129,37 @@ class EnsembleModel:
               "spd_model_mark_initialized")
         self.set_time_step(2 * DELT)
 
-    # ---- checkpoint / resume: the registry arrays plus step counter, date and CO2 absorptivity are the whole state ---
+    # ---- checkpoint / resume: the registry arrays plus the host-side control block are the whole state of a run -------
+    def control(self):
+        """spd_model_control: step counter, date, month index, coupling / CO2 flags, CO2 reference, SPPT generator position."""
+        c = _lib.ModelControl()
+        check(self._lib.spd_model_get_control(self._m, C.byref(c)), "spd_model_get_control")
+        return c
+
     def state_dict(self, member=0):
-        """Everything needed to continue a member's run elsewhere (numpy arrays in the reference's shapes)."""
-        out = {n: self.get(n, member) for n in SHAPES if n not in ("sppt_spec", "sppt_pattern")}
-        out["__current_step__"] = np.int64(self.current_step)
-        out["__date__"] = np.array(self.current_date, dtype=np.int64)
-        out["__air_absortivity_co2__"] = np.float64(self.co2)
+        """Everything needed to continue a member's run elsewhere, bit for bit (numpy arrays in the reference's shapes plus
+        the control block as `__control__/<field>` scalars)."""
+        out = {n: self.get(n, member) for n in self._shapes if n != "sppt_pattern"}  # (the pattern is recomputed every step)
+        c = self.control()
+        for name, _ in c._fields_:
+            out["__control__/" + name] = np.asarray(getattr(c, name))
         return out
 
     def load_state_dict(self, state, member=-1):
-        """Inverse of state_dict (member = -1: every member gets the same state); marks the model initialised."""
+        """Inverse of state_dict (member = -1: every member gets the same state); marks the model initialised and resets
+        nothing: month index, CO2 reference, flags and the SPPT position continue where the checkpoint left them."""
+        c = _lib.ModelControl()
+        for name, _ in c._fields_:
+            setattr(c, name, state["__control__/" + name].item())
         if state["sst_anom"].shape[2] != self.n_months + 2:
             self.init_sst_anom(state["sst_anom"].shape[2] - 2)
-        for n in SHAPES:
+        if c.sppt_on:
+            self.set_sppt(True, c.sppt_seed, c.sppt_first_member_id)
+        for n in self._shapes:
             if n in state:
                 self.set(n, state[n], member)
-        self.set_co2(float(state["__air_absortivity_co2__"]))
-        self.mark_initialized(int(state["__current_step__"]), tuple(int(v) for v in state["__date__"]))
+        check(self._lib.spd_model_set_control(self._m, C.byref(c)), "spd_model_set_control")
+        self.set_time_step(2 * DELT)
 
     def copy_member_from(self, src, src_member, dst_member):
         """Device-to-device copy of every registry variable of one member of `src` into one of this model's members."""
@@ -179,8 +201,23 @@ class EnsembleModel:
         check(self._lib.spd_model_get_date(self._m, buf), "spd_model_get_date")
         return tuple(buf)
 
-    def profile(self, enable=True):
-        check(self._lib.spd_model_profile(self._m, int(bool(enable))), "spd_model_profile")
+    def set_physics_precision(self, fp32):
+        """BASELINE cfg 5: run the arithmetic of the column physics in single precision (state and dynamics stay fp64)."""
+        check(self._lib.spd_model_set_physics_precision(self._m, int(bool(fp32))), "spd_model_set_physics_precision")
+
+    def profile(self, level=1):
+        """HIP-event brackets on the launch stream: 0 off, 1 the spectral->grid launch of every step, 2 every kernel."""
+        check(self._lib.spd_model_profile(self._m, int(level)), "spd_model_profile")
+
+    def profile_read_kernels(self):
+        """{kernel id (KERNEL_NAMES): (mean ms, min ms, brackets, units per bracket)} since profile(2)."""
+        n = len(KERNEL_NAMES)
+        mean, mn = np.zeros(n), np.zeros(n)
+        cnt, units = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+        check(self._lib.spd_model_profile_read_kernels(self._m, mean.ctypes.data_as(C.c_void_p), mn.ctypes.data_as(C.c_void_p),
+                                                       cnt.ctypes.data_as(C.c_void_p), units.ctypes.data_as(C.c_void_p)),
+              "spd_model_profile_read_kernels")
+        return {KERNEL_NAMES[k]: (float(mean[k]), float(mn[k]), int(cnt[k]), int(units[k])) for k in range(n) if cnt[k]}
 
     def profile_read(self):
         """(mean launch time in ms, number of launches, fields per launch) of the spectral->grid kernel since profile(True)."""

@@ -81,7 +81,7 @@ class ColumnPhysics:
         pslg = self.sp.spec2grid(ps, 1)
         return dict(ug=uv[0], vg=uv[1], tg=tqp[0], qg=tqp[1], phig=tqp[2], pslg=pslg)
 
-    def __call__(self, fields, tend, forcing, state, compute_shortwave, air_absortivity_co2, sppt_pattern=None):
+    def __call__(self, fields, tend, forcing, state, compute_shortwave, air_absortivity_co2, sppt_pattern=None, fp32=False):
         """Run the fused column kernel.
 
         fields : dict ug, vg, tg, qg, phig [M,8,48,96], pslg [M,48,96]
@@ -90,6 +90,7 @@ class ColumnPhysics:
         state  : PhysicsState (outputs and persisted radiation fields, updated in place)
         sppt_pattern : optional [M,8,48,96] multiplicative noise r; the physical part of every tendency is scaled by
                  1 + clip(r, -1, 1) (physics.f90:234-248; off in the reference)
+        fp32   : column arithmetic in single precision (BASELINE cfg 5); every array stays float64
         """
         M = state.nmembers
         shp = shapes(M)
@@ -125,6 +126,7 @@ class ColumnPhysics:
         put("sppt_pattern", sppt_pattern)
         args.air_absortivity_co2 = float(air_absortivity_co2)
         args.compute_shortwave = 1 if compute_shortwave else 0
+        args.fp32 = 1 if fp32 else 0
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(self._lib.spd_physics(self.sp.handle, C.byref(args), M, stream), "spd_physics")
         return tend

@@ -115,25 +115,81 @@ def test_members_of_a_large_batch_equal_single_member_runs(spectral, bc):
     assert not np.array_equal(ens.get("t", 1), ens.get("t", 2))
 
 
+def _through_a_file(snapshot):
+    with tempfile.TemporaryDirectory() as tmp:  # as a checkpoint would travel
+        np.savez(os.path.join(tmp, "ckpt.npz"), **snapshot)
+        return dict(np.load(os.path.join(tmp, "ckpt.npz")))
+
+
+def _assert_same_state(resumed, ref):
+    a, b = resumed.control(), ref.control()
+    for name, _ in a._fields_:
+        assert getattr(a, name) == getattr(b, name), name
+    for n in ref.variables():
+        assert np.array_equal(resumed.get(n, 0), ref.get(n, 0)), n
+
+
 def test_restart_from_the_registry_is_bitwise(spectral, bc):
-    """The registry IS the model state: copying every registry array of a running model into a fresh one (plus step
-    counter and date, the two host-side scalars) and continuing gives bitwise the same trajectory as the uninterrupted run
-    -- across a day boundary (daily forcing) and shortwave / non-shortwave steps."""
-    from pyspeedy_amd.model import SHAPES, EnsembleModel
+    """The registry IS the model state: copying every registry array of a running model into a fresh one (plus the
+    host-side control block) and continuing gives bitwise the same trajectory as the uninterrupted run -- across a day
+    boundary (daily forcing) and shortwave / non-shortwave steps."""
+    from pyspeedy_amd.model import EnsembleModel
     ref = EnsembleModel(spectral, 1)
     ref.set_bc(bc)
     ref.run(31)
-    snapshot = ref.state_dict(0)
-    with tempfile.TemporaryDirectory() as tmp:  # through a file, as a checkpoint would travel
-        np.savez(os.path.join(tmp, "ckpt.npz"), **snapshot)
-        snapshot = dict(np.load(os.path.join(tmp, "ckpt.npz")))
+    snapshot = _through_a_file(ref.state_dict(0))
     ref.run(17)  # crosses step 36 (new day: forcing) and several shortwave steps
     resumed = EnsembleModel(spectral, 1)
     resumed.load_state_dict(snapshot)
     resumed.run(17)
     assert resumed.current_step == ref.current_step == 48 and resumed.current_date == ref.current_date
-    for n in SHAPES:
-        assert np.array_equal(resumed.get(n, 0), ref.get(n, 0)), n
+    _assert_same_state(resumed, ref)
+
+
+def test_restart_after_a_month_boundary_with_sst_anomalies_and_co2_trend(spectral, bc):
+    """What a day-0 checkpoint cannot show: the month index (which sst_anom planes the coupler reads) and the untrended CO2
+    reference must travel with the checkpoint.  Run from 30 January into February with two months of non-zero anomalies
+    and increase_co2 on, checkpoint in February, continue both."""
+    from pyspeedy_amd.model import EnsembleModel
+
+    def fresh():
+        m = EnsembleModel(spectral, 1)
+        m.init_sst_anom(2)
+        return m
+    ref = fresh()
+    ref.set("sst_anom", np.random.default_rng(11).normal(0.0, 0.8, (96, 48, 4)))
+    ref.set_flags(True, True, True)
+    ref.set_bc(bc, start_date=(1982, 1, 30, 0, 0))
+    ref.run(36 * 3 + 7)  # 2 February, 04:40
+    c = ref.control()
+    assert (c.month, c.day, c.month_idx) == (2, 2, 2) and c.increase_co2 == 1 and c.air_absortivity_co2 != c.ablco2_ref
+    snapshot = _through_a_file(ref.state_dict(0))
+    ref.run(36 + 5)  # another day boundary: the CO2 trend is applied again, from the reference value
+    resumed = EnsembleModel(spectral, 1)
+    resumed.load_state_dict(snapshot)
+    resumed.run(36 + 5)
+    _assert_same_state(resumed, ref)
+    assert resumed.co2 == ref.co2
+    # and the planes matter: a resume that restarted the month count would read different anomalies
+    assert np.abs(ref.get("sstan_am", 0)).max() > 0.1
+
+
+def test_restart_with_sppt_and_fp32_physics(spectral, bc):
+    """The AR(1) pattern and the position of the counter-based generator are part of the checkpoint (cfg 5)."""
+    from pyspeedy_amd.model import EnsembleModel
+    ref = EnsembleModel(spectral, 1)
+    ref.set_bc(bc)
+    ref.set_sppt(True, seed=5, first_member_id=3)
+    ref.set_physics_precision(True)
+    ref.run(10)
+    snapshot = _through_a_file(ref.state_dict(0))
+    assert "sppt_spec" in snapshot and snapshot["__control__/sppt_step"] == 10
+    ref.run(9)
+    resumed = EnsembleModel(spectral, 1)
+    resumed.load_state_dict(snapshot)
+    resumed.run(9)
+    _assert_same_state(resumed, ref)
+    assert np.abs(ref.get("sppt_pattern", 0)).max() > 0.0
 
 
 def test_ten_day_forecast(spectral, bc, golden_dir):
