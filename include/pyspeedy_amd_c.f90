@@ -137,5 +137,107 @@ module pyspeedy_amd_c
             integer(c_int), value :: on
             integer(c_int64_t), value :: seed, first_member_id
         end function
+
+        ! ---- outer boundary with the reference's own procedures (include/pyspeedy_amd_driver.h) -----------------------
+        ! registry/templates/speedy_driver.f90.j2: modelstate_init :216, modelstate_init_sst_anom :225, modelstate_close :240,
+        ! create_datetime :163, get_datetime :189, close_datetime :203, controlparams_init :131, controlparams_close :151,
+        ! init :29, step :43, parallel_step :58, check :81, transform_* :94-125, get_<v> / set_<v> / get_<v>_shape :250-334
+        integer(c_int) function spd_modelstate_init(state_cnt) bind(C, name="spd_modelstate_init")
+            import :: c_int, c_int64_t
+            integer(c_int64_t), intent(out) :: state_cnt
+        end function
+        integer(c_int) function spd_modelstate_init_sst_anom(state_cnt, n_months) bind(C, name="spd_modelstate_init_sst_anom")
+            import :: c_int, c_int64_t, c_int32_t
+            integer(c_int64_t), value :: state_cnt
+            integer(c_int32_t), value :: n_months
+        end function
+        integer(c_int) function spd_modelstate_close(state_cnt) bind(C, name="spd_modelstate_close")
+            import :: c_int, c_int64_t
+            integer(c_int64_t), value :: state_cnt
+        end function
+        integer(c_int) function spd_create_datetime(year, month, day, hour, minute, datetime_cnt) &
+                bind(C, name="spd_create_datetime")
+            import :: c_int, c_int64_t, c_int32_t
+            integer(c_int32_t), value :: year, month, day, hour, minute
+            integer(c_int64_t), intent(out) :: datetime_cnt
+        end function
+        integer(c_int) function spd_get_datetime(datetime_cnt, year, month, day, hour, minute) bind(C, name="spd_get_datetime")
+            import :: c_int, c_int64_t, c_int32_t
+            integer(c_int64_t), value :: datetime_cnt
+            integer(c_int32_t), intent(out) :: year, month, day, hour, minute
+        end function
+        integer(c_int) function spd_close_datetime(datetime_cnt) bind(C, name="spd_close_datetime")
+            import :: c_int, c_int64_t
+            integer(c_int64_t), value :: datetime_cnt
+        end function
+        integer(c_int) function spd_controlparams_init(control_cnt, start_datetime_cnt, end_datetime_cnt) &
+                bind(C, name="spd_controlparams_init")
+            import :: c_int, c_int64_t
+            integer(c_int64_t), intent(out) :: control_cnt
+            integer(c_int64_t), value :: start_datetime_cnt, end_datetime_cnt
+        end function
+        integer(c_int) function spd_controlparams_close(control_cnt) bind(C, name="spd_controlparams_close")
+            import :: c_int, c_int64_t
+            integer(c_int64_t), value :: control_cnt
+        end function
+        integer(c_int) function spd_init(state_cnt, control_cnt, error_code) bind(C, name="spd_init")
+            import :: c_int, c_int64_t, c_int32_t
+            integer(c_int64_t), value :: state_cnt, control_cnt
+            integer(c_int32_t), intent(out) :: error_code
+        end function
+        integer(c_int) function spd_step(state_cnt, control_cnt, error_code) bind(C, name="spd_step")
+            import :: c_int, c_int64_t, c_int32_t
+            integer(c_int64_t), value :: state_cnt, control_cnt
+            integer(c_int32_t), intent(out) :: error_code
+        end function
+        integer(c_int) function spd_parallel_step(state_cnts, control_cnts, error_codes, n_members) &
+                bind(C, name="spd_parallel_step")
+            import :: c_int, c_int64_t, c_int32_t
+            integer(c_int64_t), intent(in) :: state_cnts(*), control_cnts(*)
+            integer(c_int32_t), intent(out) :: error_codes(*)
+            integer(c_int32_t), value :: n_members
+        end function
+        integer(c_int) function spd_check(state_cnt, error_code) bind(C, name="spd_check")
+            import :: c_int, c_int64_t, c_int32_t
+            integer(c_int64_t), value :: state_cnt
+            integer(c_int32_t), intent(out) :: error_code
+        end function
+        integer(c_int) function spd_transform_spectral2grid(state_cnt) bind(C, name="spd_transform_spectral2grid")
+            import :: c_int, c_int64_t
+            integer(c_int64_t), value :: state_cnt
+        end function
+        integer(c_int) function spd_transform_grid2spectral(state_cnt) bind(C, name="spd_transform_grid2spectral")
+            import :: c_int, c_int64_t
+            integer(c_int64_t), value :: state_cnt
+        end function
+        integer(c_int) function spd_apply_grid_filter(state_cnt) bind(C, name="spd_apply_grid_filter")
+            import :: c_int, c_int64_t
+            integer(c_int64_t), value :: state_cnt
+        end function
+        integer(c_int) function spd_get(state_cnt, name, buf, bytes) bind(C, name="spd_get")
+            import :: c_int, c_int64_t, c_char, c_size_t
+            integer(c_int64_t), value :: state_cnt
+            character(kind=c_char), intent(in) :: name(*)
+            type(*) :: buf(*)
+            integer(c_size_t), value :: bytes
+        end function
+        integer(c_int) function spd_set(state_cnt, name, buf, bytes) bind(C, name="spd_set")
+            import :: c_int, c_int64_t, c_char, c_size_t
+            integer(c_int64_t), value :: state_cnt
+            character(kind=c_char), intent(in) :: name(*)
+            type(*), intent(in) :: buf(*)
+            integer(c_size_t), value :: bytes
+        end function
+        integer(c_int) function spd_get_shape(state_cnt, name, array_shape, ndim) bind(C, name="spd_get_shape")
+            import :: c_int, c_int64_t, c_char, c_int32_t
+            integer(c_int64_t), value :: state_cnt
+            character(kind=c_char), intent(in) :: name(*)
+            integer(c_int32_t), intent(out) :: array_shape(5), ndim
+        end function
+        integer(c_int) function spd_driver_stats(state_cnt, models_alive, members_in_model) bind(C, name="spd_driver_stats")
+            import :: c_int, c_int64_t, c_int32_t
+            integer(c_int64_t), value :: state_cnt
+            integer(c_int32_t), intent(out) :: models_alive, members_in_model
+        end function
     end interface
 end module pyspeedy_amd_c

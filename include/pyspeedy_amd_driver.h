@@ -1,0 +1,83 @@
+/* pyspeedy_amd -- outer boundary: the procedures of the reference's f2py module `speedy_driver`
+ * (registry/templates/speedy_driver.f90.j2), one C entry point per procedure, same argument meaning.
+ *
+ * The reference hands Python 64-bit "containers" holding the bits of a Fortran pointer (speedy_driver.f90.j2:38-40, 222);
+ * here a container is a 64-bit key into the library's own table.  State containers own device memory on the HIP device that
+ * is current when they are created; nothing is retained from caller buffers; every call is synchronous (it returns after
+ * the GPU work it started has finished), exactly like the Fortran routines it replaces.  All functions return SPD_OK or a
+ * negative SPD_E_* code (pyspeedy_amd.h) -- that is the status of the CALL; the model's own error code of
+ * init / step / check (error_codes.f90:7-9: 0 success, -1 state not initialised, -2 variables out of range) is written
+ * to `error_code`, as the reference's `intent(out) :: error_code` arguments are.
+ *
+ * Batching.  The reference steps an ensemble with an OpenMP loop over independent containers (parallel_step, :58-79).
+ * Here spd_parallel_step advances all members with ONE set of kernel launches: the first time it is handed n > 1
+ * independent, initialised containers that agree in date, step counter and control flags, it gathers their states into one
+ * batched device model (device-to-device copies, once) and rebinds the containers to the members of that model; get / set /
+ * check / transforms keep working per container.  spd_step on a single member of such a batch, or a parallel_step over a
+ * different grouping, takes the members apart again first (correct, but it gives the batching up).
+ * spd_modelstate_init_ensemble creates n containers that are batched from the start.
+ *
+ * Date: as in the reference the CONTROL container owns the model date (ControlParams_t%model_datetime, month_idx,
+ * model_control.f90:38-47): step / parallel_step take the date from it and advance it; a member whose step fails keeps its
+ * date (speedy.f90:57-71 returns before advance_date).
+ */
+#ifndef PYSPEEDY_AMD_DRIVER_H
+#define PYSPEEDY_AMD_DRIVER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- ModelState interface (speedy_driver.f90.j2:216-248) ---- */
+int spd_modelstate_init(int64_t *state_cnt);
+int spd_modelstate_init_ensemble(int64_t *state_cnts, int32_t n_members); /* extension: members of one batched model */
+int spd_modelstate_init_sst_anom(int64_t state_cnt, int32_t n_months);    /* sst_anom(ix, il, 0:n_months+1), zero-filled */
+int spd_modelstate_close(int64_t state_cnt);
+
+/* ---- Datetime interface (:163-210) ---- */
+int spd_create_datetime(int32_t year, int32_t month, int32_t day, int32_t hour, int32_t minute, int64_t *datetime_cnt);
+int spd_get_datetime(int64_t datetime_cnt, int32_t *year, int32_t *month, int32_t *day, int32_t *hour, int32_t *minute);
+int spd_close_datetime(int64_t datetime_cnt);
+
+/* ---- ControlParams interface (:131-158); the extra getter exposes model_datetime, which the reference's Python layer
+ *      mirrors on its own (speedy.py:396-405) ---- */
+int spd_controlparams_init(int64_t *control_cnt, int64_t start_datetime_cnt, int64_t end_datetime_cnt);
+int spd_controlparams_close(int64_t control_cnt);
+int spd_controlparams_get_model_datetime(int64_t control_cnt, int32_t *ymdhm /* 5 */, int32_t *month_idx);
+
+/* ---- Speedy interface (:29-125) ---- */
+int spd_init(int64_t state_cnt, int64_t control_cnt, int32_t *error_code);
+int spd_step(int64_t state_cnt, int64_t control_cnt, int32_t *error_code);
+int spd_parallel_step(const int64_t *state_cnts, const int64_t *control_cnts, int32_t *error_codes, int32_t n_members);
+int spd_check(int64_t state_cnt, int32_t *error_code); /* diagnostics on time level 1 */
+int spd_transform_spectral2grid(int64_t state_cnt);
+int spd_transform_grid2spectral(int64_t state_cnt);
+int spd_apply_grid_filter(int64_t state_cnt);
+
+/* ---- registry access: get_<v> / set_<v> / get_<v>_shape / is_array_<v> (:250-334), driven by the variable's name instead
+ *      of one generated procedure per variable.  Buffers are HOST memory in the reference's shape and (Fortran) order;
+ *      element types as the f2py getters return them: complex(8) -> 2 doubles, real(8) -> double, lon / lat / lev ->
+ *      float, integer and logical scalars -> int32_t.  `bytes` must be exactly the size of the variable. ---- */
+#define SPD_T_FLOAT64 0
+#define SPD_T_COMPLEX128 1
+#define SPD_T_FLOAT32 2
+#define SPD_T_INT32 3
+#define SPD_T_LOGICAL 4 /* int32_t 0 / 1 */
+int spd_get(int64_t state_cnt, const char *name, void *buf_host, size_t bytes);
+int spd_set(int64_t state_cnt, const char *name, const void *buf_host, size_t bytes);
+/* shape in the reference's order; ndim = 0 for scalars; all extents 0 while a run-length array (sst_anom) is unallocated */
+int spd_get_shape(int64_t state_cnt, const char *name, int32_t *shape /* up to 5 */, int32_t *ndim);
+int spd_is_array(const char *name, int32_t *is_array);
+/* the registry itself, without a device: entry `index` (0 .. count-1); returns the number of entries */
+int spd_registry_entry(int32_t index, char *name /* 32 bytes */, int32_t *dtype, int32_t *ndim, int32_t *shape /* 5 */,
+                       int32_t *is_read_only);
+/* how many device models are alive and how many members the container's model holds (tests / diagnostics of batching) */
+int spd_driver_stats(int64_t state_cnt, int32_t *models_alive, int32_t *members_in_model);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYSPEEDY_AMD_DRIVER_H */

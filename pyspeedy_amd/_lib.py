@@ -108,6 +108,31 @@ _SIGNATURES = {
     "spd_model_init_sst_anom": (C.c_int, [C.c_void_p, C.c_int]),
     "spd_model_set_sppt": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_int64]),
     "spd_model_copy_member": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    # outer boundary (include/pyspeedy_amd_driver.h): the procedures of speedy_driver.f90.j2
+    "spd_modelstate_init": (C.c_int, [C.POINTER(C.c_int64)]),
+    "spd_modelstate_init_ensemble": (C.c_int, [C.POINTER(C.c_int64), C.c_int32]),
+    "spd_modelstate_init_sst_anom": (C.c_int, [C.c_int64, C.c_int32]),
+    "spd_modelstate_close": (C.c_int, [C.c_int64]),
+    "spd_create_datetime": (C.c_int, [C.c_int32] * 5 + [C.POINTER(C.c_int64)]),
+    "spd_get_datetime": (C.c_int, [C.c_int64] + [C.POINTER(C.c_int32)] * 5),
+    "spd_close_datetime": (C.c_int, [C.c_int64]),
+    "spd_controlparams_init": (C.c_int, [C.POINTER(C.c_int64), C.c_int64, C.c_int64]),
+    "spd_controlparams_close": (C.c_int, [C.c_int64]),
+    "spd_controlparams_get_model_datetime": (C.c_int, [C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "spd_init": (C.c_int, [C.c_int64, C.c_int64, C.POINTER(C.c_int32)]),
+    "spd_step": (C.c_int, [C.c_int64, C.c_int64, C.POINTER(C.c_int32)]),
+    "spd_parallel_step": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int32]),
+    "spd_check": (C.c_int, [C.c_int64, C.POINTER(C.c_int32)]),
+    "spd_transform_spectral2grid": (C.c_int, [C.c_int64]),
+    "spd_transform_grid2spectral": (C.c_int, [C.c_int64]),
+    "spd_apply_grid_filter": (C.c_int, [C.c_int64]),
+    "spd_get": (C.c_int, [C.c_int64, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "spd_set": (C.c_int, [C.c_int64, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "spd_get_shape": (C.c_int, [C.c_int64, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "spd_is_array": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
+    "spd_registry_entry": (C.c_int, [C.c_int32, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                     C.POINTER(C.c_int32)]),
+    "spd_driver_stats": (C.c_int, [C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "spd_model_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "spd_model_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "spd_model_profile_read_kernels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -127,6 +152,13 @@ def lib():
             raise SpeedyHipError(
                 "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C pyspeedy_amd/csrc`).  There is no CPU fallback." % LIB_PATH)
+        # PyTorch ships its own HIP / ROCr runtime libraries.  They must be in the process BEFORE this library is loaded, so that
+        # its libamdhip64 dependency binds to the copy torch initialises: with the opposite order the process holds two ROCr
+        # runtimes, only the first of which can open the GPU ("no ROCm-capable device is detected" in the other).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         try:
             handle = C.CDLL(LIB_PATH)
         except OSError as exc:

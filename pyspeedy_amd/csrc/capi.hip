@@ -122,7 +122,9 @@ int spd_create(spd_handle *out, int device) {
     *out = nullptr;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev <= 0) return fail(SPD_E_DEVICE, "spd_create: no HIP device available");
+    if (e != hipSuccess || ndev <= 0)
+        return fail(SPD_E_DEVICE, std::string("spd_create: no HIP device available (hipGetDeviceCount: ") + hipGetErrorString(e) +
+                                      ", " + std::to_string(ndev) + " devices)");
     if (device < 0 || device >= ndev) return fail(SPD_E_ARG, "spd_create: device index out of range");
     SPD_HIP(hipSetDevice(device));
     spd_context *c = new spd_context();

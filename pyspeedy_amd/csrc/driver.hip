@@ -1,0 +1,705 @@
+// Outer boundary (include/pyspeedy_amd_driver.h): the procedures of the reference's f2py module speedy_driver
+// (registry/templates/speedy_driver.f90.j2) on top of the batched device model (spd_model_*, model.hip).  Host code only:
+// containers, the name-driven registry, and the gathering of independent one-member models into one batched model so that
+// parallel_step is one set of kernel launches for the whole ensemble.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pyspeedy_amd.h"
+#include "../../include/pyspeedy_amd_driver.h"
+#include "context.hpp"
+
+namespace {
+
+constexpr int IXc = 96, ILc = 48, KXc = 8, MXc = 31, NXc = 32;
+constexpr double kDelt = 86400.0 / 36;  // params.f90:33
+
+// ---------------------------------------------------------------------------------------------------------------------
+// registry (registry/model_state_def.py:121-495): name -> element type, shape, where the value lives
+// ---------------------------------------------------------------------------------------------------------------------
+enum Where { Device, Table, Scalar, HostOnly };
+struct RegVar {
+    const char *name;
+    int dtype;
+    int ndim;
+    int shape[5];  // -1 = n_months + 2
+    Where where;
+};
+
+#define G2 2, {IXc, ILc, 0, 0, 0}
+#define G3 3, {IXc, ILc, KXc, 0, 0}
+#define GA 3, {IXc, ILc, 3, 0, 0}
+#define G12 3, {IXc, ILc, 12, 0, 0}
+const RegVar kRegistry[] = {
+    {"vor", SPD_T_COMPLEX128, 4, {MXc, NXc, KXc, 2, 0}, Device}, {"div", SPD_T_COMPLEX128, 4, {MXc, NXc, KXc, 2, 0}, Device},
+    {"t", SPD_T_COMPLEX128, 4, {MXc, NXc, KXc, 2, 0}, Device}, {"tr", SPD_T_COMPLEX128, 4, {MXc, NXc, KXc, 2, 0}, Device},
+    {"ps", SPD_T_COMPLEX128, 3, {MXc, NXc, 2, 0, 0}, Device}, {"phi", SPD_T_COMPLEX128, 3, {MXc, NXc, KXc, 0, 0}, Device},
+    {"phis", SPD_T_COMPLEX128, 2, {MXc, NXc, 0, 0, 0}, Device}, {"tcorh", SPD_T_COMPLEX128, 2, {MXc, NXc, 0, 0, 0}, Device},
+    {"qcorh", SPD_T_COMPLEX128, 2, {MXc, NXc, 0, 0, 0}, Device},
+    {"u_grid", SPD_T_FLOAT64, G3, Device}, {"v_grid", SPD_T_FLOAT64, G3, Device}, {"t_grid", SPD_T_FLOAT64, G3, Device},
+    {"q_grid", SPD_T_FLOAT64, G3, Device}, {"phi_grid", SPD_T_FLOAT64, G3, Device}, {"ps_grid", SPD_T_FLOAT64, G2, Device},
+    {"rad_st4a", SPD_T_FLOAT64, 4, {IXc, ILc, KXc, 2, 0}, Device}, {"rad_flux", SPD_T_FLOAT64, 3, {IXc, ILc, 4, 0, 0}, Device},
+    {"tt_rsw", SPD_T_FLOAT64, G3, Device}, {"rad_tau2", SPD_T_FLOAT64, 4, {IXc, ILc, KXc, 4, 0}, Device},
+    {"rad_strat_corr", SPD_T_FLOAT64, 3, {IXc, ILc, 2, 0, 0}, Device},
+    {"fmask_land", SPD_T_FLOAT64, G2, Device}, {"phis0", SPD_T_FLOAT64, G2, Device}, {"forog", SPD_T_FLOAT64, G2, Device},
+    {"sst_am", SPD_T_FLOAT64, G2, Device}, {"alb_land", SPD_T_FLOAT64, G2, Device}, {"alb_sea", SPD_T_FLOAT64, G2, Device},
+    {"snowc", SPD_T_FLOAT64, G2, Device}, {"land_temp", SPD_T_FLOAT64, G2, Device},
+    {"soil_avail_water", SPD_T_FLOAT64, G2, Device}, {"flux_solar_in", SPD_T_FLOAT64, G2, Device},
+    {"flux_ozone_upper", SPD_T_FLOAT64, G2, Device}, {"flux_ozone_lower", SPD_T_FLOAT64, G2, Device},
+    {"zenit_correction", SPD_T_FLOAT64, G2, Device}, {"stratospheric_correction", SPD_T_FLOAT64, G2, Device},
+    {"alb_surface", SPD_T_FLOAT64, G2, Device}, {"precnv", SPD_T_FLOAT64, G2, Device}, {"precls", SPD_T_FLOAT64, G2, Device},
+    {"cbmf", SPD_T_FLOAT64, G2, Device}, {"slrd", SPD_T_FLOAT64, G2, Device}, {"slr", SPD_T_FLOAT64, G2, Device},
+    {"olr", SPD_T_FLOAT64, G2, Device}, {"tsr", SPD_T_FLOAT64, G2, Device}, {"ssrd", SPD_T_FLOAT64, G2, Device},
+    {"ssr", SPD_T_FLOAT64, G2, Device}, {"qcloud_equiv", SPD_T_FLOAT64, G2, Device},
+    {"slru", SPD_T_FLOAT64, GA, Device}, {"ustr", SPD_T_FLOAT64, GA, Device}, {"vstr", SPD_T_FLOAT64, GA, Device},
+    {"shf", SPD_T_FLOAT64, GA, Device}, {"evap", SPD_T_FLOAT64, GA, Device}, {"hfluxn", SPD_T_FLOAT64, GA, Device},
+    {"stl12", SPD_T_FLOAT64, G12, Device}, {"snowd12", SPD_T_FLOAT64, G12, Device}, {"soilw12", SPD_T_FLOAT64, G12, Device},
+    {"sst12", SPD_T_FLOAT64, G12, Device}, {"sea_ice_frac12", SPD_T_FLOAT64, G12, Device},
+    {"soil_wc_l1", SPD_T_FLOAT64, G12, Device}, {"soil_wc_l2", SPD_T_FLOAT64, G12, Device},
+    {"soil_wc_l3", SPD_T_FLOAT64, G12, Device}, {"sst_anom", SPD_T_FLOAT64, 3, {IXc, ILc, -1, 0, 0}, Device},
+    {"stlcl_obs", SPD_T_FLOAT64, G2, Device}, {"snowdcl_obs", SPD_T_FLOAT64, G2, Device},
+    {"soilwcl_obs", SPD_T_FLOAT64, G2, Device}, {"stl_lm", SPD_T_FLOAT64, G2, Device}, {"snow_depth", SPD_T_FLOAT64, G2, Device},
+    {"cdland", SPD_T_FLOAT64, G2, Device}, {"rhcapl", SPD_T_FLOAT64, G2, Device}, {"sstcl_ob", SPD_T_FLOAT64, G2, Device},
+    {"sicecl_ob", SPD_T_FLOAT64, G2, Device}, {"ticecl_ob", SPD_T_FLOAT64, G2, Device}, {"sstan_ob", SPD_T_FLOAT64, G2, Device},
+    {"sst_om", SPD_T_FLOAT64, G2, Device}, {"tice_om", SPD_T_FLOAT64, G2, Device}, {"sice_om", SPD_T_FLOAT64, G2, Device},
+    {"sstan_am", SPD_T_FLOAT64, G2, Device}, {"sice_am", SPD_T_FLOAT64, G2, Device}, {"tice_am", SPD_T_FLOAT64, G2, Device},
+    {"ssti_om", SPD_T_FLOAT64, G2, Device}, {"cdsea", SPD_T_FLOAT64, G2, Device}, {"cdice", SPD_T_FLOAT64, G2, Device},
+    {"rhcaps", SPD_T_FLOAT64, G2, Device}, {"rhcapi", SPD_T_FLOAT64, G2, Device}, {"hfseacl", SPD_T_FLOAT64, G2, Device},
+    {"fmask_sea", SPD_T_FLOAT64, G2, Device}, {"alb0", SPD_T_FLOAT64, G2, Device}, {"orog", SPD_T_FLOAT64, G2, Device},
+    {"phi0", SPD_T_FLOAT64, G2, Device}, {"fmask_orig", SPD_T_FLOAT64, G2, Device}, {"veg_high", SPD_T_FLOAT64, G2, Device},
+    {"veg_low", SPD_T_FLOAT64, G2, Device}, {"bmask_land", SPD_T_FLOAT64, G2, Device}, {"bmask_sea", SPD_T_FLOAT64, G2, Device},
+    // allocated by the reference, never read by its time step: plain host arrays of the container
+    {"snowcv", SPD_T_FLOAT64, G2, HostOnly}, {"snowls", SPD_T_FLOAT64, G2, HostOnly}, {"sstcl_om", SPD_T_FLOAT64, G2, HostOnly},
+    {"wsst_ob", SPD_T_FLOAT64, G2, HostOnly}, {"sstom12", SPD_T_FLOAT64, G12, HostOnly},
+    // read-only tables of the context
+    {"lon", SPD_T_FLOAT32, 1, {IXc, 0, 0, 0, 0}, Table}, {"lat", SPD_T_FLOAT32, 1, {ILc, 0, 0, 0, 0}, Table},
+    {"lev", SPD_T_FLOAT32, 1, {KXc, 0, 0, 0, 0}, Table}, {"deglat_s", SPD_T_FLOAT64, 1, {ILc, 0, 0, 0, 0}, Table},
+    {"fband", SPD_T_FLOAT64, 2, {301, 4, 0, 0, 0}, Table}, {"xgeop1", SPD_T_FLOAT64, 1, {KXc, 0, 0, 0, 0}, Table},
+    {"xgeop2", SPD_T_FLOAT64, 1, {KXc, 0, 0, 0, 0}, Table},
+    // scalars
+    {"current_step", SPD_T_INT32, 0, {0, 0, 0, 0, 0}, Scalar}, {"increase_co2", SPD_T_LOGICAL, 0, {0, 0, 0, 0, 0}, Scalar},
+    {"compute_shortwave", SPD_T_LOGICAL, 0, {0, 0, 0, 0, 0}, Scalar},
+    {"air_absortivity_co2", SPD_T_FLOAT64, 0, {0, 0, 0, 0, 0}, Scalar},
+    {"land_coupling_flag", SPD_T_LOGICAL, 0, {0, 0, 0, 0, 0}, Scalar},
+    {"sst_anomaly_coupling_flag", SPD_T_LOGICAL, 0, {0, 0, 0, 0, 0}, Scalar},
+    {"ablco2_ref", SPD_T_FLOAT64, 0, {0, 0, 0, 0, 0}, Scalar},
+};
+#undef G2
+#undef G3
+#undef GA
+#undef G12
+constexpr int kRegistryCount = sizeof(kRegistry) / sizeof(kRegistry[0]);
+
+const RegVar *find_var(const char *name) {
+    if (!name) return nullptr;
+    for (const RegVar &v : kRegistry)
+        if (std::strcmp(v.name, name) == 0) return &v;
+    return nullptr;
+}
+size_t elem_bytes(int dtype) { return dtype == SPD_T_COMPLEX128 ? 16 : (dtype == SPD_T_FLOAT64 ? 8 : 4); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// containers
+// ---------------------------------------------------------------------------------------------------------------------
+std::atomic<int> g_models_alive{0};
+
+struct Batch {  // one device model shared by the containers of its members
+    Batch() { ++g_models_alive; }
+    Batch(const Batch &) = delete;
+    spd_handle ctx = nullptr;
+    spd_model_handle model = nullptr;
+    int device = 0, members = 0, n_months = 1;
+    bool sst_anom_allocated = false;
+    std::vector<char> initialized;
+    ~Batch() {
+        --g_models_alive;
+        if (model) {
+            (void)hipSetDevice(device);
+            (void)spd_model_destroy(model);
+        }
+    }
+};
+struct State {
+    std::shared_ptr<Batch> batch;
+    int member = 0;
+    std::map<std::string, std::vector<double>> host;  // HostOnly arrays
+    bool compute_shortwave = true;                      // model_state_def.py:312-318 default
+};
+struct Date {
+    int32_t ymdhm[5];
+};
+struct Control {  // ControlParams_t: start / end and the running model date with its month index
+    Date start, end, now;
+    int32_t month_idx = 1;
+};
+
+std::recursive_mutex g_mutex;
+int64_t g_next = 1;
+std::map<int64_t, std::shared_ptr<State>> g_states;
+std::map<int64_t, Date> g_dates;
+std::map<int64_t, Control> g_controls;
+std::map<int, spd_handle> g_contexts;  // one context per device, alive for the life of the process
+
+int fail(int code, const std::string &msg) { return spd_set_error(code, msg); }
+
+int context_for_current_device(spd_handle *out, int *device) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(SPD_E_DEVICE, "speedy driver: no HIP device (there is no CPU fallback)");
+    auto it = g_contexts.find(dev);
+    if (it == g_contexts.end()) {
+        spd_handle h = nullptr;
+        if (int rc = spd_create(&h, dev)) return rc;
+        it = g_contexts.emplace(dev, h).first;
+    }
+    *out = it->second;
+    *device = dev;
+    return SPD_OK;
+}
+
+int new_batch(int members, std::shared_ptr<Batch> *out) {
+    auto b = std::make_shared<Batch>();
+    if (int rc = context_for_current_device(&b->ctx, &b->device)) return rc;
+    if (int rc = spd_model_create(b->ctx, members, &b->model)) return rc;
+    b->members = members;
+    b->initialized.assign(members, 0);
+    *out = b;
+    return SPD_OK;
+}
+
+std::shared_ptr<State> state_of(int64_t cnt) {
+    auto it = g_states.find(cnt);
+    return it == g_states.end() ? nullptr : it->second;
+}
+
+bool same_date(const Control &a, const Control &b) {
+    return std::memcmp(a.now.ymdhm, b.now.ymdhm, sizeof(a.now.ymdhm)) == 0 && a.month_idx == b.month_idx;
+}
+
+// the model's host-side control block with the date of a control container in it
+int push_date(Batch &b, const Control &c) {
+    spd_model_control mc;
+    if (int rc = spd_model_get_control(b.model, &mc)) return rc;
+    mc.year = c.now.ymdhm[0]; mc.month = c.now.ymdhm[1]; mc.day = c.now.ymdhm[2]; mc.hour = c.now.ymdhm[3];
+    mc.minute = c.now.ymdhm[4];
+    mc.month_idx = c.month_idx;
+    return spd_model_set_control(b.model, &mc);
+}
+int pull_date(Batch &b, Control &c) {
+    spd_model_control mc;
+    if (int rc = spd_model_get_control(b.model, &mc)) return rc;
+    c.now.ymdhm[0] = mc.year; c.now.ymdhm[1] = mc.month; c.now.ymdhm[2] = mc.day; c.now.ymdhm[3] = mc.hour;
+    c.now.ymdhm[4] = mc.minute;
+    c.month_idx = mc.month_idx;
+    return SPD_OK;
+}
+
+// every container that is a member of `b`
+std::vector<std::shared_ptr<State>> members_of(const std::shared_ptr<Batch> &b) {
+    std::vector<std::shared_ptr<State>> out;
+    for (auto &kv : g_states)
+        if (kv.second->batch == b) out.push_back(kv.second);
+    return out;
+}
+
+// Take a batched model apart: every container bound to it gets a one-member model of its own (device-to-device copies).
+int split_batch(const std::shared_ptr<Batch> &b) {
+    if (b->members == 1) return SPD_OK;
+    spd_model_control mc;
+    if (int rc = spd_model_get_control(b->model, &mc)) return rc;
+    for (auto &st : members_of(b)) {
+        std::shared_ptr<Batch> single;
+        if (int rc = new_batch(1, &single)) return rc;
+        if (b->sst_anom_allocated) {
+            if (int rc = spd_model_init_sst_anom(single->model, b->n_months)) return rc;
+            single->n_months = b->n_months;
+            single->sst_anom_allocated = true;
+        }
+        if (int rc = spd_model_copy_member(single->model, 0, b->model, st->member, nullptr)) return rc;
+        single->initialized[0] = b->initialized[st->member];
+        if (single->initialized[0]) {
+            if (int rc = spd_model_set_control(single->model, &mc)) return rc;
+            if (int rc = spd_model_set_time_step(single->model, 2 * kDelt)) return rc;
+        } else {
+            (void)spd_model_set_flags(single->model, mc.land_coupling_flag, mc.sst_anomaly_coupling_flag, mc.increase_co2);
+            (void)spd_model_set_co2(single->model, mc.air_absortivity_co2);
+        }
+        st->batch = single;
+        st->member = 0;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return fail(SPD_E_DEVICE, "speedy driver: device error while splitting a batch");
+    return SPD_OK;  // (`b` dies with the caller's reference)
+}
+
+// Gather n independent, initialised one-member models that agree in their control blocks into one batched model.
+// Returns SPD_OK with *done = false when the states cannot be gathered (then the caller steps them one by one).
+int gather(const std::vector<std::shared_ptr<State>> &states, bool *done) {
+    *done = false;
+    const int n = static_cast<int>(states.size());
+    spd_model_control first{};
+    for (int i = 0; i < n; ++i) {
+        const Batch &b = *states[i]->batch;
+        if (b.members != 1 || !b.initialized[0]) return SPD_OK;
+        if (b.device != states[0]->batch->device || b.n_months != states[0]->batch->n_months ||
+            b.sst_anom_allocated != states[0]->batch->sst_anom_allocated)
+            return SPD_OK;
+        for (int j = 0; j < i; ++j)
+            if (states[j]->batch == states[i]->batch) return SPD_OK;  // the same container twice
+        spd_model_control mc;
+        if (int rc = spd_model_get_control(b.model, &mc)) return rc;
+        if (i == 0) first = mc;
+        else if (std::memcmp(&mc, &first, sizeof(mc)) != 0) return SPD_OK;
+    }
+    if (first.sppt_on) return SPD_OK;  // (the SPPT generator is keyed by member ids of the model it was set up for)
+    if (hipSetDevice(states[0]->batch->device) != hipSuccess) return fail(SPD_E_DEVICE, "speedy driver: hipSetDevice failed");
+    std::shared_ptr<Batch> big;
+    if (int rc = new_batch(n, &big)) return rc;
+    if (states[0]->batch->sst_anom_allocated) {
+        if (int rc = spd_model_init_sst_anom(big->model, states[0]->batch->n_months)) return rc;
+        big->n_months = states[0]->batch->n_months;
+        big->sst_anom_allocated = true;
+    }
+    for (int i = 0; i < n; ++i)
+        if (int rc = spd_model_copy_member(big->model, i, states[i]->batch->model, 0, nullptr)) return rc;
+    if (hipDeviceSynchronize() != hipSuccess) return fail(SPD_E_DEVICE, "speedy driver: device error while gathering a batch");
+    if (int rc = spd_model_set_control(big->model, &first)) return rc;
+    if (int rc = spd_model_set_time_step(big->model, 2 * kDelt)) return rc;
+    for (int i = 0; i < n; ++i) {
+        states[i]->batch = big;  // (the one-member model dies with its last reference)
+        states[i]->member = i;
+        big->initialized[i] = 1;
+    }
+    *done = true;
+    return SPD_OK;
+}
+
+// do_single_step + check_diagnostics for all members of `b` at the date of `c`
+int step_batch(Batch &b, const Control &c, std::vector<int32_t> &codes) {
+    codes.assign(b.members, 0);
+    for (int i = 0; i < b.members; ++i)
+        if (!b.initialized[i]) {
+            codes.assign(b.members, -1);  // E_STATE_NOT_INITIALIZED
+            return SPD_OK;
+        }
+    if (hipSetDevice(b.device) != hipSuccess) return fail(SPD_E_DEVICE, "speedy driver: hipSetDevice failed");
+    if (int rc = push_date(b, c)) return rc;
+    if (int rc = spd_model_step(b.model, 1, nullptr)) return rc;
+    return spd_model_check(b.model, 2, codes.data(), nullptr, nullptr);
+}
+
+int table_values(const RegVar &v, spd_handle ctx, std::vector<double> &out64, std::vector<float> &out32) {
+    auto tab = [&](const char *name, std::vector<double> &dst) -> int {
+        const long n = spd_get_table_host(ctx, name, nullptr, 0);
+        if (n < 0) return static_cast<int>(n);
+        dst.resize(n);
+        return spd_get_table_host(ctx, name, dst.data(), dst.size()) < 0 ? SPD_E_ARG : SPD_OK;
+    };
+    const std::string s(v.name);
+    std::vector<double> a, b;
+    if (s == "lon") {  // initialization.f90:86
+        for (int i = 0; i < IXc; ++i) out32.push_back(3.75f * static_cast<float>(i));
+    } else if (s == "lat" || s == "deglat_s") {  // initialization.f90:87 (default real) / sea_model.f90 (real(p))
+        if (int rc = tab("radang", a)) return rc;
+        for (int j = 0; j < ILc; ++j) {
+            if (s == "lat") out32.push_back(static_cast<float>(a[j]) * 90.0f / std::asin(1.0f));
+            else out64.push_back(a[j] * 90.0 / std::asin(1.0));
+        }
+    } else if (s == "lev") {  // initialization.f90:85
+        if (int rc = tab("fsg", a)) return rc;
+        for (int k = 0; k < KXc; ++k) out32.push_back(static_cast<float>(a[k]));
+    } else if (s == "fband") {
+        if (int rc = tab("fband", out64)) return rc;
+    } else {  // xgeop1 / xgeop2, geopotential.f90:16-31
+        if (int rc = tab("hsg", a)) return rc;
+        if (int rc = tab("fsg", b)) return rc;
+        const double rgas = static_cast<double>(2.0f / 7.0f) * 1004.0;
+        out64.assign(KXc, 0.0);
+        for (int k = 0; k < KXc; ++k) {
+            if (s == "xgeop1") out64[k] = rgas * std::log(a[k + 1] / b[k]);
+            else if (k > 0) out64[k] = rgas * std::log(b[k] / a[k]);
+        }
+    }
+    return SPD_OK;
+}
+
+size_t var_bytes(const RegVar &v, const Batch &b) {
+    size_t n = elem_bytes(v.dtype);
+    for (int d = 0; d < v.ndim; ++d) n *= static_cast<size_t>(v.shape[d] < 0 ? b.n_months + 2 : v.shape[d]);
+    return n;
+}
+
+}  // namespace
+
+#define LOCK std::lock_guard<std::recursive_mutex> lock_(g_mutex)
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ModelState
+// ---------------------------------------------------------------------------------------------------------------------
+int spd_modelstate_init(int64_t *state_cnt) {
+    if (!state_cnt) return fail(SPD_E_ARG, "spd_modelstate_init: null argument");
+    return spd_modelstate_init_ensemble(state_cnt, 1);
+}
+
+int spd_modelstate_init_ensemble(int64_t *state_cnts, int32_t n_members) {
+    if (!state_cnts || n_members < 1) return fail(SPD_E_ARG, "spd_modelstate_init_ensemble: bad argument");
+    LOCK;
+    std::shared_ptr<Batch> b;
+    if (int rc = new_batch(n_members, &b)) return rc;
+    for (int i = 0; i < n_members; ++i) {
+        auto st = std::make_shared<State>();
+        st->batch = b;
+        st->member = i;
+        state_cnts[i] = g_next++;
+        g_states[state_cnts[i]] = st;
+    }
+    return SPD_OK;
+}
+
+int spd_modelstate_init_sst_anom(int64_t state_cnt, int32_t n_months) {
+    LOCK;
+    auto st = state_of(state_cnt);
+    if (!st) return fail(SPD_E_ARG, "spd_modelstate_init_sst_anom: not a live state container");
+    Batch &b = *st->batch;
+    if (b.sst_anom_allocated && b.n_months == n_months) return SPD_OK;
+    if (int rc = spd_model_init_sst_anom(b.model, n_months)) return rc;
+    b.n_months = n_months;
+    b.sst_anom_allocated = true;
+    return SPD_OK;
+}
+
+int spd_modelstate_close(int64_t state_cnt) {
+    LOCK;
+    auto it = g_states.find(state_cnt);
+    if (it == g_states.end()) return SPD_OK;
+    g_states.erase(it);  // the device model goes with its last container
+    return SPD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Datetime, ControlParams
+// ---------------------------------------------------------------------------------------------------------------------
+int spd_create_datetime(int32_t year, int32_t month, int32_t day, int32_t hour, int32_t minute, int64_t *datetime_cnt) {
+    if (!datetime_cnt) return fail(SPD_E_ARG, "spd_create_datetime: null argument");
+    LOCK;
+    *datetime_cnt = g_next++;
+    g_dates[*datetime_cnt] = Date{{year, month, day, hour, minute}};
+    return SPD_OK;
+}
+
+int spd_get_datetime(int64_t cnt, int32_t *year, int32_t *month, int32_t *day, int32_t *hour, int32_t *minute) {
+    LOCK;
+    auto it = g_dates.find(cnt);
+    if (it == g_dates.end() || !year || !month || !day || !hour || !minute)
+        return fail(SPD_E_ARG, "spd_get_datetime: not a live datetime container");
+    *year = it->second.ymdhm[0]; *month = it->second.ymdhm[1]; *day = it->second.ymdhm[2];
+    *hour = it->second.ymdhm[3]; *minute = it->second.ymdhm[4];
+    return SPD_OK;
+}
+
+int spd_close_datetime(int64_t cnt) {
+    LOCK;
+    g_dates.erase(cnt);
+    return SPD_OK;
+}
+
+int spd_controlparams_init(int64_t *control_cnt, int64_t start_cnt, int64_t end_cnt) {
+    if (!control_cnt) return fail(SPD_E_ARG, "spd_controlparams_init: null argument");
+    LOCK;
+    auto a = g_dates.find(start_cnt), b = g_dates.find(end_cnt);
+    if (a == g_dates.end() || b == g_dates.end()) return fail(SPD_E_ARG, "spd_controlparams_init: not a live datetime container");
+    const Date &s = a->second;
+    if (s.ymdhm[1] < 1 || s.ymdhm[1] > 12 || s.ymdhm[2] < 1 || s.ymdhm[2] > 31)
+        return fail(SPD_E_ARG, "spd_controlparams_init: bad start date");
+    Control c;
+    c.start = s;
+    c.end = b->second;
+    c.now = s;  // initialize_control, model_control.f90:91: the model datetime starts at the start datetime
+    c.month_idx = 1;
+    *control_cnt = g_next++;
+    g_controls[*control_cnt] = c;
+    return SPD_OK;
+}
+
+int spd_controlparams_close(int64_t cnt) {
+    LOCK;
+    g_controls.erase(cnt);
+    return SPD_OK;
+}
+
+int spd_controlparams_get_model_datetime(int64_t cnt, int32_t *ymdhm, int32_t *month_idx) {
+    LOCK;
+    auto it = g_controls.find(cnt);
+    if (it == g_controls.end() || !ymdhm) return fail(SPD_E_ARG, "spd_controlparams_get_model_datetime: not a live control container");
+    std::memcpy(ymdhm, it->second.now.ymdhm, sizeof(it->second.now.ymdhm));
+    if (month_idx) *month_idx = it->second.month_idx;
+    return SPD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// init / step / parallel_step / check / transforms
+// ---------------------------------------------------------------------------------------------------------------------
+int spd_init(int64_t state_cnt, int64_t control_cnt, int32_t *error_code) {
+    if (!error_code) return fail(SPD_E_ARG, "spd_init: null argument");
+    LOCK;
+    auto st = state_of(state_cnt);
+    auto ci = g_controls.find(control_cnt);
+    if (!st || ci == g_controls.end()) return fail(SPD_E_ARG, "spd_init: not a live state / control container");
+    Control &c = ci->second;
+    std::shared_ptr<Batch> b = st->batch;
+    if (hipSetDevice(b->device) != hipSuccess) return fail(SPD_E_DEVICE, "spd_init: hipSetDevice failed");
+    const int32_t *d = c.start.ymdhm;
+    if (b->members == 1) {
+        if (int rc = spd_model_init(b->model, d[0], d[1], d[2], d[3], d[4], nullptr)) return rc;
+    } else {
+        // a member of a batched model: initialise a scratch one-member model from this member's boundary fields and copy the
+        // resulting state into the member's slot; the batch takes its date when its last member has been initialised
+        std::shared_ptr<Batch> scratch;
+        if (int rc = new_batch(1, &scratch)) return rc;
+        int rc = SPD_OK;
+        if (b->sst_anom_allocated) rc = spd_model_init_sst_anom(scratch->model, b->n_months);
+        spd_model_control mc;
+        if (rc == SPD_OK) rc = spd_model_get_control(b->model, &mc);
+        if (rc == SPD_OK) rc = spd_model_copy_member(scratch->model, 0, b->model, st->member, nullptr);
+        if (rc == SPD_OK) rc = spd_model_set_flags(scratch->model, mc.land_coupling_flag, mc.sst_anomaly_coupling_flag, mc.increase_co2);
+        if (rc == SPD_OK) rc = spd_model_set_co2(scratch->model, mc.air_absortivity_co2);
+        if (rc == SPD_OK) rc = spd_model_init(scratch->model, d[0], d[1], d[2], d[3], d[4], nullptr);
+        if (rc == SPD_OK) rc = spd_model_copy_member(b->model, st->member, scratch->model, 0, nullptr);
+        if (rc == SPD_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(SPD_E_DEVICE, "spd_init: device error");
+        if (rc == SPD_OK) rc = spd_model_mark_initialized(b->model, 0, d[0], d[1], d[2], d[3], d[4]);
+        if (rc == SPD_OK) rc = spd_model_set_time_step(b->model, 2 * kDelt);
+        if (rc != SPD_OK) return rc;  // (the scratch model dies at the end of this block)
+    }
+    b->initialized[st->member] = 1;
+    c.now = c.start;
+    c.month_idx = 1;
+    *error_code = 0;
+    return SPD_OK;
+}
+
+int spd_parallel_step(const int64_t *state_cnts, const int64_t *control_cnts, int32_t *error_codes, int32_t n) {
+    if (n < 0 || (n > 0 && (!state_cnts || !control_cnts || !error_codes))) return fail(SPD_E_ARG, "spd_parallel_step: bad argument");
+    LOCK;
+    std::vector<std::shared_ptr<State>> states(n);
+    std::vector<Control *> controls(n);
+    for (int i = 0; i < n; ++i) {
+        states[i] = state_of(state_cnts[i]);
+        auto ci = g_controls.find(control_cnts[i]);
+        if (!states[i] || ci == g_controls.end()) return fail(SPD_E_ARG, "spd_parallel_step: not a live state / control container");
+        controls[i] = &ci->second;
+    }
+    bool dates_agree = true;
+    for (int i = 1; i < n; ++i) dates_agree = dates_agree && same_date(*controls[0], *controls[i]);
+    // n independent one-member models -> one batched model (once; later calls find them batched)
+    if (n > 1 && dates_agree) {
+        bool singles = true;
+        for (int i = 0; i < n; ++i) singles = singles && states[i]->batch->members == 1;
+        if (singles) {
+            bool done = false;
+            if (int rc = gather(states, &done)) return rc;
+        }
+    }
+    std::vector<char> handled(n, 0);
+    for (int i = 0; i < n; ++i) {
+        if (handled[i]) continue;
+        std::shared_ptr<Batch> b = states[i]->batch;
+        // positions of the argument list that belong to this model
+        std::vector<int> mine;
+        for (int j = i; j < n; ++j)
+            if (states[j]->batch == b) mine.push_back(j);
+        bool whole = static_cast<int>(mine.size()) == b->members;
+        std::vector<char> seen(b->members, 0);
+        for (int j : mine) {
+            whole = whole && !seen[states[j]->member] && same_date(*controls[i], *controls[j]);
+            seen[states[j]->member] = 1;
+        }
+        if (!whole) {  // a different grouping than the batch: take it apart and step this container on its own
+            if (int rc = split_batch(b)) return rc;
+            b = states[i]->batch;
+            mine.assign(1, i);
+        }
+        std::vector<int32_t> codes;
+        if (int rc = step_batch(*b, *controls[i], codes)) return rc;
+        Control advanced = *controls[i];
+        if (int rc = pull_date(*b, advanced)) return rc;
+        for (int j : mine) {
+            const int32_t code = codes[states[j]->member];
+            error_codes[j] = code;
+            if (code == 0) {  // speedy.f90:57-71: the date only advances after a successful check
+                controls[j]->now = advanced.now;
+                controls[j]->month_idx = advanced.month_idx;
+            }
+            handled[j] = 1;
+        }
+    }
+    return SPD_OK;
+}
+
+int spd_step(int64_t state_cnt, int64_t control_cnt, int32_t *error_code) {
+    if (!error_code) return fail(SPD_E_ARG, "spd_step: null argument");
+    return spd_parallel_step(&state_cnt, &control_cnt, error_code, 1);
+}
+
+int spd_check(int64_t state_cnt, int32_t *error_code) {
+    if (!error_code) return fail(SPD_E_ARG, "spd_check: null argument");
+    LOCK;
+    auto st = state_of(state_cnt);
+    if (!st) return fail(SPD_E_ARG, "spd_check: not a live state container");
+    Batch &b = *st->batch;
+    if (!b.initialized[st->member]) {
+        *error_code = -1;
+        return SPD_OK;
+    }
+    if (hipSetDevice(b.device) != hipSuccess) return fail(SPD_E_DEVICE, "spd_check: hipSetDevice failed");
+    std::vector<int32_t> codes(b.members, 0);
+    if (int rc = spd_model_check(b.model, 1, codes.data(), nullptr, nullptr)) return rc;
+    *error_code = codes[st->member];
+    return SPD_OK;
+}
+
+static int transform(int64_t state_cnt, int which, const char *who) {
+    LOCK;
+    auto st = state_of(state_cnt);
+    if (!st) return fail(SPD_E_ARG, std::string(who) + ": not a live state container");
+    Batch &b = *st->batch;
+    if (hipSetDevice(b.device) != hipSuccess) return fail(SPD_E_DEVICE, std::string(who) + ": hipSetDevice failed");
+    int rc;
+    if (which == 0) rc = spd_model_spectral2grid(b.model, st->member, 1, nullptr);
+    else if (which == 1) rc = spd_model_grid2spectral(b.model, st->member, 1, nullptr);
+    else rc = spd_model_grid_filter(b.model, st->member, 1, nullptr);
+    if (rc == SPD_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = fail(SPD_E_DEVICE, std::string(who) + ": device error");
+    return rc;
+}
+int spd_transform_spectral2grid(int64_t state_cnt) { return transform(state_cnt, 0, "spd_transform_spectral2grid"); }
+int spd_transform_grid2spectral(int64_t state_cnt) { return transform(state_cnt, 1, "spd_transform_grid2spectral"); }
+int spd_apply_grid_filter(int64_t state_cnt) { return transform(state_cnt, 2, "spd_apply_grid_filter"); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// registry access
+// ---------------------------------------------------------------------------------------------------------------------
+static int access(int64_t state_cnt, const char *name, void *buf, size_t bytes, bool set) {
+    const char *who = set ? "spd_set" : "spd_get";
+    LOCK;
+    auto st = state_of(state_cnt);
+    const RegVar *v = find_var(name);
+    if (!st || !buf) return fail(SPD_E_ARG, std::string(who) + ": not a live state container / null buffer");
+    if (!v) return fail(SPD_E_ARG, std::string(who) + ": unknown variable '" + (name ? name : "") + "'");
+    std::shared_ptr<Batch> b = st->batch;
+    const size_t need = var_bytes(*v, *b);
+    if (bytes != need)
+        return fail(SPD_E_SIZE, std::string(who) + ": '" + name + "' is " + std::to_string(need) + " bytes (Array shape missmatch)");
+    if (hipSetDevice(b->device) != hipSuccess) return fail(SPD_E_DEVICE, std::string(who) + ": hipSetDevice failed");
+    switch (v->where) {
+        case Device:
+            return set ? spd_model_set(b->model, name, st->member, buf, bytes) : spd_model_get(b->model, name, st->member, buf, bytes);
+        case HostOnly: {
+            std::vector<double> &h = st->host[name];
+            h.resize(need / sizeof(double), 0.0);
+            if (set) std::memcpy(h.data(), buf, need);
+            else std::memcpy(buf, h.data(), need);
+            return SPD_OK;
+        }
+        case Table: {
+            if (set) return fail(SPD_E_ARG, std::string("spd_set: '") + name + "' is a read-only table of the device context");
+            std::vector<double> t64;
+            std::vector<float> t32;
+            if (int rc = table_values(*v, b->ctx, t64, t32)) return rc;
+            if (v->dtype == SPD_T_FLOAT32) std::memcpy(buf, t32.data(), need);
+            else std::memcpy(buf, t64.data(), need);
+            return SPD_OK;
+        }
+        case Scalar: break;
+    }
+    spd_model_control mc;
+    if (int rc = spd_model_get_control(b->model, &mc)) return rc;
+    const std::string s(name);
+    if (!set) {
+        if (s == "current_step") *static_cast<int32_t *>(buf) = mc.current_step;
+        else if (s == "increase_co2") *static_cast<int32_t *>(buf) = mc.increase_co2;
+        else if (s == "compute_shortwave") *static_cast<int32_t *>(buf) = st->compute_shortwave ? 1 : 0;
+        else if (s == "land_coupling_flag") *static_cast<int32_t *>(buf) = mc.land_coupling_flag;
+        else if (s == "sst_anomaly_coupling_flag") *static_cast<int32_t *>(buf) = mc.sst_anomaly_coupling_flag;
+        else if (s == "air_absortivity_co2") *static_cast<double *>(buf) = mc.air_absortivity_co2;
+        else *static_cast<double *>(buf) = mc.ablco2_ref;
+        return SPD_OK;
+    }
+    if (s == "current_step") return fail(SPD_E_ARG, "spd_set: current_step is advanced by the model");
+    if (s == "compute_shortwave") {  // recomputed from the step counter by every step (speedy.f90:53); kept as a mirror
+        st->compute_shortwave = *static_cast<const int32_t *>(buf) != 0;
+        return SPD_OK;
+    }
+    spd_model_control want = mc;
+    if (s == "increase_co2") want.increase_co2 = *static_cast<const int32_t *>(buf) != 0;
+    else if (s == "land_coupling_flag") want.land_coupling_flag = *static_cast<const int32_t *>(buf) != 0;
+    else if (s == "sst_anomaly_coupling_flag") want.sst_anomaly_coupling_flag = *static_cast<const int32_t *>(buf) != 0;
+    else if (s == "air_absortivity_co2") want.air_absortivity_co2 = *static_cast<const double *>(buf);
+    else want.ablco2_ref = *static_cast<const double *>(buf);
+    if (std::memcmp(&want, &mc, sizeof(mc)) == 0) return SPD_OK;
+    if (b->members > 1) {  // the scalars are per model: a member that wants its own leaves the batch
+        if (int rc = split_batch(b)) return rc;
+        b = st->batch;
+    }
+    if (b->initialized[0]) return spd_model_set_control(b->model, &want);
+    if (int rc = spd_model_set_flags(b->model, want.land_coupling_flag, want.sst_anomaly_coupling_flag, want.increase_co2)) return rc;
+    return spd_model_set_co2(b->model, want.air_absortivity_co2);
+}
+
+int spd_get(int64_t state_cnt, const char *name, void *buf, size_t bytes) { return access(state_cnt, name, buf, bytes, false); }
+int spd_set(int64_t state_cnt, const char *name, const void *buf, size_t bytes) {
+    return access(state_cnt, name, const_cast<void *>(buf), bytes, true);
+}
+
+int spd_get_shape(int64_t state_cnt, const char *name, int32_t *shape, int32_t *ndim) {
+    LOCK;
+    auto st = state_of(state_cnt);
+    const RegVar *v = find_var(name);
+    if (!st || !shape || !ndim) return fail(SPD_E_ARG, "spd_get_shape: not a live state container / null argument");
+    if (!v) return fail(SPD_E_ARG, std::string("spd_get_shape: unknown variable '") + (name ? name : "") + "'");
+    *ndim = v->ndim;
+    for (int d = 0; d < v->ndim; ++d) shape[d] = v->shape[d] < 0 ? st->batch->n_months + 2 : v->shape[d];
+    if (std::strcmp(v->name, "sst_anom") == 0 && !st->batch->sst_anom_allocated)
+        for (int d = 0; d < v->ndim; ++d) shape[d] = 0;  // get_<v>_shape of an unallocated array, speedy_driver.f90.j2:277-281
+    return SPD_OK;
+}
+
+int spd_is_array(const char *name, int32_t *is_array) {
+    const RegVar *v = find_var(name);
+    if (!v || !is_array) return fail(SPD_E_ARG, std::string("spd_is_array: unknown variable '") + (name ? name : "") + "'");
+    *is_array = v->where == Scalar ? 0 : 1;
+    return SPD_OK;
+}
+
+int spd_registry_entry(int32_t index, char *name, int32_t *dtype, int32_t *ndim, int32_t *shape, int32_t *is_read_only) {
+    if (index < 0 || index >= kRegistryCount) return kRegistryCount;
+    const RegVar &v = kRegistry[index];
+    if (name) {
+        std::strncpy(name, v.name, 31);
+        name[31] = '\0';
+    }
+    if (dtype) *dtype = v.dtype;
+    if (ndim) *ndim = v.ndim;
+    if (shape)
+        for (int d = 0; d < 5; ++d) shape[d] = d < v.ndim ? v.shape[d] : 0;
+    if (is_read_only) *is_read_only = v.where == Table ? 1 : 0;
+    return kRegistryCount;
+}
+
+int spd_driver_stats(int64_t state_cnt, int32_t *models_alive, int32_t *members_in_model) {
+    LOCK;
+    if (models_alive) *models_alive = g_models_alive.load();
+    if (members_in_model) {
+        auto st = state_of(state_cnt);
+        *members_in_model = st ? st->batch->members : 0;
+    }
+    return SPD_OK;
+}
+
+}  // extern "C"

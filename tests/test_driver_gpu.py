@@ -1,0 +1,202 @@
+"""GPU tier: the outer C boundary (include/pyspeedy_amd_driver.h) called the way the reference's Python layer calls its
+f2py module -- modelstate_init, set_<v> of the 12 boundary fields, controlparams_init, init, step / parallel_step, check,
+transform_spectral2grid, get_<v> -- against the reference-generated goldens, and the batching of independent containers."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BC_MAP = (("orog", "orog"), ("fmask_orig", "lsm"), ("alb0", "alb"), ("veg_high", "vegh"), ("veg_low", "vegl"),
+          ("stl12", "stl"), ("snowd12", "snowd"), ("soil_wc_l1", "swl1"), ("soil_wc_l2", "swl2"), ("soil_wc_l3", "swl3"),
+          ("sst12", "sst"), ("sea_ice_frac12", "icec"))
+
+
+class Driver:
+    """The `_speedy` function set over the C ABI, for the tests."""
+
+    def __init__(self, lib):
+        self.L = lib
+
+    def ok(self, rc):
+        assert rc == 0, self.L.spd_last_error()
+
+    def date(self, *ymdhm):
+        c = C.c_int64()
+        self.ok(self.L.spd_create_datetime(*ymdhm, C.byref(c)))
+        return c.value
+
+    def control(self, start, end):
+        c = C.c_int64()
+        self.ok(self.L.spd_controlparams_init(C.byref(c), self.date(*start), self.date(*end)))
+        return c.value
+
+    def state(self):
+        c = C.c_int64()
+        self.ok(self.L.spd_modelstate_init(C.byref(c)))
+        return c.value
+
+    def set(self, cnt, name, value):
+        a = np.ascontiguousarray(np.asarray(value).ravel(order="F"))
+        self.ok(self.L.spd_set(cnt, name.encode(), a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def shape(self, cnt, name):
+        shp, nd = (C.c_int32 * 5)(), C.c_int32()
+        self.ok(self.L.spd_get_shape(cnt, name.encode(), shp, C.byref(nd)))
+        return tuple(shp[:nd.value])
+
+    def get(self, cnt, name, dtype=np.float64):
+        shape = self.shape(cnt, name)
+        a = np.zeros(int(np.prod(shape)) if shape else 1, dtype=dtype)
+        self.ok(self.L.spd_get(cnt, name.encode(), a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return a.reshape(shape, order="F") if shape else a[0]
+
+    def set_bc(self, cnt, bc, perturb=None):
+        for state_name, bc_name in BC_MAP:
+            self.set(cnt, state_name, np.asarray(bc[bc_name], dtype=np.float64))
+        if perturb is not None:
+            self.set(cnt, "sst12", np.asarray(bc["sst"], dtype=np.float64) + perturb)
+
+    def init(self, state, control):
+        code = C.c_int32(99)
+        self.ok(self.L.spd_init(state, control, C.byref(code)))
+        return code.value
+
+    def step(self, state, control):
+        code = C.c_int32(99)
+        self.ok(self.L.spd_step(state, control, C.byref(code)))
+        return code.value
+
+    def parallel_step(self, states, controls):
+        n = len(states)
+        codes = (C.c_int32 * n)(*([99] * n))
+        self.ok(self.L.spd_parallel_step((C.c_int64 * n)(*states), (C.c_int64 * n)(*controls), codes, n))
+        return list(codes)
+
+    def stats(self, cnt):
+        alive, members = C.c_int32(), C.c_int32()
+        self.ok(self.L.spd_driver_stats(cnt, C.byref(alive), C.byref(members)))
+        return alive.value, members.value
+
+    def model_date(self, control):
+        now, midx = (C.c_int32 * 5)(), C.c_int32()
+        self.ok(self.L.spd_controlparams_get_model_datetime(control, now, C.byref(midx)))
+        return tuple(now), midx.value
+
+    def close(self, *states):
+        for s in states:
+            self.ok(self.L.spd_modelstate_close(s))
+
+
+@pytest.fixture(scope="module")
+def drv(spectral, hip_lib):
+    return Driver(hip_lib)
+
+
+@pytest.fixture(scope="module")
+def bc():
+    import pyspeedy_amd
+    with np.load(pyspeedy_amd.example_bc_file()) as z:
+        return {k: z[k] for k in z.files}
+
+
+START, END = (1982, 1, 1, 0, 0), (1982, 1, 4, 0, 0)
+
+
+def test_one_container_like_the_reference_python_layer(drv, bc, golden_dir):
+    """modelstate_init -> set_<v> x 12 -> init -> 36 x step -> transform_spectral2grid -> get_<v>: equals the reference run
+    (tests/golden/export.npz, 1 day) at the 36-step tolerance."""
+    st, ctl = drv.state(), drv.control(START, END)
+    assert drv.shape(st, "sst_anom") == (0, 0, 0)  # not allocated yet (get_sst_anom_shape of the reference returns zeros)
+    drv.ok(drv.L.spd_modelstate_init_sst_anom(st, 1))
+    assert drv.shape(st, "sst_anom") == (96, 48, 3) and drv.shape(st, "vor") == (31, 32, 8, 2)
+    drv.set_bc(st, bc)
+    code = C.c_int32(5)
+    drv.ok(drv.L.spd_check(st, C.byref(code)))
+    assert code.value == -1 and drv.step(st, ctl) == -1  # E_STATE_NOT_INITIALIZED
+    assert drv.init(st, ctl) == 0
+    for _ in range(36):
+        assert drv.step(st, ctl) == 0
+    assert drv.model_date(ctl) == ((1982, 1, 2, 0, 0), 1)
+    assert drv.get(st, "current_step", np.int32) == 36
+    drv.ok(drv.L.spd_transform_spectral2grid(st))
+    gold = np.load(os.path.join(golden_dir, "export.npz"))
+    for name in ("t_grid", "u_grid", "ps_grid"):
+        got, ref = drv.get(st, name), gold["d1_" + name]
+        assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max(), name
+    # tables and scalars through the same name-driven access
+    lat = drv.get(st, "lat", np.float32)
+    assert lat.dtype == np.float32 and abs(lat[0] + 87.2165) < 1e-3 and abs(lat[-1] - 87.2165) < 1e-3
+    assert drv.get(st, "air_absortivity_co2") == 6.0 and drv.get(st, "land_coupling_flag", np.int32) == 1
+    v = np.zeros(8)
+    assert drv.L.spd_set(st, b"xgeop1", v.ctypes.data_as(C.c_void_p), v.nbytes) < 0  # read-only table
+    assert drv.L.spd_get(st, b"olr", v.ctypes.data_as(C.c_void_p), v.nbytes) < 0  # wrong size: "Array shape missmatch"
+    drv.close(st)
+
+
+def test_parallel_step_gathers_independent_containers_into_one_batched_model(drv, bc):
+    """Three containers created and initialised one by one (different SSTs) are stepped with parallel_step: after the first
+    call they are the members of ONE device model (one set of launches per step) and every member's trajectory is bitwise
+    what the same container gives when it is stepped alone with step()."""
+    alive0, _ = drv.stats(0)
+    pert = [None, 0.3 * np.ones((96, 48, 12)), -0.2 * np.ones((96, 48, 12))]
+    batched = [drv.state() for _ in range(3)]
+    alone = [drv.state() for _ in range(3)]
+    ctl_b = [drv.control(START, END) for _ in range(3)]
+    ctl_a = [drv.control(START, END) for _ in range(3)]
+    for group, ctls in ((batched, ctl_b), (alone, ctl_a)):
+        for s, c, p in zip(group, ctls, pert):
+            drv.set_bc(s, bc, p)
+            assert drv.init(s, c) == 0
+    assert drv.stats(batched[0]) == (alive0 + 6, 1)
+    for _ in range(40):  # across a day boundary
+        assert drv.parallel_step(batched, ctl_b) == [0, 0, 0]
+    assert drv.stats(batched[0]) == (alive0 + 4, 3) and drv.stats(batched[2])[1] == 3
+    for s, c in zip(alone, ctl_a):
+        for _ in range(40):
+            assert drv.step(s, c) == 0
+    assert drv.model_date(ctl_b[1]) == drv.model_date(ctl_a[1]) == ((1982, 1, 2, 2, 40), 1)
+    for sb, sa in zip(batched, alone):
+        for name, dt in (("vor", np.complex128), ("t", np.complex128), ("ps", np.complex128), ("tr", np.complex128)):
+            assert np.array_equal(drv.get(sb, name, dt), drv.get(sa, name, dt)), name
+        for name in ("olr", "precnv", "land_temp", "sst_am", "hfluxn", "rad_tau2"):
+            assert np.array_equal(drv.get(sb, name), drv.get(sa, name)), name
+    assert not np.array_equal(drv.get(batched[0], "sst_am"), drv.get(batched[1], "sst_am"))
+    # stepping ONE member of the batch on its own takes the batch apart again -- and stays on the same trajectory
+    assert drv.step(batched[1], ctl_b[1]) == 0 and drv.step(alone[1], ctl_a[1]) == 0
+    assert drv.stats(batched[1])[1] == 1 and drv.stats(batched[0])[1] == 1
+    assert np.array_equal(drv.get(batched[1], "t", np.complex128), drv.get(alone[1], "t", np.complex128))
+    # members 0 and 2 are one step behind member 1 now: parallel_step over all three cannot batch them (dates differ) ...
+    codes = drv.parallel_step(batched, ctl_b)
+    assert codes == [0, 0, 0] and drv.stats(batched[0])[1] == 1
+    drv.close(*batched, *alone)
+    assert drv.stats(0)[0] == alive0
+
+
+def test_ensemble_containers_are_batched_from_the_start(drv, bc):
+    n = 4
+    cnts = (C.c_int64 * n)()
+    drv.ok(drv.L.spd_modelstate_init_ensemble(cnts, n))
+    states = list(cnts)
+    controls = [drv.control(START, END) for _ in range(n)]
+    assert drv.stats(states[0])[1] == n
+    for i, (s, c) in enumerate(zip(states, controls)):
+        drv.set_bc(s, bc, 0.1 * i * np.ones((96, 48, 12)))
+        assert drv.init(s, c) == 0
+    single, cs = drv.state(), drv.control(START, END)
+    drv.set_bc(single, bc, 0.2 * np.ones((96, 48, 12)))
+    assert drv.init(single, cs) == 0
+    for _ in range(9):
+        assert drv.parallel_step(states, controls) == [0] * n
+        assert drv.step(single, cs) == 0
+    assert drv.stats(states[0])[1] == n
+    assert np.array_equal(drv.get(states[2], "t", np.complex128), drv.get(single, "t", np.complex128))
+    # a scalar that differs from the rest of the batch makes its member leave the batch
+    one = np.array([1], dtype=np.int32)
+    drv.ok(drv.L.spd_set(states[3], b"increase_co2", one.ctypes.data_as(C.c_void_p), 4))
+    assert drv.stats(states[3])[1] == 1 and drv.get(states[3], "increase_co2", np.int32) == 1
+    assert drv.get(states[0], "increase_co2", np.int32) == 0
+    drv.close(single, *states)
