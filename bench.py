@@ -49,10 +49,11 @@ NG = 96 * 48
 # Algorithmic HBM bytes of each step kernel PER MEMBER, counted from the kernels' argument lists (DESIGN.md section 5 has
 # the itemised lists).  Transforms: SURVEY 8d's contract figure S + G per field.
 COLUMN_DOUBLES = {"column_sw": 254, "column": 243}  # doubles moved per column (dynamics 50 in / 55 out + physics)
+DIAG_DOUBLES = 39           # of those, stores of diagnostics nothing on the device reads: only on the last step of a call
+COUPLER_DOUBLES = (55, 29)  # per column: with the climatologies interpolated (first coupling of a day) / re-used
 ALGO_BYTES = {
     "geopotential": 17 * S_BYTES,
     "spectral_step": 215 * S_BYTES,
-    "coupler": 55 * 8 * NG,
     "forcing": 19 * 8 * NG + 2 * (S_BYTES + G_BYTES),
     "dyn_grid": (50 + 55 + 18) * 8 * NG,
 }
@@ -273,25 +274,31 @@ def kernel_table(model, M, inv_per_member, sppt):
     the 8 TB/s HBM peak.  Measured in a separate one-day pass with a bracket around every launch."""
     from pyspeedy_amd.model import KERNEL_NAMES  # noqa: F401
     model.profile(2)
-    model.run(36)
+    model.run(36)  # one call, one simulated day: 12 shortwave steps, one daily forcing, one midnight coupling
     prof = model.profile_read_kernels()
     model.profile(0)
     extra = 8 if sppt else 0  # the column kernel also reads the SPPT pattern
+    # average over the 36 launches of the pass: the diagnostics-only stores happen on the last step only (unless the model
+    # is told to store them every step), the coupler interpolates its climatologies on one step of the day
+    diag = DIAG_DOUBLES * (0.0 if model.config()["diag_every_step"] else 35.0 / 36.0)
+    coupler = (COUPLER_DOUBLES[0] + 35 * COUPLER_DOUBLES[1]) / 36.0
     rows = []
     for name, (mean_ms, min_ms, n, units) in prof.items():
         if name == "spec2grid" or name == "grid2spec":
             algo = (S_BYTES + G_BYTES) * units
         elif name in COLUMN_DOUBLES:
-            algo = (COLUMN_DOUBLES[name] + extra) * 8 * NG * units
+            algo = (COLUMN_DOUBLES[name] + extra - diag) * 8 * NG * units
         elif name in ("physics_sw", "physics"):
             algo = (COLUMN_DOUBLES["column_sw" if name == "physics_sw" else "column"] - 105 + 18 + extra) * 8 * NG * units
         elif name == "sppt":
             algo = 16 * S_BYTES * (units // 8) + (S_BYTES + G_BYTES) * units
+        elif name == "coupler":
+            algo = coupler * 8 * NG * units
         else:
             algo = ALGO_BYTES[name] * units
         gbs = algo / (mean_ms * 1e-3) / 1e9
         rows.append({"kernel": name, "launches_timed": n, "avg_launch_us": mean_ms * 1e3, "min_launch_us": min_ms * 1e3,
-                     "algorithmic_bytes_per_launch": algo, "achieved": gbs, "frac": gbs / 8000.0})
+                     "algorithmic_bytes_per_launch": int(round(algo)), "achieved": gbs, "frac": gbs / 8000.0})
     return rows
 
 

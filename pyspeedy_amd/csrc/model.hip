@@ -20,14 +20,14 @@ hipError_t run_spec2grid_table(const DeviceTables &T, const FieldDesc *table, in
 hipError_t run_grid2spec_table(const DeviceTables &T, const FieldDesc *table, int nfields, hipStream_t st);
 hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nmembers, int fp32, hipStream_t s);
 hipError_t run_dyn_physics(const ModelPtrs &P, const DynDeviceTables &D, const DeviceTables &T, const spd_physics_args &a,
-                           int first, int nmembers, int fp32, hipStream_t s);
+                           int first, int nmembers, int fp32, int diag, hipStream_t s);
 hipError_t run_geopotential(const ModelPtrs &P, const DynDeviceTables &D, int first, int count, int tl, hipStream_t s);
 hipError_t run_dyn_grid(const ModelPtrs &P, const DynDeviceTables &D, int M, hipStream_t s);
 hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const DynDeviceTables &D, int M, int first, int count,
                              int j1, double dt, double eps, hipStream_t s);
 hipError_t run_diagnostics(const ModelPtrs &P, const DeviceTables &T, int M, int tl, int *err, double *diag, hipStream_t s);
 hipError_t run_coupler(const SurfacePtrs &S, int first, int count, const TimeInterp &w, int day, int land_coupling,
-                       int sst_anomaly, int anom_planes, hipStream_t s);
+                       int sst_anomaly, int anom_planes, int fresh, hipStream_t s);
 hipError_t run_forcing(const SurfacePtrs &S, int first, int count, const ZonalDevice &Z, double gamlat, double *corh_t,
                        double *corh_q, hipStream_t s);
 hipError_t run_rest_state(const RestPtrs &R, int M, const RestConsts &c, hipStream_t s);
@@ -94,15 +94,22 @@ struct spd_model {
     double *sppt_spec = nullptr, *sppt_grid = nullptr;
     // Members are stepped in `nchunks` groups on separate HIP streams (spd_model_step): a group's kernels overlap with
     // the other groups' (different kernels, complementary resources, no idle tail between dependent launches).
-    // spectral -> grid transforms per member and step: 91 as in the reference, or 77 with PYSPEEDY_AMD_PRUNE_DEAD=1, which
-    // drops the 14 whose results nothing reads (u, v above the lowest level at the physics' time level: physics.f90:93-94
-    // computes them, get_surface_fluxes only uses level kx).  Off by default: the measured step is the reference's step.
-    int inv_per_member = 91;
+    // spectral -> grid transforms per member and step: 77 = the reference's 91 minus the 14 whose results nothing reads (u, v
+    // above the lowest level at the physics' time level: physics.f90:93-94 computes them, get_surface_fluxes only uses level
+    // kx; every registry variable stays bitwise identical, tests/test_run_gpu.py).  PYSPEEDY_AMD_PRUNE_DEAD=0 restores all 91.
+    int inv_per_member = 77;
     int nchunks = 1;
     hipStream_t cstream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t cev[4] = {nullptr, nullptr, nullptr, nullptr}, ev_start = nullptr;
     bool split_dyn_physics = false;  // PYSPEEDY_AMD_SPLIT_DYN=1: separate dynamics and physics launches (for measurements)
     int phys_fp32 = 0;               // spd_model_set_physics_precision: column physics arithmetic in fp32 (BASELINE cfg 5)
+    // Dead-store elimination inside multi-step calls (PYSPEEDY_AMD_DIAG_EVERY_STEP=1 switches it off): only the LAST step
+    // of a spd_model_step call stores the physics outputs that no later kernel reads -- the host can only look at the
+    // state between calls, and every earlier value would be overwritten before that.
+    bool diag_every_step = false;
+    // The coupler's climatology interpolation is valid for a day (surface.hip): true after a coupling, false after anything
+    // wrote to the state from outside the step
+    bool surf_cache_valid = false;
     int land_coupling_flag = 1, sst_anomaly_flag = 1, increase_co2 = 0, anom_planes = 3;
     double ablco2_ref = 6.0;
     double *corh_t = nullptr, *corh_q = nullptr, *scratch_spec = nullptr;  // [M][NG], [M][NG], [2][M][992] complex
@@ -260,7 +267,9 @@ int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
     m->ctx = h;
     m->M = nmembers;
     if (const char *env = getenv("PYSPEEDY_AMD_SPLIT_DYN")) m->split_dyn_physics = atoi(env) != 0;
+    m->inv_per_member = 77;
     if (const char *env = getenv("PYSPEEDY_AMD_PRUNE_DEAD")) m->inv_per_member = atoi(env) != 0 ? 77 : 91;
+    if (const char *env = getenv("PYSPEEDY_AMD_DIAG_EVERY_STEP")) m->diag_every_step = atoi(env) != 0;
     // PYSPEEDY_AMD_CHUNKS = 2 or 3 steps the members in that many groups on separate streams: measured -6 % / -8 % per step
     // at 64 members (4 groups: +7 %).  Off by default: with overlapping launches the duration of a single kernel -- what the
     // roofline accounting of bench.py and the committed rocprof summaries are about -- is no longer attributable to it.
@@ -431,6 +440,7 @@ static int xfer(spd_model_handle m, const char *name, int member, void *host, si
     if (member < -1 || member >= m->M) return m_fail(SPD_E_ARG, "spd_model_get/set: member index out of range");
     if (member == -1 && !to_device) return m_fail(SPD_E_ARG, "spd_model_get: member = -1 (broadcast) is only valid for set");
     M_HIP(hipSetDevice(m->ctx->device));
+    if (to_device) m->surf_cache_valid = false;
     const int first = member < 0 ? 0 : member, last = member < 0 ? m->M - 1 : member;
     for (int i = first; i <= last; ++i) {
         char *dev = static_cast<char *>(e.ptr) + static_cast<size_t>(i) * e.bytes_member;
@@ -452,6 +462,7 @@ int spd_model_get(spd_model_handle m, const char *name, int member, void *host, 
 void *spd_model_device_ptr(spd_model_handle m, const char *name) {
     if (!m || !name) return nullptr;
     auto it = m->reg.find(name);
+    m->surf_cache_valid = false;  // the caller may write through the pointer
     return it == m->reg.end() ? nullptr : it->second.ptr;
 }
 
@@ -506,7 +517,8 @@ struct ProfScope {
 };
 
 // one `step(state, j1, j2, dt)` of time_stepping.f90 for the members [first, first + count) on stream s
-static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int compute_shortwave, int first, int count, hipStream_t s) {
+static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int compute_shortwave, int first, int count, int diag,
+                             hipStream_t s) {
     const DeviceTables &T = m->ctx->dev;
     const int M = m->M;
     hipError_t e;
@@ -542,7 +554,7 @@ static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int comput
             }
         } else {
             ProfScope ps(m, compute_shortwave ? SPD_K_COLUMN_SW : SPD_K_COLUMN, count, s);
-            e = run_dyn_physics(m->P, m->D, T, pa, first, count, m->phys_fp32, s);        // both in one launch
+            e = run_dyn_physics(m->P, m->D, T, pa, first, count, m->phys_fp32, diag, s);        // both in one launch
         }
     }
     if (e == hipSuccess) {                                                                // :238-268
@@ -562,7 +574,7 @@ int spd_model_step_dynamics(spd_model_handle m, int j1, int j2, double dt, int c
     if (!m) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: null model");
     if (j1 < 1 || j1 > 2 || j2 < 1 || j2 > 2) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: time levels are 1 or 2");
     if (m->dynh->dt == 0.0) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: call spd_model_set_time_step first");
-    const hipError_t e = step_range(m, j1, j2, dt, compute_shortwave, 0, m->M, static_cast<hipStream_t>(stream));
+    const hipError_t e = step_range(m, j1, j2, dt, compute_shortwave, 0, m->M, 1, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_step_dynamics: ") + hipGetErrorString(e));
     return SPD_OK;
 }
@@ -651,20 +663,20 @@ static int forcing_range(spd_model *m, const ZonalDevice &zd, int first, int cou
 
 static int set_forcing(spd_model *m, int imode, hipStream_t s) { return forcing_range(m, forcing_host(m, imode), 0, m->M, s); }
 
-static int couple_range(spd_model *m, int day, int first, int count, hipStream_t s) {  // couple_sea_land, coupler.f90:35-48
+static int couple_range(spd_model *m, int day, int first, int count, int fresh, hipStream_t s) {  // couple_sea_land, coupler.f90:35-48
     const TimeInterp w = time_interp(m->cal);
     if (m->sst_anomaly_flag && (w.a0 < 0 || w.a1 < 0 || w.a0 >= m->anom_planes || w.a1 >= m->anom_planes))
         return m_fail(SPD_E_ARG, "SST anomaly planes do not cover the simulated period (speedy.py:338-372)");
     hipError_t e;
     {
         ProfScope ps(m, SPD_K_COUPLER, count, s);
-        e = run_coupler(m->S, first, count, w, day, m->land_coupling_flag, m->sst_anomaly_flag, m->anom_planes, s);
+        e = run_coupler(m->S, first, count, w, day, m->land_coupling_flag, m->sst_anomaly_flag, m->anom_planes, fresh, s);
     }
     if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("couple_sea_land: ") + hipGetErrorString(e));
     return SPD_OK;
 }
 
-static int couple(spd_model *m, int day, hipStream_t s) { return couple_range(m, day, 0, m->M, s); }
+static int couple(spd_model *m, int day, hipStream_t s) { return couple_range(m, day, 0, m->M, 1, s); }
 
 // initialize_state for every member from the boundary fields previously stored with spd_model_set:
 // orog, fmask_orig, alb0, veg_high, veg_low, stl12, snowd12, soil_wc_l1, soil_wc_l2, sst12, sea_ice_frac12 [, sst_anom].
@@ -678,6 +690,7 @@ int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, i
     M_HIP(hipStreamSynchronize(s));
     m->cal.set(year, month, day, hour, minute);
     m->current_step = 0;
+    m->surf_cache_valid = false;
     // ---- land_model_init / sea_model_init on the host, member by member (runs once)
     const size_t G12 = static_cast<size_t>(12) * NG;
     auto down = [&](const double *dev, size_t n, int i, std::vector<double> &v) {
@@ -789,11 +802,12 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
         ZonalDevice zd{};
         if (new_day) zd = forcing_host(m, 1);
         const int sw = (m->current_step % 3 == 0) ? 1 : 0;
+        const int diag = (m->diag_every_step || it == nsteps - 1) ? 1 : 0;
         for (int g = 0, first = 0; g < G && rc == SPD_OK; ++g) {
             const int count = base + (g < extra ? 1 : 0);
             if (new_day) rc = forcing_range(m, zd, first, count, gs[g]);
             if (rc == SPD_OK) {
-                const hipError_t e = step_range(m, 2, 2, 2 * delt, sw, first, count, gs[g]);
+                const hipError_t e = step_range(m, 2, 2, 2 * delt, sw, first, count, diag, gs[g]);
                 if (e != hipSuccess) rc = m_fail(SPD_E_DEVICE, std::string("spd_model_step: ") + hipGetErrorString(e));
             }
             first += count;
@@ -801,11 +815,15 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
         if (rc != SPD_OK) break;
         m->current_step += 1;
         m->cal.advance();
+        // the interpolation weights of the climatologies change at midnight only: first coupling of a day (or of a state the
+        // host touched) interpolates, the others re-use what it stored
+        const int fresh = (!m->surf_cache_valid || (m->cal.hour == 0 && m->cal.minute == 0)) ? 1 : 0;
         for (int g = 0, first = 0; g < G && rc == SPD_OK; ++g) {
             const int count = base + (g < extra ? 1 : 0);
-            rc = couple_range(m, 1 + m->current_step / 36, first, count, gs[g]);
+            rc = couple_range(m, 1 + m->current_step / 36, first, count, fresh, gs[g]);
             first += count;
         }
+        if (rc == SPD_OK) m->surf_cache_valid = true;
     }
     if (G > 1)
         for (int g = 0; g < G; ++g) {
@@ -874,6 +892,7 @@ int spd_model_mark_initialized(spd_model_handle m, int current_step, int year, i
     if (!m) return m_fail(SPD_E_ARG, "spd_model_mark_initialized: null model");
     m->cal.set(year, month, day, hour, minute);
     m->current_step = current_step;
+    m->surf_cache_valid = false;
     m->ablco2_ref = m->air_absortivity_co2;  // set_forcing(imode = 0), forcing.f90:40
     m->initialized = true;
     return SPD_OK;
@@ -908,6 +927,7 @@ int spd_model_set_control(spd_model_handle m, const spd_model_control *in) {
         return m_fail(SPD_E_ARG, "spd_model_set_control: SPPT is on in the control block: call spd_model_set_sppt and load sppt_spec first");
     m->cal.set(in->year, in->month, in->day, in->hour, in->minute);
     m->cal.month_idx = in->month_idx;
+    m->surf_cache_valid = false;
     m->current_step = in->current_step;
     m->land_coupling_flag = in->land_coupling_flag ? 1 : 0;
     m->sst_anomaly_flag = in->sst_anomaly_coupling_flag ? 1 : 0;
@@ -930,6 +950,15 @@ int spd_model_get_date(spd_model_handle m, int *ymdhm) {
     return SPD_OK;
 }
 
+int spd_model_get_config(spd_model_handle m, int32_t *cfg) {
+    if (!m || !cfg) return m_fail(SPD_E_ARG, "spd_model_get_config: null argument");
+    cfg[0] = m->inv_per_member;
+    cfg[1] = m->diag_every_step ? 1 : 0;
+    cfg[2] = m->nchunks;
+    cfg[3] = m->split_dyn_physics ? 1 : 0;
+    return SPD_OK;
+}
+
 int spd_model_set_physics_precision(spd_model_handle m, int fp32) {
     if (!m) return m_fail(SPD_E_ARG, "spd_model_set_physics_precision: null model");
     m->phys_fp32 = fp32 ? 1 : 0;
@@ -941,6 +970,7 @@ int spd_model_set_flags(spd_model_handle m, int land_coupling_flag, int sst_anom
     m->land_coupling_flag = land_coupling_flag ? 1 : 0;
     m->sst_anomaly_flag = sst_anomaly_coupling_flag ? 1 : 0;
     m->increase_co2 = increase_co2 ? 1 : 0;
+    m->surf_cache_valid = false;
     return SPD_OK;
 }
 
@@ -1033,6 +1063,7 @@ int spd_model_init_sst_anom(spd_model_handle m, int n_months) {
     if (int rc = dalloc(m, static_cast<size_t>(m->M) * planes * NG, &p, "sst_anom", planes * NG * sizeof(double))) return rc;
     m->S.sst_anom = p;  // the previous array stays allocated until spd_model_destroy
     m->anom_planes = static_cast<int>(planes);
+    m->surf_cache_valid = false;
     return SPD_OK;
 }
 
@@ -1042,6 +1073,7 @@ int spd_model_copy_member(spd_model_handle dst, int di, spd_model_handle src, in
     if (di < 0 || di >= dst->M || si < 0 || si >= src->M) return m_fail(SPD_E_ARG, "spd_model_copy_member: member index out of range");
     if (dst->ctx->device != src->ctx->device) return m_fail(SPD_E_ARG, "spd_model_copy_member: models live on different devices");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    dst->surf_cache_valid = false;
     for (const auto &kv : src->reg) {
         auto it = dst->reg.find(kv.first);
         if (it == dst->reg.end() || it->second.bytes_member != kv.second.bytes_member)

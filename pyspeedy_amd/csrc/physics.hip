@@ -121,7 +121,7 @@ ColTables<R> col_tables(const DeviceTables &T) {
 // tendency with the physics increment at the end.
 template <int W, bool FUSED, bool KEEP, typename R>
 __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_args a, ColTables<R> CT, int first, int nmembers,
-                                                                  ModelPtrs MP, DynDeviceTables MD) {
+                                                                  ModelPtrs MP, DynDeviceTables MD, int diag) {
     using C = PhysConst<R>;
     constexpr bool MIXED = !std::is_same<R, double>::value;
     static_assert(!KEEP || FUSED, "KEEP is a variant of the fused kernel");
@@ -297,8 +297,10 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
                 dfqa[k - 1] = fuq - fdq - precnv;
             }
     }
-    stream_store(&a.cbmf[o2], cbmf);
-    stream_store(&a.precnv[o2], precnv);
+    if (diag) {
+        stream_store(&a.cbmf[o2], cbmf);
+        stream_store(&a.precnv[o2], precnv);
+    }
     const int icnv = KX - itop;  // physics.f90:132
     int iptop = itop;
 
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         qtend[0] = qtend[0] + dfqa[0] + R(0.0f);
         precls = precls * psa;
     }
-    stream_store(&a.precls[o2], precls);
+    if (diag) stream_store(&a.precls[o2], precls);
 
     const R gse = (se[nl1 - 1] - se[KX - 1]) / (phi[nl1 - 1] - phi[KX - 1]);  // physics.f90:152 (used on shortwave steps)
     const R phi_kx = phi[KX - 1];
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         cloudc = rmin<R>(1.0f, wpcl * rsqrt_(pr1) + cq * cq);
         icltop = iptop < icltop ? iptop : icltop;
         const R qcloud = qa[nl1 - 1];
-        stream_store(&a.qcloud_equiv[o2], qcloud);
+        stream_store(&a.qcloud_equiv[o2], qcloud);  // (shortwave-step outputs persist over the next two steps: always stored)
         const R clfact = 1.2f, rgse = 1.0f / (gse_s1 - gse_s0);
         const R fstab = rmax<R>(0.0f, rmin<R>(1.0f, rgse * (gse - gse_s0)));
         clstr = fstab * rmax<R>(clsmax - clfact * cloudc, 0.0f);
@@ -646,11 +648,13 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         const R corlw = C::EPSLW * C::EMISFC * st4a[KX - 1][0];
         dfabs[KX - 1] = dfabs[KX - 1] - corlw;
         slrd = slrd + corlw;
-        stream_store(&a.slrd[o2], slrd);
+        if (diag) {
+            stream_store(&a.slrd[o2], slrd);
 #pragma unroll
-        for (int k = 0; k < KX; ++k) {
-            stream_store(&a.rad_st4a[os + static_cast<size_t>(NG) * k], st4a[k][0]);
-            stream_store(&a.rad_st4a[os + static_cast<size_t>(NG) * (k + KX)], st4a[k][1]);
+            for (int k = 0; k < KX; ++k) {
+                stream_store(&a.rad_st4a[os + static_cast<size_t>(NG) * k], st4a[k][0]);
+                stream_store(&a.rad_st4a[os + static_cast<size_t>(NG) * (k + KX)], st4a[k][1]);
+            }
         }
 
         // -------------------------------------------------------------- surface fluxes, surface_fluxes.f90:40-320
@@ -715,12 +719,17 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         const R slru3 = slru2 + fmask * (slru1 - slru2);
         const R tsfc = tsea + fmask * (land_temp - tsea);
         const R tskin_avg = tsea + fmask * (tskin - tsea);
-        stream_store(&a.ustr[oa], ustr1); a.ustr[oa + NG] = ustr2; a.ustr[oa + 2 * NG] = ustr3;
-        stream_store(&a.vstr[oa], vstr1); a.vstr[oa + NG] = vstr2; a.vstr[oa + 2 * NG] = vstr3;
-        stream_store(&a.shf[oa], shf1);   a.shf[oa + NG] = shf2;   a.shf[oa + 2 * NG] = shf3;
-        stream_store(&a.evap[oa], evap1); a.evap[oa + NG] = evap2; a.evap[oa + 2 * NG] = evap3;
-        stream_store(&a.slru[oa], slru1); a.slru[oa + NG] = slru2; a.slru[oa + 2 * NG] = slru3;
+        // consumed by the slab models of the coupler (land_model.f90:195-215, sea_model.f90:313-383): always stored
+        a.shf[oa + NG] = shf2;
+        a.evap[oa + NG] = evap2;
         stream_store(&a.hfluxn[oa], hfl1); a.hfluxn[oa + NG] = hfl2;
+        if (diag) {
+            stream_store(&a.ustr[oa], ustr1); a.ustr[oa + NG] = ustr2; a.ustr[oa + 2 * NG] = ustr3;
+            stream_store(&a.vstr[oa], vstr1); a.vstr[oa + NG] = vstr2; a.vstr[oa + 2 * NG] = vstr3;
+            stream_store(&a.shf[oa], shf1);   a.shf[oa + 2 * NG] = shf3;
+            stream_store(&a.evap[oa], evap1); a.evap[oa + 2 * NG] = evap3;
+            stream_store(&a.slru[oa], slru1); a.slru[oa + NG] = slru2; a.slru[oa + 2 * NG] = slru3;
+        }
         if (a.ts) stream_store(&a.ts[o2], tsfc);
         if (a.tskin) stream_store(&a.tskin[o2], tskin_avg);
         if (a.u0) stream_store(&a.u0[o2], u0);
@@ -729,7 +738,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
 
         // -------------------------------------------------------------- longwave, upward sweep (:124-205)
         const R refsfc = 1.0f - C::EMISFC;
-        stream_store(&a.slr[o2], slru3 - slrd);
+        if (diag) stream_store(&a.slr[o2], slru3 - slrd);
 #pragma unroll
         for (int b = 0; b < 4; ++b) flux[b] = fband_at(CT.fband, tsfc, b) * slru3 + refsfc * flux[b];
         dfabs[KX - 1] = dfabs[KX - 1] + C::EPSLW * slru3;
@@ -762,9 +771,11 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         R olr = corlw1 + corlw2;
 #pragma unroll
         for (int b = 0; b < 4; ++b) olr = olr + flux[b];
-        stream_store(&a.olr[o2], olr);
+        if (diag) {
+            stream_store(&a.olr[o2], olr);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) a.rad_flux[of4 + static_cast<size_t>(NG) * b] = flux[b];
+            for (int b = 0; b < 4; ++b) a.rad_flux[of4 + static_cast<size_t>(NG) * b] = flux[b];
+        }
         // physics.f90:207-211: ttend = ttend + tt_rsw + tt_rlw
 #pragma unroll
         for (int k = 0; k < KX; ++k) ttend[k] = ttend[k] + dfabs[k] * rps * CT.grdscp[k];
@@ -811,11 +822,11 @@ static int physics_waves32() {
 
 template <int W, bool FUSED, bool KEEP, typename R>
 static hipError_t launch_physics(const DeviceTables &T, const spd_physics_args &a, int first, int nmembers, const ModelPtrs &P,
-                                 const DynDeviceTables &D, hipStream_t s) {
+                                 const DynDeviceTables &D, int diag, hipStream_t s) {
     const long total = static_cast<long>(nmembers) * NG;
     const unsigned blocks = static_cast<unsigned>((total + kPhysThreads - 1) / kPhysThreads);
     hipLaunchKernelGGL((physics_kernel<W, FUSED, KEEP, R>), dim3(blocks), dim3(kPhysThreads), 0, s, a, col_tables<R>(T), first,
-                       nmembers, P, D);
+                       nmembers, P, D, diag);
     return hipGetLastError();
 }
 
@@ -825,29 +836,34 @@ hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nme
     const DynDeviceTables md{};
     if (fp32) {
         switch (physics_waves32()) {
-            case 2: return launch_physics<2, false, false, float>(T, a, 0, nmembers, mp, md, s);
-            case 3: return launch_physics<3, false, false, float>(T, a, 0, nmembers, mp, md, s);
-            default: return launch_physics<4, false, false, float>(T, a, 0, nmembers, mp, md, s);
+            case 2: return launch_physics<2, false, false, float>(T, a, 0, nmembers, mp, md, 1, s);
+            case 3: return launch_physics<3, false, false, float>(T, a, 0, nmembers, mp, md, 1, s);
+            default: return launch_physics<4, false, false, float>(T, a, 0, nmembers, mp, md, 1, s);
         }
     }
-    if (physics_waves() == 1) return launch_physics<1, false, false, double>(T, a, 0, nmembers, mp, md, s);
-    return launch_physics<2, false, false, double>(T, a, 0, nmembers, mp, md, s);
+    if (physics_waves() == 1) return launch_physics<1, false, false, double>(T, a, 0, nmembers, mp, md, 1, s);
+    return launch_physics<2, false, false, double>(T, a, 0, nmembers, mp, md, 1, s);
 }
 
 // grid-point dynamics + physics of every column in one launch (the model step); a.ttend / a.qtend / a.utend / a.vtend must be
 // the dynamics' tendency arrays (P.ttend, P.trtend, P.utend, P.vtend)
+//
+// diag == 0: the outputs that no later kernel reads -- precipitation, cloud-base mass flux, the radiative fluxes and their
+// band / level decompositions, wind stress, the land / average parts of the surface fluxes: 39 doubles per column -- are
+// computed as always but NOT stored (what a shortwave step leaves for the following steps is always stored).  The model passes 0 for every step of a multi-step call except
+// the last one: such a value would be overwritten by the next step before anything could read it (model.hip).
 hipError_t run_dyn_physics(const ModelPtrs &P, const DynDeviceTables &D, const DeviceTables &T, const spd_physics_args &a,
-                           int first, int nmembers, int fp32, hipStream_t s) {
+                           int first, int nmembers, int fp32, int diag, hipStream_t s) {
     if (fp32) {
         switch (physics_waves32()) {
-            case 2: return launch_physics<2, true, true, float>(T, a, first, nmembers, P, D, s);
-            case 3: return launch_physics<3, true, true, float>(T, a, first, nmembers, P, D, s);
-            default: return launch_physics<4, true, true, float>(T, a, first, nmembers, P, D, s);
+            case 2: return launch_physics<2, true, true, float>(T, a, first, nmembers, P, D, diag, s);
+            case 3: return launch_physics<3, true, true, float>(T, a, first, nmembers, P, D, diag, s);
+            default: return launch_physics<4, true, true, float>(T, a, first, nmembers, P, D, diag, s);
         }
     }
-    if (a.sppt_pattern) return launch_physics<2, true, true, double>(T, a, first, nmembers, P, D, s);
-    if (physics_waves() == 1) return launch_physics<1, true, false, double>(T, a, first, nmembers, P, D, s);
-    return launch_physics<2, true, false, double>(T, a, first, nmembers, P, D, s);
+    if (a.sppt_pattern) return launch_physics<2, true, true, double>(T, a, first, nmembers, P, D, diag, s);
+    if (physics_waves() == 1) return launch_physics<1, true, false, double>(T, a, first, nmembers, P, D, diag, s);
+    return launch_physics<2, true, false, double>(T, a, first, nmembers, P, D, diag, s);
 }
 
 }  // namespace spd

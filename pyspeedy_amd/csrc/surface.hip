@@ -33,19 +33,32 @@ __device__ inline double qsat_p(double ta, double pr) {  // humidity.f90:44-78 w
 }
 }  // namespace
 
+// `fresh` = the monthly climatologies are interpolated to the model date.  The interpolation weights depend on the month and
+// the day only (model_control.f90:162-185), so between two midnights the reference recomputes, step after step, values it
+// already holds in stlcl_obs, snowdcl_obs, soilwcl_obs, sstcl_ob, sicecl_ob, ticecl_ob, sstan_ob (and copies of them in
+// snow_depth, soil_avail_water, sice_om, sice_am, sstan_am).  With fresh == 0 the kernel reads those stored values instead of
+// the 16 climatology / anomaly planes and does not store them again: bitwise the same state, 29 instead of 55 doubles moved
+// per column.  The host passes fresh != 0 on the first coupling of a day and after anything wrote to the state (model.hip).
 __global__ __launch_bounds__(kT) void coupler_kernel(SurfacePtrs S, int first, int count, TimeInterp w, int day, int land_coupling,
-                                                     int sst_anomaly, int anom_planes) {
+                                                     int sst_anomaly, int anom_planes, int fresh) {
     const int gid = blockIdx.x * kT + threadIdx.x;
     if (gid >= count * NG) return;
     const int lm = gid / NG, mem = first + lm, p = gid - lm * NG;
     const size_t o = static_cast<size_t>(mem) * NG + p, o12 = static_cast<size_t>(mem) * 12 * NG + p;
     // ---- land (land_model.f90:151-215)
-    const double stlcl = forin5(S.stl12, o12, w);
-    const double snowdcl = forint(S.snowd12, o12, w);
-    const double soilwcl = forint(S.soilw12, o12, w);
-    stream_store(&S.stlcl_obs[o], stlcl);
-    stream_store(&S.snowdcl_obs[o], snowdcl);
-    stream_store(&S.soilwcl_obs[o], soilwcl);
+    double stlcl;
+    if (fresh) {
+        stlcl = forin5(S.stl12, o12, w);
+        const double snowdcl = forint(S.snowd12, o12, w);
+        const double soilwcl = forint(S.soilw12, o12, w);
+        stream_store(&S.stlcl_obs[o], stlcl);
+        stream_store(&S.snowdcl_obs[o], snowdcl);
+        stream_store(&S.soilwcl_obs[o], soilwcl);
+        stream_store(&S.snow_depth[o], snowdcl);
+        stream_store(&S.soil_avail_water[o], soilwcl);
+    } else {
+        stlcl = S.stlcl_obs[o];
+    }
     if (day == 0) {
         stream_store(&S.stl_lm[o], stlcl);
         stream_store(&S.land_temp[o], stlcl);
@@ -55,36 +68,39 @@ __global__ __launch_bounds__(kT) void coupler_kernel(SurfacePtrs S, int first, i
         const double stl = tanom + stlcl;
         stream_store(&S.stl_lm[o], stl);
         stream_store(&S.land_temp[o], stl);
-    } else {
+    } else if (fresh) {
         stream_store(&S.land_temp[o], stlcl);
     }
-    stream_store(&S.snow_depth[o], snowdcl);
-    stream_store(&S.soil_avail_water[o], soilwcl);
 
     // ---- sea (sea_model.f90:193-316)
-    double sstcl = forin5(S.sst12, o12, w);
-    double sicecl = forint(S.sea_ice_frac12, o12, w);
-    double sstan_ob = S.sstan_ob[o];
-    if (sst_anomaly) {
-        const size_t oa = static_cast<size_t>(mem) * anom_planes * NG + p;
-        const double a = S.sst_anom[oa + static_cast<size_t>(NG) * w.a0];
-        sstan_ob = a + w.wan * (S.sst_anom[oa + static_cast<size_t>(NG) * w.a1] - a);
-        stream_store(&S.sstan_ob[o], sstan_ob);
-    }
     const double sstfr = 273.2f - 1.8f;  // single-precision subtraction, sea_model.f90:229
-    double ticecl;
-    if (sstcl > sstfr) {
-        sicecl = fmin(0.5, sicecl);
-        ticecl = sstfr;
-        if (sicecl > 0.0) sstcl = sstfr + (sstcl - sstfr) / (1.0f - sicecl);
+    double sstcl, sicecl, ticecl, sstan_ob = S.sstan_ob[o];
+    if (fresh) {
+        sstcl = forin5(S.sst12, o12, w);
+        sicecl = forint(S.sea_ice_frac12, o12, w);
+        if (sst_anomaly) {
+            const size_t oa = static_cast<size_t>(mem) * anom_planes * NG + p;
+            const double a = S.sst_anom[oa + static_cast<size_t>(NG) * w.a0];
+            sstan_ob = a + w.wan * (S.sst_anom[oa + static_cast<size_t>(NG) * w.a1] - a);
+            stream_store(&S.sstan_ob[o], sstan_ob);
+        }
+        if (sstcl > sstfr) {
+            sicecl = fmin(0.5, sicecl);
+            ticecl = sstfr;
+            if (sicecl > 0.0) sstcl = sstfr + (sstcl - sstfr) / (1.0f - sicecl);
+        } else {
+            sicecl = fmax(0.5, sicecl);
+            ticecl = sstfr + (sstcl - sstfr) / sicecl;
+            sstcl = sstfr;
+        }
+        stream_store(&S.sstcl_ob[o], sstcl);
+        stream_store(&S.sicecl_ob[o], sicecl);
+        stream_store(&S.ticecl_ob[o], ticecl);
     } else {
-        sicecl = fmax(0.5, sicecl);
-        ticecl = sstfr + (sstcl - sstfr) / sicecl;
-        sstcl = sstfr;
+        sstcl = S.sstcl_ob[o];
+        sicecl = S.sicecl_ob[o];
+        ticecl = S.ticecl_ob[o];
     }
-    stream_store(&S.sstcl_ob[o], sstcl);
-    stream_store(&S.sicecl_ob[o], sicecl);
-    stream_store(&S.ticecl_ob[o], ticecl);
     double sst_om, tice_om, sice_om;
     if (day == 0) {
         sst_om = 0.0;  // sea_coupling_flag <= 0 (sea_model.f90:261)
@@ -113,11 +129,13 @@ __global__ __launch_bounds__(kT) void coupler_kernel(SurfacePtrs S, int first, i
     }
     stream_store(&S.sst_om[o], sst_om);
     stream_store(&S.tice_om[o], tice_om);
-    stream_store(&S.sice_om[o], sice_om);
     const double sstan_am = sst_anomaly ? sstan_ob : 0.0;
-    stream_store(&S.sstan_am[o], sstan_am);
+    if (fresh) {  // (unchanged until the next fresh coupling: sice_om = sice_am = sicecl_ob, sstan_am = sstan_ob or 0)
+        stream_store(&S.sice_om[o], sice_om);
+        stream_store(&S.sstan_am[o], sstan_am);
+        stream_store(&S.sice_am[o], sice_om);
+    }
     double sst_am = sstcl + sstan_am;
-    stream_store(&S.sice_am[o], sice_om);
     stream_store(&S.tice_am[o], tice_om);
     sst_am = sst_am + sice_om * (tice_om - sst_am);
     stream_store(&S.sst_am[o], sst_am);
@@ -235,9 +253,9 @@ hipError_t run_rest_surface(const double *phis0, double *forog, double *surf_ps,
 
 // members [first, first + count)
 hipError_t run_coupler(const SurfacePtrs &S, int first, int count, const TimeInterp &w, int day, int land_coupling,
-                       int sst_anomaly, int anom_planes, hipStream_t s) {
+                       int sst_anomaly, int anom_planes, int fresh, hipStream_t s) {
     hipLaunchKernelGGL(coupler_kernel, dim3((count * NG + kT - 1) / kT), dim3(kT), 0, s, S, first, count, w, day, land_coupling,
-                       sst_anomaly, anom_planes);
+                       sst_anomaly, anom_planes, fresh);
     return hipGetLastError();
 }
 hipError_t run_forcing(const SurfacePtrs &S, int first, int count, const ZonalDevice &Z, double gamlat, double *corh_t,

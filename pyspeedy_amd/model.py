@@ -205,6 +205,12 @@ class EnsembleModel:
         """BASELINE cfg 5: run the arithmetic of the column physics in single precision (state and dynamics stay fp64)."""
         check(self._lib.spd_model_set_physics_precision(self._m, int(bool(fp32))), "spd_model_set_physics_precision")
 
+    def config(self):
+        """How the step is configured: dict(inv_per_member, diag_every_step, chunks, split_dyn) -- spd_model_get_config."""
+        cfg = (C.c_int32 * 4)()
+        check(self._lib.spd_model_get_config(self._m, cfg), "spd_model_get_config")
+        return dict(inv_per_member=cfg[0], diag_every_step=bool(cfg[1]), chunks=cfg[2], split_dyn=bool(cfg[3]))
+
     def profile(self, level=1):
         """HIP-event brackets on the launch stream: 0 off, 1 the spectral->grid launch of every step, 2 every kernel."""
         check(self._lib.spd_model_profile(self._m, int(level)), "spd_model_profile")

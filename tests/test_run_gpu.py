@@ -238,6 +238,31 @@ def test_member_groups_on_separate_streams_are_bitwise(spectral, bc, monkeypatch
             assert np.array_equal(a, b), n
 
 
+def test_multi_step_calls_leave_the_same_state_as_single_steps(spectral, bc, monkeypatch):
+    """Inside a multi-step spd_model_step call only the last step stores the physics outputs no later kernel reads, and the
+    coupler re-uses the day's interpolated climatologies: every registry variable after run(n) equals, bit for bit, the
+    one-step-per-call run (which stores everything every step) and the run with PYSPEEDY_AMD_DIAG_EVERY_STEP=1."""
+    from pyspeedy_amd.model import EnsembleModel
+    states = []
+    for mode in ("single", "multi", "every"):
+        if mode == "every":
+            monkeypatch.setenv("PYSPEEDY_AMD_DIAG_EVERY_STEP", "1")
+        model = EnsembleModel(spectral, 2)
+        model.set_bc(bc)
+        if mode == "single":
+            for _ in range(41):
+                model.run(1)
+        else:
+            model.run(30)
+            model.run(11)  # ends on a non-shortwave step after a day boundary
+        states.append({n: model.get(n, 1) for n in model.variables()})
+        model.close()
+    for n in states[0]:
+        assert np.array_equal(states[0][n], states[1][n]), n
+        assert np.array_equal(states[0][n], states[2][n]), n
+    assert np.abs(states[0]["olr"]).max() > 100.0 and np.abs(states[0]["rad_st4a"]).max() > 0.0
+
+
 def test_pruning_the_unused_transforms_changes_nothing(spectral, bc, monkeypatch):
     """PYSPEEDY_AMD_PRUNE_DEAD=1 drops the 14 inverse transforms per member-step whose results nothing reads (u, v above the
     lowest level at the physics' time level): every registry variable stays bitwise identical."""
