@@ -60,9 +60,26 @@ __device__ inline void uv_stencil(const d2 *a, const d2 *b, int k, int m, int n,
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------
-// geopotential from temperature at time level `tl` (geopotential.f90:49-77)
+// geopotential from temperature (geopotential.f90:49-77).  The arithmetic lives in two inline functions with explicit
+// fused multiply-adds, because it exists twice -- in the stand-alone kernel below and at the end of spectral_step_kernel,
+// which computes the geopotential of the NEXT step from the temperature it has just advanced -- and both must give the
+// same bits (a run resumed from a checkpoint starts with the stand-alone kernel).
 // ---------------------------------------------------------------------------------------------------------
+namespace {
+// phi(l) from phi(l + 1): geopotential.f90:62-65
+__device__ __forceinline__ d2 geo_up(d2 ph_below, d2 t_below, d2 t_here, double xg2_below, double xg1_here) {
+    return d2{fma(xg1_here, t_here.x, fma(xg2_below, t_below.x, ph_below.x)),
+              fma(xg1_here, t_here.y, fma(xg2_below, t_below.y, ph_below.y))};
+}
+// lapse-rate correction of the zonal-mean coefficients in the free troposphere: geopotential.f90:68-74
+__device__ __forceinline__ d2 geo_corr(d2 ph, d2 t_below, d2 t_above, double corf) {
+    return d2{fma(corf, t_below.x - t_above.x, ph.x), fma(corf, t_below.y - t_above.y, ph.y)};
+}
+}  // namespace
+
+// geopotential from temperature at time level `tl`
 __global__ __launch_bounds__(kT) void geopotential_kernel(ModelPtrs P, DynDeviceTables D, int first, int count, int tl) {
+    // (writes P.phi: the geopotential the current step uses)
     const int gid = blockIdx.x * kT + threadIdx.x;
     if (gid >= count * NSPEC) return;
     const int lm = gid / NSPEC, mem = first + lm, k = gid - lm * NSPEC, m = k % MX;
@@ -72,18 +89,12 @@ __global__ __launch_bounds__(kT) void geopotential_kernel(ModelPtrs P, DynDevice
 #pragma unroll
     for (int l = 0; l < KX; ++l) tt[l] = t[static_cast<size_t>(l) * NSPEC];
     const d2 phis = reinterpret_cast<const d2 *>(P.phis)[static_cast<size_t>(mem) * NSPEC + k];
-    ph[KX - 1] = d2{phis.x + D.xgeop1[KX - 1] * tt[KX - 1].x, phis.y + D.xgeop1[KX - 1] * tt[KX - 1].y};
+    ph[KX - 1] = d2{fma(D.xgeop1[KX - 1], tt[KX - 1].x, phis.x), fma(D.xgeop1[KX - 1], tt[KX - 1].y, phis.y)};
 #pragma unroll
-    for (int l = KX - 2; l >= 0; --l) {
-        ph[l].x = ph[l + 1].x + D.xgeop2[l + 1] * tt[l + 1].x + D.xgeop1[l] * tt[l].x;
-        ph[l].y = ph[l + 1].y + D.xgeop2[l + 1] * tt[l + 1].y + D.xgeop1[l] * tt[l].y;
-    }
+    for (int l = KX - 2; l >= 0; --l) ph[l] = geo_up(ph[l + 1], tt[l + 1], tt[l], D.xgeop2[l + 1], D.xgeop1[l]);
     if (m == 0) {
 #pragma unroll
-        for (int l = 1; l < KX - 1; ++l) {
-            ph[l].x = ph[l].x + D.geo_corf[l] * (tt[l + 1].x - tt[l - 1].x);
-            ph[l].y = ph[l].y + D.geo_corf[l] * (tt[l + 1].y - tt[l - 1].y);
-        }
+        for (int l = 1; l < KX - 1; ++l) ph[l] = geo_corr(ph[l], tt[l + 1], tt[l - 1], D.geo_corf[l]);
     }
 #pragma unroll
     for (int l = 0; l < KX; ++l) phi[static_cast<size_t>(l) * NSPEC] = ph[l];
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTa
     const d2 qcorh = reinterpret_cast<const d2 *>(P.qcorh)[static_cast<size_t>(mem) * NSPEC + k];
     const double sdrag = 1.0f / (TDRSd * 3600.0f);
     auto diffuse = [](d2 field, d2 fdt, double a, double b) { return d2{(fdt.x - a * field.x) * b, (fdt.y - a * field.y) * b}; };
-    auto advance = [&](d2 *base, size_t stride, d2 fdt) {  // step_field_2d, time_stepping.f90:164-188
+    auto advance = [&](d2 *base, size_t stride, d2 fdt) -> d2 {  // step_field_2d, time_stepping.f90:164-188; returns level 1
         const d2 o1 = base[0], o2 = base[stride];
         fdt = d2{fdt.x * trf, fdt.y * trf};
         const d2 oj = (j1 == 0) ? o1 : o2;
@@ -272,6 +283,7 @@ __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTa
         const d2 n2 = d2{fnew.x - we2 * (n1.x - 2.0f * oja.x + fnew.x), fnew.y - we2 * (n1.y - 2.0f * oja.y + fnew.y)};
         stream_store(&base[0], n1);
         stream_store(&base[stride], n2);
+        return n1;
     };
     {
         const d2 vor1 = vorS[0], t1 = tS[0], tr1 = trS[0];
@@ -291,8 +303,33 @@ __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTa
         const d2 qd = diffuse(cq, trdt, dmpd, dmp1d);
         advance(vorS, lvl, vd);
         advance(divS, lvl, dd);
-        advance(tS, lvl, td);
+        const d2 t_new = advance(tS, lvl, td);
         advance(trS, lvl, qd);
+        // geopotential of the NEXT step (geopotential.f90:49-77 on the temperature at time level 1 as it is now): each lane
+        // integrates from the lowest level up to its own, in the order and with the arithmetic of geopotential_kernel
+        if (P.phi_next) {
+            d2 tall[KX];
+            gather_levels(t_new, kk, tall);
+            const d2 phis = reinterpret_cast<const d2 *>(P.phis)[static_cast<size_t>(mem) * NSPEC + k];
+            d2 ph = d2{fma(D.xgeop1[KX - 1], tall[KX - 1].x, phis.x), fma(D.xgeop1[KX - 1], tall[KX - 1].y, phis.y)};
+#pragma unroll
+            for (int j = KX - 2; j >= 0; --j) {
+                const d2 up = geo_up(ph, tall[j + 1], tall[j], D.xgeop2[j + 1], D.xgeop1[j]);
+                ph = (j >= l) ? up : ph;
+            }
+            if (m == 0 && l >= 1 && l < KX - 1) {
+                d2 tb = tall[2], ta = tall[0];  // l == 1; the select chain below picks the neighbours of the other levels
+                double corf = D.geo_corf[1];
+#pragma unroll
+                for (int j = 2; j < KX - 1; ++j) {
+                    tb = (l == j) ? tall[j + 1] : tb;
+                    ta = (l == j) ? tall[j - 1] : ta;
+                    corf = (l == j) ? D.geo_corf[j] : corf;
+                }
+                ph = geo_corr(ph, tb, ta, corf);
+            }
+            stream_store(&reinterpret_cast<d2 *>(P.phi_next)[f8 + fo + k], ph);
+        }
     }
     if (l == 0) advance(psS, NSPEC, psdt);  // ln ps has no vertical index: the two time levels are NSPEC apart
 }

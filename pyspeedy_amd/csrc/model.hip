@@ -13,6 +13,7 @@
 #include "../../include/pyspeedy_amd.h"
 #include "context.hpp"
 #include "model.hpp"
+#include "coupler_point.hpp"
 #include "surface.hpp"
 
 namespace spd {
@@ -20,7 +21,7 @@ hipError_t run_spec2grid_table(const DeviceTables &T, const FieldDesc *table, in
 hipError_t run_grid2spec_table(const DeviceTables &T, const FieldDesc *table, int nfields, hipStream_t st);
 hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nmembers, int fp32, hipStream_t s);
 hipError_t run_dyn_physics(const ModelPtrs &P, const DynDeviceTables &D, const DeviceTables &T, const spd_physics_args &a,
-                           int first, int nmembers, int fp32, int diag, hipStream_t s);
+                           int first, int nmembers, int fp32, int diag, const CoupleArgs &cpl, hipStream_t s);
 hipError_t run_geopotential(const ModelPtrs &P, const DynDeviceTables &D, int first, int count, int tl, hipStream_t s);
 hipError_t run_dyn_grid(const ModelPtrs &P, const DynDeviceTables &D, int M, hipStream_t s);
 hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const DynDeviceTables &D, int M, int first, int count,
@@ -71,8 +72,19 @@ struct spd_model {
     spd_physics_args pa{};
     std::vector<void *> allocs;
     std::map<std::string, RegEntry> reg;
-    FieldDesc *inv_table[2] = {nullptr, nullptr};  // by dynamics time level j2 (0-based)
+    FieldDesc *inv_table[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [dynamics time level j2 (0-based)][phi buffer]
     FieldDesc *fwd_table = nullptr;
+    // Geopotential, double-buffered.  spectral_step_kernel ends by computing the geopotential the NEXT step needs (from the
+    // temperature it has just advanced) into the buffer that is not in use; the next step switches to it instead of running
+    // geopotential_kernel.  The registry's "phi" is always the buffer the last step USED (the reference's state%phi after a
+    // step).  phi_ahead is dropped whenever something outside the step may have changed the temperature.
+    double *phi_buf[2] = {nullptr, nullptr};
+    int phi_cur = 0;
+    // fold_geo: on by default for small ensembles (<= 16 members), where the step is bound by launch and dependent-latency
+    // chains and one launch less is worth 3-4 %; at 64 members the longer spectral_step_kernel costs 1 % more than the
+    // geopotential launch it saves (A/B in one session, profiles/).  PYSPEEDY_AMD_FOLD_GEO=0 / 1 overrides.
+    bool phi_ahead = false, fold_geo = true;
+    bool fuse_coupler = true;  // PYSPEEDY_AMD_FUSE_COUPLER=0: the coupling is a launch of its own (for measurements)
     int *d_err = nullptr;
     double *d_diag = nullptr;
     // asynchronous range check (spd_model_check_begin / _end): two pinned result slots with their events
@@ -124,7 +136,7 @@ struct spd_model {
     size_t prof_used = 0;
     // grid-space copies of the prognostic variables in output units (prognostics.f90:125-219) and their transform tables
     double *u_grid = nullptr, *v_grid = nullptr, *t_grid = nullptr, *q_grid = nullptr, *phi_grid = nullptr, *ps_grid = nullptr;
-    FieldDesc *exp_inv_table = nullptr, *exp_fwd_table = nullptr;  // 41 / 40 entries per member, member-major
+    FieldDesc *exp_inv_table[2] = {nullptr, nullptr}, *exp_fwd_table[2] = {nullptr, nullptr};  // 41 / 40 per member; [phi buffer]
     double *d_dmp1 = nullptr, *d_dmp1d = nullptr, *d_dmp1s = nullptr, *d_elz = nullptr, *d_xj = nullptr, *d_xc = nullptr,
            *d_xd = nullptr;
 };
@@ -161,11 +173,12 @@ static int build_tables(spd_model *m) {
     const spd_physics_args &pa = m->pa;
     auto spec = [](double *base, size_t field) { return base + field * NSPEC * C; };
     auto grid = [](double *base, size_t field) { return base + field * NG; };
-    for (int j2 = 0; j2 < 2; ++j2) {
+    for (int j2 = 0; j2 < 4; ++j2) {
+        const int par = j2 >> 1;  // (j2 & 1) = dynamics time level, par = phi buffer
         std::vector<FieldDesc> t;
         t.reserve(static_cast<size_t>(M) * 91);
         for (int i = 0; i < M; ++i) {
-            const size_t w = static_cast<size_t>(i) * 8, st = (static_cast<size_t>(i) * 2 + j2) * 8, s1 = static_cast<size_t>(i) * 2 * 8;
+            const size_t w = static_cast<size_t>(i) * 8, st = (static_cast<size_t>(i) * 2 + (j2 & 1)) * 8, s1 = static_cast<size_t>(i) * 2 * 8;
             // Entry order inside a member is variable-major, level-minor: workgroups are handed to the 8 XCDs round-robin by
             // workgroup id, so all entries of level k of a member land on the same XCD and the four transforms that read
             // vor_k / div_k (vorticity, divergence, u, v) share them through that XCD's L2 instead of fetching them four times.
@@ -183,22 +196,22 @@ static int build_tables(spd_model *m) {
                 e[7][k] = {spec(P.tr, st + k), grid(P.trg2, w + k), 1, 0};
                 e[8][k] = {spec(P.t, s1 + k), grid(const_cast<double *>(pa.tg), w + k), 1, 0};
                 e[9][k] = {spec(P.tr, s1 + k), grid(const_cast<double *>(pa.qg), w + k), 1, 0};
-                e[10][k] = {spec(P.phi, w + k), grid(const_cast<double *>(pa.phig), w + k), 1, 0};
+                e[10][k] = {spec(m->phi_buf[par], w + k), grid(const_cast<double *>(pa.phig), w + k), 1, 0};
             }
             const bool prune = m->inv_per_member == 77;
             for (int v = 0; v < 11; ++v)
                 for (int k = 0; k < 8; ++k)
                     if (!(prune && (v == 4 || v == 5) && k < 7)) t.push_back(e[v][k]);
             // grad ln ps at the dynamics' time level (tendencies.f90:144-146): gradient applied while staging (mode 3 / 4)
-            t.push_back({spec(P.ps, static_cast<size_t>(i) * 2 + j2), grid(P.px, i), 2, 3, nullptr});
-            t.push_back({spec(P.ps, static_cast<size_t>(i) * 2 + j2), grid(P.py, i), 2, 4, nullptr});
+            t.push_back({spec(P.ps, static_cast<size_t>(i) * 2 + (j2 & 1)), grid(P.px, i), 2, 3, nullptr});
+            t.push_back({spec(P.ps, static_cast<size_t>(i) * 2 + (j2 & 1)), grid(P.py, i), 2, 4, nullptr});
             t.push_back({spec(P.ps, static_cast<size_t>(i) * 2), grid(const_cast<double *>(pa.pslg), i), 1, 0});
         }
         void *d = nullptr;
         M_HIP(hipMalloc(&d, t.size() * sizeof(FieldDesc)));
         m->allocs.push_back(d);
         M_HIP(hipMemcpy(d, t.data(), t.size() * sizeof(FieldDesc), hipMemcpyHostToDevice));
-        m->inv_table[j2] = static_cast<FieldDesc *>(d);
+        m->inv_table[j2 & 1][par] = static_cast<FieldDesc *>(d);
     }
     std::vector<FieldDesc> t;
     t.reserve(static_cast<size_t>(M) * 73);
@@ -225,7 +238,7 @@ static int build_tables(spd_model *m) {
     M_HIP(hipMemcpy(d, t.data(), t.size() * sizeof(FieldDesc), hipMemcpyHostToDevice));
     m->fwd_table = static_cast<FieldDesc *>(d);
     // export tables (prognostics.f90:125-219), time level 1.  sv holds ucos | vcos in the [M][2][8] layout of vor / div.
-    {
+    for (int par = 0; par < 2; ++par) {
         std::vector<FieldDesc> ti, tf;
         const size_t half = static_cast<size_t>(M) * 16;  // fields in the ucos block of sv
         for (int i = 0; i < M; ++i) {
@@ -235,12 +248,12 @@ static int build_tables(spd_model *m) {
                 ti.push_back({spec(P.sv, half + s1 + k), grid(m->v_grid, w + k), 2, 0});
                 ti.push_back({spec(P.t, s1 + k), grid(m->t_grid, w + k), 1, 0});
                 ti.push_back({spec(P.tr, s1 + k), grid(m->q_grid, w + k), 1, 0});
-                ti.push_back({spec(P.phi, w + k), grid(m->phi_grid, w + k), 1, 0});
+                ti.push_back({spec(m->phi_buf[par], w + k), grid(m->phi_grid, w + k), 1, 0});
                 tf.push_back({grid(m->u_grid, w + k), spec(P.sv, s1 + k), 1, 0});  // kcos = 2: rows times cosgr
                 tf.push_back({grid(m->v_grid, w + k), spec(P.sv, half + s1 + k), 1, 0});
                 tf.push_back({grid(m->t_grid, w + k), spec(P.t, s1 + k), 0, 0});
                 tf.push_back({grid(m->q_grid, w + k), spec(P.tr, s1 + k), 0, 0});
-                tf.push_back({grid(m->phi_grid, w + k), spec(P.phi, w + k), 0, 0});
+                tf.push_back({grid(m->phi_grid, w + k), spec(m->phi_buf[par], w + k), 0, 0});
             }
             ti.push_back({spec(P.ps, static_cast<size_t>(i) * 2), grid(m->ps_grid, i), 1, 0});
         }
@@ -250,7 +263,7 @@ static int build_tables(spd_model *m) {
             M_HIP(hipMalloc(&dd, t.size() * sizeof(FieldDesc)));
             m->allocs.push_back(dd);
             M_HIP(hipMemcpy(dd, t.data(), t.size() * sizeof(FieldDesc), hipMemcpyHostToDevice));
-            (pass ? m->exp_fwd_table : m->exp_inv_table) = static_cast<FieldDesc *>(dd);
+            (pass ? m->exp_fwd_table : m->exp_inv_table)[par] = static_cast<FieldDesc *>(dd);
         }
     }
     return SPD_OK;
@@ -270,6 +283,9 @@ int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
     m->inv_per_member = 77;
     if (const char *env = getenv("PYSPEEDY_AMD_PRUNE_DEAD")) m->inv_per_member = atoi(env) != 0 ? 77 : 91;
     if (const char *env = getenv("PYSPEEDY_AMD_DIAG_EVERY_STEP")) m->diag_every_step = atoi(env) != 0;
+    m->fold_geo = nmembers <= 16;
+    if (const char *env = getenv("PYSPEEDY_AMD_FOLD_GEO")) m->fold_geo = atoi(env) != 0;
+    if (const char *env = getenv("PYSPEEDY_AMD_FUSE_COUPLER")) m->fuse_coupler = atoi(env) != 0;
     // PYSPEEDY_AMD_CHUNKS = 2 or 3 steps the members in that many groups on separate streams: measured -6 % / -8 % per step
     // at 64 members (4 groups: +7 %).  Off by default: with overlapping launches the duration of a single kernel -- what the
     // roofline accounting of bench.py and the committed rocprof summaries are about -- is no longer attributable to it.
@@ -291,6 +307,8 @@ int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
     A(P.tr, M * 2 * 8 * S, "tr", 2 * 8 * S);
     A(P.ps, M * 2 * S, "ps", 2 * S);
     A(P.phi, M * 8 * S, "phi", 8 * S);
+    A(m->phi_buf[1], M * 8 * S, nullptr, 0);
+    m->phi_buf[0] = P.phi;
     A(P.phis, M * S, "phis", S);
     A(P.tcorh, M * S, "tcorh", S);
     A(P.qcorh, M * S, "qcorh", S);
@@ -440,7 +458,7 @@ static int xfer(spd_model_handle m, const char *name, int member, void *host, si
     if (member < -1 || member >= m->M) return m_fail(SPD_E_ARG, "spd_model_get/set: member index out of range");
     if (member == -1 && !to_device) return m_fail(SPD_E_ARG, "spd_model_get: member = -1 (broadcast) is only valid for set");
     M_HIP(hipSetDevice(m->ctx->device));
-    if (to_device) m->surf_cache_valid = false;
+    if (to_device) m->surf_cache_valid = m->phi_ahead = false;
     const int first = member < 0 ? 0 : member, last = member < 0 ? m->M - 1 : member;
     for (int i = first; i <= last; ++i) {
         char *dev = static_cast<char *>(e.ptr) + static_cast<size_t>(i) * e.bytes_member;
@@ -462,7 +480,7 @@ int spd_model_get(spd_model_handle m, const char *name, int member, void *host, 
 void *spd_model_device_ptr(spd_model_handle m, const char *name) {
     if (!m || !name) return nullptr;
     auto it = m->reg.find(name);
-    m->surf_cache_valid = false;  // the caller may write through the pointer
+    m->surf_cache_valid = m->phi_ahead = false;  // the caller may write through the pointer
     return it == m->reg.end() ? nullptr : it->second.ptr;
 }
 
@@ -517,18 +535,32 @@ struct ProfScope {
 };
 
 // one `step(state, j1, j2, dt)` of time_stepping.f90 for the members [first, first + count) on stream s
+// Which geopotential buffer the step that is about to be issued uses: the look-ahead of the previous spectral_step_kernel if
+// there is one (then no geopotential launch is needed), otherwise the current buffer, to be filled by geopotential_kernel.
+// Returns whether the stand-alone kernel has to run.  Called once per step (not per member group).
+static bool begin_step_geopotential(spd_model *m) {
+    const bool ahead = m->fold_geo && m->phi_ahead;
+    if (ahead) m->phi_cur ^= 1;
+    m->P.phi = m->phi_buf[m->phi_cur];
+    m->P.phi_next = m->fold_geo ? m->phi_buf[m->phi_cur ^ 1] : nullptr;
+    m->reg["phi"].ptr = m->P.phi;
+    m->phi_ahead = m->fold_geo;  // true once the spectral step of this step has been issued
+    return !ahead;
+}
+
 static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int compute_shortwave, int first, int count, int diag,
-                             hipStream_t s) {
+                             bool run_geo, const CoupleArgs &cpl, hipStream_t s) {
     const DeviceTables &T = m->ctx->dev;
     const int M = m->M;
-    hipError_t e;
-    {
+    hipError_t e = hipSuccess;
+    if (run_geo) {
         ProfScope ps(m, SPD_K_GEOPOTENTIAL, count, s);
         e = run_geopotential(m->P, m->D, first, count, 0, s);                             // tendencies.f90:229
     }
     if (e == hipSuccess) {                                                                // :109-146, physics.f90:89-101
         ProfScope ps(m, SPD_K_SPEC2GRID, m->inv_per_member * count, s);
-        e = run_spec2grid_table(T, m->inv_table[j2 - 1] + static_cast<size_t>(first) * m->inv_per_member, m->inv_per_member * count, s);
+        e = run_spec2grid_table(T, m->inv_table[j2 - 1][m->phi_cur] + static_cast<size_t>(first) * m->inv_per_member,
+                                m->inv_per_member * count, s);
     }
     spd_physics_args pa = m->pa;
     pa.compute_shortwave = compute_shortwave ? 1 : 0;
@@ -554,7 +586,7 @@ static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int comput
             }
         } else {
             ProfScope ps(m, compute_shortwave ? SPD_K_COLUMN_SW : SPD_K_COLUMN, count, s);
-            e = run_dyn_physics(m->P, m->D, T, pa, first, count, m->phys_fp32, diag, s);        // both in one launch
+            e = run_dyn_physics(m->P, m->D, T, pa, first, count, m->phys_fp32, diag, cpl, s);        // both in one launch
         }
     }
     if (e == hipSuccess) {                                                                // :238-268
@@ -574,7 +606,8 @@ int spd_model_step_dynamics(spd_model_handle m, int j1, int j2, double dt, int c
     if (!m) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: null model");
     if (j1 < 1 || j1 > 2 || j2 < 1 || j2 > 2) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: time levels are 1 or 2");
     if (m->dynh->dt == 0.0) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: call spd_model_set_time_step first");
-    const hipError_t e = step_range(m, j1, j2, dt, compute_shortwave, 0, m->M, 1, static_cast<hipStream_t>(stream));
+    const bool run_geo = begin_step_geopotential(m);
+    const hipError_t e = step_range(m, j1, j2, dt, compute_shortwave, 0, m->M, 1, run_geo, CoupleArgs{}, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_step_dynamics: ") + hipGetErrorString(e));
     return SPD_OK;
 }
@@ -690,7 +723,7 @@ int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, i
     M_HIP(hipStreamSynchronize(s));
     m->cal.set(year, month, day, hour, minute);
     m->current_step = 0;
-    m->surf_cache_valid = false;
+    m->surf_cache_valid = m->phi_ahead = false;
     // ---- land_model_init / sea_model_init on the host, member by member (runs once)
     const size_t G12 = static_cast<size_t>(12) * NG;
     auto down = [&](const double *dev, size_t n, int i, std::vector<double> &v) {
@@ -803,27 +836,44 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
         if (new_day) zd = forcing_host(m, 1);
         const int sw = (m->current_step % 3 == 0) ? 1 : 0;
         const int diag = (m->diag_every_step || it == nsteps - 1) ? 1 : 0;
+        // The land / sea-ice coupling that follows the step (speedy.f90:72) happens at the date AFTER the step and for the
+        // incremented step counter.  The interpolation weights of the climatologies change at midnight only: the first
+        // coupling of a day (or of a state the host touched) interpolates, the others re-use what it stored (surface.hip).
+        Calendar next = m->cal;
+        next.advance();
+        CoupleArgs cpl{};
+        cpl.S = m->S;
+        cpl.w = time_interp(next);
+        cpl.day = 1 + (m->current_step + 1) / 36;
+        cpl.land_coupling = m->land_coupling_flag;
+        cpl.sst_anomaly = m->sst_anomaly_flag;
+        cpl.anom_planes = m->anom_planes;
+        cpl.fresh = (!m->surf_cache_valid || (next.hour == 0 && next.minute == 0)) ? 1 : 0;
+        if (m->sst_anomaly_flag && (cpl.w.a0 < 0 || cpl.w.a1 < 0 || cpl.w.a0 >= m->anom_planes || cpl.w.a1 >= m->anom_planes))
+            return m_fail(SPD_E_ARG, "SST anomaly planes do not cover the simulated period (speedy.py:338-372)");
+        // ... at the end of the column kernel, for its own column (the fluxes it needs are in registers there); with the
+        // dynamics and the physics in separate launches it is a launch of its own after the step
+        cpl.on = (m->split_dyn_physics || !m->fuse_coupler) ? 0 : 1;
+        const bool run_geo = begin_step_geopotential(m);
         for (int g = 0, first = 0; g < G && rc == SPD_OK; ++g) {
             const int count = base + (g < extra ? 1 : 0);
             if (new_day) rc = forcing_range(m, zd, first, count, gs[g]);
             if (rc == SPD_OK) {
-                const hipError_t e = step_range(m, 2, 2, 2 * delt, sw, first, count, diag, gs[g]);
+                const hipError_t e = step_range(m, 2, 2, 2 * delt, sw, first, count, diag, run_geo, cpl, gs[g]);
                 if (e != hipSuccess) rc = m_fail(SPD_E_DEVICE, std::string("spd_model_step: ") + hipGetErrorString(e));
+            }
+            if (rc == SPD_OK && !cpl.on) {
+                ProfScope ps(m, SPD_K_COUPLER, count, gs[g]);
+                const hipError_t e = run_coupler(m->S, first, count, cpl.w, cpl.day, cpl.land_coupling, cpl.sst_anomaly,
+                                                 cpl.anom_planes, cpl.fresh, gs[g]);
+                if (e != hipSuccess) rc = m_fail(SPD_E_DEVICE, std::string("couple_sea_land: ") + hipGetErrorString(e));
             }
             first += count;
         }
         if (rc != SPD_OK) break;
         m->current_step += 1;
-        m->cal.advance();
-        // the interpolation weights of the climatologies change at midnight only: first coupling of a day (or of a state the
-        // host touched) interpolates, the others re-use what it stored
-        const int fresh = (!m->surf_cache_valid || (m->cal.hour == 0 && m->cal.minute == 0)) ? 1 : 0;
-        for (int g = 0, first = 0; g < G && rc == SPD_OK; ++g) {
-            const int count = base + (g < extra ? 1 : 0);
-            rc = couple_range(m, 1 + m->current_step / 36, first, count, fresh, gs[g]);
-            first += count;
-        }
-        if (rc == SPD_OK) m->surf_cache_valid = true;
+        m->cal = next;
+        m->surf_cache_valid = true;
     }
     if (G > 1)
         for (int g = 0; g < G; ++g) {
@@ -993,7 +1043,7 @@ int spd_model_spectral2grid(spd_model_handle m, int first, int count, void *stre
     // vort2vel over both time levels of the members (contiguous); only level 1 is transformed
     hipError_t e = run_vort2vel(T, m->P.vor + off * S, m->P.div + off * S, m->P.sv + off * S, m->P.sv + (half + off) * S,
                                 count * 16, s);
-    if (e == hipSuccess) e = run_spec2grid_table(T, m->exp_inv_table + static_cast<size_t>(first) * 41, count * 41, s);
+    if (e == hipSuccess) e = run_spec2grid_table(T, m->exp_inv_table[m->phi_cur] + static_cast<size_t>(first) * 41, count * 41, s);
     if (e == hipSuccess)
         e = run_export_units(m->q_grid + static_cast<size_t>(first) * 8 * NG, m->phi_grid + static_cast<size_t>(first) * 8 * NG,
                              m->ps_grid + static_cast<size_t>(first) * NG, static_cast<long>(count) * NG, s);
@@ -1008,7 +1058,8 @@ int spd_model_grid2spectral(spd_model_handle m, int first, int count, void *stre
     hipStream_t s = static_cast<hipStream_t>(stream);
     const DeviceTables &T = m->ctx->dev;
     const size_t S = NSPEC * C, half = static_cast<size_t>(m->M) * 16;
-    hipError_t e = run_grid2spec_table(T, m->exp_fwd_table + static_cast<size_t>(first) * 40, count * 40, s);
+    m->phi_ahead = false;  // the temperature changes under the look-ahead geopotential
+    hipError_t e = run_grid2spec_table(T, m->exp_fwd_table[m->phi_cur] + static_cast<size_t>(first) * 40, count * 40, s);
     for (int i = first; i < first + count && e == hipSuccess; ++i) {
         const size_t s1 = static_cast<size_t>(i) * 16;
         e = run_vel2vort(T, m->P.sv + s1 * S, m->P.sv + (half + s1) * S, m->P.vor + s1 * S, m->P.div + s1 * S, 8, s);
@@ -1073,7 +1124,7 @@ int spd_model_copy_member(spd_model_handle dst, int di, spd_model_handle src, in
     if (di < 0 || di >= dst->M || si < 0 || si >= src->M) return m_fail(SPD_E_ARG, "spd_model_copy_member: member index out of range");
     if (dst->ctx->device != src->ctx->device) return m_fail(SPD_E_ARG, "spd_model_copy_member: models live on different devices");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    dst->surf_cache_valid = false;
+    dst->surf_cache_valid = dst->phi_ahead = false;
     for (const auto &kv : src->reg) {
         auto it = dst->reg.find(kv.first);
         if (it == dst->reg.end() || it->second.bytes_member != kv.second.bytes_member)

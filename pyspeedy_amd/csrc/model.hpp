@@ -9,7 +9,8 @@ struct ModelPtrs {
     // prognostic spectral state (complex as interleaved doubles)
     double *vor, *div, *t, *tr;  // [M][2][8][992]
     double *ps;                  // [M][2][992]
-    double *phi;                 // [M][8][992]
+    double *phi;                 // [M][8][992]   geopotential of the current step (the registry's "phi")
+    double *phi_next;            // [M][8][992]   written by spectral_step_kernel for the next step (nullptr: not wanted)
     double *phis;                // [M][992]
     double *tcorh, *qcorh;       // [M][992]   horizontal parts of the orographic diffusion corrections
     // spectral work of the grid <-> spectral export routines (ucos | vcos in the [M][2][8] layout of vor / div)

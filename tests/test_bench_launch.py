@@ -66,7 +66,7 @@ def test_bench_two_ranks_share_the_gpu():
     years = 8 * 86400.0 / (weak["ms_per_step"] * 1e-3 * 13140)
     assert abs(weak["value"] - years) < 1e-6 * years
     names = {k["kernel"] for k in weak["roofline"]["kernels"]}
-    assert {"geopotential", "spec2grid", "column_sw", "column", "grid2spec", "spectral_step", "coupler"} <= names
+    assert {"spec2grid", "column_sw", "column", "grid2spec", "spectral_step"} <= names
 
 
 @pytest.mark.gpu
