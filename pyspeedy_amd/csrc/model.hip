@@ -458,6 +458,9 @@ static int xfer(spd_model_handle m, const char *name, int member, void *host, si
     if (member < -1 || member >= m->M) return m_fail(SPD_E_ARG, "spd_model_get/set: member index out of range");
     if (member == -1 && !to_device) return m_fail(SPD_E_ARG, "spd_model_get: member = -1 (broadcast) is only valid for set");
     M_HIP(hipSetDevice(m->ctx->device));
+    // the copies below are blocking copies on the null stream, which does not order against the (non-blocking) streams the
+    // model's kernels were issued on: wait for everything in flight on the device first
+    M_HIP(hipDeviceSynchronize());
     if (to_device) m->surf_cache_valid = m->phi_ahead = false;
     const int first = member < 0 ? 0 : member, last = member < 0 ? m->M - 1 : member;
     for (int i = first; i <= last; ++i) {
@@ -720,7 +723,7 @@ int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, i
     const int M = m->M;
     const DeviceTables &T = m->ctx->dev;
     M_HIP(hipSetDevice(m->ctx->device));
-    M_HIP(hipStreamSynchronize(s));
+    M_HIP(hipDeviceSynchronize());  // (blocking host <-> device copies follow; see xfer)
     m->cal.set(year, month, day, hour, minute);
     m->current_step = 0;
     m->surf_cache_valid = m->phi_ahead = false;
@@ -1124,6 +1127,8 @@ int spd_model_copy_member(spd_model_handle dst, int di, spd_model_handle src, in
     if (di < 0 || di >= dst->M || si < 0 || si >= src->M) return m_fail(SPD_E_ARG, "spd_model_copy_member: member index out of range");
     if (dst->ctx->device != src->ctx->device) return m_fail(SPD_E_ARG, "spd_model_copy_member: models live on different devices");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    M_HIP(hipSetDevice(dst->ctx->device));
+    M_HIP(hipDeviceSynchronize());  // the two models may have been driven on different streams
     dst->surf_cache_valid = dst->phi_ahead = false;
     for (const auto &kv : src->reg) {
         auto it = dst->reg.find(kv.first);

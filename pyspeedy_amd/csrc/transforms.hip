@@ -451,15 +451,24 @@ __global__ __launch_bounds__(kThreads) void grid2spec_table_kernel(const FieldDe
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-template <typename K>
-static hipError_t configure(K kernel) {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               static_cast<int>(kLdsBytes));
+// (the attribute is per device: a process that drives several GPUs sets it once on each; `done` belongs to the call site)
+static hipError_t configure_once(const void *kernel, bool (&done)[64]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (done[dev]) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBytes));
+    done[dev] = e == hipSuccess;
+    return e;
 }
+#define SPD_CONFIGURE(kernel)                                            \
+    ([] {                                                                \
+        static bool done[64] = {};                                       \
+        return configure_once(reinterpret_cast<const void *>(kernel), done); \
+    }())
 
 template <Stage ST>
 static hipError_t launch_s2g(const double *src, double *dst, const DeviceTables &T, int nfields, int kcos, hipStream_t st) {
-    static hipError_t cfg = configure(&spec2grid_kernel<ST>);
+    const hipError_t cfg = SPD_CONFIGURE(&spec2grid_kernel<ST>);
     if (cfg != hipSuccess) return cfg;
     hipLaunchKernelGGL((spec2grid_kernel<ST>), dim3(nfields), dim3(kThreads), kLdsBytes, st, src, dst, T, kcos);
     return hipGetLastError();
@@ -468,7 +477,7 @@ static hipError_t launch_s2g(const double *src, double *dst, const DeviceTables 
 template <Stage ST>
 static hipError_t launch_g2s(const double *src, double *dst, const DeviceTables &T, int nfields, int prescale,
                              hipStream_t st) {
-    static hipError_t cfg = configure(&grid2spec_kernel<ST>);
+    const hipError_t cfg = SPD_CONFIGURE(&grid2spec_kernel<ST>);
     if (cfg != hipSuccess) return cfg;
     hipLaunchKernelGGL((grid2spec_kernel<ST>), dim3(nfields), dim3(kThreads), kLdsBytes, st, src, dst, T, prescale);
     return hipGetLastError();
@@ -476,7 +485,7 @@ static hipError_t launch_g2s(const double *src, double *dst, const DeviceTables 
 
 hipError_t run_spec2grid_table(const DeviceTables &T, const FieldDesc *table, int nfields, hipStream_t st) {
     if (nfields == 0) return hipSuccess;
-    static hipError_t cfg = configure(&spec2grid_table_kernel);
+    const hipError_t cfg = SPD_CONFIGURE(&spec2grid_table_kernel);
     if (cfg != hipSuccess) return cfg;
     hipLaunchKernelGGL(spec2grid_table_kernel, dim3(nfields), dim3(kThreads), kLdsBytes, st, table, T);
     return hipGetLastError();
@@ -484,7 +493,7 @@ hipError_t run_spec2grid_table(const DeviceTables &T, const FieldDesc *table, in
 
 hipError_t run_grid2spec_table(const DeviceTables &T, const FieldDesc *table, int nfields, hipStream_t st) {
     if (nfields == 0) return hipSuccess;
-    static hipError_t cfg = configure(&grid2spec_table_kernel);
+    const hipError_t cfg = SPD_CONFIGURE(&grid2spec_table_kernel);
     if (cfg != hipSuccess) return cfg;
     hipLaunchKernelGGL(grid2spec_table_kernel, dim3(nfields), dim3(kThreads), kLdsBytes, st, table, T);
     return hipGetLastError();

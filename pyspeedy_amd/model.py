@@ -77,10 +77,15 @@ class EnsembleModel:
               "spd_model_get(%s)" % name)
         return flat.reshape(shape, order="F")
 
+    # work arrays of the step that are registered with the C model without being registry variables of the reference: the
+    # grid-point inputs of the column physics (physics.f90:89-101) as the last step left them
+    WORK_ARRAYS = {"u_grid_phys": (96, 48, 8), "v_grid_phys": (96, 48, 8), "t_grid_phys": (96, 48, 8), "q_grid_phys": (96, 48, 8),
+                   "phi_grid_phys": (96, 48, 8), "pslg_phys": (96, 48)}
+
     def device_view(self, name):
         """Zero-copy torch view [nmembers, *reversed reference shape] of a registry variable in HBM (C order == the
         reference's Fortran order inside a member).  For on-device post-processing such as ensemble statistics."""
-        dtype, shape = self.shape(name)
+        dtype, shape = (np.float64, self.WORK_ARRAYS[name]) if name in self.WORK_ARRAYS else self.shape(name)
         ptr = self._lib.spd_model_device_ptr(self._m, name.encode())
         if not ptr:
             raise KeyError(name)

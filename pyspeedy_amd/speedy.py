@@ -191,8 +191,9 @@ class Speedy:
     # ---- run -------------------------------------------------------------------------------------------------
     def run(self, callbacks=None):
         """Run from `start_date` to `end_date`, calling every callback after each 40-minute step.  The reference's range
-        check runs after every step as upstream, but its result is collected one step later so that the GPU is never left
-        waiting for the host: a RuntimeError for step k is raised once step k + 1 has been enqueued (or at the end)."""
+        check runs after every step as upstream.  On steps where no callback is due its result is collected one step later,
+        so that the GPU is never left waiting for the host; on a step where a callback IS due the check of that step is
+        collected first: as in the reference (speedy.py:398-405) no callback ever sees a state that failed the check."""
         callbacks = list(callbacks or [])
         if not self._initialized_bc:
             raise RuntimeError("The SPEEDY model was not initialized. Call the `set_bc` method to initialize the model.")
@@ -203,6 +204,9 @@ class Speedy:
             self._collect(pending)
             pending = token
             self.current_date += _DT_STEP
+            if _callbacks_due(callbacks, self):
+                self._collect(pending)
+                pending = None
             for callback in callbacks:
                 callback(self)
         self._collect(pending)
@@ -240,6 +244,11 @@ class Speedy:
             arrays[var] = values.transpose(*range(values.ndim - 1, -1, -1))[None]
         members = [self.member_id] if self.is_ensemble_member else None
         return _build_dataset(self, arrays, members, self.current_date)
+
+
+def _callbacks_due(callbacks, model):
+    """Whether any hook will act at this step (plain callables have no gating: they always act)."""
+    return any(not cb.skip_flag(model) if hasattr(cb, "skip_flag") else True for cb in callbacks)
 
 
 def _exportable(var):
@@ -326,6 +335,9 @@ class SpeedyEns:
             self.current_date += _DT_STEP
             for member in self:
                 member.current_date = self.current_date
+            if _callbacks_due(callbacks, self):
+                Speedy._collect(pending)
+                pending = None
             for callback in callbacks:
                 callback(self)
         Speedy._collect(pending)

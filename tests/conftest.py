@@ -21,6 +21,16 @@ def pytest_configure(config):
 _SPAWNING_MODULES = ("test_fortran_host.py", "test_ensemble_dist.py", "test_bench_launch.py")
 
 
+def pytest_sessionstart(session):
+    """Build (make: a no-op when up to date) the CPU oracle and the HIP library BEFORE any test can initialise the GPU: the
+    GPU box refuses to start programs (make, gcc, hipcc) from a process that has."""
+    import oracle as orc
+    orc.build()
+    import pyspeedy_amd
+    if not os.path.isfile(pyspeedy_amd._lib.LIB_PATH):
+        pyspeedy_amd.build()
+
+
 def pytest_collection_modifyitems(config, items):
     items.sort(key=lambda item: 0 if os.path.basename(str(item.fspath)) in _SPAWNING_MODULES else 1)
 
@@ -32,17 +42,14 @@ def golden_dir():
 
 @pytest.fixture(scope="session")
 def oracle():
-    """The CPU oracle (test infrastructure).  Built on demand with gcc."""
+    """The CPU oracle (test infrastructure); built with gcc in pytest_sessionstart."""
     import oracle as orc
-    orc.build()
     return orc
 
 
 @pytest.fixture(scope="session")
 def hip_lib():
     import pyspeedy_amd
-    if not os.path.isfile(pyspeedy_amd._lib.LIB_PATH):
-        pyspeedy_amd.build()
     return pyspeedy_amd.lib()
 
 
