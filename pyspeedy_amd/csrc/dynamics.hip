@@ -146,6 +146,9 @@ __device__ inline d2 pick(const d2 (&a)[N], int l) {
 }
 }  // namespace
 
+// FOLD: the kernel ends by computing the geopotential of the next step into P.phi_next (a template parameter and not a run-time
+// switch: the extra code costs the 64-member launch 7 % even when it is skipped).
+template <bool FOLD>
 __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTables T, DynDeviceTables D, int M, int first,
                                                            int count, int j1, double dt, double eps) {
     // XCD-aware block order: workgroups are dealt to the 8 XCDs round-robin, and the n-1 / n+1 neighbours of the vel2vort
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTa
         advance(trS, lvl, qd);
         // geopotential of the NEXT step (geopotential.f90:49-77 on the temperature at time level 1 as it is now): each lane
         // integrates from the lowest level up to its own, in the order and with the arithmetic of geopotential_kernel
-        if (P.phi_next) {
+        if (FOLD) {
             d2 tall[KX];
             gather_levels(t_new, kk, tall);
             const d2 phis = reinterpret_cast<const d2 *>(P.phis)[static_cast<size_t>(mem) * NSPEC + k];
@@ -381,8 +384,12 @@ hipError_t run_dyn_grid(const ModelPtrs &P, const DynDeviceTables &D, int M, hip
 }
 hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const DynDeviceTables &D, int M, int first, int count,
                              int j1, double dt, double eps, hipStream_t s) {
-    hipLaunchKernelGGL(spectral_step_kernel, dim3((count * NSPEC * KX + kT - 1) / kT), dim3(kT), 0, s, P, T, D, M, first, count,
-                       j1, dt, eps);
+    if (P.phi_next)
+        hipLaunchKernelGGL(spectral_step_kernel<true>, dim3((count * NSPEC * KX + kT - 1) / kT), dim3(kT), 0, s, P, T, D, M, first,
+                           count, j1, dt, eps);
+    else
+        hipLaunchKernelGGL(spectral_step_kernel<false>, dim3((count * NSPEC * KX + kT - 1) / kT), dim3(kT), 0, s, P, T, D, M, first,
+                           count, j1, dt, eps);
     return hipGetLastError();
 }
 hipError_t run_diagnostics(const ModelPtrs &P, const DeviceTables &T, int M, int tl, int *err, double *diag, hipStream_t s) {

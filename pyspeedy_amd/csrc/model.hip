@@ -13,7 +13,6 @@
 #include "../../include/pyspeedy_amd.h"
 #include "context.hpp"
 #include "model.hpp"
-#include "coupler_point.hpp"
 #include "surface.hpp"
 
 namespace spd {
@@ -21,7 +20,7 @@ hipError_t run_spec2grid_table(const DeviceTables &T, const FieldDesc *table, in
 hipError_t run_grid2spec_table(const DeviceTables &T, const FieldDesc *table, int nfields, hipStream_t st);
 hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nmembers, int fp32, hipStream_t s);
 hipError_t run_dyn_physics(const ModelPtrs &P, const DynDeviceTables &D, const DeviceTables &T, const spd_physics_args &a,
-                           int first, int nmembers, int fp32, int diag, const CoupleArgs &cpl, hipStream_t s);
+                           int first, int nmembers, int fp32, int diag, hipStream_t s);
 hipError_t run_geopotential(const ModelPtrs &P, const DynDeviceTables &D, int first, int count, int tl, hipStream_t s);
 hipError_t run_dyn_grid(const ModelPtrs &P, const DynDeviceTables &D, int M, hipStream_t s);
 hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const DynDeviceTables &D, int M, int first, int count,
@@ -80,11 +79,10 @@ struct spd_model {
     // step).  phi_ahead is dropped whenever something outside the step may have changed the temperature.
     double *phi_buf[2] = {nullptr, nullptr};
     int phi_cur = 0;
-    // fold_geo: on by default for small ensembles (<= 16 members), where the step is bound by launch and dependent-latency
-    // chains and one launch less is worth 3-4 %; at 64 members the longer spectral_step_kernel costs 1 % more than the
+    // fold_geo: on by default for small ensembles (<= 8 members), where the step is bound by launch and dependent-latency
+    // chains and one launch less is worth 1-3 %; at 64 members the longer spectral_step_kernel costs 2 % more than the
     // geopotential launch it saves (A/B in one session, profiles/).  PYSPEEDY_AMD_FOLD_GEO=0 / 1 overrides.
     bool phi_ahead = false, fold_geo = true;
-    bool fuse_coupler = true;  // PYSPEEDY_AMD_FUSE_COUPLER=0: the coupling is a launch of its own (for measurements)
     int *d_err = nullptr;
     double *d_diag = nullptr;
     // asynchronous range check (spd_model_check_begin / _end): two pinned result slots with their events
@@ -283,9 +281,8 @@ int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
     m->inv_per_member = 77;
     if (const char *env = getenv("PYSPEEDY_AMD_PRUNE_DEAD")) m->inv_per_member = atoi(env) != 0 ? 77 : 91;
     if (const char *env = getenv("PYSPEEDY_AMD_DIAG_EVERY_STEP")) m->diag_every_step = atoi(env) != 0;
-    m->fold_geo = nmembers <= 16;
+    m->fold_geo = nmembers <= 8;
     if (const char *env = getenv("PYSPEEDY_AMD_FOLD_GEO")) m->fold_geo = atoi(env) != 0;
-    if (const char *env = getenv("PYSPEEDY_AMD_FUSE_COUPLER")) m->fuse_coupler = atoi(env) != 0;
     // PYSPEEDY_AMD_CHUNKS = 2 or 3 steps the members in that many groups on separate streams: measured -6 % / -8 % per step
     // at 64 members (4 groups: +7 %).  Off by default: with overlapping launches the duration of a single kernel -- what the
     // roofline accounting of bench.py and the committed rocprof summaries are about -- is no longer attributable to it.
@@ -552,7 +549,7 @@ static bool begin_step_geopotential(spd_model *m) {
 }
 
 static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int compute_shortwave, int first, int count, int diag,
-                             bool run_geo, const CoupleArgs &cpl, hipStream_t s) {
+                             bool run_geo, hipStream_t s) {
     const DeviceTables &T = m->ctx->dev;
     const int M = m->M;
     hipError_t e = hipSuccess;
@@ -589,7 +586,7 @@ static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int comput
             }
         } else {
             ProfScope ps(m, compute_shortwave ? SPD_K_COLUMN_SW : SPD_K_COLUMN, count, s);
-            e = run_dyn_physics(m->P, m->D, T, pa, first, count, m->phys_fp32, diag, cpl, s);        // both in one launch
+            e = run_dyn_physics(m->P, m->D, T, pa, first, count, m->phys_fp32, diag, s);        // both in one launch
         }
     }
     if (e == hipSuccess) {                                                                // :238-268
@@ -610,7 +607,7 @@ int spd_model_step_dynamics(spd_model_handle m, int j1, int j2, double dt, int c
     if (j1 < 1 || j1 > 2 || j2 < 1 || j2 > 2) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: time levels are 1 or 2");
     if (m->dynh->dt == 0.0) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: call spd_model_set_time_step first");
     const bool run_geo = begin_step_geopotential(m);
-    const hipError_t e = step_range(m, j1, j2, dt, compute_shortwave, 0, m->M, 1, run_geo, CoupleArgs{}, static_cast<hipStream_t>(stream));
+    const hipError_t e = step_range(m, j1, j2, dt, compute_shortwave, 0, m->M, 1, run_geo, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_step_dynamics: ") + hipGetErrorString(e));
     return SPD_OK;
 }
@@ -844,31 +841,22 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
         // coupling of a day (or of a state the host touched) interpolates, the others re-use what it stored (surface.hip).
         Calendar next = m->cal;
         next.advance();
-        CoupleArgs cpl{};
-        cpl.S = m->S;
-        cpl.w = time_interp(next);
-        cpl.day = 1 + (m->current_step + 1) / 36;
-        cpl.land_coupling = m->land_coupling_flag;
-        cpl.sst_anomaly = m->sst_anomaly_flag;
-        cpl.anom_planes = m->anom_planes;
-        cpl.fresh = (!m->surf_cache_valid || (next.hour == 0 && next.minute == 0)) ? 1 : 0;
-        if (m->sst_anomaly_flag && (cpl.w.a0 < 0 || cpl.w.a1 < 0 || cpl.w.a0 >= m->anom_planes || cpl.w.a1 >= m->anom_planes))
+        const TimeInterp w = time_interp(next);
+        const int fresh = (!m->surf_cache_valid || (next.hour == 0 && next.minute == 0)) ? 1 : 0;
+        if (m->sst_anomaly_flag && (w.a0 < 0 || w.a1 < 0 || w.a0 >= m->anom_planes || w.a1 >= m->anom_planes))
             return m_fail(SPD_E_ARG, "SST anomaly planes do not cover the simulated period (speedy.py:338-372)");
-        // ... at the end of the column kernel, for its own column (the fluxes it needs are in registers there); with the
-        // dynamics and the physics in separate launches it is a launch of its own after the step
-        cpl.on = (m->split_dyn_physics || !m->fuse_coupler) ? 0 : 1;
         const bool run_geo = begin_step_geopotential(m);
         for (int g = 0, first = 0; g < G && rc == SPD_OK; ++g) {
             const int count = base + (g < extra ? 1 : 0);
             if (new_day) rc = forcing_range(m, zd, first, count, gs[g]);
             if (rc == SPD_OK) {
-                const hipError_t e = step_range(m, 2, 2, 2 * delt, sw, first, count, diag, run_geo, cpl, gs[g]);
+                const hipError_t e = step_range(m, 2, 2, 2 * delt, sw, first, count, diag, run_geo, gs[g]);
                 if (e != hipSuccess) rc = m_fail(SPD_E_DEVICE, std::string("spd_model_step: ") + hipGetErrorString(e));
             }
-            if (rc == SPD_OK && !cpl.on) {
+            if (rc == SPD_OK) {
                 ProfScope ps(m, SPD_K_COUPLER, count, gs[g]);
-                const hipError_t e = run_coupler(m->S, first, count, cpl.w, cpl.day, cpl.land_coupling, cpl.sst_anomaly,
-                                                 cpl.anom_planes, cpl.fresh, gs[g]);
+                const hipError_t e = run_coupler(m->S, first, count, w, 1 + (m->current_step + 1) / 36, m->land_coupling_flag,
+                                                 m->sst_anomaly_flag, m->anom_planes, fresh, gs[g]);
                 if (e != hipSuccess) rc = m_fail(SPD_E_DEVICE, std::string("couple_sea_land: ") + hipGetErrorString(e));
             }
             first += count;

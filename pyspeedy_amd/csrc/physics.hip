@@ -24,7 +24,6 @@
 
 #include "../../include/pyspeedy_amd.h"
 #include "device_tables.hpp"
-#include "coupler_point.hpp"
 #include "dyn_column.hpp"
 #include "stream_store.hpp"
 
@@ -122,7 +121,7 @@ ColTables<R> col_tables(const DeviceTables &T) {
 // tendency with the physics increment at the end.
 template <int W, bool FUSED, bool KEEP, typename R>
 __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_args a, ColTables<R> CT, int first, int nmembers,
-                                                                  ModelPtrs MP, DynDeviceTables MD, int diag, CoupleArgs CPL) {
+                                                                  ModelPtrs MP, DynDeviceTables MD, int diag) {
     using C = PhysConst<R>;
     constexpr bool MIXED = !std::is_same<R, double>::value;
     static_assert(!KEEP || FUSED, "KEEP is a variant of the fused kernel");
@@ -798,11 +797,6 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
             a.ttend[o3 + NG * k] = finish(ttend[k], tdyn, k);
         }
         stream_store(&a.qtend[okx], finish(qkx, qdyn_kx, KX - 1));
-        // land / sea-ice coupling of this step (speedy.f90:72), with the fluxes the slab models read still in registers
-        if (FUSED && CPL.on)
-            coupler_point<true>(CPL.S, mem, p, CPL.w, CPL.day, CPL.land_coupling, CPL.sst_anomaly, CPL.anom_planes, CPL.fresh,
-                                CoupleFluxes{static_cast<double>(hfl1), static_cast<double>(hfl2), static_cast<double>(ssrd),
-                                             static_cast<double>(shf2), static_cast<double>(evap2)});
     }
     if (a.iptop) a.iptop[o2] = iptop;
     if (a.icltop) a.icltop[o2] = icltop;
@@ -828,11 +822,11 @@ static int physics_waves32() {
 
 template <int W, bool FUSED, bool KEEP, typename R>
 static hipError_t launch_physics(const DeviceTables &T, const spd_physics_args &a, int first, int nmembers, const ModelPtrs &P,
-                                 const DynDeviceTables &D, int diag, const CoupleArgs &cpl, hipStream_t s) {
+                                 const DynDeviceTables &D, int diag, hipStream_t s) {
     const long total = static_cast<long>(nmembers) * NG;
     const unsigned blocks = static_cast<unsigned>((total + kPhysThreads - 1) / kPhysThreads);
     hipLaunchKernelGGL((physics_kernel<W, FUSED, KEEP, R>), dim3(blocks), dim3(kPhysThreads), 0, s, a, col_tables<R>(T), first,
-                       nmembers, P, D, diag, cpl);
+                       nmembers, P, D, diag);
     return hipGetLastError();
 }
 
@@ -840,16 +834,15 @@ static hipError_t launch_physics(const DeviceTables &T, const spd_physics_args &
 hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nmembers, int fp32, hipStream_t s) {
     const ModelPtrs mp{};
     const DynDeviceTables md{};
-    const CoupleArgs nc{};
     if (fp32) {
         switch (physics_waves32()) {
-            case 2: return launch_physics<2, false, false, float>(T, a, 0, nmembers, mp, md, 1, nc, s);
-            case 3: return launch_physics<3, false, false, float>(T, a, 0, nmembers, mp, md, 1, nc, s);
-            default: return launch_physics<4, false, false, float>(T, a, 0, nmembers, mp, md, 1, nc, s);
+            case 2: return launch_physics<2, false, false, float>(T, a, 0, nmembers, mp, md, 1, s);
+            case 3: return launch_physics<3, false, false, float>(T, a, 0, nmembers, mp, md, 1, s);
+            default: return launch_physics<4, false, false, float>(T, a, 0, nmembers, mp, md, 1, s);
         }
     }
-    if (physics_waves() == 1) return launch_physics<1, false, false, double>(T, a, 0, nmembers, mp, md, 1, nc, s);
-    return launch_physics<2, false, false, double>(T, a, 0, nmembers, mp, md, 1, nc, s);
+    if (physics_waves() == 1) return launch_physics<1, false, false, double>(T, a, 0, nmembers, mp, md, 1, s);
+    return launch_physics<2, false, false, double>(T, a, 0, nmembers, mp, md, 1, s);
 }
 
 // grid-point dynamics + physics of every column in one launch (the model step); a.ttend / a.qtend / a.utend / a.vtend must be
@@ -859,19 +852,18 @@ hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nme
 // band / level decompositions, wind stress, the land / average parts of the surface fluxes: 39 doubles per column -- are
 // computed as always but NOT stored (what a shortwave step leaves for the following steps is always stored).  The model passes 0 for every step of a multi-step call except
 // the last one: such a value would be overwritten by the next step before anything could read it (model.hip).
-// cpl.on != 0: the kernel ends with the land / sea-ice coupling of the step for its column (coupler_point.hpp).
 hipError_t run_dyn_physics(const ModelPtrs &P, const DynDeviceTables &D, const DeviceTables &T, const spd_physics_args &a,
-                           int first, int nmembers, int fp32, int diag, const CoupleArgs &cpl, hipStream_t s) {
+                           int first, int nmembers, int fp32, int diag, hipStream_t s) {
     if (fp32) {
         switch (physics_waves32()) {
-            case 2: return launch_physics<2, true, true, float>(T, a, first, nmembers, P, D, diag, cpl, s);
-            case 3: return launch_physics<3, true, true, float>(T, a, first, nmembers, P, D, diag, cpl, s);
-            default: return launch_physics<4, true, true, float>(T, a, first, nmembers, P, D, diag, cpl, s);
+            case 2: return launch_physics<2, true, true, float>(T, a, first, nmembers, P, D, diag, s);
+            case 3: return launch_physics<3, true, true, float>(T, a, first, nmembers, P, D, diag, s);
+            default: return launch_physics<4, true, true, float>(T, a, first, nmembers, P, D, diag, s);
         }
     }
-    if (a.sppt_pattern) return launch_physics<2, true, true, double>(T, a, first, nmembers, P, D, diag, cpl, s);
-    if (physics_waves() == 1) return launch_physics<1, true, false, double>(T, a, first, nmembers, P, D, diag, cpl, s);
-    return launch_physics<2, true, false, double>(T, a, first, nmembers, P, D, diag, cpl, s);
+    if (a.sppt_pattern) return launch_physics<2, true, true, double>(T, a, first, nmembers, P, D, diag, s);
+    if (physics_waves() == 1) return launch_physics<1, true, false, double>(T, a, first, nmembers, P, D, diag, s);
+    return launch_physics<2, true, false, double>(T, a, first, nmembers, P, D, diag, s);
 }
 
 }  // namespace spd
