@@ -60,7 +60,7 @@ def main():
         member["t_grid"] = t + rng.normal(0.0, 0.01, t.shape)
         member.grid2spectral()
 
-    model = drv._lookup(ens.members[0]._state_cnt, drv._State).batch.model  # the batched device model of this rank
+    model = drv.device_model(ens.members[0]._state_cnt)[0]  # the batched device model of this rank
 
     def write_statistics(_ens):
         if _ens.get_current_step() % 36:

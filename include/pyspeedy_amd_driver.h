@@ -52,6 +52,13 @@ int spd_controlparams_get_model_datetime(int64_t control_cnt, int32_t *ymdhm /* 
 int spd_init(int64_t state_cnt, int64_t control_cnt, int32_t *error_code);
 int spd_step(int64_t state_cnt, int64_t control_cnt, int32_t *error_code);
 int spd_parallel_step(const int64_t *state_cnts, const int64_t *control_cnts, int32_t *error_codes, int32_t n_members);
+/* Extension: the same step with its range check overlapped.  _begin enqueues the step and its check for all containers and
+ * returns a token; _end waits for that check only and hands out the codes.  A host loop that begins step k + 1 before ending
+ * step k never leaves the GPU waiting for the host; the price is that the code of step k is seen after step k + 1 has been
+ * enqueued.  The model dates in the control containers advance at _begin and are put back at _end for a member whose check
+ * failed.  At most two steps may be in flight per device model. */
+int spd_parallel_step_begin(const int64_t *state_cnts, const int64_t *control_cnts, int32_t n_members, int64_t *token);
+int spd_parallel_step_end(int64_t token, int32_t *error_codes /* n_members of the matching _begin */);
 int spd_check(int64_t state_cnt, int32_t *error_code); /* diagnostics on time level 1 */
 int spd_transform_spectral2grid(int64_t state_cnt);
 int spd_transform_grid2spectral(int64_t state_cnt);
@@ -74,6 +81,10 @@ int spd_is_array(const char *name, int32_t *is_array);
 /* the registry itself, without a device: entry `index` (0 .. count-1); returns the number of entries */
 int spd_registry_entry(int32_t index, char *name /* 32 bytes */, int32_t *dtype, int32_t *ndim, int32_t *shape /* 5 */,
                        int32_t *is_read_only);
+/* the batched device model behind a container (spd_model_handle of pyspeedy_amd.h, owned by the driver: do not destroy it)
+ * and the container's member index in it -- for zero-copy access to the state (spd_model_device_ptr) and the extensions of
+ * the model level (SPPT, physics precision, profiling).  The binding changes when parallel_step gathers or splits. */
+int spd_driver_model(int64_t state_cnt, void **model, int32_t *member, int32_t *members_in_model);
 /* how many device models are alive and how many members the container's model holds (tests / diagnostics of batching) */
 int spd_driver_stats(int64_t state_cnt, int32_t *models_alive, int32_t *members_in_model);
 

@@ -122,6 +122,9 @@ _SIGNATURES = {
     "spd_init": (C.c_int, [C.c_int64, C.c_int64, C.POINTER(C.c_int32)]),
     "spd_step": (C.c_int, [C.c_int64, C.c_int64, C.POINTER(C.c_int32)]),
     "spd_parallel_step": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int32]),
+    "spd_parallel_step_begin": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_int64)]),
+    "spd_parallel_step_end": (C.c_int, [C.c_int64, C.POINTER(C.c_int32)]),
+    "spd_driver_model": (C.c_int, [C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "spd_check": (C.c_int, [C.c_int64, C.POINTER(C.c_int32)]),
     "spd_transform_spectral2grid": (C.c_int, [C.c_int64]),
     "spd_transform_grid2spectral": (C.c_int, [C.c_int64]),

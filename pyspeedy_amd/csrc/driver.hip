@@ -485,15 +485,31 @@ int spd_init(int64_t state_cnt, int64_t control_cnt, int32_t *error_code) {
     return SPD_OK;
 }
 
-int spd_parallel_step(const int64_t *state_cnts, const int64_t *control_cnts, int32_t *error_codes, int32_t n) {
-    if (n < 0 || (n > 0 && (!state_cnts || !control_cnts || !error_codes))) return fail(SPD_E_ARG, "spd_parallel_step: bad argument");
-    LOCK;
+// One group of a parallel step: the containers of the argument list that are (all) the members of one device model.
+struct StepGroup {
+    std::shared_ptr<Batch> batch;
+    std::vector<int> positions;  // indices into the argument list
+    std::vector<int> members;    // member index of each position
+    std::vector<Control *> controls;    // valid during the call that planned the step
+    std::vector<int64_t> control_ids;   // ... and how to find them again later (begin / end form)
+    Control before;              // model date before the step
+    int slot = -1;               // pending check (begin / end form); -1: the members were not initialised
+};
+struct PendingStep {
+    int n = 0;
+    std::vector<StepGroup> groups;
+};
+std::map<int64_t, PendingStep> g_pending;
+
+// resolve the containers, gather independent one-member models into one batch where possible, split batches that are asked
+// for in a different grouping, and return the groups to step
+static int plan_step(const int64_t *state_cnts, const int64_t *control_cnts, int n, std::vector<StepGroup> &groups, const char *who) {
     std::vector<std::shared_ptr<State>> states(n);
     std::vector<Control *> controls(n);
     for (int i = 0; i < n; ++i) {
         states[i] = state_of(state_cnts[i]);
         auto ci = g_controls.find(control_cnts[i]);
-        if (!states[i] || ci == g_controls.end()) return fail(SPD_E_ARG, "spd_parallel_step: not a live state / control container");
+        if (!states[i] || ci == g_controls.end()) return fail(SPD_E_ARG, std::string(who) + ": not a live state / control container");
         controls[i] = &ci->second;
     }
     bool dates_agree = true;
@@ -511,8 +527,7 @@ int spd_parallel_step(const int64_t *state_cnts, const int64_t *control_cnts, in
     for (int i = 0; i < n; ++i) {
         if (handled[i]) continue;
         std::shared_ptr<Batch> b = states[i]->batch;
-        // positions of the argument list that belong to this model
-        std::vector<int> mine;
+        std::vector<int> mine;  // positions of the argument list that belong to this model
         for (int j = i; j < n; ++j)
             if (states[j]->batch == b) mine.push_back(j);
         bool whole = static_cast<int>(mine.size()) == b->members;
@@ -526,18 +541,94 @@ int spd_parallel_step(const int64_t *state_cnts, const int64_t *control_cnts, in
             b = states[i]->batch;
             mine.assign(1, i);
         }
-        std::vector<int32_t> codes;
-        if (int rc = step_batch(*b, *controls[i], codes)) return rc;
-        Control advanced = *controls[i];
-        if (int rc = pull_date(*b, advanced)) return rc;
+        StepGroup g;
+        g.batch = b;
+        g.positions = mine;
         for (int j : mine) {
-            const int32_t code = codes[states[j]->member];
-            error_codes[j] = code;
-            if (code == 0) {  // speedy.f90:57-71: the date only advances after a successful check
-                controls[j]->now = advanced.now;
-                controls[j]->month_idx = advanced.month_idx;
-            }
+            g.members.push_back(states[j]->member);
+            g.controls.push_back(controls[j]);
+            g.control_ids.push_back(control_cnts[j]);
             handled[j] = 1;
+        }
+        g.before = *controls[i];
+        groups.push_back(g);
+    }
+    return SPD_OK;
+}
+
+static bool all_initialized(const Batch &b) {
+    for (int i = 0; i < b.members; ++i)
+        if (!b.initialized[i]) return false;
+    return true;
+}
+
+int spd_parallel_step(const int64_t *state_cnts, const int64_t *control_cnts, int32_t *error_codes, int32_t n) {
+    if (n < 0 || (n > 0 && (!state_cnts || !control_cnts || !error_codes))) return fail(SPD_E_ARG, "spd_parallel_step: bad argument");
+    LOCK;
+    std::vector<StepGroup> groups;
+    if (int rc = plan_step(state_cnts, control_cnts, n, groups, "spd_parallel_step")) return rc;
+    for (StepGroup &g : groups) {
+        std::vector<int32_t> codes;
+        if (int rc = step_batch(*g.batch, g.before, codes)) return rc;
+        Control advanced = g.before;
+        if (all_initialized(*g.batch))
+            if (int rc = pull_date(*g.batch, advanced)) return rc;
+        for (size_t k = 0; k < g.positions.size(); ++k) {
+            const int32_t code = codes[g.members[k]];
+            error_codes[g.positions[k]] = code;
+            if (code == 0) {  // speedy.f90:57-71: the date only advances after a successful check
+                g.controls[k]->now = advanced.now;
+                g.controls[k]->month_idx = advanced.month_idx;
+            }
+        }
+    }
+    return SPD_OK;
+}
+
+int spd_parallel_step_begin(const int64_t *state_cnts, const int64_t *control_cnts, int32_t n, int64_t *token) {
+    if (n < 0 || !token || (n > 0 && (!state_cnts || !control_cnts))) return fail(SPD_E_ARG, "spd_parallel_step_begin: bad argument");
+    LOCK;
+    PendingStep p;
+    p.n = n;
+    if (int rc = plan_step(state_cnts, control_cnts, n, p.groups, "spd_parallel_step_begin")) return rc;
+    for (StepGroup &g : p.groups) {
+        Batch &b = *g.batch;
+        if (!all_initialized(b)) continue;  // slot stays -1: E_STATE_NOT_INITIALIZED at _end
+        if (hipSetDevice(b.device) != hipSuccess) return fail(SPD_E_DEVICE, "spd_parallel_step_begin: hipSetDevice failed");
+        if (int rc = push_date(b, g.before)) return rc;
+        if (int rc = spd_model_step(b.model, 1, nullptr)) return rc;
+        g.slot = spd_model_check_begin(b.model, 2, nullptr);
+        if (g.slot < 0) return g.slot;
+        Control advanced = g.before;
+        if (int rc = pull_date(b, advanced)) return rc;
+        for (Control *c : g.controls) {
+            c->now = advanced.now;
+            c->month_idx = advanced.month_idx;
+        }
+    }
+    *token = g_next++;
+    g_pending[*token] = std::move(p);
+    return SPD_OK;
+}
+
+int spd_parallel_step_end(int64_t token, int32_t *error_codes) {
+    LOCK;
+    auto it = g_pending.find(token);
+    if (it == g_pending.end() || !error_codes) return fail(SPD_E_ARG, "spd_parallel_step_end: not a pending step");
+    PendingStep p = std::move(it->second);
+    g_pending.erase(it);
+    for (StepGroup &g : p.groups) {
+        std::vector<int32_t> codes(g.batch->members, -1);
+        if (g.slot >= 0)
+            if (int rc = spd_model_check_end(g.batch->model, g.slot, codes.data())) return rc;
+        for (size_t k = 0; k < g.positions.size(); ++k) {
+            const int32_t code = codes[g.members[k]];
+            error_codes[g.positions[k]] = code;
+            auto ci = g_controls.find(g.control_ids[k]);
+            if (code != 0 && g.slot >= 0 && ci != g_controls.end()) {  // the reference would not have advanced this date
+                ci->second.now = g.before.now;
+                ci->second.month_idx = g.before.month_idx;
+            }
         }
     }
     return SPD_OK;
@@ -690,6 +781,16 @@ int spd_registry_entry(int32_t index, char *name, int32_t *dtype, int32_t *ndim,
         for (int d = 0; d < 5; ++d) shape[d] = d < v.ndim ? v.shape[d] : 0;
     if (is_read_only) *is_read_only = v.where == Table ? 1 : 0;
     return kRegistryCount;
+}
+
+int spd_driver_model(int64_t state_cnt, void **model, int32_t *member, int32_t *members_in_model) {
+    LOCK;
+    auto st = state_of(state_cnt);
+    if (!st || !model) return fail(SPD_E_ARG, "spd_driver_model: not a live state container");
+    *model = st->batch->model;
+    if (member) *member = st->member;
+    if (members_in_model) *members_in_model = st->batch->members;
+    return SPD_OK;
 }
 
 int spd_driver_stats(int64_t state_cnt, int32_t *models_alive, int32_t *members_in_model) {

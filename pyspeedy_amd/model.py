@@ -37,12 +37,26 @@ class EnsembleModel:
         self._m = C.c_void_p()
         self.n_months = 1  # sst_anom holds n_months + 2 planes
         self._shapes = dict(SHAPES)  # per model: set_sppt adds the two SPPT arrays
+        self._owned = True
         with torch.cuda.device(spectral.device):
             check(self._lib.spd_model_create(spectral.handle, self.nmembers, C.byref(self._m)), "spd_model_create")
 
+    @classmethod
+    def borrowed(cls, handle, nmembers, device, n_months=1):
+        """A view of a device model that something else owns (the C driver's containers, speedy_driver.device_model): the
+        same methods, nothing is created and nothing destroyed."""
+        import types
+        self = cls.__new__(cls)
+        self.sp = types.SimpleNamespace(device=device)
+        self.nmembers, self.n_months = int(nmembers), int(n_months)
+        self._lib, self._m, self._owned = _lib.lib(), handle, False
+        self._shapes = dict(SHAPES)
+        return self
+
     def close(self):
         if getattr(self, "_m", None) is not None and self._m:
-            self._lib.spd_model_destroy(self._m)
+            if self._owned:
+                self._lib.spd_model_destroy(self._m)
             self._m = None
 
     def __del__(self):

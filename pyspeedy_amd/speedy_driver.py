@@ -1,5 +1,6 @@
 """The function set of the reference's f2py module `pyspeedy.speedy_driver.speedy_driver` (imported there as
-`_speedy`; generated from registry/templates/speedy_driver.f90.j2) on top of the MI355X C ABI.
+`_speedy`; generated from registry/templates/speedy_driver.f90.j2), bound to the C entry points of the same names in
+libpyspeedy_amd.so (include/pyspeedy_amd_driver.h, csrc/driver.hip).
 
 Same names, argument order and return conventions, so that `pyspeedy/speedy.py`-style host code runs unchanged:
 
@@ -12,225 +13,129 @@ Same names, argument order and return conventions, so that `pyspeedy/speedy.py`-
     get_<v>(state_cnt[, n_months])              set_<v>(state_cnt, value[, n_months])
     get_<v>_shape(state_cnt) -> int tuple (zeros while unallocated)                             is_array_<v>() -> bool
 
-Containers are int64 handles (the reference hands out the bits of a Fortran pointer, speedy_driver.f90.j2:38-40); here
-they index a table of Python objects.  Error codes (error_codes.f90:7-9): 0 ok, -1 state not initialised, -2 prognostic
-variables out of range.  A state container created by modelstate_init() owns a one-member model on the current GPU.
+Everything with a reference counterpart is ONE call into the C library: this module holds no model logic.  Containers are
+the library's int64 keys.  Error codes (error_codes.f90:7-9): 0 ok, -1 state not initialised, -2 prognostic variables out of
+range.  As in the reference the control container owns the model date (`get_model_datetime`).
 
-Extension for ensembles (the reference steps members one by one under OpenMP, speedy_driver.f90.j2:58-79):
-`modelstate_init_ensemble(n)` returns n state containers that are the members of ONE batched device model; parallel_step
-on exactly those containers advances all of them with one set of kernel launches.  Members of a batched model share the
-model date, so they cannot be stepped individually.
+parallel_step over independent containers: the library gathers them into one batched device model on the first call (one set
+of kernel launches per step for all of them afterwards) -- see include/pyspeedy_amd_driver.h.
+
+Extensions (no counterpart in the reference): `modelstate_init_ensemble(n)` (containers batched from the start),
+`parallel_step_begin / parallel_step_end` (range check overlapped with the next step), `device_model(state_cnt)` (the batched
+device model behind a container, for zero-copy access to the state), `ensemble_grid_arrays`.
 """
-import itertools
-import threading
+import ctypes as C
 
 import numpy as np
 
+from . import _lib
 from . import registry as R
 
 ERROR_CODES = {0: "Run successful.",
                -1: "The model state was not initialized. Initialize it (init) before running the model.",
                -2: "Model variables out of the accepted range (diagnostics.f90)."}
 
-_lock = threading.Lock()
-_ids = itertools.count(1)
-_objects = {}
-_contexts = {}  # device index -> ModSpectral
+
+def _L():
+    """The HIP library (raises if it was not built).  Calls that need a device fail in the library itself when there is none
+    ("no HIP device": there is no CPU fallback); containers of dates and control parameters work without one."""
+    return _lib.lib()
 
 
-def _register(obj):
-    with _lock:
-        cnt = next(_ids)
-        _objects[cnt] = obj
-    return cnt
+def _ok(rc, what):
+    if rc == _lib.SPD_E_SIZE:
+        raise ValueError("Array shape missmatch")  # pyspeedy/speedy.py:153
+    if rc == _lib.SPD_E_ARG:
+        msg = _lib.lib().spd_last_error()
+        raise ValueError("%s: %s" % (what, msg.decode() if msg else "bad argument"))
+    _lib.check(rc, what)
 
 
-def _lookup(cnt, kind):
-    obj = _objects.get(int(cnt))
-    if not isinstance(obj, kind):
-        raise ValueError("container %r is not a live %s" % (cnt, kind.__name__))
-    return obj
-
-
-def _context():
-    import torch
-    from .spectral import ModSpectral
-    dev = torch.cuda.current_device() if torch.cuda.is_available() else None
-    if dev is None:
-        raise RuntimeError("pyspeedy_amd.speedy_driver needs a HIP device; there is no CPU fallback")
-    with _lock:
-        if dev not in _contexts:
-            _contexts[dev] = ModSpectral(dev)
-        return _contexts[dev]
+def _cnts(values):
+    a = np.asarray(values, dtype=np.int64).ravel()
+    return (C.c_int64 * a.size)(*a.tolist()), a.size
 
 
 # --------------------------------------------------------------------------------------------------------------------
 # containers
 # --------------------------------------------------------------------------------------------------------------------
-class _Date:
-    def __init__(self, y, m, d, h, mi):
-        self.ymdhm = (int(y), int(m), int(d), int(h), int(mi))
-
-
-class _Control:  # ControlParams_t, model_control.f90:32-47: start / end date; the running model date lives with the state
-    def __init__(self, start, end):
-        self.start, self.end = start.ymdhm, end.ymdhm
-
-
-class _Batch:
-    """One device model shared by its member containers."""
-
-    def __init__(self, nmembers):
-        from .model import EnsembleModel
-        self.sp = _context()
-        self.model = EnsembleModel(self.sp, nmembers)
-        self.nmembers = nmembers
-        self.initialized = [False] * nmembers
-        self.n_months = 1  # allocation of sst_anom: n_months + 2 planes (3 right after modelstate_init)
-        self.sst_anom_allocated = False
-        self.refs = nmembers
-
-    def release(self):
-        self.refs -= 1
-        if self.refs == 0:
-            self.model.close()
-
-
-class _State:
-    def __init__(self, batch, member):
-        self.batch, self.member = batch, member
-        self.host = {}  # registry arrays of kind "host"
-        self.scalars = {"increase_co2": False, "compute_shortwave": True, "air_absortivity_co2": 6.0,
-                        "land_coupling_flag": True, "sst_anomaly_coupling_flag": True, "ablco2_ref": 6.0}
-
-
 def modelstate_init():
-    return _register(_State(_Batch(1), 0))
+    c = C.c_int64()
+    _ok(_L().spd_modelstate_init(C.byref(c)), "modelstate_init")
+    return c.value
 
 
 def modelstate_init_ensemble(nmembers):
-    batch = _Batch(int(nmembers))
-    return [_register(_State(batch, i)) for i in range(batch.nmembers)]
+    arr = (C.c_int64 * int(nmembers))()
+    _ok(_L().spd_modelstate_init_ensemble(arr, int(nmembers)), "modelstate_init_ensemble")
+    return list(arr)
 
 
 def modelstate_init_sst_anom(state_cnt, n_months):
-    st = _lookup(state_cnt, _State)
-    b = st.batch
-    if not b.sst_anom_allocated or b.n_months != int(n_months):
-        b.model.init_sst_anom(int(n_months))
-        b.n_months = int(n_months)
-        b.sst_anom_allocated = True
+    _ok(_L().spd_modelstate_init_sst_anom(int(state_cnt), int(n_months)), "modelstate_init_sst_anom")
 
 
 def modelstate_close(state_cnt):
-    with _lock:
-        st = _objects.pop(int(state_cnt), None)
-    if isinstance(st, _State):
-        st.batch.release()
+    _ok(_lib.lib().spd_modelstate_close(int(state_cnt)), "modelstate_close")
 
 
 def create_datetime(year, month, day, hour, minute):
-    return _register(_Date(year, month, day, hour, minute))
+    c = C.c_int64()
+    _ok(_lib.lib().spd_create_datetime(int(year), int(month), int(day), int(hour), int(minute), C.byref(c)), "create_datetime")
+    return c.value
 
 
 def get_datetime(cnt):
-    return _lookup(cnt, _Date).ymdhm
+    v = [C.c_int32() for _ in range(5)]
+    _ok(_lib.lib().spd_get_datetime(int(cnt), *[C.byref(x) for x in v]), "get_datetime")
+    return tuple(x.value for x in v)
 
 
 def close_datetime(cnt):
-    with _lock:
-        _objects.pop(int(cnt), None)
+    _ok(_lib.lib().spd_close_datetime(int(cnt)), "close_datetime")
 
 
 def controlparams_init(start_cnt, end_cnt):
-    return _register(_Control(_lookup(start_cnt, _Date), _lookup(end_cnt, _Date)))
+    c = C.c_int64()
+    _ok(_lib.lib().spd_controlparams_init(C.byref(c), int(start_cnt), int(end_cnt)), "controlparams_init")
+    return c.value
 
 
 def controlparams_close(control_cnt):
-    with _lock:
-        _objects.pop(int(control_cnt), None)
+    _ok(_lib.lib().spd_controlparams_close(int(control_cnt)), "controlparams_close")
+
+
+def get_model_datetime(control_cnt):
+    """ControlParams_t%model_datetime (year, month, day, hour, minute) and month_idx of a control container."""
+    now, midx = (C.c_int32 * 5)(), C.c_int32()
+    _ok(_lib.lib().spd_controlparams_get_model_datetime(int(control_cnt), now, C.byref(midx)), "get_model_datetime")
+    return tuple(now), midx.value
 
 
 # --------------------------------------------------------------------------------------------------------------------
 # model control
 # --------------------------------------------------------------------------------------------------------------------
-def _push_flags(st, co2=True):
-    s = st.scalars
-    m = st.batch.model
-    m.set_flags(s["land_coupling_flag"], s["sst_anomaly_coupling_flag"], s["increase_co2"])
-    if co2:  # (the model raises its own value daily when increase_co2 is set: do not overwrite it with the mirror)
-        m.set_co2(s["air_absortivity_co2"])
-
-
 def init(state_cnt, control_cnt):
     """initialize_state (initialization.f90:13-91) from the boundary fields already stored with set_<v>."""
-    st, ctl = _lookup(state_cnt, _State), _lookup(control_cnt, _Control)
-    b = st.batch
-    if b.nmembers == 1:
-        _push_flags(st)
-        b.model.init(ctl.start)
-    else:
-        # one member of a batched model: initialise a scratch one-member model from this member's boundary fields and
-        # copy the resulting state into the member's slot
-        from .model import EnsembleModel
-        scratch = EnsembleModel(b.sp, 1)
-        try:
-            if b.sst_anom_allocated:
-                scratch.init_sst_anom(b.n_months)
-            scratch.copy_member_from(b.model, st.member, 0)
-            s = st.scalars
-            scratch.set_flags(s["land_coupling_flag"], s["sst_anomaly_coupling_flag"], s["increase_co2"])
-            scratch.set_co2(s["air_absortivity_co2"])
-            scratch.init(ctl.start)
-            b.model.copy_member_from(scratch, 0, st.member)
-            b.model.sync()
-        finally:
-            scratch.close()
-        _push_flags(st)
-        b.model.mark_initialized(0, ctl.start)
-    b.initialized[st.member] = True
-    return 0
-
-
-def _step_batch(b):
-    if not all(b.initialized):
-        return np.full(b.nmembers, -1, dtype=np.int32)
-    b.model.run(1)
-    return b.model.check(2).astype(np.int32)
-
-
-def _group(state_cnts, control_cnts):
-    """The distinct device models behind the containers, each with the positions of its members in the argument list."""
-    state_cnts = np.asarray(state_cnts, dtype=np.int64).ravel()
-    if np.asarray(control_cnts).size != state_cnts.size:
-        raise ValueError("parallel_step: one control container per state container")
-    states = [_lookup(c, _State) for c in state_cnts]
-    groups = []
-    for st in states:
-        b = st.batch
-        if any(g[0] is b for g in groups):
-            continue
-        mine = [i for i, s in enumerate(states) if s.batch is b]
-        if sorted(states[i].member for i in mine) != list(range(b.nmembers)):
-            raise ValueError("parallel_step needs every member of a batched ensemble model exactly once")
-        groups.append((b, mine, [states[i].member for i in mine]))
-    return len(states), groups
+    code = C.c_int32(0)
+    _ok(_L().spd_init(int(state_cnt), int(control_cnt), C.byref(code)), "init")
+    return code.value
 
 
 def step(state_cnt, control_cnt):
     """do_single_step (speedy.f90:20-74) followed by the range check of diagnostics.f90."""
-    st = _lookup(state_cnt, _State)
-    _lookup(control_cnt, _Control)
-    if st.batch.nmembers != 1:
-        raise ValueError("a member of a batched ensemble model cannot be stepped on its own; use parallel_step")
-    return int(_step_batch(st.batch)[0])
+    code = C.c_int32(0)
+    _ok(_L().spd_step(int(state_cnt), int(control_cnt), C.byref(code)), "step")
+    return code.value
 
 
 def parallel_step(state_cnts, control_cnts):
-    n, groups = _group(state_cnts, control_cnts)
+    s, n = _cnts(state_cnts)
+    c, nc = _cnts(control_cnts)
+    if n != nc:
+        raise ValueError("parallel_step: one control container per state container")
     codes = np.zeros(n, dtype=np.int32)
-    for b, positions, members in groups:
-        codes[positions] = _step_batch(b)[members]
+    _ok(_L().spd_parallel_step(s, c, codes.ctypes.data_as(C.POINTER(C.c_int32)), n), "parallel_step")
     return codes
 
 
@@ -238,125 +143,108 @@ def parallel_step(state_cnts, control_cnts):
 # a token; parallel_step_end(token) waits for that check only.  A loop that begins step k + 1 before ending step k never
 # leaves the GPU waiting for the host (the synchronous form costs ~0.1 ms per step at 64 members); the price is that the
 # error code of step k is seen after step k + 1 has been enqueued.  At most two steps may be in flight per model.
+_pending_sizes = {}
+
+
 def parallel_step_begin(state_cnts, control_cnts):
-    n, groups = _group(state_cnts, control_cnts)
-    pending = []
-    for b, positions, members in groups:
-        if not all(b.initialized):
-            pending.append((b, positions, members, None))
-        else:
-            b.model.run(1)
-            pending.append((b, positions, members, b.model.check_begin(2)))
-    return _register((n, pending))
+    s, n = _cnts(state_cnts)
+    c, nc = _cnts(control_cnts)
+    if n != nc:
+        raise ValueError("parallel_step: one control container per state container")
+    token = C.c_int64()
+    _ok(_L().spd_parallel_step_begin(s, c, n, C.byref(token)), "parallel_step_begin")
+    _pending_sizes[token.value] = n
+    return token.value
 
 
 def parallel_step_end(token):
-    with _lock:
-        n, pending = _objects.pop(int(token))
-    codes = np.zeros(n, dtype=np.int32)
-    for b, positions, members, slot in pending:
-        codes[positions] = -1 if slot is None else b.model.check_end(slot)[members]
+    codes = np.zeros(_pending_sizes.pop(int(token)), dtype=np.int32)
+    _ok(_lib.lib().spd_parallel_step_end(int(token), codes.ctypes.data_as(C.POINTER(C.c_int32))), "parallel_step_end")
     return codes
 
 
 def check(state_cnt):
-    st = _lookup(state_cnt, _State)
-    if not st.batch.initialized[st.member]:
-        return -1
-    return int(st.batch.model.check(1)[st.member])
+    code = C.c_int32(0)
+    _ok(_L().spd_check(int(state_cnt), C.byref(code)), "check")
+    return code.value
 
 
 def transform_spectral2grid(state_cnt):
-    st = _lookup(state_cnt, _State)
-    st.batch.model.spectral2grid(st.member, 1)
+    _ok(_L().spd_transform_spectral2grid(int(state_cnt)), "transform_spectral2grid")
 
 
 def transform_grid2spectral(state_cnt):
-    st = _lookup(state_cnt, _State)
-    st.batch.model.grid2spectral(st.member, 1)
+    _ok(_L().spd_transform_grid2spectral(int(state_cnt)), "transform_grid2spectral")
+
+
+def apply_grid_filter(state_cnt):
+    _ok(_L().spd_apply_grid_filter(int(state_cnt)), "apply_grid_filter")
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# extensions on the batched device model behind a container
+# --------------------------------------------------------------------------------------------------------------------
+def device_model(state_cnt):
+    """(EnsembleModel view of the batched device model the container belongs to, member index of the container).  The
+    model stays owned by the library; the binding changes when parallel_step gathers or splits containers."""
+    import torch
+    from .model import EnsembleModel
+    handle, member, members = C.c_void_p(), C.c_int32(), C.c_int32()
+    _ok(_L().spd_driver_model(int(state_cnt), C.byref(handle), C.byref(member), C.byref(members)), "device_model")
+    n_months = _shape("sst_anom", state_cnt)[2] - 2
+    return EnsembleModel.borrowed(handle, members.value, torch.device("cuda", torch.cuda.current_device()),
+                                  max(n_months, 1)), member.value
 
 
 def ensemble_grid_arrays(state_cnt, names):
     """Extension: the grid-space variables `names` of ALL members of the batched model `state_cnt` belongs to, after one
     batched spectral2grid: dict name -> float64 array [member, (lev,) lat, lon] (one device-to-host copy per variable)."""
-    b = _lookup(state_cnt, _State).batch
-    b.model.spectral2grid()
-    return {n: b.model.device_view(n).cpu().numpy() for n in names}
+    model, _ = device_model(state_cnt)
+    model.spectral2grid()
+    return {n: model.device_view(n).cpu().numpy() for n in names}
 
 
-def apply_grid_filter(state_cnt):
-    st = _lookup(state_cnt, _State)
-    st.batch.model.grid_filter(st.member, 1)
+def driver_stats(state_cnt=0):
+    """(device models alive, members in the model of `state_cnt`)"""
+    alive, members = C.c_int32(), C.c_int32()
+    _ok(_lib.lib().spd_driver_stats(int(state_cnt), C.byref(alive), C.byref(members)), "driver_stats")
+    return alive.value, members.value
 
 
 # --------------------------------------------------------------------------------------------------------------------
 # registry access: get_<v>, set_<v>, get_<v>_shape, is_array_<v> (generated per variable in the reference)
 # --------------------------------------------------------------------------------------------------------------------
-def _table(st, name):
-    sp = st.batch.sp
-    if name == "lon":  # initialization.f90:86
-        return (np.float32(3.75) * np.arange(R.IX, dtype=np.float32)).astype(np.float32)
-    if name == "lat":  # initialization.f90:87: real(radang) * 90.0 / asin(1.0), default real
-        return (sp.table("radang").astype(np.float32) * np.float32(90.0) / np.arcsin(np.float32(1.0))).astype(np.float32)
-    if name == "lev":  # initialization.f90:85
-        return sp.table("fsg").astype(np.float32)
-    if name == "deglat_s":  # sea_model.f90: grid latitudes in degrees
-        return sp.table("radang") * 90.0 / np.arcsin(1.0)
-    if name == "fband":
-        return sp.table("fband").reshape((301, 4), order="F")
-    if name in ("xgeop1", "xgeop2"):  # geopotential.f90:16-31
-        hsg, fsg = sp.table("hsg"), sp.table("fsg")
-        rgas = float(np.float32(2.0) / np.float32(7.0)) * 1004.0
-        if name == "xgeop1":
-            return rgas * np.log(hsg[1:] / fsg)
-        out = np.zeros(R.KX)
-        out[1:] = rgas * np.log(fsg[1:] / hsg[1:-1])
-        return out
-    raise KeyError(name)
+def _shape(name, state_cnt):
+    shp, nd = (C.c_int32 * 5)(), C.c_int32()
+    _ok(_L().spd_get_shape(int(state_cnt), name.encode(), shp, C.byref(nd)), "get_%s_shape" % name)
+    return tuple(shp[:nd.value])
+
+
+def _ctype_of(v):
+    """element type the C boundary uses for a registry entry: logicals and integers travel as int32"""
+    return np.int32 if v.dtype in (np.bool_, np.int32) else v.dtype
 
 
 def _get(name, state_cnt, n_months=None):
-    st = _lookup(state_cnt, _State)
     v = R.REGISTRY[name]
-    b = st.batch
-    if v.where == "device":
-        return b.model.get(name, st.member)
-    if v.where == "table":
-        return _table(st, name)
-    if v.where == "host":
-        return st.host.setdefault(name, np.zeros(R.shape_of(name), dtype=v.dtype, order="F")).copy(order="F")
-    if name == "current_step":
-        return b.model.current_step
-    if name == "air_absortivity_co2":
-        return b.model.co2
-    return st.scalars[name]
+    shape = _shape(name, state_cnt) if v.shape is not None else ()
+    buf = np.zeros(int(np.prod(shape)) if shape else 1, dtype=_ctype_of(v))
+    _ok(_L().spd_get(int(state_cnt), name.encode(), buf.ctypes.data_as(C.c_void_p), buf.nbytes), "get_" + name)
+    if v.shape is None:
+        return v.dtype(buf[0]).item()
+    return buf.reshape(shape, order="F")
 
 
 def _set(name, state_cnt, value, n_months=None):
-    st = _lookup(state_cnt, _State)
     v = R.REGISTRY[name]
-    b = st.batch
-    if v.where == "device":
-        b.model.set(name, np.asarray(value), st.member)
-    elif v.where == "host":
-        a = np.asarray(value, dtype=v.dtype)
-        if a.shape != R.shape_of(name):
-            raise ValueError("Array shape missmatch")
-        st.host[name] = np.array(a, order="F")
-    elif v.where == "table":
-        raise ValueError("'%s' is a read-only table of the device context" % name)
-    elif name == "current_step":
-        raise ValueError("current_step is advanced by the model")
+    if v.shape is None:
+        a = np.array([v.dtype(value)], dtype=_ctype_of(v))
     else:
-        st.scalars[name] = v.dtype(value).item()
-        _push_flags(st, co2=(name == "air_absortivity_co2"))
-
-
-def _shape(name, state_cnt):
-    st = _lookup(state_cnt, _State)
-    if name == "sst_anom":
-        return (R.IX, R.IL, st.batch.n_months + 2)
-    return R.shape_of(name)
+        a = np.asarray(value, dtype=v.dtype)
+        if a.shape != _shape(name, state_cnt):
+            raise ValueError("Array shape missmatch")
+        a = np.ascontiguousarray(a.ravel(order="F"))
+    _ok(_L().spd_set(int(state_cnt), name.encode(), a.ctypes.data_as(C.c_void_p), a.nbytes), "set_" + name)
 
 
 def __getattr__(attr):  # PEP 562: the per-variable functions

@@ -229,7 +229,7 @@ def test_ensemble_statistics_on_device():
         member["t_grid"] = t + rng.normal(0.0, 0.01, t.shape)
         member.grid2spectral()
     ens.run()
-    model = drv._lookup(ens.members[0]._state_cnt, drv._State).batch.model
+    model = drv.device_model(ens.members[0]._state_cnt)[0]
     model.spectral2grid()
     view = model.device_view("t_grid")
     assert tuple(view.shape) == (4, 8, 48, 96) and view.is_cuda

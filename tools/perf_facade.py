@@ -33,7 +33,7 @@ def run(callbacks):
 
 t_init, ms_plain, ens = run([])
 print("M=%d  set_bc of all members %.2f s;  SpeedyEns.run (step + check each step): %.3f ms/step" % (M, t_init, ms_plain))
-model = drv._lookup(ens.members[0]._state_cnt, drv._State).batch.model
+model = drv.device_model(ens.members[0]._state_cnt)[0]
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 model.run(72)
