@@ -294,6 +294,10 @@ def kernel_table(model, M, inv_per_member, sppt):
             algo = 16 * S_BYTES * (units // 8) + (S_BYTES + G_BYTES) * units
         elif name == "coupler":
             algo = coupler * 8 * NG * units
+        elif name == "spectral_step":  # (+ the coupling and / or the next geopotential when they ride in this launch)
+            cfg = model.config()
+            algo = (ALGO_BYTES[name] + (coupler * 8 * NG if cfg["coupler_in_spectral"] else 0) +
+                    (8 * S_BYTES if cfg["fold_geo"] else 0)) * units
         else:
             algo = ALGO_BYTES[name] * units
         gbs = algo / (mean_ms * 1e-3) / 1e9

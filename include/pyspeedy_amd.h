@@ -215,8 +215,9 @@ int spd_model_profile_read_kernels(spd_model_handle m, double *mean_ms, double *
 /* how the step is configured (environment switches read at spd_model_create): cfg[0] = spectral->grid transforms per member
  * and step (77, or the reference's 91 with PYSPEEDY_AMD_PRUNE_DEAD=0), cfg[1] = 1 when every step stores the diagnostics-only
  * physics outputs (PYSPEEDY_AMD_DIAG_EVERY_STEP=1; default 0: only the last step of a multi-step call does), cfg[2] = member
- * groups stepped on separate streams (PYSPEEDY_AMD_CHUNKS), cfg[3] = 1 for separate dynamics / physics launches */
-int spd_model_get_config(spd_model_handle m, int32_t *cfg /* 4 */);
+ * groups stepped on separate streams (PYSPEEDY_AMD_CHUNKS), cfg[3] = 1 for separate dynamics / physics launches, cfg[4] = 1
+ * when spectral_step_kernel also computes the next step's geopotential, cfg[5] = 1 when it carries the land / sea-ice coupling */
+int spd_model_get_config(spd_model_handle m, int32_t *cfg /* 6 */);
 /* BASELINE cfg 5: fp32 != 0 runs the arithmetic of the column physics (physics.f90:107-256 and the schemes it calls) in
  * single precision; the model state, the grid-point dynamics and the tendencies handed to the transforms stay fp64 (the
  * physics increment is formed in fp32 and added to the fp64 dynamics tendency).  Not bitwise comparable with the reference:

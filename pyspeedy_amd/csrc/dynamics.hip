@@ -15,6 +15,9 @@
 // One lane per spectral coefficient or grid column (spectral_step_kernel: per coefficient and level); unit-stride accesses.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
+#include "coupler_point.hpp"
 #include "device_tables.hpp"
 #include "dyn_column.hpp"
 #include "model.hpp"
@@ -148,13 +151,32 @@ __device__ inline d2 pick(const d2 (&a)[N], int l) {
 
 // FOLD: the kernel ends by computing the geopotential of the next step into P.phi_next (a template parameter and not a run-time
 // switch: the extra code costs the 64-member launch 7 % even when it is skipped).
-template <bool FOLD>
+//
+// CA = CouplerArgs: horizontal fusion with the land / sea-ice coupling of the step (speedy.f90:72).  The coupling depends on the
+// column kernel only, as this kernel's spectral work depends on the transforms only: the blocks behind the spectral ones
+// do the coupling for 256 grid points each, in the same launch -- one kernel boundary less and, for ensembles that do not
+// fill the GPU, the coupling runs beside the spectral step instead of after it.  CA = NoCoupler (empty): spectral work only.
+struct NoCoupler {};
+template <bool FOLD, typename CA>
 __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTables T, DynDeviceTables D, int M, int first,
-                                                           int count, int j1, double dt, double eps) {
+                                                           int count, int j1, double dt, double eps, CA cpl) {
+    int nblocks = gridDim.x;  // blocks of spectral work
+    if constexpr (std::is_same<CA, CouplerArgs>::value) {
+        nblocks = (count * NSPEC * KX + kT - 1) / kT;
+        if (static_cast<int>(blockIdx.x) >= nblocks) {
+            const int gid = (blockIdx.x - nblocks) * kT + threadIdx.x;
+            if (gid < cpl.count * NG) {
+                const int lm = gid / NG;
+                coupler_point(cpl.S, cpl.first + lm, gid - lm * NG, cpl.w, cpl.day, cpl.land_coupling, cpl.sst_anomaly,
+                              cpl.anom_planes, cpl.fresh);
+            }
+            return;
+        }
+    }
     // XCD-aware block order: workgroups are dealt to the 8 XCDs round-robin, and the n-1 / n+1 neighbours of the vel2vort
     // stencils live one workgroup away (31 coefficients), so each XCD is given a CONTIGUOUS range of the work -- the halo
     // lines are then found in that XCD's L2 instead of being fetched again by every neighbour's XCD.
-    const int xcd = blockIdx.x & 7, q = gridDim.x >> 3, r = gridDim.x & 7;  // XCD c owns q + (c < r) consecutive blocks
+    const int xcd = blockIdx.x & 7, q = nblocks >> 3, r = nblocks & 7;  // XCD c owns q + (c < r) consecutive blocks
     const int block = xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3);
     const int gid = block * kT + threadIdx.x;
     const int w = gid >> 6, lane = gid & 63;
@@ -382,14 +404,23 @@ hipError_t run_dyn_grid(const ModelPtrs &P, const DynDeviceTables &D, int M, hip
     hipLaunchKernelGGL(dyn_grid_kernel, dim3((M * NG + kT - 1) / kT), dim3(kT), 0, s, P, D, M);
     return hipGetLastError();
 }
+// cpl != nullptr: the coupling of the step rides in the same launch (tail blocks)
 hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const DynDeviceTables &D, int M, int first, int count,
-                             int j1, double dt, double eps, hipStream_t s) {
-    if (P.phi_next)
-        hipLaunchKernelGGL(spectral_step_kernel<true>, dim3((count * NSPEC * KX + kT - 1) / kT), dim3(kT), 0, s, P, T, D, M, first,
-                           count, j1, dt, eps);
-    else
-        hipLaunchKernelGGL(spectral_step_kernel<false>, dim3((count * NSPEC * KX + kT - 1) / kT), dim3(kT), 0, s, P, T, D, M, first,
-                           count, j1, dt, eps);
+                             int j1, double dt, double eps, const CouplerArgs *cpl, hipStream_t s) {
+    const int nspec = (count * NSPEC * KX + kT - 1) / kT;
+    if (cpl) {
+        const dim3 grid(nspec + (cpl->count * NG + kT - 1) / kT);
+        if (P.phi_next)
+            hipLaunchKernelGGL((spectral_step_kernel<true, CouplerArgs>), grid, dim3(kT), 0, s, P, T, D, M, first, count, j1, dt, eps, *cpl);
+        else
+            hipLaunchKernelGGL((spectral_step_kernel<false, CouplerArgs>), grid, dim3(kT), 0, s, P, T, D, M, first, count, j1, dt, eps, *cpl);
+    } else if (P.phi_next) {
+        hipLaunchKernelGGL((spectral_step_kernel<true, NoCoupler>), dim3(nspec), dim3(kT), 0, s, P, T, D, M, first, count, j1, dt,
+                           eps, NoCoupler{});
+    } else {
+        hipLaunchKernelGGL((spectral_step_kernel<false, NoCoupler>), dim3(nspec), dim3(kT), 0, s, P, T, D, M, first, count, j1, dt,
+                           eps, NoCoupler{});
+    }
     return hipGetLastError();
 }
 hipError_t run_diagnostics(const ModelPtrs &P, const DeviceTables &T, int M, int tl, int *err, double *diag, hipStream_t s) {

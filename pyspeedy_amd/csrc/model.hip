@@ -13,6 +13,7 @@
 #include "../../include/pyspeedy_amd.h"
 #include "context.hpp"
 #include "model.hpp"
+#include "coupler_point.hpp"
 #include "surface.hpp"
 
 namespace spd {
@@ -24,7 +25,7 @@ hipError_t run_dyn_physics(const ModelPtrs &P, const DynDeviceTables &D, const D
 hipError_t run_geopotential(const ModelPtrs &P, const DynDeviceTables &D, int first, int count, int tl, hipStream_t s);
 hipError_t run_dyn_grid(const ModelPtrs &P, const DynDeviceTables &D, int M, hipStream_t s);
 hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const DynDeviceTables &D, int M, int first, int count,
-                             int j1, double dt, double eps, hipStream_t s);
+                             int j1, double dt, double eps, const CouplerArgs *cpl, hipStream_t s);
 hipError_t run_diagnostics(const ModelPtrs &P, const DeviceTables &T, int M, int tl, int *err, double *diag, hipStream_t s);
 hipError_t run_coupler(const SurfacePtrs &S, int first, int count, const TimeInterp &w, int day, int land_coupling,
                        int sst_anomaly, int anom_planes, int fresh, hipStream_t s);
@@ -120,6 +121,9 @@ struct spd_model {
     // The coupler's climatology interpolation is valid for a day (surface.hip): true after a coupling, false after anything
     // wrote to the state from outside the step
     bool surf_cache_valid = false;
+    // The coupling of the step rides in the launch of spectral_step_kernel (tail blocks, dynamics.hip) instead of being a
+    // launch of its own: PYSPEEDY_AMD_COUPLER_IN_SPECTRAL=0 / 1
+    bool coupler_in_spectral = true;
     int land_coupling_flag = 1, sst_anomaly_flag = 1, increase_co2 = 0, anom_planes = 3;
     double ablco2_ref = 6.0;
     double *corh_t = nullptr, *corh_q = nullptr, *scratch_spec = nullptr;  // [M][NG], [M][NG], [2][M][992] complex
@@ -282,6 +286,7 @@ int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
     if (const char *env = getenv("PYSPEEDY_AMD_PRUNE_DEAD")) m->inv_per_member = atoi(env) != 0 ? 77 : 91;
     if (const char *env = getenv("PYSPEEDY_AMD_DIAG_EVERY_STEP")) m->diag_every_step = atoi(env) != 0;
     m->fold_geo = nmembers <= 8;
+    if (const char *env = getenv("PYSPEEDY_AMD_COUPLER_IN_SPECTRAL")) m->coupler_in_spectral = atoi(env) != 0;
     if (const char *env = getenv("PYSPEEDY_AMD_FOLD_GEO")) m->fold_geo = atoi(env) != 0;
     // PYSPEEDY_AMD_CHUNKS = 2 or 3 steps the members in that many groups on separate streams: measured -6 % / -8 % per step
     // at 64 members (4 groups: +7 %).  Off by default: with overlapping launches the duration of a single kernel -- what the
@@ -548,8 +553,9 @@ static bool begin_step_geopotential(spd_model *m) {
     return !ahead;
 }
 
+// cpl != nullptr: the coupling that follows the step is part of the last launch
 static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int compute_shortwave, int first, int count, int diag,
-                             bool run_geo, hipStream_t s) {
+                             bool run_geo, const CouplerArgs *cpl, hipStream_t s) {
     const DeviceTables &T = m->ctx->dev;
     const int M = m->M;
     hipError_t e = hipSuccess;
@@ -596,7 +602,7 @@ static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int comput
     const double eps = (j1 == 1) ? 0.0 : static_cast<double>(0.05f);                      // rob, time_stepping.f90:130-134
     if (e == hipSuccess) {
         ProfScope ps(m, SPD_K_SPECTRAL_STEP, count, s);
-        e = run_spectral_step(m->P, T, m->D, M, first, count, j1 - 1, dt, eps, s);
+        e = run_spectral_step(m->P, T, m->D, M, first, count, j1 - 1, dt, eps, cpl, s);
     }
     return e;
 }
@@ -607,7 +613,7 @@ int spd_model_step_dynamics(spd_model_handle m, int j1, int j2, double dt, int c
     if (j1 < 1 || j1 > 2 || j2 < 1 || j2 > 2) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: time levels are 1 or 2");
     if (m->dynh->dt == 0.0) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: call spd_model_set_time_step first");
     const bool run_geo = begin_step_geopotential(m);
-    const hipError_t e = step_range(m, j1, j2, dt, compute_shortwave, 0, m->M, 1, run_geo, static_cast<hipStream_t>(stream));
+    const hipError_t e = step_range(m, j1, j2, dt, compute_shortwave, 0, m->M, 1, run_geo, nullptr, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_step_dynamics: ") + hipGetErrorString(e));
     return SPD_OK;
 }
@@ -849,11 +855,14 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
         for (int g = 0, first = 0; g < G && rc == SPD_OK; ++g) {
             const int count = base + (g < extra ? 1 : 0);
             if (new_day) rc = forcing_range(m, zd, first, count, gs[g]);
+            CouplerArgs cpl{m->S, w, first, count, 1 + (m->current_step + 1) / 36, m->land_coupling_flag, m->sst_anomaly_flag,
+                            m->anom_planes, fresh};
+            const bool ride = m->coupler_in_spectral;
             if (rc == SPD_OK) {
-                const hipError_t e = step_range(m, 2, 2, 2 * delt, sw, first, count, diag, run_geo, gs[g]);
+                const hipError_t e = step_range(m, 2, 2, 2 * delt, sw, first, count, diag, run_geo, ride ? &cpl : nullptr, gs[g]);
                 if (e != hipSuccess) rc = m_fail(SPD_E_DEVICE, std::string("spd_model_step: ") + hipGetErrorString(e));
             }
-            if (rc == SPD_OK) {
+            if (rc == SPD_OK && !ride) {
                 ProfScope ps(m, SPD_K_COUPLER, count, gs[g]);
                 const hipError_t e = run_coupler(m->S, first, count, w, 1 + (m->current_step + 1) / 36, m->land_coupling_flag,
                                                  m->sst_anomaly_flag, m->anom_planes, fresh, gs[g]);
@@ -997,6 +1006,8 @@ int spd_model_get_config(spd_model_handle m, int32_t *cfg) {
     cfg[1] = m->diag_every_step ? 1 : 0;
     cfg[2] = m->nchunks;
     cfg[3] = m->split_dyn_physics ? 1 : 0;
+    cfg[4] = m->fold_geo ? 1 : 0;
+    cfg[5] = m->coupler_in_spectral ? 1 : 0;
     return SPD_OK;
 }
 

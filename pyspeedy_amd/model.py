@@ -226,9 +226,10 @@ class EnsembleModel:
 
     def config(self):
         """How the step is configured: dict(inv_per_member, diag_every_step, chunks, split_dyn) -- spd_model_get_config."""
-        cfg = (C.c_int32 * 4)()
+        cfg = (C.c_int32 * 6)()
         check(self._lib.spd_model_get_config(self._m, cfg), "spd_model_get_config")
-        return dict(inv_per_member=cfg[0], diag_every_step=bool(cfg[1]), chunks=cfg[2], split_dyn=bool(cfg[3]))
+        return dict(inv_per_member=cfg[0], diag_every_step=bool(cfg[1]), chunks=cfg[2], split_dyn=bool(cfg[3]),
+                    fold_geo=bool(cfg[4]), coupler_in_spectral=bool(cfg[5]))
 
     def profile(self, level=1):
         """HIP-event brackets on the launch stream: 0 off, 1 the spectral->grid launch of every step, 2 every kernel."""
