@@ -804,7 +804,12 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
     if (a.clstr) stream_store(&a.clstr[o2], clstr);
 }
 
-static int physics_waves() {
+// Launch-bounds variant of the fp64 kernels: 2 waves per SIMD (256 VGPRs, a few spilled values).  The 1-wave build (512
+// registers, no spills; PYSPEEDY_AMD_PHYS_WAVES=1) is 2.8 % faster per step at 8 members and 1.2 % at 1, 14 % slower at 16
+// (profiles/r02_small_ensemble_experiments.txt) -- but the compiler contracts a few multiply-adds differently in the two
+// builds, so their results differ in the last bits, and a member's trajectory must not depend on the size of the ensemble it
+// is stepped in (tests/test_run_gpu.py): one build for every size.
+static int physics_waves(int) {
     static const int waves = [] {
         const char *e = getenv("PYSPEEDY_AMD_PHYS_WAVES");
         return e ? atoi(e) : 2;
@@ -841,7 +846,7 @@ hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nme
             default: return launch_physics<4, false, false, float>(T, a, 0, nmembers, mp, md, 1, s);
         }
     }
-    if (physics_waves() == 1) return launch_physics<1, false, false, double>(T, a, 0, nmembers, mp, md, 1, s);
+    if (physics_waves(nmembers) == 1) return launch_physics<1, false, false, double>(T, a, 0, nmembers, mp, md, 1, s);
     return launch_physics<2, false, false, double>(T, a, 0, nmembers, mp, md, 1, s);
 }
 
@@ -862,7 +867,7 @@ hipError_t run_dyn_physics(const ModelPtrs &P, const DynDeviceTables &D, const D
         }
     }
     if (a.sppt_pattern) return launch_physics<2, true, true, double>(T, a, first, nmembers, P, D, diag, s);
-    if (physics_waves() == 1) return launch_physics<1, true, false, double>(T, a, first, nmembers, P, D, diag, s);
+    if (physics_waves(nmembers) == 1) return launch_physics<1, true, false, double>(T, a, first, nmembers, P, D, diag, s);
     return launch_physics<2, true, false, double>(T, a, first, nmembers, P, D, diag, s);
 }
 
