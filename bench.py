@@ -290,8 +290,8 @@ def kernel_table(model, M, inv_per_member, sppt):
             algo = (COLUMN_DOUBLES[name] + extra - diag) * 8 * NG * units
         elif name in ("physics_sw", "physics"):
             algo = (COLUMN_DOUBLES["column_sw" if name == "physics_sw" else "column"] - 105 + 18 + extra) * 8 * NG * units
-        elif name == "sppt":
-            algo = 16 * S_BYTES * (units // 8) + (S_BYTES + G_BYTES) * units
+        elif name == "sppt":  # the AR(1) update of the spectral pattern; its 8 transforms per member ride in spec2grid
+            algo = 2 * S_BYTES * units
         elif name == "coupler":
             algo = coupler * 8 * NG * units
         elif name == "spectral_step":  # (+ the coupling and / or the next geopotential when they ride in this launch)

@@ -73,6 +73,7 @@ struct spd_model {
     std::vector<void *> allocs;
     std::map<std::string, RegEntry> reg;
     FieldDesc *inv_table[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [dynamics time level j2 (0-based)][phi buffer]
+    FieldDesc *inv_table_sppt[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // the same + 8 SPPT pattern transforms per member
     FieldDesc *fwd_table = nullptr;
     // Geopotential, double-buffered.  spectral_step_kernel ends by computing the geopotential the NEXT step needs (from the
     // temperature it has just advanced) into the buffer that is not in use; the next step switches to it instead of running
@@ -169,7 +170,10 @@ static int upload_const(spd_model *m, const double *src, size_t n, const double 
     return SPD_OK;
 }
 
-static int build_tables(spd_model *m) {
+// The four spectral -> grid descriptor tables ([dynamics time level][phi buffer]) of the step.  with_sppt: every member's
+// entries are followed by the 8 transforms of its SPPT pattern (spectral AR(1) state -> grid, kcos = 1), so that they ride
+// in the same launch instead of being a launch of their own.
+static int build_inverse_tables(spd_model *m, bool with_sppt, FieldDesc *(&out)[2][2]) {
     const int M = m->M;
     const ModelPtrs &P = m->P;
     const spd_physics_args &pa = m->pa;
@@ -178,7 +182,7 @@ static int build_tables(spd_model *m) {
     for (int j2 = 0; j2 < 4; ++j2) {
         const int par = j2 >> 1;  // (j2 & 1) = dynamics time level, par = phi buffer
         std::vector<FieldDesc> t;
-        t.reserve(static_cast<size_t>(M) * 91);
+        t.reserve(static_cast<size_t>(M) * 99);
         for (int i = 0; i < M; ++i) {
             const size_t w = static_cast<size_t>(i) * 8, st = (static_cast<size_t>(i) * 2 + (j2 & 1)) * 8, s1 = static_cast<size_t>(i) * 2 * 8;
             // Entry order inside a member is variable-major, level-minor: workgroups are handed to the 8 XCDs round-robin by
@@ -208,13 +212,24 @@ static int build_tables(spd_model *m) {
             t.push_back({spec(P.ps, static_cast<size_t>(i) * 2 + (j2 & 1)), grid(P.px, i), 2, 3, nullptr});
             t.push_back({spec(P.ps, static_cast<size_t>(i) * 2 + (j2 & 1)), grid(P.py, i), 2, 4, nullptr});
             t.push_back({spec(P.ps, static_cast<size_t>(i) * 2), grid(const_cast<double *>(pa.pslg), i), 1, 0});
+            if (with_sppt)
+                for (int k = 0; k < 8; ++k) t.push_back({spec(m->sppt_spec, w + k), grid(m->sppt_grid, w + k), 1, 0});
         }
         void *d = nullptr;
         M_HIP(hipMalloc(&d, t.size() * sizeof(FieldDesc)));
         m->allocs.push_back(d);
         M_HIP(hipMemcpy(d, t.data(), t.size() * sizeof(FieldDesc), hipMemcpyHostToDevice));
-        m->inv_table[j2 & 1][par] = static_cast<FieldDesc *>(d);
+        out[j2 & 1][par] = static_cast<FieldDesc *>(d);
     }
+    return SPD_OK;
+}
+
+static int build_tables(spd_model *m) {
+    const int M = m->M;
+    const ModelPtrs &P = m->P;
+    auto spec = [](double *base, size_t field) { return base + field * NSPEC * C; };
+    auto grid = [](double *base, size_t field) { return base + field * NG; };
+    if (int rc = build_inverse_tables(m, false, m->inv_table)) return rc;
     std::vector<FieldDesc> t;
     t.reserve(static_cast<size_t>(M) * 73);
     const size_t pair = static_cast<size_t>(M) * 8;
@@ -563,11 +578,6 @@ static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int comput
         ProfScope ps(m, SPD_K_GEOPOTENTIAL, count, s);
         e = run_geopotential(m->P, m->D, first, count, 0, s);                             // tendencies.f90:229
     }
-    if (e == hipSuccess) {                                                                // :109-146, physics.f90:89-101
-        ProfScope ps(m, SPD_K_SPEC2GRID, m->inv_per_member * count, s);
-        e = run_spec2grid_table(T, m->inv_table[j2 - 1][m->phi_cur] + static_cast<size_t>(first) * m->inv_per_member,
-                                m->inv_per_member * count, s);
-    }
     spd_physics_args pa = m->pa;
     pa.compute_shortwave = compute_shortwave ? 1 : 0;
     pa.air_absortivity_co2 = m->air_absortivity_co2;
@@ -575,10 +585,15 @@ static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int comput
     if (e == hipSuccess && m->sppt_on) {  // physics.f90:234-236: a new pattern for every call of the physics (whole model)
         ProfScope ps(m, SPD_K_SPPT, 8 * M, s);
         e = run_sppt_update(m->sppt_spec, T, M, m->sppt_seed, m->sppt_member_base, m->sppt_step, m->sppt_first ? 1 : 0, s);
-        if (e == hipSuccess) e = run_spec2grid(T, 0, m->sppt_spec, m->sppt_grid, 1, 8 * M, s);
         m->sppt_first = false;
         m->sppt_step += 1;
-        pa.sppt_pattern = m->sppt_grid;
+        pa.sppt_pattern = m->sppt_grid;  // its 8 transforms per member ride in the spectral -> grid launch below
+    }
+    if (e == hipSuccess) {                                                                // :109-146, physics.f90:89-101
+        const int per = m->inv_per_member + (m->sppt_on ? 8 : 0);
+        FieldDesc *table = (m->sppt_on ? m->inv_table_sppt : m->inv_table)[j2 - 1][m->phi_cur];
+        ProfScope ps(m, SPD_K_SPEC2GRID, per * count, s);
+        e = run_spec2grid_table(T, table + static_cast<size_t>(first) * per, per * count, s);
     }
     if (e == hipSuccess) {
         if (m->split_dyn_physics) {  // whole model only; the default is the fused launch (with SPPT: its KEEP variant)
@@ -1097,6 +1112,7 @@ int spd_model_set_sppt(spd_model_handle m, int on, uint64_t seed, int64_t first_
         const size_t M = m->M;
         if (int rc = dalloc(m, M * 8 * NSPEC * C, &m->sppt_spec, "sppt_spec", 8 * NSPEC * C * sizeof(double))) return rc;
         if (int rc = dalloc(m, M * 8 * NG, &m->sppt_grid, "sppt_pattern", static_cast<size_t>(8) * NG * sizeof(double))) return rc;
+        if (int rc = build_inverse_tables(m, true, m->inv_table_sppt)) return rc;
     }
     m->sppt_on = on != 0;
     m->sppt_seed = seed;
