@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpyspeedy_amd.so")
+# PYSPEEDY_AMD_LIB: another build of the same library (A/B measurements of kernel variants in one session)
+LIB_PATH = os.environ.get("PYSPEEDY_AMD_LIB") or os.path.join(_HERE, "libpyspeedy_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 IX, IL, IY, KX, MX, NX, TRUNC = 96, 48, 24, 8, 31, 32, 30

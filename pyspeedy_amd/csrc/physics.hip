@@ -152,10 +152,14 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
     // ------------------------------------------------------------------ tendencies so far (dynamics)
     // FUSED: computed here and parked in LDS until the condensation scheme picks them up, so that they do not occupy 32
     // VGPRs through the convection scheme, the register peak of the kernel.
-    double utend_dyn = 0.0, vtend_dyn = 0.0;
+    // (the dynamics' wind tendencies of the lowest level wait in LDS for the surface stress at the very end of the kernel:
+    // kept in registers they are spilled to scratch memory by the allocator, 16 bytes out and back per lane)
+    __shared__ double park_uv[2][kPhysThreads];
     if (FUSED) {
-        double tt[KX], qt[KX];
+        double tt[KX], qt[KX], utend_dyn = 0.0, vtend_dyn = 0.0;
         dyn_column<false>(MP, MD, mem, p, j, tt, qt, utend_dyn, vtend_dyn);
+        park_uv[0][lane] = utend_dyn;
+        park_uv[1][lane] = vtend_dyn;
 #pragma unroll
         for (int k = 0; k < KX; ++k) {
             park_t[k][lane] = tt[k];
@@ -785,7 +789,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         const R vt_kx = R(0.0f) + vstr3 * rps * CT.grdsig[KX - 1];
         ttend[KX - 1] = ttend[KX - 1] + shf3 * rps * CT.grdscp[KX - 1];
         const size_t okx = o3 + static_cast<size_t>(NG) * (KX - 1);
-        const double ud = FUSED ? utend_dyn : a.utend[okx], vd = FUSED ? vtend_dyn : a.vtend[okx];
+        const double ud = FUSED ? park_uv[0][lane] : a.utend[okx], vd = FUSED ? park_uv[1][lane] : a.vtend[okx];
         const R qkx = qtend_kx + evap3 * rps * CT.grdsig[KX - 1];
         // (above the lowest level the physics leaves the wind tendencies alone: ut_pbl, vt_pbl are zero there)
         stream_store(&a.utend[okx], finish(MIXED ? ut_kx : static_cast<R>(ud) + ut_kx, ud, KX - 1));
@@ -816,7 +820,8 @@ static int physics_waves(int) {
     }();
     return waves;
 }
-// launch-bounds variant of the fp32 kernels (waves per SIMD the register allocator leaves room for): profiles/ compares them
+// launch-bounds variant of the fp32 kernels (waves per SIMD the register allocator leaves room for: 2 or 3; a 4-wave build
+// spilled 368 bytes per lane and was 40 % slower): profiles/r02_cfg5_fp32_vs_fp64.txt
 static int physics_waves32() {
     static const int waves = [] {
         const char *e = getenv("PYSPEEDY_AMD_PHYS_WAVES32");
@@ -842,8 +847,7 @@ hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nme
     if (fp32) {
         switch (physics_waves32()) {
             case 2: return launch_physics<2, false, false, float>(T, a, 0, nmembers, mp, md, 1, s);
-            case 3: return launch_physics<3, false, false, float>(T, a, 0, nmembers, mp, md, 1, s);
-            default: return launch_physics<4, false, false, float>(T, a, 0, nmembers, mp, md, 1, s);
+            default: return launch_physics<3, false, false, float>(T, a, 0, nmembers, mp, md, 1, s);
         }
     }
     if (physics_waves(nmembers) == 1) return launch_physics<1, false, false, double>(T, a, 0, nmembers, mp, md, 1, s);
@@ -862,8 +866,7 @@ hipError_t run_dyn_physics(const ModelPtrs &P, const DynDeviceTables &D, const D
     if (fp32) {
         switch (physics_waves32()) {
             case 2: return launch_physics<2, true, true, float>(T, a, first, nmembers, P, D, diag, s);
-            case 3: return launch_physics<3, true, true, float>(T, a, first, nmembers, P, D, diag, s);
-            default: return launch_physics<4, true, true, float>(T, a, first, nmembers, P, D, diag, s);
+            default: return launch_physics<3, true, true, float>(T, a, first, nmembers, P, D, diag, s);
         }
     }
     if (a.sppt_pattern) return launch_physics<2, true, true, double>(T, a, first, nmembers, P, D, diag, s);
