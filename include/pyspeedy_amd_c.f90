@@ -197,6 +197,19 @@ module pyspeedy_amd_c
             integer(c_int32_t), intent(out) :: error_codes(*)
             integer(c_int32_t), value :: n_members
         end function
+        ! extension: the same step with its range check overlapped with the next step
+        integer(c_int) function spd_parallel_step_begin(state_cnts, control_cnts, n_members, token) &
+                bind(C, name="spd_parallel_step_begin")
+            import :: c_int, c_int64_t, c_int32_t
+            integer(c_int64_t), intent(in) :: state_cnts(*), control_cnts(*)
+            integer(c_int32_t), value :: n_members
+            integer(c_int64_t), intent(out) :: token
+        end function
+        integer(c_int) function spd_parallel_step_end(token, error_codes) bind(C, name="spd_parallel_step_end")
+            import :: c_int, c_int64_t, c_int32_t
+            integer(c_int64_t), value :: token
+            integer(c_int32_t), intent(out) :: error_codes(*)
+        end function
         integer(c_int) function spd_check(state_cnt, error_code) bind(C, name="spd_check")
             import :: c_int, c_int64_t, c_int32_t
             integer(c_int64_t), value :: state_cnt
@@ -233,6 +246,17 @@ module pyspeedy_amd_c
             integer(c_int64_t), value :: state_cnt
             character(kind=c_char), intent(in) :: name(*)
             integer(c_int32_t), intent(out) :: array_shape(5), ndim
+        end function
+        integer(c_int) function spd_driver_model(state_cnt, model, member, members_in_model) bind(C, name="spd_driver_model")
+            import :: c_int, c_int64_t, c_int32_t, c_ptr
+            integer(c_int64_t), value :: state_cnt
+            type(c_ptr), intent(out) :: model          ! spd_model_handle owned by the driver
+            integer(c_int32_t), intent(out) :: member, members_in_model
+        end function
+        integer(c_int) function spd_modelstate_init_ensemble(state_cnts, n_members) bind(C, name="spd_modelstate_init_ensemble")
+            import :: c_int, c_int64_t, c_int32_t
+            integer(c_int64_t), intent(out) :: state_cnts(*)
+            integer(c_int32_t), value :: n_members
         end function
         integer(c_int) function spd_driver_stats(state_cnt, models_alive, members_in_model) bind(C, name="spd_driver_stats")
             import :: c_int, c_int64_t, c_int32_t

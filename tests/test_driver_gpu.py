@@ -200,3 +200,31 @@ def test_ensemble_containers_are_batched_from_the_start(drv, bc):
     assert drv.stats(states[3])[1] == 1 and drv.get(states[3], "increase_co2", np.int32) == 1
     assert drv.get(states[0], "increase_co2", np.int32) == 0
     drv.close(single, *states)
+
+
+def test_a_failing_member_keeps_its_date_and_reports_minus_two(drv, bc):
+    """speedy.f90:57-71: the range check runs before advance_date; a member that leaves the accepted range returns -2 and its
+    control container keeps the date, the others advance -- in the synchronous form and in the overlapped begin / end form."""
+    states = [drv.state() for _ in range(2)]
+    controls = [drv.control(START, END) for _ in range(2)]
+    for s, c in zip(states, controls):
+        drv.set_bc(s, bc)
+        assert drv.init(s, c) == 0
+    assert drv.parallel_step(states, controls) == [0, 0]
+    t = drv.get(states[1], "t", np.complex128)
+    t[0, 0, :, :] = 500.0 * np.sqrt(2.0)  # global-mean temperature of 500 K: outside 180 ... 320 K (diagnostics.f90:57-66)
+    drv.set(states[1], "t", t)
+    before = drv.model_date(controls[1])
+    assert drv.parallel_step(states, controls) == [0, -2]
+    assert drv.model_date(controls[1]) == before
+    assert drv.model_date(controls[0])[0] == (1982, 1, 1, 1, 20)
+    # overlapped form: the date moves at _begin and is put back at _end for the failing member
+    n = 2
+    token = C.c_int64()
+    drv.ok(drv.L.spd_parallel_step_begin((C.c_int64 * n)(*states), (C.c_int64 * n)(*controls), n, C.byref(token)))
+    codes = (C.c_int32 * n)()
+    drv.ok(drv.L.spd_parallel_step_end(token, codes))
+    assert list(codes) == [0, -2]
+    assert drv.model_date(controls[1]) == before and drv.model_date(controls[0])[0] == (1982, 1, 1, 2, 0)
+    assert drv.L.spd_parallel_step_end(token, codes) < 0  # a token is good for one _end
+    drv.close(*states)
