@@ -60,6 +60,33 @@ __device__ inline void uv_stencil(const d2 *a, const d2 *b, int k, int m, int n,
         rb = d2{-cm * bp.x + cp * bn.x + zp.x, -cm * bp.y + cp * bn.y + zp.y};
     }
 }
+
+// The same stencil in two halves: all six loads first (neighbour indices clamped into the field, so the loads need no
+// branch), the arithmetic of uv_stencil afterwards.
+struct Stencil {
+    d2 ac, bc, ap, bp, an, bn;
+};
+__device__ inline Stencil load_stencil(const d2 *a, const d2 *b, int k, int n) {
+    const int kp = n > 0 ? k - MX : k, kn = n < NX - 1 ? k + MX : k;
+    return Stencil{a[k], b[k], a[kp], b[kp], a[kn], b[kn]};
+}
+template <int MODE>
+__device__ inline void apply_stencil(const Stencil &s, int k, int m, int n, const DeviceTables &T, d2 &ra, d2 &rb) {
+    const double *tym = MODE == 0 ? T.uvdym : T.vddym, *typ = MODE == 0 ? T.uvdyp : T.vddyp;
+    const double dx = MODE == 0 ? T.uvdx[k] : T.gradx[m];
+    const double cm = tym[k], cp = typ[k];
+    const d2 zp = times_i(d2{dx * s.ac.x, dx * s.ac.y}), zc = times_i(d2{dx * s.bc.x, dx * s.bc.y});
+    if (n == 0) {
+        ra = d2{zc.x - cp * s.an.x, zc.y - cp * s.an.y};
+        rb = d2{zp.x + cp * s.bn.x, zp.y + cp * s.bn.y};
+    } else if (n == NX - 1) {
+        ra = d2{cm * s.ap.x, cm * s.ap.y};
+        rb = d2{-cm * s.bp.x, -cm * s.bp.y};
+    } else {
+        ra = d2{cm * s.ap.x - cp * s.an.x + zc.x, cm * s.ap.y - cp * s.an.y + zc.y};
+        rb = d2{-cm * s.bp.x + cp * s.bn.x + zp.x, -cm * s.bp.y + cp * s.bn.y + zp.y};
+    }
+}
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------
@@ -157,7 +184,7 @@ __device__ inline d2 pick(const d2 (&a)[N], int l) {
 // do the coupling for 256 grid points each, in the same launch -- one kernel boundary less and, for ensembles that do not
 // fill the GPU, the coupling runs beside the spectral step instead of after it.  CA = NoCoupler (empty): spectral work only.
 struct NoCoupler {};
-template <bool FOLD, typename CA>
+template <bool FOLD, bool EARLY, typename CA>
 __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTables T, DynDeviceTables D, int M, int first,
                                                            int count, int j1, double dt, double eps, CA cpl) {
     int nblocks = gridDim.x;  // blocks of spectral work
@@ -189,29 +216,69 @@ __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTa
     const d2 *su = reinterpret_cast<const d2 *>(P.specu) + f8 + fo, *sv = reinterpret_cast<const d2 *>(P.specv) + f8 + fo;
     const double el2 = T.el2[k];
     d2 vordt, divdt, tdt, trdt, dump;
-    uv_stencil<1>(su, sv, k, m, n, T, vordt, divdt);                                     // grid_vel2vort(utend, vtend)
-    {
-        const d2 ke = reinterpret_cast<const d2 *>(P.spec_ke)[f8 + fo + k];
-        const d2 lap = d2{-ke.x * el2, -ke.y * el2};                                     // laplacian(grid2spec(KE))
-        divdt = d2{divdt.x - lap.x, divdt.y - lap.y};
-        uv_stencil<1>(su + pair, sv + pair, k, m, n, T, dump, tdt);                      // div of (-uT', -vT')
-        const d2 stt = reinterpret_cast<const d2 *>(P.spec_tt)[f8 + fo + k];
-        tdt = d2{tdt.x + stt.x, tdt.y + stt.y};
-        uv_stencil<1>(su + 2 * pair, sv + 2 * pair, k, m, n, T, dump, trdt);             // div of (-uq, -vq)
-        const d2 str = reinterpret_cast<const d2 *>(P.spec_tr)[f8 + fo + k];
-        trdt = d2{trdt.x + str.x, trdt.y + str.y};
-    }
-    d2 psdt = reinterpret_cast<const d2 *>(P.spec_ps)[static_cast<size_t>(mem) * NSPEC + k];
-    if (k == 0) psdt = d2{0.0, 0.0};
-
-    // ---- state at time level 1 (index 0), this lane's level ----
+    // ---- state at both time levels, this lane's level ----
     const size_t s0 = static_cast<size_t>(mem) * 2 * 8 * NSPEC + fo + k;
     const size_t lvl = static_cast<size_t>(8) * NSPEC;               // distance between the two time levels
     d2 *vorS = reinterpret_cast<d2 *>(P.vor) + s0, *divS = reinterpret_cast<d2 *>(P.div) + s0;
     d2 *tS = reinterpret_cast<d2 *>(P.t) + s0, *trS = reinterpret_cast<d2 *>(P.tr) + s0;
     d2 *psS = reinterpret_cast<d2 *>(P.ps) + static_cast<size_t>(mem) * 2 * NSPEC + k;
-    const d2 div1 = divS[0];
-    const d2 ps1 = psS[0];
+    const int l_tot = m + n;  // total wavenumber; xj(:, :, l_tot) with 1-based third index
+    // EARLY: every global load of the kernel is issued in two batches -- here and right after the stencils -- and not where
+    // its value is first needed.  The kernel is a chain of short dependent phases; when the ensemble does not fill the GPU
+    // its duration is the number of memory round trips on that chain (about 20 in the other form, whose loads sit inside the
+    // stencils' branches and the matrix loops), and registers are free.  The other form keeps 4 wavefronts per SIMD.
+    d2 ke, stt, str, psdt, ph, div1, ps1;                                  // first batch
+    d2 vor1, t1, tr1, tcorh, qcorh, phis_k{0.0, 0.0}, vor2{}, div2{}, t2{}, tr2{}, ps2{};  // second batch
+    double xc_l[KX], xj_l[KX], xd_l[KX], elz, dmp, dmp1, dmpd, dmp1d, dmps, dmp1s, trf;
+    auto load_diffusion = [&]() {
+        dmp = D.dmp[k], dmp1 = D.dmp1[k], dmpd = D.dmpd[k], dmp1d = D.dmp1d[k], dmps = D.dmps[k], dmp1s = D.dmp1s[k];
+        trf = T.trfilt[k];
+        tcorh = reinterpret_cast<const d2 *>(P.tcorh)[static_cast<size_t>(mem) * NSPEC + k];
+        qcorh = reinterpret_cast<const d2 *>(P.qcorh)[static_cast<size_t>(mem) * NSPEC + k];
+    };
+    if constexpr (EARLY) {
+        const Stencil s_uv = load_stencil(su, sv, k, n);
+        const Stencil s_ut = load_stencil(su + pair, sv + pair, k, n);
+        const Stencil s_uq = load_stencil(su + 2 * pair, sv + 2 * pair, k, n);
+        ke = reinterpret_cast<const d2 *>(P.spec_ke)[f8 + fo + k];
+        stt = reinterpret_cast<const d2 *>(P.spec_tt)[f8 + fo + k];
+        str = reinterpret_cast<const d2 *>(P.spec_tr)[f8 + fo + k];
+        psdt = reinterpret_cast<const d2 *>(P.spec_ps)[static_cast<size_t>(mem) * NSPEC + k];
+        ph = reinterpret_cast<const d2 *>(P.phi)[f8 + fo + k];
+        div1 = divS[0];
+        ps1 = psS[0];
+        const double *xj = D.xj + static_cast<size_t>(KX) * KX * (l_tot > 0 ? l_tot - 1 : 0);
+#pragma unroll
+        for (int k1 = 0; k1 < KX; ++k1) xc_l[k1] = D.xc[l + KX * k1], xj_l[k1] = xj[l + KX * k1], xd_l[k1] = D.xd[l + KX * k1];
+        elz = D.elz[k];
+        load_diffusion();
+        vor1 = vorS[0], t1 = tS[0], tr1 = trS[0];
+        vor2 = vorS[lvl], div2 = divS[lvl], t2 = tS[lvl], tr2 = trS[lvl], ps2 = psS[NSPEC];
+        if (FOLD) phis_k = reinterpret_cast<const d2 *>(P.phis)[static_cast<size_t>(mem) * NSPEC + k];
+        apply_stencil<1>(s_uv, k, m, n, T, vordt, divdt);                                // grid_vel2vort(utend, vtend)
+        const d2 lap = d2{-ke.x * el2, -ke.y * el2};                                     // laplacian(grid2spec(KE))
+        divdt = d2{divdt.x - lap.x, divdt.y - lap.y};
+        apply_stencil<1>(s_ut, k, m, n, T, dump, tdt);                                   // div of (-uT', -vT')
+        tdt = d2{tdt.x + stt.x, tdt.y + stt.y};
+        apply_stencil<1>(s_uq, k, m, n, T, dump, trdt);                                  // div of (-uq, -vq)
+        trdt = d2{trdt.x + str.x, trdt.y + str.y};
+    } else {
+        uv_stencil<1>(su, sv, k, m, n, T, vordt, divdt);
+        ke = reinterpret_cast<const d2 *>(P.spec_ke)[f8 + fo + k];
+        const d2 lap = d2{-ke.x * el2, -ke.y * el2};
+        divdt = d2{divdt.x - lap.x, divdt.y - lap.y};
+        uv_stencil<1>(su + pair, sv + pair, k, m, n, T, dump, tdt);
+        stt = reinterpret_cast<const d2 *>(P.spec_tt)[f8 + fo + k];
+        tdt = d2{tdt.x + stt.x, tdt.y + stt.y};
+        uv_stencil<1>(su + 2 * pair, sv + 2 * pair, k, m, n, T, dump, trdt);
+        str = reinterpret_cast<const d2 *>(P.spec_tr)[f8 + fo + k];
+        trdt = d2{trdt.x + str.x, trdt.y + str.y};
+        psdt = reinterpret_cast<const d2 *>(P.spec_ps)[static_cast<size_t>(mem) * NSPEC + k];
+        div1 = divS[0];
+        ps1 = psS[0];
+    }
+    if (k == 0) psdt = d2{0.0, 0.0};
+
     const double tref_l = pick(D.tref, l);
 
     // ---- spectral tendencies (tendencies.f90:283-352, called with time level 1 because alph = 0.5) ----
@@ -246,8 +313,8 @@ __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTa
         tdt.x = tdt.x - (dumk_l1.x + dumk_l.x) * dhsr_l + tref3_l * (sig_l1.x + sig_l.x) - tref2_l * dmeanc.x;
         tdt.y = tdt.y - (dumk_l1.y + dumk_l.y) * dhsr_l + tref3_l * (sig_l1.y + sig_l.y) - tref2_l * dmeanc.y;
     }
-    {   // geopotential (already valid for time level 1: geopotential_kernel ran before the physics) and its Laplacian
-        const d2 ph = reinterpret_cast<const d2 *>(P.phi)[f8 + fo + k];
+    {   // geopotential (valid for time level 1: formed before the physics) and its Laplacian
+        if constexpr (!EARLY) ph = reinterpret_cast<const d2 *>(P.phi)[f8 + fo + k];
         const double c = RGASd * tref_l;
         const d2 x = d2{ph.x + c * ps1.x, ph.y + c * ps1.y};
         const d2 lap = d2{-x.x * el2, -x.y * el2};
@@ -261,21 +328,20 @@ __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTa
         d2 ye{0.0, 0.0};
 #pragma unroll
         for (int k1 = 0; k1 < KX; ++k1) {
-            const double x = D.xd[l + KX * k1];
+            const double x = EARLY ? xd_l[k1] : D.xd[l + KX * k1];
             ye = d2{ye.x + x * all[k1].x, ye.y + x * all[k1].y};
         }
-        const double elz = D.elz[k];
+        if constexpr (!EARLY) elz = D.elz[k];
         const double c = RGASd * tref_l;
         ye = d2{ye.x + c * psdt.x, ye.y + c * psdt.y};
         const d2 yf = d2{divdt.x + elz * ye.x, divdt.y + elz * ye.y};
         divdt = d2{0.0, 0.0};
-        const int l_tot = m + n;  // total wavenumber; xj(:, :, l_tot) with 1-based third index
         gather_levels(yf, kk, all);
         if (l_tot != 0) {
             const double *xj = D.xj + static_cast<size_t>(KX) * KX * (l_tot - 1);
 #pragma unroll
             for (int k1 = 0; k1 < KX; ++k1) {
-                const double x = xj[l + KX * k1];
+                const double x = EARLY ? xj_l[k1] : xj[l + KX * k1];
                 divdt = d2{divdt.x + x * all[k1].x, divdt.y + x * all[k1].y};
             }
         }
@@ -284,20 +350,18 @@ __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTa
         for (int j = 0; j < KX; ++j) psdt = d2{psdt.x - all[j].x * D.dhsx[j], psdt.y - all[j].y * D.dhsx[j]};
 #pragma unroll
         for (int k1 = 0; k1 < KX; ++k1) {
-            const double x = D.xc[l + KX * k1];
+            const double x = EARLY ? xc_l[k1] : D.xc[l + KX * k1];
             tdt = d2{tdt.x + x * all[k1].x, tdt.y + x * all[k1].y};
         }
     }
 
     // ---- horizontal diffusion (time_stepping.f90:78-122) and time integration (:130-188) ----
-    const double dmp = D.dmp[k], dmp1 = D.dmp1[k], dmpd = D.dmpd[k], dmp1d = D.dmp1d[k], dmps = D.dmps[k], dmp1s = D.dmp1s[k];
-    const double trf = T.trfilt[k];
-    const d2 tcorh = reinterpret_cast<const d2 *>(P.tcorh)[static_cast<size_t>(mem) * NSPEC + k];
-    const d2 qcorh = reinterpret_cast<const d2 *>(P.qcorh)[static_cast<size_t>(mem) * NSPEC + k];
+    if constexpr (!EARLY) load_diffusion();
     const double sdrag = 1.0f / (TDRSd * 3600.0f);
     auto diffuse = [](d2 field, d2 fdt, double a, double b) { return d2{(fdt.x - a * field.x) * b, (fdt.y - a * field.y) * b}; };
-    auto advance = [&](d2 *base, size_t stride, d2 fdt) -> d2 {  // step_field_2d, time_stepping.f90:164-188; returns level 1
-        const d2 o1 = base[0], o2 = base[stride];
+    // step_field_2d, time_stepping.f90:164-188, on the two time levels o1, o2 of a field (loaded above); returns level 1
+    auto advance = [&](d2 *base, size_t stride, d2 o1, d2 o2, d2 fdt) -> d2 {
+        if (!EARLY) o1 = base[0], o2 = base[stride];
         fdt = d2{fdt.x * trf, fdt.y * trf};
         const d2 oj = (j1 == 0) ? o1 : o2;
         const d2 fnew = d2{o1.x + dt * fdt.x, o1.y + dt * fdt.y};
@@ -311,7 +375,7 @@ __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTa
         return n1;
     };
     {
-        const d2 vor1 = vorS[0], t1 = tS[0], tr1 = trS[0];
+        if constexpr (!EARLY) vor1 = vorS[0], t1 = tS[0], tr1 = trS[0];
         d2 vd = diffuse(vor1, vordt, dmp, dmp1);
         d2 dd = diffuse(div1, divdt, dmpd, dmp1d);
         const double tcorv_l = pick(D.tcorv, l), qcorv_l = pick(D.qcorv, l);
@@ -326,21 +390,21 @@ __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTa
         td = diffuse(ct, td, dmps, dmp1s);
         const d2 cq = d2{tr1.x + qcorh.x * qcorv_l, tr1.y + qcorh.y * qcorv_l};
         const d2 qd = diffuse(cq, trdt, dmpd, dmp1d);
-        advance(vorS, lvl, vd);
-        advance(divS, lvl, dd);
-        const d2 t_new = advance(tS, lvl, td);
-        advance(trS, lvl, qd);
+        advance(vorS, lvl, vor1, vor2, vd);
+        advance(divS, lvl, div1, div2, dd);
+        const d2 t_new = advance(tS, lvl, t1, t2, td);
+        advance(trS, lvl, tr1, tr2, qd);
         // geopotential of the NEXT step (geopotential.f90:49-77 on the temperature at time level 1 as it is now): each lane
         // integrates from the lowest level up to its own, in the order and with the arithmetic of geopotential_kernel
         if (FOLD) {
             d2 tall[KX];
             gather_levels(t_new, kk, tall);
-            const d2 phis = reinterpret_cast<const d2 *>(P.phis)[static_cast<size_t>(mem) * NSPEC + k];
-            d2 ph = d2{fma(D.xgeop1[KX - 1], tall[KX - 1].x, phis.x), fma(D.xgeop1[KX - 1], tall[KX - 1].y, phis.y)};
+            if constexpr (!EARLY) phis_k = reinterpret_cast<const d2 *>(P.phis)[static_cast<size_t>(mem) * NSPEC + k];
+            d2 pn = d2{fma(D.xgeop1[KX - 1], tall[KX - 1].x, phis_k.x), fma(D.xgeop1[KX - 1], tall[KX - 1].y, phis_k.y)};
 #pragma unroll
             for (int j = KX - 2; j >= 0; --j) {
-                const d2 up = geo_up(ph, tall[j + 1], tall[j], D.xgeop2[j + 1], D.xgeop1[j]);
-                ph = (j >= l) ? up : ph;
+                const d2 up = geo_up(pn, tall[j + 1], tall[j], D.xgeop2[j + 1], D.xgeop1[j]);
+                pn = (j >= l) ? up : pn;
             }
             if (m == 0 && l >= 1 && l < KX - 1) {
                 d2 tb = tall[2], ta = tall[0];  // l == 1; the select chain below picks the neighbours of the other levels
@@ -351,12 +415,12 @@ __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTa
                     ta = (l == j) ? tall[j - 1] : ta;
                     corf = (l == j) ? D.geo_corf[j] : corf;
                 }
-                ph = geo_corr(ph, tb, ta, corf);
+                pn = geo_corr(pn, tb, ta, corf);
             }
-            stream_store(&reinterpret_cast<d2 *>(P.phi_next)[f8 + fo + k], ph);
+            stream_store(&reinterpret_cast<d2 *>(P.phi_next)[f8 + fo + k], pn);
         }
     }
-    if (l == 0) advance(psS, NSPEC, psdt);  // ln ps has no vertical index: the two time levels are NSPEC apart
+    if (l == 0) advance(psS, NSPEC, ps1, ps2, psdt);  // ln ps has no vertical index: the two time levels are NSPEC apart
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -404,23 +468,32 @@ hipError_t run_dyn_grid(const ModelPtrs &P, const DynDeviceTables &D, int M, hip
     hipLaunchKernelGGL(dyn_grid_kernel, dim3((M * NG + kT - 1) / kT), dim3(kT), 0, s, P, D, M);
     return hipGetLastError();
 }
-// cpl != nullptr: the coupling of the step rides in the same launch (tail blocks)
+// cpl != nullptr: the coupling of the step rides in the same launch (tail blocks).  Small launches use the form of the kernel
+// with all loads up front (EARLY): same arithmetic, 2 instead of 4 wavefronts per SIMD, a fraction of the memory round trips.
+namespace {
+template <bool FOLD, bool EARLY, typename CA>
+void launch_spectral_step(dim3 grid, hipStream_t s, const ModelPtrs &P, const DeviceTables &T, const DynDeviceTables &D, int M,
+                          int first, int count, int j1, double dt, double eps, const CA &cpl) {
+    hipLaunchKernelGGL((spectral_step_kernel<FOLD, EARLY, CA>), grid, dim3(kT), 0, s, P, T, D, M, first, count, j1, dt, eps, cpl);
+}
+template <typename CA>
+void dispatch_spectral_step(bool fold, bool early, dim3 grid, hipStream_t s, const ModelPtrs &P, const DeviceTables &T,
+                            const DynDeviceTables &D, int M, int first, int count, int j1, double dt, double eps, const CA &cpl) {
+    if (fold && early) launch_spectral_step<true, true, CA>(grid, s, P, T, D, M, first, count, j1, dt, eps, cpl);
+    else if (fold) launch_spectral_step<true, false, CA>(grid, s, P, T, D, M, first, count, j1, dt, eps, cpl);
+    else if (early) launch_spectral_step<false, true, CA>(grid, s, P, T, D, M, first, count, j1, dt, eps, cpl);
+    else launch_spectral_step<false, false, CA>(grid, s, P, T, D, M, first, count, j1, dt, eps, cpl);
+}
+}  // namespace
 hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const DynDeviceTables &D, int M, int first, int count,
-                             int j1, double dt, double eps, const CouplerArgs *cpl, hipStream_t s) {
+                             int j1, double dt, double eps, const CouplerArgs *cpl, bool early, hipStream_t s) {
     const int nspec = (count * NSPEC * KX + kT - 1) / kT;
-    if (cpl) {
-        const dim3 grid(nspec + (cpl->count * NG + kT - 1) / kT);
-        if (P.phi_next)
-            hipLaunchKernelGGL((spectral_step_kernel<true, CouplerArgs>), grid, dim3(kT), 0, s, P, T, D, M, first, count, j1, dt, eps, *cpl);
-        else
-            hipLaunchKernelGGL((spectral_step_kernel<false, CouplerArgs>), grid, dim3(kT), 0, s, P, T, D, M, first, count, j1, dt, eps, *cpl);
-    } else if (P.phi_next) {
-        hipLaunchKernelGGL((spectral_step_kernel<true, NoCoupler>), dim3(nspec), dim3(kT), 0, s, P, T, D, M, first, count, j1, dt,
-                           eps, NoCoupler{});
-    } else {
-        hipLaunchKernelGGL((spectral_step_kernel<false, NoCoupler>), dim3(nspec), dim3(kT), 0, s, P, T, D, M, first, count, j1, dt,
-                           eps, NoCoupler{});
-    }
+    const bool fold = P.phi_next != nullptr;
+    if (cpl)
+        dispatch_spectral_step(fold, early, dim3(nspec + (cpl->count * NG + kT - 1) / kT), s, P, T, D, M, first, count, j1, dt, eps,
+                               *cpl);
+    else
+        dispatch_spectral_step(fold, early, dim3(nspec), s, P, T, D, M, first, count, j1, dt, eps, NoCoupler{});
     return hipGetLastError();
 }
 hipError_t run_diagnostics(const ModelPtrs &P, const DeviceTables &T, int M, int tl, int *err, double *diag, hipStream_t s) {

@@ -25,7 +25,7 @@ hipError_t run_dyn_physics(const ModelPtrs &P, const DynDeviceTables &D, const D
 hipError_t run_geopotential(const ModelPtrs &P, const DynDeviceTables &D, int first, int count, int tl, hipStream_t s);
 hipError_t run_dyn_grid(const ModelPtrs &P, const DynDeviceTables &D, int M, hipStream_t s);
 hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const DynDeviceTables &D, int M, int first, int count,
-                             int j1, double dt, double eps, const CouplerArgs *cpl, hipStream_t s);
+                             int j1, double dt, double eps, const CouplerArgs *cpl, bool early, hipStream_t s);
 hipError_t run_diagnostics(const ModelPtrs &P, const DeviceTables &T, int M, int tl, int *err, double *diag, hipStream_t s);
 hipError_t run_coupler(const SurfacePtrs &S, int first, int count, const TimeInterp &w, int day, int land_coupling,
                        int sst_anomaly, int anom_planes, int fresh, hipStream_t s);
@@ -125,6 +125,7 @@ struct spd_model {
     // The coupling of the step rides in the launch of spectral_step_kernel (tail blocks, dynamics.hip) instead of being a
     // launch of its own: PYSPEEDY_AMD_COUPLER_IN_SPECTRAL=0 / 1
     bool coupler_in_spectral = true;
+    int spectral_early = -1;  // spectral_step_kernel with all loads up front: -1 = for launches of up to 8 members, 0 / 1 = never / always
     int land_coupling_flag = 1, sst_anomaly_flag = 1, increase_co2 = 0, anom_planes = 3;
     double ablco2_ref = 6.0;
     double *corh_t = nullptr, *corh_q = nullptr, *scratch_spec = nullptr;  // [M][NG], [M][NG], [2][M][992] complex
@@ -302,6 +303,7 @@ int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
     if (const char *env = getenv("PYSPEEDY_AMD_DIAG_EVERY_STEP")) m->diag_every_step = atoi(env) != 0;
     m->fold_geo = nmembers <= 8;
     if (const char *env = getenv("PYSPEEDY_AMD_COUPLER_IN_SPECTRAL")) m->coupler_in_spectral = atoi(env) != 0;
+    if (const char *env = getenv("PYSPEEDY_AMD_SPECTRAL_EARLY")) m->spectral_early = atoi(env);
     if (const char *env = getenv("PYSPEEDY_AMD_FOLD_GEO")) m->fold_geo = atoi(env) != 0;
     // PYSPEEDY_AMD_CHUNKS = 2 or 3 steps the members in that many groups on separate streams: measured -6 % / -8 % per step
     // at 64 members (4 groups: +7 %).  Off by default: with overlapping launches the duration of a single kernel -- what the
@@ -617,7 +619,8 @@ static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int comput
     const double eps = (j1 == 1) ? 0.0 : static_cast<double>(0.05f);                      // rob, time_stepping.f90:130-134
     if (e == hipSuccess) {
         ProfScope ps(m, SPD_K_SPECTRAL_STEP, count, s);
-        e = run_spectral_step(m->P, T, m->D, M, first, count, j1 - 1, dt, eps, cpl, s);
+        const bool early = m->spectral_early < 0 ? count <= 8 : m->spectral_early != 0;
+        e = run_spectral_step(m->P, T, m->D, M, first, count, j1 - 1, dt, eps, cpl, early, s);
     }
     return e;
 }
