@@ -277,3 +277,22 @@ def test_pruning_the_unused_transforms_changes_nothing(spectral, bc, monkeypatch
         model.close()
     for n in SHAPES:
         assert np.array_equal(states[0][n], states[1][n]), n
+
+
+def test_both_forms_of_the_spectral_step_kernel_are_bitwise(spectral, bc, monkeypatch):
+    """spectral_step_kernel<..., EARLY> (all loads up front; small launches) and the form that loads where the values are
+    needed (large launches) run the same arithmetic: forcing either one leaves every registry variable bitwise identical, with
+    and without the geopotential of the next step folded into the kernel."""
+    from pyspeedy_amd.model import SHAPES, EnsembleModel
+    for fold in ("0", "1"):
+        monkeypatch.setenv("PYSPEEDY_AMD_FOLD_GEO", fold)
+        states = []
+        for early in ("0", "1"):
+            monkeypatch.setenv("PYSPEEDY_AMD_SPECTRAL_EARLY", early)
+            model = EnsembleModel(spectral, 3)
+            model.set_bc(bc)
+            model.run(40)
+            states.append({n: model.get(n, 1) for n in SHAPES})
+            model.close()
+        for n in SHAPES:
+            assert np.array_equal(states[0][n], states[1][n]), (fold, n)
