@@ -186,10 +186,14 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
     const R psa = rexp(R(a.pslg[o2]));
     const R rps = 1.0f / psa;
 #pragma unroll
-    for (int k = 0; k < KX; ++k) {
+    for (int k = 0; k < KX; ++k) {  // all 24 loads first: one memory round trip, not one per group of levels
         ta[k] = R(stream_load(&a.tg[o3 + NG * k]));
-        qa[k] = rmax<R>(R(stream_load(&a.qg[o3 + NG * k])), 0.0f);
+        qa[k] = R(stream_load(&a.qg[o3 + NG * k]));
         phi[k] = R(stream_load(&a.phig[o3 + NG * k]));
+    }
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        qa[k] = rmax<R>(qa[k], 0.0f);
         se[k] = C::CP * ta[k] + phi[k];
         qsat[k] = qsat_point<R>(ta[k], CT.fsg[k] * psa);
         rh[k] = qa[k] / qsat[k];
@@ -438,6 +442,9 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
                      absaer = 0.033f, abswv1 = 0.022f, abswv2 = 15.000f, abscl1 = 0.015f, abscl2 = 0.15f,
                      ablwin = 0.3f, ablwv1 = 0.7f, ablwv2 = 50.0f, ablcl1 = 12.0f, ablcl2 = 0.6f;
         const R fmask = R(a.fmask_land[o2]);
+        // (the other inputs of the block, requested in the same batch)
+        const R zenit = R(a.zenit_correction[o2]), solar = R(a.flux_solar_in[o2]), ozupp = R(a.flux_ozone_upper[o2]);
+        const R ozlow = R(a.flux_ozone_lower[o2]), alb_sfc = R(a.alb_surface[o2]);
         // clouds, shortwave_radiation.f90:325-404
         const R rrcl = 1.f / (rhcl2 - rhcl1);
         if (rh[nl1 - 1] > rhcl1) {
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         for (int k = 1; k <= KX; ++k)
             if (k == icltop) refl[k - 1] = albcl * cloudc;
         refl[KX - 1] = albcls * clstr;
-        const R psaz = psa * R(a.zenit_correction[o2]);
+        const R psaz = psa * zenit;
         R acloud = cloudc * rmin<R>(abscl1 * qcloud, abscl2);
         R tsw1[KX], tsw2[KX];  // shortwave transmissivities, bands 1 and 2
         tsw1[0] = rexp(-psaz * CT.dhs[0] * absdry);
@@ -494,15 +501,14 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
 #pragma unroll
         for (int k = 2; k <= KX; ++k) tsw2[k - 1] = rexp(-psaz * CT.dhs[k - 1] * abswv2 * qa[k - 1]);
 
-        const R solar = R(a.flux_solar_in[o2]);
         R tsr = solar;
         R tt_rsw[KX];
         R f1 = solar * fband1, f2 = solar * fband2;
         tt_rsw[0] = f1;
-        f1 = tsw1[0] * (f1 - R(a.flux_ozone_upper[o2]) * psa);
+        f1 = tsw1[0] * (f1 - ozupp * psa);
         tt_rsw[0] = tt_rsw[0] - f1;
         tt_rsw[1] = f1;
-        f1 = tsw1[1] * (f1 - R(a.flux_ozone_lower[o2]) * psa);
+        f1 = tsw1[1] * (f1 - ozlow * psa);
         tt_rsw[1] = tt_rsw[1] - f1;
 #pragma unroll
         for (int k = 3; k <= KX; ++k) {
@@ -519,7 +525,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
             tt_rsw[k - 1] = tt_rsw[k - 1] - f2;
         }
         ssrd = f1 + f2;
-        f1 = f1 * R(a.alb_surface[o2]);
+        f1 = f1 * alb_sfc;
         stream_store(&a.ssrd[o2], ssrd);
         stream_store(&a.ssr[o2], ssrd - f1);
 #pragma unroll
@@ -574,7 +580,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
             tau_s[k - 1 + KX * 3][lane] = t3;
         }
         const R eps1 = C::EPSLW / (CT.dhs[0] + CT.dhs[1]);
-        strat1 = R(a.stratospheric_correction[o2]) * psa;
+        strat1 = R(a.stratospheric_correction[o2]) * psa;  // (requested here: one more live value above costs the kernel scratch)
         strat2 = eps1 * psa;
         stream_store(&a.rad_strat_corr[oc], strat1);
         stream_store(&a.rad_strat_corr[oc + NG], strat2);
@@ -668,6 +674,9 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         const R ua = R(a.ug[o3 + NG * (KX - 1)]), va = R(a.vg[o3 + NG * (KX - 1)]);
         const R fmask = R(a.fmask_land[o2]), phi0 = R(a.phis0[o2]), tsea = R(a.sst_am[o2]), land_temp = R(a.land_temp[o2]);
         const R alb_land = R(a.alb_land[o2]), swav = R(a.soil_avail_water[o2]);
+        // (every input of the block is requested here, in one batch: a load issued where its value is first needed costs the
+        // wavefront one more memory round trip on its dependent chain)
+        const R forog = R(a.forog[o2]), snowc = R(a.snowc[o2]), alb_sea = R(a.alb_sea[o2]);
         const R u0 = fwind0 * ua, v0 = fwind0 * va;
         const R gtemp0 = 1.0f - ftemp0, rcp = 1.0f / C::CP;
         const R dt1 = CT.wvi[8 + KX - 1] * (ta[KX - 1] - ta[nl1 - 1]);
@@ -688,7 +697,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         const R rdth = fstab / dtheta, astab = 0.5f;
         const R dthl = (tskin > t2l) ? rmin<R>(dtheta, tskin - t2l) : rmax<R>(-dtheta, astab * (tskin - t2l));
         const R den1 = den0 * (1.0f + dthl * rdth);
-        const R cdldv = cdl * den0 * R(a.forog[o2]);
+        const R cdldv = cdl * den0 * forog;
         const R ustr1 = -cdldv * ua, vstr1 = -cdldv * va;
         const R chlcp = chl * C::CP;
         R shf1 = chlcp * den1 * (tskin - t1l);
@@ -699,7 +708,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         const R dslr = 4.0f * esbc * tsk3;
         R slru1 = esbc * tsk3 * tskin;
         R hfl1 = ssrd * (1.0f - alb_land) + slrd - (slru1 + shf1 + C::ALHC * evap1);
-        const R clamb = clambda + R(a.snowc[o2]) * (clambsn - clambda);
+        const R clamb = clambda + snowc * (clambsn - clambda);
         hfl1 = hfl1 - clamb * (tskin - land_temp);
         R dqs = qsat_point<R>(tskin + 1.0f, R(1.0f) * psa);
         dqs = (evap1 > R(0.0f)) ? swav * (dqs - qs0l) : R(0.0f);
@@ -717,7 +726,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         const R qs0s = qsat_point<R>(tsea, R(1.0f) * psa);
         const R evap2 = chs * den2 * (qs0s - q1);
         const R slru2 = esbc * pow4<R>(tsea);
-        const R hfl2 = ssrd * (1.0f - R(a.alb_sea[o2])) + slrd - slru2 + shf2 + C::ALHC * evap2;
+        const R hfl2 = ssrd * (1.0f - alb_sea) + slrd - slru2 + shf2 + C::ALHC * evap2;
         const R ustr3 = ustr2 + fmask * (ustr1 - ustr2), vstr3 = vstr2 + fmask * (vstr1 - vstr2);
         const R shf3 = shf2 + fmask * (shf1 - shf2), evap3 = evap2 + fmask * (evap1 - evap2);
         const R slru3 = slru2 + fmask * (slru1 - slru2);
@@ -743,18 +752,24 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         // -------------------------------------------------------------- longwave, upward sweep (:124-205)
         const R refsfc = 1.0f - C::EMISFC;
         if (diag) stream_store(&a.slr[o2], slru3 - slrd);
+        R fsfc[4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) flux[b] = fband_at(CT.fband, tsfc, b) * slru3 + refsfc * flux[b];
+        for (int b = 0; b < 4; ++b) fsfc[b] = fband_at(CT.fband, tsfc, b);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) flux[b] = fsfc[b] * slru3 + refsfc * flux[b];
         dfabs[KX - 1] = dfabs[KX - 1] + C::EPSLW * slru3;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             R tb[KX];
 #pragma unroll
             for (int k = 2; k <= KX; ++k) tb[k - 1] = tau_s[k - 1 + KX * b][lane];
+            R fb[KX];  // the band's table values of all levels in one batch of loads, not one round trip per level
+#pragma unroll
+            for (int k = 2; k <= KX; ++k) fb[k - 1] = CT.fband[itab[k - 1] + 301 * b];
 #pragma unroll
             for (int k = KX; k >= 2; --k) {
                 const R emis = 1.0f - tb[k - 1];
-                const R brad = CT.fband[itab[k - 1] + 301 * b] * (st4a[k - 1][0] - emis * st4a[k - 1][1]);
+                const R brad = fb[k - 1] * (st4a[k - 1][0] - emis * st4a[k - 1][1]);
                 dfabs[k - 1] = dfabs[k - 1] + flux[b];
                 flux[b] = tb[k - 1] * flux[b] + emis * brad;
                 dfabs[k - 1] = dfabs[k - 1] - flux[b];
