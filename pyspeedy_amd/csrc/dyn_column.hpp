@@ -11,9 +11,15 @@ namespace spd {
 // Column p (0 .. ix*il-1, latitude row j) of member `mem`.  Stores utend / vtend above the lowest level, the kinetic energy
 // and flux products and the surface-pressure tendency; RETURNS the temperature / tracer tendencies of all levels and the
 // wind tendencies of the lowest level in registers (the physics adds to exactly those) -- or stores them too when STORE_ALL.
-template <bool STORE_ALL>
+// `before_products` is called once the tendencies are formed, in front of the 40 product stores: the fused kernel issues the
+// loads of its next phase there, so that they travel while the stores are issued (nothing, for the stand-alone kernel).
+struct NoPrefetch {
+    __device__ void operator()() const {}
+};
+template <bool STORE_ALL, typename F = NoPrefetch>
 __device__ __forceinline__ void dyn_column(const ModelPtrs &P, const DynDeviceTables &D, int mem, int p, int j,
-                                           double (&ttend)[KX], double (&trtend)[KX], double &utend_kx, double &vtend_kx) {
+                                           double (&ttend)[KX], double (&trtend)[KX], double &utend_kx, double &vtend_kx,
+                                           F before_products = F{}) {
     constexpr int NG = IX * IL;
     constexpr double AKAPd = 2.0f / 7.0f, RGASd = AKAPd * static_cast<double>(1004.0f);
     const size_t o3 = static_cast<size_t>(mem) * KX * NG + p, o2 = static_cast<size_t>(mem) * NG + p;
@@ -25,10 +31,15 @@ __device__ __forceinline__ void dyn_column(const ModelPtrs &P, const DynDeviceTa
         vg[k] = stream_load(&P.vg2[o3 + NG * k]);
         tg[k] = stream_load(&P.tg2[o3 + NG * k]);
         trg[k] = stream_load(&P.trg2[o3 + NG * k]);
-        vorg[k] = stream_load(&P.vorg[o3 + NG * k]) + cor;
+        vorg[k] = stream_load(&P.vorg[o3 + NG * k]);
         divg[k] = stream_load(&P.divg[o3 + NG * k]);
     }
     const double px = stream_load(&P.px[o2]), py = stream_load(&P.py[o2]);
+    // all 50 loads are issued before the first value is used (left to itself the scheduler keeps ~14 in flight and the column
+    // waits for memory four times instead of once)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < KX; ++k) vorg[k] = vorg[k] + cor;  // absolute vorticity
     double umean = 0.0, vmean = 0.0, dmean = 0.0;
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
@@ -90,6 +101,7 @@ __device__ __forceinline__ void dyn_column(const ModelPtrs &P, const DynDeviceTa
         trtend[k] = trg[k] * divg[k] - (temp[k + 1] + temp[k]) * D.dhsr[k];
         if (STORE_ALL) stream_store(&P.trtend[o3 + NG * k], trtend[k]);
     }
+    before_products();
     // inputs of the forward transforms (tendencies.f90:247-266)
 #pragma unroll
     for (int k = 0; k < KX; ++k) {

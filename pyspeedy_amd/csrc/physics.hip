@@ -155,9 +155,24 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
     // (the dynamics' wind tendencies of the lowest level wait in LDS for the surface stress at the very end of the kernel:
     // kept in registers they are spilled to scratch memory by the allocator, 16 bytes out and back per lane)
     __shared__ double park_uv[2][kPhysThreads];
+    // (FUSED, fp64: the physics' first inputs are requested by the dynamics phase, in front of its product stores)
+    double in_t[KX], in_q[KX], in_phi[KX], in_ps;
+    auto load_column = [&]() {
+#pragma unroll
+        for (int k = 0; k < KX; ++k) {
+            in_t[k] = stream_load(&a.tg[o3 + NG * k]);
+            in_q[k] = stream_load(&a.qg[o3 + NG * k]);
+            in_phi[k] = stream_load(&a.phig[o3 + NG * k]);
+        }
+        in_ps = a.pslg[o2];
+        __builtin_amdgcn_sched_barrier(0);
+    };
     if (FUSED) {
         double tt[KX], qt[KX], utend_dyn = 0.0, vtend_dyn = 0.0;
-        dyn_column<false>(MP, MD, mem, p, j, tt, qt, utend_dyn, vtend_dyn);
+        if constexpr (MIXED)  // (the 3-wave fp32 kernel has no registers to spare for that: +4 % when tried)
+            dyn_column<false>(MP, MD, mem, p, j, tt, qt, utend_dyn, vtend_dyn);
+        else
+            dyn_column<false>(MP, MD, mem, p, j, tt, qt, utend_dyn, vtend_dyn, load_column);
         park_uv[0][lane] = utend_dyn;
         park_uv[1][lane] = vtend_dyn;
 #pragma unroll
@@ -183,17 +198,14 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
 
     // ------------------------------------------------------------------ thermodynamics, physics.f90:107-116
     R ta[KX], qa[KX], phi[KX], se[KX], qsat[KX], rh[KX];
-    const R psa = rexp(R(a.pslg[o2]));
+    if (!FUSED || MIXED) load_column();  // all 25 loads first: one memory round trip, not one per group of levels
+    const R psa = rexp(R(in_ps));
     const R rps = 1.0f / psa;
 #pragma unroll
-    for (int k = 0; k < KX; ++k) {  // all 24 loads first: one memory round trip, not one per group of levels
-        ta[k] = R(stream_load(&a.tg[o3 + NG * k]));
-        qa[k] = R(stream_load(&a.qg[o3 + NG * k]));
-        phi[k] = R(stream_load(&a.phig[o3 + NG * k]));
-    }
-#pragma unroll
     for (int k = 0; k < KX; ++k) {
-        qa[k] = rmax<R>(qa[k], 0.0f);
+        ta[k] = R(in_t[k]);
+        phi[k] = R(in_phi[k]);
+        qa[k] = rmax<R>(R(in_q[k]), 0.0f);
         se[k] = C::CP * ta[k] + phi[k];
         qsat[k] = qsat_point<R>(ta[k], CT.fsg[k] * psa);
         rh[k] = qa[k] / qsat[k];
