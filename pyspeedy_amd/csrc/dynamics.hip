@@ -37,32 +37,10 @@ __device__ constexpr double WILd = 0.53f, TDRSd = 24.0f * 30.0f;
 __device__ inline d2 times_i(d2 z) { return d2{-z.y, z.x}; }
 __device__ inline d2 operator_scale(double c, d2 z) { return d2{c * z.x, c * z.y}; }
 
-// vort2vel (MODE 0, tables uvdx/uvdym/uvdyp) or vel2vort (MODE 1, gradx/vddym/vddyp) at coefficient k = m + 31 n of
-// the fields a, b (pointers to the field start); returns the two results.
-template <int MODE>
-__device__ inline void uv_stencil(const d2 *a, const d2 *b, int k, int m, int n, const DeviceTables &T, d2 &ra, d2 &rb) {
-    const double *tym = MODE == 0 ? T.uvdym : T.vddym, *typ = MODE == 0 ? T.uvdyp : T.vddyp;
-    const double dx = MODE == 0 ? T.uvdx[k] : T.gradx[m];
-    const double cm = tym[k], cp = typ[k];
-    const d2 za = a[k], zb = b[k];
-    const d2 zp = times_i(d2{dx * za.x, dx * za.y}), zc = times_i(d2{dx * zb.x, dx * zb.y});
-    if (n == 0) {
-        const d2 an = a[k + MX], bn = b[k + MX];
-        ra = d2{zc.x - cp * an.x, zc.y - cp * an.y};
-        rb = d2{zp.x + cp * bn.x, zp.y + cp * bn.y};
-    } else if (n == NX - 1) {
-        const d2 ap = a[k - MX], bp = b[k - MX];
-        ra = d2{cm * ap.x, cm * ap.y};
-        rb = d2{-cm * bp.x, -cm * bp.y};
-    } else {
-        const d2 ap = a[k - MX], bp = b[k - MX], an = a[k + MX], bn = b[k + MX];
-        ra = d2{cm * ap.x - cp * an.x + zc.x, cm * ap.y - cp * an.y + zc.y};
-        rb = d2{-cm * bp.x + cp * bn.x + zp.x, -cm * bp.y + cp * bn.y + zp.y};
-    }
-}
-
-// The same stencil in two halves: all six loads first (neighbour indices clamped into the field, so the loads need no
-// branch), the arithmetic of uv_stencil afterwards.
+// vort2vel (MODE 0, tables uvdx/uvdym/uvdyp) or vel2vort (MODE 1, gradx/vddym/vddyp) at coefficient k = m + 31 n of the
+// fields a, b (pointers to the field start), in two halves: all six loads first (neighbour indices clamped into the field,
+// so that the loads need no branch and a lane can have the loads of several stencils in flight at once), the arithmetic
+// afterwards (spectral.f90:190-214 / 275-296: first, last and inner total wavenumbers have different formulas).
 struct Stencil {
     d2 ac, bc, ap, bp, an, bn;
 };
@@ -223,10 +201,10 @@ __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTa
     d2 *tS = reinterpret_cast<d2 *>(P.t) + s0, *trS = reinterpret_cast<d2 *>(P.tr) + s0;
     d2 *psS = reinterpret_cast<d2 *>(P.ps) + static_cast<size_t>(mem) * 2 * NSPEC + k;
     const int l_tot = m + n;  // total wavenumber; xj(:, :, l_tot) with 1-based third index
-    // EARLY: every global load of the kernel is issued in two batches -- here and right after the stencils -- and not where
-    // its value is first needed.  The kernel is a chain of short dependent phases; when the ensemble does not fill the GPU
-    // its duration is the number of memory round trips on that chain (about 20 in the other form, whose loads sit inside the
-    // stencils' branches and the matrix loops), and registers are free.  The other form keeps 4 wavefronts per SIMD.
+    // EARLY: every global load of the kernel is issued in one batch, here, and not where its value is first needed.  The
+    // kernel is a chain of short dependent phases; when the ensemble does not fill the GPU its duration is the number of
+    // memory round trips on that chain (about 15 in the other form, whose loads sit inside the matrix loops and in front of
+    // each use), and registers are free.  The other form keeps 4 wavefronts per SIMD (122 VGPRs).
     d2 ke, stt, str, psdt, ph, div1, ps1;                                  // first batch
     d2 vor1, t1, tr1, tcorh, qcorh, phis_k{0.0, 0.0}, vor2{}, div2{}, t2{}, tr2{}, ps2{};  // second batch
     double xc_l[KX], xj_l[KX], xd_l[KX], elz, dmp, dmp1, dmpd, dmp1d, dmps, dmp1s, trf;
@@ -262,16 +240,19 @@ __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTa
         tdt = d2{tdt.x + stt.x, tdt.y + stt.y};
         apply_stencil<1>(s_uq, k, m, n, T, dump, trdt);                                  // div of (-uq, -vq)
         trdt = d2{trdt.x + str.x, trdt.y + str.y};
-    } else {
-        uv_stencil<1>(su, sv, k, m, n, T, vordt, divdt);
+    } else {  // the stencils' 18 loads in one batch (their branches would each wait for their own), the rest where it is used
+        const Stencil s_uv = load_stencil(su, sv, k, n);
+        const Stencil s_ut = load_stencil(su + pair, sv + pair, k, n);
+        const Stencil s_uq = load_stencil(su + 2 * pair, sv + 2 * pair, k, n);
         ke = reinterpret_cast<const d2 *>(P.spec_ke)[f8 + fo + k];
+        stt = reinterpret_cast<const d2 *>(P.spec_tt)[f8 + fo + k];
+        str = reinterpret_cast<const d2 *>(P.spec_tr)[f8 + fo + k];
+        apply_stencil<1>(s_uv, k, m, n, T, vordt, divdt);
         const d2 lap = d2{-ke.x * el2, -ke.y * el2};
         divdt = d2{divdt.x - lap.x, divdt.y - lap.y};
-        uv_stencil<1>(su + pair, sv + pair, k, m, n, T, dump, tdt);
-        stt = reinterpret_cast<const d2 *>(P.spec_tt)[f8 + fo + k];
+        apply_stencil<1>(s_ut, k, m, n, T, dump, tdt);
         tdt = d2{tdt.x + stt.x, tdt.y + stt.y};
-        uv_stencil<1>(su + 2 * pair, sv + 2 * pair, k, m, n, T, dump, trdt);
-        str = reinterpret_cast<const d2 *>(P.spec_tr)[f8 + fo + k];
+        apply_stencil<1>(s_uq, k, m, n, T, dump, trdt);
         trdt = d2{trdt.x + str.x, trdt.y + str.y};
         psdt = reinterpret_cast<const d2 *>(P.spec_ps)[static_cast<size_t>(mem) * NSPEC + k];
         div1 = divS[0];
