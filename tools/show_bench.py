@@ -14,6 +14,9 @@ for f in sys.argv[1:]:
         for k in r.get("kernels") or []:
             print("   %-14s n=%3d avg %7.1f us  min %7.1f us  algo %6.1f MB  %6.0f GB/s  frac %.3f" % (
                 k["kernel"], k["launches_timed"], k["avg_launch_us"], k["min_launch_us"], k["algorithmic_bytes_per_launch"] / 1e6, k["achieved"], k["frac"]))
+        if "overlapped_member_groups" in d:
+            o = d["overlapped_member_groups"]
+            print("   two member groups on two streams: %.4f ms/step  value %.0f" % (o["ms_per_step"], o["value"]))
         if "cpu_baseline" in d:
             b = d["cpu_baseline"]
             print("   cpu 1 core: %.1f sy/d (%.2f ms/step);" % (b["value"], b["ms_per_member_step"]), end=" ")
