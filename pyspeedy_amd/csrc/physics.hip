@@ -109,8 +109,8 @@ ColTables<R> col_tables(const DeviceTables &T) {
 
 }  // namespace
 
-// W = minimum waves per SIMD the register allocator must leave room for (launch-bounds hint): 2 by default (256 VGPRs, a
-// handful of spilled values), 1 with PYSPEEDY_AMD_PHYS_WAVES=1 for comparison; 3 and 4 spill heavily and were 1.5-2x slower.
+// W = minimum waves per SIMD the register allocator must leave room for (launch-bounds hint): 2 by default (256 VGPRs, no
+// scratch), 1 with PYSPEEDY_AMD_PHYS_WAVES=1 for comparison; 3 and 4 spill heavily and were 1.5-2x slower.
 //
 // FUSED: the kernel first runs the grid-point dynamics of the column (dyn_column.hpp, tendencies.f90:125-224) and keeps the
 // temperature / humidity tendencies it produces in registers -- the physics adds to exactly those -- so they are written
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
     if (a.clstr) stream_store(&a.clstr[o2], clstr);
 }
 
-// Launch-bounds variant of the fp64 kernels: 2 waves per SIMD (256 VGPRs, a few spilled values).  The 1-wave build (512
+// Launch-bounds variant of the fp64 kernels: 2 waves per SIMD (256 VGPRs, no scratch in the fused kernel).  The 1-wave build (512
 // registers, no spills; PYSPEEDY_AMD_PHYS_WAVES=1) is 2.8 % faster per step at 8 members and 1.2 % at 1, 14 % slower at 16
 // (profiles/r02_small_ensemble_experiments.txt) -- but the compiler contracts a few multiply-adds differently in the two
 // builds, so their results differ in the last bits, and a member's trajectory must not depend on the size of the ensemble it
