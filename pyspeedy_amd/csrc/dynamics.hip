@@ -405,10 +405,12 @@ __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTa
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// diagnostics (diagnostics.f90:16-76): one wavefront per (member, level); sets err[member] = -2 when out of range
+// diagnostics (diagnostics.f90:16-76): one workgroup per member, one wavefront per level; writes err[member] = 0 or -2 (out of
+// range) -- always, so that the caller does not have to clear it first
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void diagnostics_kernel(ModelPtrs P, DeviceTables T, int M, int tl, int *err, double *diag) {
-    const int mem = blockIdx.x / KX, l = blockIdx.x - mem * KX, lane = threadIdx.x;
+__global__ __launch_bounds__(64 * KX) void diagnostics_kernel(ModelPtrs P, DeviceTables T, int M, int tl, int *err, double *diag) {
+    __shared__ int bad[KX];
+    const int mem = blockIdx.x, l = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t so = ((static_cast<size_t>(mem) * 2 + tl) * 8 + l) * NSPEC;
     const d2 *vor = reinterpret_cast<const d2 *>(P.vor) + so, *div = reinterpret_cast<const d2 *>(P.div) + so;
     double d1 = 0.0, d2s = 0.0;
@@ -433,7 +435,14 @@ __global__ __launch_bounds__(64) void diagnostics_kernel(ModelPtrs P, DeviceTabl
             dg[l + KX] = d2s;
             dg[l + 2 * KX] = tmean;
         }
-        if (d1 > 500.0f || d2s > 500.0f || tmean < 180.0f || tmean > 320.0f) atomicExch(&err[mem], -2);
+        bad[l] = (d1 > 500.0f || d2s > 500.0f || tmean < 180.0f || tmean > 320.0f) ? 1 : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int any = 0;
+#pragma unroll
+        for (int k = 0; k < KX; ++k) any |= bad[k];
+        err[mem] = any ? -2 : 0;
     }
 }
 
@@ -478,7 +487,7 @@ hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const Dy
     return hipGetLastError();
 }
 hipError_t run_diagnostics(const ModelPtrs &P, const DeviceTables &T, int M, int tl, int *err, double *diag, hipStream_t s) {
-    hipLaunchKernelGGL(diagnostics_kernel, dim3(M * KX), dim3(64), 0, s, P, T, M, tl, err, diag);
+    hipLaunchKernelGGL(diagnostics_kernel, dim3(M), dim3(64 * KX), 0, s, P, T, M, tl, err, diag);
     return hipGetLastError();
 }
 

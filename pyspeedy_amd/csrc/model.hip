@@ -88,7 +88,7 @@ struct spd_model {
     int *d_err = nullptr;
     double *d_diag = nullptr;
     // asynchronous range check (spd_model_check_begin / _end): two pinned result slots with their events
-    int *h_err[2] = {nullptr, nullptr};
+    int *h_err[2] = {nullptr, nullptr}, *h_err_sync = nullptr;  // (h_err_sync: pinned staging of the synchronous check)
     int *d_err_slot[2] = {nullptr, nullptr};
     hipEvent_t err_event[2] = {nullptr, nullptr};
     int next_slot = 0;
@@ -445,6 +445,7 @@ int spd_model_destroy(spd_model_handle m) {
         if (m->cev[i]) (void)hipEventDestroy(m->cev[i]);
     }
     if (m->ev_start) (void)hipEventDestroy(m->ev_start);
+    if (m->h_err_sync) (void)hipHostFree(m->h_err_sync);
     for (int i = 0; i < 2; ++i) {
         if (m->h_err[i]) (void)hipHostFree(m->h_err[i]);
         if (m->err_event[i]) (void)hipEventDestroy(m->err_event[i]);
@@ -641,12 +642,19 @@ int spd_model_check(spd_model_handle m, int time_level, int32_t *error_codes_hos
     if (!m || !error_codes_host) return m_fail(SPD_E_ARG, "spd_model_check: null argument");
     if (time_level < 1 || time_level > 2) return m_fail(SPD_E_ARG, "spd_model_check: time level is 1 or 2");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    M_HIP(hipMemsetAsync(m->d_err, 0, sizeof(int) * m->M, s));
     hipError_t e = run_diagnostics(m->P, m->ctx->dev, m->M, time_level - 1, m->d_err, m->d_diag, s);
     if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_check: ") + hipGetErrorString(e));
-    M_HIP(hipMemcpyAsync(error_codes_host, m->d_err, sizeof(int) * m->M, hipMemcpyDeviceToHost, s));
+    // the codes travel through pinned memory: a device-to-host copy into the caller's pageable buffer is staged by the runtime
+    // and costs this synchronous call -- made once per model step by hosts with the reference's loop -- tens of microseconds
+    if (!m->h_err_sync) {
+        void *p = nullptr;
+        M_HIP(hipHostMalloc(&p, sizeof(int) * m->M, hipHostMallocDefault));
+        m->h_err_sync = static_cast<int *>(p);
+    }
+    M_HIP(hipMemcpyAsync(m->h_err_sync, m->d_err, sizeof(int) * m->M, hipMemcpyDeviceToHost, s));
     if (diag_host) M_HIP(hipMemcpyAsync(diag_host, m->d_diag, sizeof(double) * m->M * 24, hipMemcpyDeviceToHost, s));
     M_HIP(hipStreamSynchronize(s));
+    std::memcpy(error_codes_host, m->h_err_sync, sizeof(int) * m->M);
     return SPD_OK;
 }
 
@@ -669,7 +677,6 @@ int spd_model_check_begin(spd_model_handle m, int time_level, void *stream) {
         m->d_err_slot[slot] = static_cast<int *>(p);
         M_HIP(hipEventCreateWithFlags(&m->err_event[slot], hipEventDisableTiming));
     }
-    M_HIP(hipMemsetAsync(m->d_err_slot[slot], 0, sizeof(int) * m->M, s));
     hipError_t e = run_diagnostics(m->P, m->ctx->dev, m->M, time_level - 1, m->d_err_slot[slot], m->d_diag, s);
     if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_check_begin: ") + hipGetErrorString(e));
     M_HIP(hipMemcpyAsync(m->h_err[slot], m->d_err_slot[slot], sizeof(int) * m->M, hipMemcpyDeviceToHost, s));
