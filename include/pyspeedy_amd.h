@@ -218,6 +218,15 @@ int spd_model_profile_read_kernels(spd_model_handle m, double *mean_ms, double *
  * groups stepped on separate streams (PYSPEEDY_AMD_CHUNKS), cfg[3] = 1 for separate dynamics / physics launches, cfg[4] = 1
  * when spectral_step_kernel also computes the next step's geopotential, cfg[5] = 1 when it carries the land / sea-ice coupling */
 int spd_model_get_config(spd_model_handle m, int32_t *cfg /* 6 */);
+/* The launch-plan switches that can change on a live model, by name (the environment variables of README.md set the same
+ * fields when the model is created; none of them changes the state a step leaves behind):
+ *   "diag_every_step"      0 / 1   store the diagnostics-only physics outputs on every step of a multi-step call
+ *   "coupler_in_spectral"  0 / 1   land / sea-ice coupling as tail blocks of spectral_step_kernel or as a launch of its own
+ *   "spectral_early"      -1 / 0 / 1   spectral_step_kernel with all loads up front: automatic (up to 8 members) / never / always
+ *   "split_dyn"            0 / 1   separate launches for grid-point dynamics and column physics
+ * Returns SPD_E_ARG for an unknown name or a value outside the list.  What is fixed at creation (member groups on separate
+ * streams, the pruned transform table, the geopotential fold) is read from the environment only. */
+int spd_model_set_option(spd_model_handle m, const char *name, int32_t value);
 /* BASELINE cfg 5: fp32 != 0 runs the arithmetic of the column physics (physics.f90:107-256 and the schemes it calls) in
  * single precision; the model state, the grid-point dynamics and the tendencies handed to the transforms stay fp64 (the
  * physics increment is formed in fp32 and added to the fp64 dynamics tendency).  Not bitwise comparable with the reference:

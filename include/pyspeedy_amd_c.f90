@@ -131,6 +131,20 @@ module pyspeedy_amd_c
             type(c_ptr), value :: model
             integer(c_int), value :: land_coupling, sst_anomaly_coupling, increase_co2
         end function
+        ! cfg 5: fp32 /= 0 runs the arithmetic of the column physics in single precision (state and dynamics stay fp64)
+        integer(c_int) function spd_model_set_physics_precision(model, fp32) bind(C, name="spd_model_set_physics_precision")
+            import :: c_ptr, c_int
+            type(c_ptr), value :: model
+            integer(c_int), value :: fp32
+        end function
+        ! launch-plan switches by name ("diag_every_step", "coupler_in_spectral", "spectral_early", "split_dyn"); name is
+        ! a C string: pass "diag_every_step"//c_null_char
+        integer(c_int) function spd_model_set_option(model, name, value) bind(C, name="spd_model_set_option")
+            import :: c_ptr, c_int, c_char, c_int32_t
+            type(c_ptr), value :: model
+            character(kind=c_char), intent(in) :: name(*)
+            integer(c_int32_t), value :: value
+        end function
         integer(c_int) function spd_model_set_sppt(model, on, seed, first_member_id) bind(C, name="spd_model_set_sppt")
             import :: c_ptr, c_int, c_int64_t
             type(c_ptr), value :: model

@@ -1036,6 +1036,18 @@ int spd_model_get_config(spd_model_handle m, int32_t *cfg) {
     return SPD_OK;
 }
 
+int spd_model_set_option(spd_model_handle m, const char *name, int32_t value) {
+    if (!m || !name) return m_fail(SPD_E_ARG, "spd_model_set_option: null argument");
+    const std::string key(name);
+    const bool flag = value == 0 || value == 1;
+    if (key == "diag_every_step" && flag) m->diag_every_step = value != 0;
+    else if (key == "coupler_in_spectral" && flag) m->coupler_in_spectral = value != 0;
+    else if (key == "split_dyn" && flag) m->split_dyn_physics = value != 0;
+    else if (key == "spectral_early" && value >= -1 && value <= 1) m->spectral_early = value;
+    else return m_fail(SPD_E_ARG, "spd_model_set_option: unknown option or value out of range: " + key);
+    return SPD_OK;
+}
+
 int spd_model_set_physics_precision(spd_model_handle m, int fp32) {
     if (!m) return m_fail(SPD_E_ARG, "spd_model_set_physics_precision: null model");
     m->phys_fp32 = fp32 ? 1 : 0;

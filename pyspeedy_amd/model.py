@@ -231,6 +231,14 @@ class EnsembleModel:
         return dict(inv_per_member=cfg[0], diag_every_step=bool(cfg[1]), chunks=cfg[2], split_dyn=bool(cfg[3]),
                     fold_geo=bool(cfg[4]), coupler_in_spectral=bool(cfg[5]))
 
+    def set_option(self, name, value):
+        """A launch-plan switch of the live model by name (spd_model_set_option: diag_every_step, coupler_in_spectral,
+        spectral_early, split_dyn); none of them changes the state a step leaves behind.  ValueError for an unknown name."""
+        rc = self._lib.spd_model_set_option(self._m, name.encode(), int(value))
+        if rc == _lib.SPD_E_ARG:
+            raise ValueError("unknown option or value out of range: %s = %r" % (name, value))
+        check(rc, "spd_model_set_option")
+
     def profile(self, level=1):
         """HIP-event brackets on the launch stream: 0 off, 1 the spectral->grid launch of every step, 2 every kernel."""
         check(self._lib.spd_model_profile(self._m, int(level)), "spd_model_profile")

@@ -296,3 +296,29 @@ def test_both_forms_of_the_spectral_step_kernel_are_bitwise(spectral, bc, monkey
             model.close()
         for n in SHAPES:
             assert np.array_equal(states[0][n], states[1][n]), (fold, n)
+
+
+def test_launch_plan_options_by_name(spectral, bc):
+    """spd_model_set_option: the switches the environment variables set at creation can be flipped on a live model; the state
+    a step leaves behind does not depend on them; unknown names and values outside the list are refused."""
+    from pyspeedy_amd.model import SHAPES, EnsembleModel
+    a, b = EnsembleModel(spectral, 2), EnsembleModel(spectral, 2)
+    for m in (a, b):
+        m.set_bc(bc)
+    b.set_option("diag_every_step", 1)
+    b.set_option("coupler_in_spectral", 0)
+    b.set_option("spectral_early", 0)
+    cfg = b.config()
+    assert cfg["diag_every_step"] and not cfg["coupler_in_spectral"] and a.config()["coupler_in_spectral"]
+    a.run(12)
+    b.run(5)
+    b.set_option("coupler_in_spectral", 1)
+    b.set_option("spectral_early", -1)
+    b.run(7)
+    for n in SHAPES:
+        assert np.array_equal(a.get(n, 1), b.get(n, 1)), n
+    for name, value in (("no_such_switch", 1), ("diag_every_step", 2), ("spectral_early", 5)):
+        with pytest.raises(ValueError):
+            b.set_option(name, value)
+    a.close()
+    b.close()
