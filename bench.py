@@ -300,6 +300,8 @@ def kernel_table(model, M, inv_per_member, sppt):
             cfg = model.config()
             algo = (ALGO_BYTES[name] + (coupler * 8 * NG if cfg["coupler_in_spectral"] else 0) +
                     (8 * S_BYTES if cfg["fold_geo"] else 0)) * units
+        elif name == "geopotential":  # (+ the SPPT pattern update of 8 spectral fields per member, which rides in this launch)
+            algo = (ALGO_BYTES[name] + (2 * 8 * S_BYTES if sppt else 0)) * units
         else:
             algo = ALGO_BYTES[name] * units
         gbs = algo / (mean_ms * 1e-3) / 1e9

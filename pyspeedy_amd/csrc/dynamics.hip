@@ -21,6 +21,7 @@
 #include "device_tables.hpp"
 #include "dyn_column.hpp"
 #include "model.hpp"
+#include "sppt_point.hpp"
 
 namespace spd {
 
@@ -85,9 +86,17 @@ __device__ __forceinline__ d2 geo_corr(d2 ph, d2 t_below, d2 t_above, double cor
 }
 }  // namespace
 
-// geopotential from temperature at time level `tl`
-__global__ __launch_bounds__(kT) void geopotential_kernel(ModelPtrs P, DynDeviceTables D, int first, int count, int tl) {
+// geopotential from temperature at time level `tl`.  SPPT: the blocks behind the geopotential ones advance the AR(1) pattern
+// of the stochastic physics (sppt_point.hpp) -- both are the small launches that open a step of an ensemble with SPPT, neither
+// depends on the other, so they share one (tendencies.f90:229 and physics.f90:234-236 in one launch).
+template <bool SPPT>
+__global__ __launch_bounds__(kT) void geopotential_kernel(ModelPtrs P, DynDeviceTables D, int first, int count, int tl, SpptArgs sp) {
     // (writes P.phi: the geopotential the current step uses)
+    const int ngeo = (count * NSPEC + kT - 1) / kT;
+    if (SPPT && static_cast<int>(blockIdx.x) >= ngeo) {
+        sppt_update_point(sp, static_cast<long>(blockIdx.x - ngeo) * kT + threadIdx.x);
+        return;
+    }
     const int gid = blockIdx.x * kT + threadIdx.x;
     if (gid >= count * NSPEC) return;
     const int lm = gid / NSPEC, mem = first + lm, k = gid - lm * NSPEC, m = k % MX;
@@ -450,8 +459,17 @@ __global__ __launch_bounds__(64 * KX) void diagnostics_kernel(ModelPtrs P, Devic
 // launchers
 // ---------------------------------------------------------------------------------------------------------
 // (first, count): the members the launch works on; M: members in the arrays (strides between the blocks of specu / specv)
-hipError_t run_geopotential(const ModelPtrs &P, const DynDeviceTables &D, int first, int count, int tl, hipStream_t s) {
-    hipLaunchKernelGGL(geopotential_kernel, dim3((count * NSPEC + kT - 1) / kT), dim3(kT), 0, s, P, D, first, count, tl);
+// sppt != nullptr: the launch also advances the SPPT pattern (all members of the model) in its tail blocks
+hipError_t run_geopotential(const ModelPtrs &P, const DynDeviceTables &D, int first, int count, int tl, const SpptArgs *sppt,
+                            hipStream_t s) {
+    const int ngeo = (count * NSPEC + kT - 1) / kT;
+    if (sppt) {
+        const long n = static_cast<long>(sppt->M) * KX * NSPEC;
+        hipLaunchKernelGGL(geopotential_kernel<true>, dim3(ngeo + static_cast<unsigned>((n + kT - 1) / kT)), dim3(kT), 0, s, P, D,
+                           first, count, tl, *sppt);
+    } else {
+        hipLaunchKernelGGL(geopotential_kernel<false>, dim3(ngeo), dim3(kT), 0, s, P, D, first, count, tl, SpptArgs{});
+    }
     return hipGetLastError();
 }
 hipError_t run_dyn_grid(const ModelPtrs &P, const DynDeviceTables &D, int M, hipStream_t s) {

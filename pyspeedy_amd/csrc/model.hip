@@ -14,6 +14,7 @@
 #include "context.hpp"
 #include "model.hpp"
 #include "coupler_point.hpp"
+#include "sppt_point.hpp"
 #include "surface.hpp"
 
 namespace spd {
@@ -22,7 +23,8 @@ hipError_t run_grid2spec_table(const DeviceTables &T, const FieldDesc *table, in
 hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nmembers, int fp32, hipStream_t s);
 hipError_t run_dyn_physics(const ModelPtrs &P, const DynDeviceTables &D, const DeviceTables &T, const spd_physics_args &a,
                            int first, int nmembers, int fp32, int diag, hipStream_t s);
-hipError_t run_geopotential(const ModelPtrs &P, const DynDeviceTables &D, int first, int count, int tl, hipStream_t s);
+hipError_t run_geopotential(const ModelPtrs &P, const DynDeviceTables &D, int first, int count, int tl, const SpptArgs *sppt,
+                            hipStream_t s);
 hipError_t run_dyn_grid(const ModelPtrs &P, const DynDeviceTables &D, int M, hipStream_t s);
 hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const DynDeviceTables &D, int M, int first, int count,
                              int j1, double dt, double eps, const CouplerArgs *cpl, bool early, hipStream_t s);
@@ -40,8 +42,9 @@ hipError_t run_grid2spec(const DeviceTables &T, int stage, const double *src, do
 hipError_t run_spec2grid(const DeviceTables &T, int stage, const double *src, double *dst, int kcos, int nfields,
                          hipStream_t stream);
 hipError_t run_scale(const double *in, double *out, const double *table, double sign, int nfields, hipStream_t s);
-hipError_t run_sppt_update(double *spec, const DeviceTables &T, int M, unsigned long long seed, long long member_base,
-                           long long step, int first, hipStream_t s);
+SpptArgs sppt_args(double *spec, const DeviceTables &T, int M, unsigned long long seed, long long member_base, long long step,
+                   int first);
+hipError_t run_sppt_update(const SpptArgs &a, hipStream_t s);
 hipError_t run_export_units(double *q, double *phi, double *ps, long n2d, hipStream_t s);
 hipError_t run_log_ps(const double *ps_grid, double *out, long n2d, hipStream_t s);
 hipError_t run_vort2vel(const DeviceTables &T, const double *vor, const double *div, double *ucos, double *vcos, int nfields,
@@ -577,17 +580,22 @@ static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int comput
     const DeviceTables &T = m->ctx->dev;
     const int M = m->M;
     hipError_t e = hipSuccess;
+    // physics.f90:234-236: a new SPPT pattern for every call of the physics (whole model: SPPT steps are never chunked).  Its
+    // AR(1) update rides in the geopotential launch when there is one (both open the step, neither needs the other)
+    SpptArgs sp{};
+    if (m->sppt_on) sp = sppt_args(m->sppt_spec, T, M, m->sppt_seed, m->sppt_member_base, m->sppt_step, m->sppt_first ? 1 : 0);
     if (run_geo) {
         ProfScope ps(m, SPD_K_GEOPOTENTIAL, count, s);
-        e = run_geopotential(m->P, m->D, first, count, 0, s);                             // tendencies.f90:229
+        e = run_geopotential(m->P, m->D, first, count, 0, m->sppt_on ? &sp : nullptr, s);  // tendencies.f90:229
+    } else if (m->sppt_on) {
+        ProfScope ps(m, SPD_K_SPPT, 8 * M, s);
+        e = run_sppt_update(sp, s);
     }
     spd_physics_args pa = m->pa;
     pa.compute_shortwave = compute_shortwave ? 1 : 0;
     pa.air_absortivity_co2 = m->air_absortivity_co2;
     pa.sppt_pattern = nullptr;
-    if (e == hipSuccess && m->sppt_on) {  // physics.f90:234-236: a new pattern for every call of the physics (whole model)
-        ProfScope ps(m, SPD_K_SPPT, 8 * M, s);
-        e = run_sppt_update(m->sppt_spec, T, M, m->sppt_seed, m->sppt_member_base, m->sppt_step, m->sppt_first ? 1 : 0, s);
+    if (e == hipSuccess && m->sppt_on) {
         m->sppt_first = false;
         m->sppt_step += 1;
         pa.sppt_pattern = m->sppt_grid;  // its 8 transforms per member ride in the spectral -> grid launch below

@@ -19,50 +19,16 @@
 #include <cmath>
 
 #include "device_tables.hpp"
+#include "sppt_point.hpp"
 
 namespace spd {
 
 namespace {
-using d2 = double __attribute__((ext_vector_type(2)));
 constexpr int kT = 256;
 
-__host__ __device__ inline unsigned long long mix64(unsigned long long z) {  // splitmix64 finaliser
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-
-// one lane per (member, level, coefficient): AR(1) update of the spectral pattern
-__global__ __launch_bounds__(kT) void sppt_update_kernel(d2 *__restrict__ spec, const double *__restrict__ el2, int M,
-                                                         unsigned long long seed, long long member_base, long long step,
-                                                         double phi, double f0, double quarter_len2, int first) {
-    const long gid = static_cast<long>(blockIdx.x) * kT + threadIdx.x;
-    if (gid >= static_cast<long>(M) * KX * NSPEC) return;
-    const int idx = static_cast<int>(gid % NSPEC);
-    const long mk = gid / NSPEC;
-    const int k = static_cast<int>(mk % KX);
-    const unsigned long long member = static_cast<unsigned long long>(member_base + mk / KX);
-    const unsigned long long counter =
-        (member << 40) | (static_cast<unsigned long long>(step) << 14) | static_cast<unsigned long long>(k * NSPEC + idx);
-    const unsigned long long h1 = mix64(seed ^ mix64(counter));
-    const unsigned long long h2 = mix64(h1 + 0x9E3779B97F4A7C15ull);
-    const double u1 = (static_cast<double>(h1 >> 11) + 1.0) * 0x1.0p-53;  // (0, 1]
-    const double u2 = static_cast<double>(h2 >> 11) * 0x1.0p-53;          // [0, 1)
-    const double rad = sqrt(-2.0 * log(u1));
-    const double ang = 6.283185307179586 * u2;
-    double er = rad * cos(ang), ei = rad * sin(ang);
-    er = fmin(10.0, fabs(er)) * (er < 0.0 ? -1.0 : 1.0);  // sppt.f90:70-74
-    ei = fmin(10.0, fabs(ei)) * (ei < 0.0 ? -1.0 : 1.0);
-    const double sigma = f0 * exp(-quarter_len2 * el2[idx]);
-    d2 r;
-    if (first) {
-        const double a = sigma / sqrt(1.0 - phi * phi);
-        r = d2{a * er, a * ei};
-    } else {
-        const d2 old = spec[gid];
-        r = d2{phi * old.x + sigma * er, phi * old.y + sigma * ei};
-    }
-    spec[gid] = r;
+// one lane per (member, level, coefficient): AR(1) update of the spectral pattern (sppt_point.hpp)
+__global__ __launch_bounds__(kT) void sppt_update_kernel(SpptArgs a) {
+    sppt_update_point(a, static_cast<long>(blockIdx.x) * kT + threadIdx.x);
 }
 }  // namespace
 
@@ -78,13 +44,17 @@ void sppt_constants(double *phi, double *f0, double *quarter_len2) {
     *quarter_len2 = 0.25 * len_decorr * len_decorr;
 }
 
-hipError_t run_sppt_update(double *spec, const DeviceTables &T, int M, unsigned long long seed, long long member_base,
-                           long long step, int first, hipStream_t s) {
-    double phi, f0, q;
-    sppt_constants(&phi, &f0, &q);
-    const long n = static_cast<long>(M) * KX * NSPEC;
-    hipLaunchKernelGGL(sppt_update_kernel, dim3(static_cast<unsigned>((n + kT - 1) / kT)), dim3(kT), 0, s,
-                       reinterpret_cast<d2 *>(spec), T.el2, M, seed, member_base, step, phi, f0, q, first);
+SpptArgs sppt_args(double *spec, const DeviceTables &T, int M, unsigned long long seed, long long member_base, long long step,
+                   int first) {
+    SpptArgs a{};
+    a.spec = spec, a.el2 = T.el2, a.M = M, a.first = first, a.seed = seed, a.member_base = member_base, a.step = step;
+    sppt_constants(&a.phi, &a.f0, &a.quarter_len2);
+    return a;
+}
+
+hipError_t run_sppt_update(const SpptArgs &a, hipStream_t s) {
+    const long n = static_cast<long>(a.M) * KX * NSPEC;
+    hipLaunchKernelGGL(sppt_update_kernel, dim3(static_cast<unsigned>((n + kT - 1) / kT)), dim3(kT), 0, s, a);
     return hipGetLastError();
 }
 
