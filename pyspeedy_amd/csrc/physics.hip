@@ -835,11 +835,10 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
     if (a.clstr) stream_store(&a.clstr[o2], clstr);
 }
 
-// Launch-bounds variant of the fp64 kernels: 2 waves per SIMD (256 VGPRs, no scratch in the fused kernel).  The 1-wave build (512
-// registers, no spills; PYSPEEDY_AMD_PHYS_WAVES=1) is 2.8 % faster per step at 8 members and 1.2 % at 1, 14 % slower at 16
-// (profiles/r02_small_ensemble_experiments.txt) -- but the compiler contracts a few multiply-adds differently in the two
-// builds, so their results differ in the last bits, and a member's trajectory must not depend on the size of the ensemble it
-// is stepped in (tests/test_run_gpu.py): one build for every size.
+// Launch-bounds variant of the fp64 kernels: 2 waves per SIMD (256 VGPRs, no scratch in the fused kernel).  The 1-wave build
+// (PYSPEEDY_AMD_PHYS_WAVES=1) exists for comparison: it was 2.8 % faster per step at 8 members before the kernel requested its
+// loads in batches and is equal since (14 % slower at 16 members and above); with -ffp-contract=on (Makefile) the two builds
+// give the same bits, which they did not while the back end was free to fuse across statements.
 static int physics_waves(int) {
     static const int waves = [] {
         const char *e = getenv("PYSPEEDY_AMD_PHYS_WAVES");
