@@ -10,6 +10,7 @@ OUT=$R/gpurun_out/final
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+python3 $R/bench.py --overlap-leg --no-cpu-baseline > $OUT/${TAG}_bench_overlap_leg.json 2>> $OUT/bench.err
 python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_20.json 2>> $OUT/bench.err
 python3 $R/bench.py --config cfg5 --no-cpu-baseline > $OUT/${TAG}_bench_cfg5.json 2>> $OUT/bench.err
 python3 $R/bench.py --scaling strong --members 8 --no-cpu-baseline > $OUT/${TAG}_bench_m8.json 2>> $OUT/bench.err
