@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--config cfg4|cfg5] [--members M]
 
 One "step" = one call of the reference's do_single_step (speedy.f90:20-74) for EVERY ensemble member resident on each
-GPU: daily forcing when due, shortwave every third step, the leapfrog step (91 spectral->grid transforms, grid-point
+GPU: daily forcing when due, shortwave every third step, the leapfrog step (spectral->grid transforms, grid-point
 dynamics, fused column physics, 73 grid->spectral transforms, spectral tendencies, semi-implicit correction, horizontal
 diffusion, Robert-Asselin-Williams filter), date advance and the land / sea-ice coupling.  Nothing crosses PCIe inside a
 step; the state of all members stays in HBM.
@@ -20,14 +20,32 @@ reference's own initial state (example boundary fields, resting atmosphere, firs
 examples/Ensemble_forecast.ipynb does (t_grid += N(0, 0.01 K), grid2spectral; seed = global member id) and spun up
 `warmup` steps.
 
+What the ONE JSON line of rank 0 holds:
+  value / ms_per_step   the headline: `spd_model_step(m, K)` regions in the library's default launch plan (two member groups
+                        on two HIP streams from 32 members per GPU up, `config.plan`), median region.
+  roofline              the dominant transform kernel (spec2grid) timed by HIP events on its launch stream in further
+                        regions of K steps issued in the SERIAL plan (one member group: with overlapping groups a
+                        kernel's duration is not its own); `serial_plan_ms_per_step` beside it; `kernels[]` = every
+                        kernel of the step from a bracketed one-day pass.
+  cpu_baseline          the reference Fortran itself (oracle/_ref; the C port when it did not travel) on one host core
+                        and on all host cores, measured BEFORE any process touches the GPU -- by the launcher (N > 1 through
+                        this script), or by rank 0 while the other ranks wait (N > 1 under torch.distributed.run).
+  vs_baseline           value / cpu_baseline.all_cores.value: BASELINE.md holds no published number; north_star's target is
+                        stated against the host-CPU reference ("core count stated"), so that is the ratio given (+ note).
+  cfg4_strong (N > 1)   BASELINE cfg 4 to the letter beside the weak headline: 64 members in total, block-sharded.
+  drop_in_step (N = 1)  the reference-shaped host loop: spd_parallel_step once per model step (step + range check + codes
+                        back), synchronous and in the overlapped begin / end form, over independent containers.
+  every_step_stores (N = 1)  the step with every store of the reference restored (all 91 spectral->grid transforms, the
+                        diagnostics-only physics outputs on every step).
+
 Launching: with N > 1 and no torchrun environment, this process only starts N rank processes (before touching the GPU),
 relays rank 0's JSON line and fails if any rank fails.  Under `python -m torch.distributed.run ... bench.py --gpus N` each
 process is one rank.  PYSPEEDY_AMD_BENCH_BACKEND=gloo rehearses the N-rank control flow when the ranks share one GPU.
 
 Timing: W warm-up steps, then regions of EXACTLY K steps, each bracketed by barrier + synchronize on both sides and reduced
-with MAX over ranks.  When one region is shorter than a second it is repeated (up to 100 regions) and `ms_per_step` is the
-MEDIAN region (minimum and count reported beside it), so that a 20-step run is not a 7 ms sample.
-Prints ONE JSON line on rank 0.
+with MAX over ranks.  Regions are repeated until `--min-seconds` (default 3) of timed GPU work have accumulated (the run
+stays inside the SST-anomaly months it allocates) and `ms_per_step` is the MEDIAN region (minimum and count beside it): a
+20-step run is then several hundred 5-ms samples, and the GPU is busy for seconds, not milliseconds.
 """
 import argparse
 import json
@@ -43,7 +61,8 @@ sys.path.insert(0, ROOT)
 
 STEPS_PER_YEAR = 36 * 365  # model_control.f90:57-60, params.f90:32
 S_BYTES, G_BYTES = 15872, 36864  # one spectral / one grid field
-MAX_STEPS = STEPS_PER_YEAR        # the run stays inside the 14 months of (zero) SST anomalies the bench allocates
+ANOM_MONTHS = 26                  # sst_anom(ix, il, 0:27), zero: December 1981 ... January 1984
+MAX_STEPS = 2 * STEPS_PER_YEAR    # the run stays inside the months of (zero) SST anomalies the bench allocates
 NG = 96 * 48
 
 # Algorithmic HBM bytes of each step kernel PER MEMBER, counted from the kernels' argument lists (DESIGN.md section 5 has
@@ -68,11 +87,12 @@ def parse(argv=None):
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--members", type=int, default=None, help="members per GPU (weak) or in total (strong)")
     ap.add_argument("--regions", type=int, default=0, help="timed regions of `steps` steps (0 = automatic)")
+    ap.add_argument("--min-seconds", type=float, default=3.0, help="timed regions are repeated until this much GPU time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap-leg", action="store_true",
-                    help="also measure the same ensemble stepped as two member groups on two HIP streams (an extra object in "
-                         "the line; off by default so that a profile of the default command holds launches of one size only)")
-    ap.add_argument("--no-overlap-leg", action="store_true", help=argparse.SUPPRESS)  # (accepted, it is the default)
+    ap.add_argument("--no-legs", action="store_true",
+                    help="headline and roofline only: no drop_in_step / every_step_stores / cfg4_strong objects (profiles of "
+                         "this command then hold launches of one size and one plan per region kind)")
+    ap.add_argument("--serial-plan", action="store_true", help="headline in the serial plan too (one member group)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--cpu-worker", type=float, nargs=2, default=None, metavar=("T_START", "SECONDS"), help=argparse.SUPPRESS)
     return ap.parse_args(argv)
@@ -97,9 +117,17 @@ def free_port():
 def launch_ranks(args, argv):
     port = str(free_port())
     procs = []
+    baseline_file = None
+    if not args.no_cpu_baseline:  # the host baseline of an N-rank line: measured here, before any rank exists
+        import tempfile
+        fd, baseline_file = tempfile.mkstemp(prefix="pyspeedy_bench_cpu_", suffix=".json")
+        with os.fdopen(fd, "w") as fh:
+            json.dump(cpu_baseline(args.cpu_seconds), fh)
     for r in range(args.gpus):
         env = dict(os.environ, WORLD_SIZE=str(args.gpus), RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=port)
+        if baseline_file:
+            env["PYSPEEDY_AMD_BENCH_CPU_BASELINE"] = baseline_file
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE,
                                       text=True))
@@ -121,6 +149,8 @@ def launch_ranks(args, argv):
             except subprocess.TimeoutExpired:
                 p.kill()
     outs = [p.stdout.read() for p in procs]
+    if baseline_file:
+        os.unlink(baseline_file)
     if failed is not None:
         sys.stderr.write("bench.py: rank %d exited with code %s\n%s" % (failed, procs[failed].returncode, outs[failed]))
         raise SystemExit(1)
@@ -256,7 +286,7 @@ def build_ensemble(args, M, first_id, device, dist, rank, coll_device):
     from pyspeedy_amd.model import EnsembleModel
     sp = pyspeedy_amd.ModSpectral(device.index)
     model = EnsembleModel(sp, M)
-    model.init_sst_anom(14)  # sst_anom(ix, il, 0:15), zero: December 1981 ... February 1983 (speedy.py:338-372)
+    model.init_sst_anom(ANOM_MONTHS)  # zero anomalies over the whole run (speedy.py:338-372)
     # rank 0 reads the boundary file; one RCCL broadcast (~3.4 MB over xGMI) hands it to the other GPUs
     bc = E.broadcast_boundary_conditions(dict(load_bc()) if rank == 0 else None, dist, coll_device)
     model.set_bc(bc, start_date=(1982, 1, 1, 0, 0))
@@ -312,39 +342,103 @@ def kernel_table(model, M, inv_per_member, sppt):
     return rows
 
 
-def overlapped_leg(args, M, first_id, device, dist, rank, coll_device, barrier, regions):
-    """Median seconds per region of `steps` steps for the same ensemble built with PYSPEEDY_AMD_CHUNKS=2 (member groups on
-    separate HIP streams), or None when the leg does not apply: fewer than 16 members per GPU (nothing to overlap: slower),
-    the switch already set by the caller, or no --overlap-leg.  Every rank takes part (same barriers and max over ranks)."""
+def timed_regions(model, args, barrier, dist, coll_device, steps_left, min_seconds, max_regions=1000):
+    """Regions of EXACTLY args.steps steps between barrier + synchronize, MAX over ranks; repeated until `min_seconds` of
+    timed work (or --regions, or the months of SST anomaly run out).  Returns the list of region seconds."""
     from pyspeedy_amd import ensemble as E
-    if not args.overlap_leg or M < 16 or "PYSPEEDY_AMD_CHUNKS" in os.environ:
-        return None
-    os.environ["PYSPEEDY_AMD_CHUNKS"] = "2"  # read when the model is created
-    try:
-        sp, model = build_ensemble(args, M, first_id, device, dist, rank, coll_device)
-    finally:
-        del os.environ["PYSPEEDY_AMD_CHUNKS"]
-    model.run(args.warmup)
-    seconds = []
-    for _ in range(max(1, min(regions, 10, (MAX_STEPS - args.warmup) // max(args.steps, 1)))):
+    regions, out, r = max(args.regions, 1), [], 0
+    while r < regions:
         barrier()
         t0 = time.perf_counter()
         model.run(args.steps)
         barrier()
-        seconds.append(E.max_over_ranks(time.perf_counter() - t0, dist, coll_device))
+        out.append(E.max_over_ranks(time.perf_counter() - t0, dist, coll_device))
+        if r == 0 and args.regions == 0:  # identical on every rank: it is the all-reduced time
+            regions = min(max_regions, int(math.ceil(min_seconds / max(out[0], 1e-6))))
+        regions = max(1, min(regions, steps_left // max(args.steps, 1)))
+        r += 1
+    return out
+
+
+def median(values):
+    v = sorted(values)
+    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+
+def fidelity_leg(args, M, first_id, device, dist, rank, coll_device, barrier):
+    """ms/step of the same ensemble with every store of the reference restored: all 91 spectral->grid transforms
+    (PYSPEEDY_AMD_PRUNE_DEAD=0) and the diagnostics-only physics outputs on every step."""
+    os.environ["PYSPEEDY_AMD_PRUNE_DEAD"] = "0"  # read when the model is created
+    try:
+        sp, model = build_ensemble(args, M, first_id, device, dist, rank, coll_device)
+    finally:
+        del os.environ["PYSPEEDY_AMD_PRUNE_DEAD"]
+    model.set_option("diag_every_step", 1)
+    model.run(args.warmup)
+    secs = timed_regions(model, args, barrier, dist, coll_device, MAX_STEPS - args.warmup - 36, 0.5, 200)
     ok = (model.check(2) == 0).all()
+    cfg = model.config()
     model.close()
     sp.close()
     if not ok:
-        raise SystemExit("bench.py: members left the accepted range in the overlapped leg")
-    seconds.sort()
-    return seconds[len(seconds) // 2]
+        raise SystemExit("bench.py: members left the accepted range in the every-step-stores leg")
+    return {"ms_per_step": median(secs) / args.steps * 1e3, "regions": len(secs), "spec2grid_per_member": cfg["inv_per_member"],
+            "plan": plan_name(cfg, M),
+            "note": "the reference's every store: 91 spectral->grid transforms per member (14 of them feed nothing) and the 39 "
+                    "diagnostics-only physics outputs per column stored on every step of the call"}
+
+
+def drop_in_leg(M, steps):
+    """The reference-shaped host loop over M independent containers through the outer C boundary (include/pyspeedy_amd_driver.h):
+    spd_parallel_step once per model step -- step, range check, error codes back -- synchronously and in the overlapped
+    begin / end form.  Per-step wall times, medians (the runtime stalls once per process for ~40 ms shortly after the first
+    launches; a median keeps that out)."""
+    import torch
+    from datetime import datetime
+    from pyspeedy_amd import speedy_driver as drv
+    from pyspeedy_amd.speedy import SpeedyEns
+    ens = SpeedyEns(M, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 3, 1))
+    for member in ens:
+        member.set_bc()
+    states = [m._state_cnt for m in ens.members]
+    controls = [m._control_cnt for m in ens.members]
+    for _ in range(12):
+        assert (drv.parallel_step(states, controls) == 0).all()
+    torch.cuda.synchronize()
+    sync = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        codes = drv.parallel_step(states, controls)
+        sync.append(time.perf_counter() - t0)
+    assert (codes == 0).all()
+    ovl = []
+    token = drv.parallel_step_begin(states, controls)
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        nxt = drv.parallel_step_begin(states, controls)
+        assert (drv.parallel_step_end(token) == 0).all()
+        token = nxt
+        ovl.append(time.perf_counter() - t0)
+    assert (drv.parallel_step_end(token) == 0).all()
+    del ens
+    return {"containers": M, "steps_timed": steps, "sync_ms_per_step": median(sync) * 1e3,
+            "begin_end_ms_per_step": median(ovl) * 1e3,
+            "note": "spd_parallel_step(state_cnts, control_cnts, error_codes, n) once per model step over independent containers "
+                    "(gathered into one device model on the first call): every step stores all diagnostics and runs the range "
+                    "check as a launch of its own; sync = the call returns the codes, begin_end = the check of step k is "
+                    "collected after step k + 1 has been enqueued; medians of per-step wall times"}
+
+
+def plan_name(cfg, M):
+    g = cfg["chunks"]
+    return ("%d member groups of %d / %d members on %d HIP streams" % (g, (M + g - 1) // g, M // g, g)) if g > 1 else \
+        "serial: one member group on one stream"
 
 
 def load_traffic(nfields):
     """HBM bytes per spec2grid launch from the committed PMC measurement of this very kernel inside this bench (rocprofv3
     cannot run inside bench.py): FETCH_SIZE doubled as the gfx950 guide prescribes, scaled per field."""
-    for name in ("r02_pmc_model_step.json", "r01_pmc_model_step.json"):
+    for name in ("r03_pmc_model_step.json", "r02_pmc_model_step.json", "r01_pmc_model_step.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 tj = json.load(fh)["kernels"]["spd::spec2grid_table_kernel"]
@@ -355,13 +449,37 @@ def load_traffic(nfields):
     return None, None
 
 
+def wait_for_ranks(rank, world, what):
+    """A file barrier under /tmp keyed by the rendezvous port: used ONCE, before any process group exists, so that rank 0
+    measures the host baseline while the other ranks have finished importing torch and sit idle."""
+    import tempfile
+    # (the ranks of one job are children of one launcher process: its pid keeps the files of an earlier job apart)
+    base = os.path.join(tempfile.gettempdir(), "pyspeedy_bench_%s_%d_%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid(), what))
+    open("%s.%d" % (base, rank), "w").close()
+    deadline = time.time() + 600.0
+    while time.time() < deadline:
+        if all(os.path.exists("%s.%d" % (base, r)) for r in range(world)):
+            return True
+        time.sleep(0.05)
+    return False
+
+
 def run_rank(args):
     baseline = None
-    world_env = int(os.environ.get("WORLD_SIZE", "1"))
-    if world_env == 1 and not args.no_cpu_baseline:
-        baseline = cpu_baseline(args.cpu_seconds)  # spawns processes: must come before the first GPU call
+    world_env, rank_env = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    import torch  # (importing torch does not initialise the GPU; the first import on a fresh box takes a minute or two)
+    if os.environ.get("PYSPEEDY_AMD_BENCH_CPU_BASELINE"):  # measured by bench.py's launcher before it started the ranks
+        if rank_env == 0:
+            with open(os.environ["PYSPEEDY_AMD_BENCH_CPU_BASELINE"]) as fh:
+                baseline = json.load(fh)
+    elif not args.no_cpu_baseline:
+        # spawns processes: must come before the first GPU call of this process.  Under torch.distributed.run rank 0 measures
+        # it while the other ranks -- torch imported, GPU untouched -- wait for it in the rendezvous of the process group.
+        if world_env > 1:
+            wait_for_ranks(rank_env, world_env, "imported")
+        if rank_env == 0:
+            baseline = cpu_baseline(args.cpu_seconds)
 
-    import torch
     import pyspeedy_amd
     from pyspeedy_amd import ensemble as E
     pyspeedy_amd.lib()  # load (or fail loudly) before the GPU is initialised; there is no CPU fallback
@@ -389,51 +507,80 @@ def run_rank(args):
 
     M, first_id, total_members = workload(args, world, rank)
     sp, model = build_ensemble(args, M, first_id, device, dist, rank, coll_device)
+    if args.serial_plan:
+        model.set_option("member_groups", 1)
+    cfg = model.config()
+    sppt = args.config == "cfg5"
+    plan = "serial: one member group on one stream (SPPT steps are not grouped)" if sppt else plan_name(cfg, M)
     model.run(args.warmup)
+    budget = MAX_STEPS - args.warmup - 36  # model steps this ensemble may still take (36: the bracketed one-day pass)
+    # ---- headline: the library's default plan
+    region_s = timed_regions(model, args, barrier, dist, coll_device, budget * 3 // 4, args.min_seconds)
+    budget -= len(region_s) * args.steps
+    # ---- roofline: the dominant transform kernel by HIP events on its launch stream, serial plan (profiling implies it)
     model.profile(1)
-    regions, region_s = max(args.regions, 1), []
-    r = 0
-    while r < regions:
-        barrier()
-        t0 = time.perf_counter()
-        model.run(args.steps)
-        barrier()
-        region_s.append(E.max_over_ranks(time.perf_counter() - t0, dist, coll_device))
-        if r == 0 and args.regions == 0 and region_s[0] < 1.0:  # identical on every rank: it is the all-reduced time
-            regions = min(100, int(math.ceil(1.0 / max(region_s[0], 1e-6))))
-        regions = max(1, min(regions, (MAX_STEPS - args.warmup - 36) // max(args.steps, 1)))
-        r += 1
+    saved_regions, args.regions = args.regions, (min(args.regions, 10) if args.regions else 0)
+    serial_s = timed_regions(model, args, barrier, dist, coll_device, budget, min(args.min_seconds, 1.0), 200)
+    args.regions = saved_regions
     kern_ms, launches, nfields = model.profile_read()
     codes = model.check(2)
     if (codes != 0).any():
         raise SystemExit("bench.py: %d members left the accepted range (diagnostics.f90)" % int((codes != 0).sum()))
     model.profile(0)
-    kernels = kernel_table(model, M, nfields // M, args.config == "cfg5") if rank == 0 or dist is None else None
-    overlap_s = overlapped_leg(args, M, first_id, device, dist, rank, coll_device, barrier, len(region_s))
+    kernels = kernel_table(model, M, nfields // M, sppt) if rank == 0 or dist is None else None
+    model.close()
+    sp.close()
+    legs = {}
+    if not args.no_legs:
+        if n_gpus == 1 and args.config == "cfg4":
+            legs["every_step_stores"] = fidelity_leg(args, M, first_id, device, dist, rank, coll_device, barrier)
+            legs["drop_in_step"] = drop_in_leg(M, 360)
+        if n_gpus > 1 and args.scaling == "weak" and args.config == "cfg4" and args.members is None:
+            # BASELINE cfg 4 to the letter next to the weak headline: 64 members in total, block-sharded over the ranks
+            strong = argparse.Namespace(**dict(vars(args), scaling="strong", members=None))
+            Ms, first_s, total_s = workload(strong, world, rank)
+            sp2, m2 = build_ensemble(strong, Ms, first_s, device, dist, rank, coll_device)
+            m2.run(args.warmup)
+            secs = timed_regions(m2, strong, barrier, dist, coll_device, MAX_STEPS - args.warmup - 36, 1.0, 500)
+            ok = (m2.check(2) == 0).all()
+            scfg = m2.config()
+            m2.close()
+            sp2.close()
+            if not ok:
+                raise SystemExit("bench.py: members left the accepted range in the cfg4_strong leg")
+            ms_s = median(secs) / args.steps * 1e3
+            legs["cfg4_strong"] = {
+                "members_total": total_s, "members_per_gpu": Ms, "ms_per_step": ms_s, "regions": len(secs), "scaling": "strong",
+                "value": E.simulated_years_per_day(total_s, ms_s * 1e-3, STEPS_PER_YEAR), "unit": "simulated-years/day",
+                "plan": plan_name(scfg, Ms),
+                "note": "BASELINE cfg 4 as worded: 64 members sharded %d per GPU over %d GPUs, same timing rules" % (Ms, n_gpus)}
 
     if rank == 0:
-        ordered = sorted(region_s)
-        median = ordered[len(ordered) // 2] if len(ordered) % 2 else 0.5 * (ordered[len(ordered) // 2 - 1] + ordered[len(ordered) // 2])
-        ms_step, ms_min = median / args.steps * 1e3, ordered[0] / args.steps * 1e3
+        ms_step, ms_min = median(region_s) / args.steps * 1e3, min(region_s) / args.steps * 1e3
         value = E.simulated_years_per_day(total_members, ms_step * 1e-3, STEPS_PER_YEAR)
         achieved = (S_BYTES + G_BYTES) * nfields / (kern_ms * 1e-3) / 1e9
         traffic, traffic_src = load_traffic(nfields)
         physics = "fp64 column physics" if args.config == "cfg4" else "SPPT on, fp32 arithmetic in the column physics (fp64 state)"
+        all_cores = (baseline or {}).get("all_cores")
         line = {
             "metric": "simulated-years/day (whole node), T30L8", "value": value, "unit": "simulated-years/day",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": (value / all_cores["value"]) if all_cores else None,
+            "vs_baseline_note": "BASELINE.md holds no published number for this metric; the ratio is to cpu_baseline.all_cores (the "
+                                "reference Fortran, one member per core on the %s host cores of this box), the comparison "
+                                "north_star asks for" % (all_cores["cores"] if all_cores else "?"),
             "dtype": "f64" if args.config == "cfg4" else "f64 state and dynamics, f32 column physics",
             "data": "reference example_bc boundary fields (committed fixture, no download); state generated by the model: "
                     "resting atmosphere + first_step, members perturbed with t_grid += N(0, 0.01 K) (seed = global member "
                     "id), %d spin-up steps" % args.warmup,
-            "ms_per_step_min": ms_min, "regions": len(region_s),
+            "ms_per_step_min": ms_min, "regions": len(region_s), "timed_seconds": sum(region_s),
             "config": {
                 "workload": "BASELINE %s ensemble (%s scaling): %d members per GPU, %d in total, T30L8 96x48x8, %s; full "
                             "do_single_step per member (%d spec2grid + grid-point dynamics + fused column physics + 73 "
                             "grid2spec + spectral tendencies/semi-implicit/diffusion/RAW filter + coupler + daily "
                             "forcing), all on the GPU" % (args.config, args.scaling, M, total_members, physics, nfields // M),
-                "members_per_gpu": M, "members_total": total_members,
+                "members_per_gpu": M, "members_total": total_members, "plan": plan,
                 "ms_per_member_step": ms_step * n_gpus / total_members, "simulated_days_per_region": args.steps / 36.0,
                 "parallelism": "ensemble members sharded per GPU, no collective in the step",
                 "backend": backend if dist is not None else "none (single process)",
@@ -443,21 +590,20 @@ def run_rank(args):
                           "staging the wind and pressure-gradient fields of each member), %d fields/launch" % nfields,
                 "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "algorithmic_bytes_per_field": S_BYTES + G_BYTES, "avg_launch_ms": kern_ms, "launches_timed": launches,
+                "measured_in": "%d further regions of %d steps issued in the serial plan (one member group on one stream: the "
+                               "duration of a kernel that shares the GPU with another group's kernels is not its own); HIP events "
+                               "on the launch stream around every spec2grid launch" % (len(serial_s), args.steps),
+                "serial_plan_ms_per_step": median(serial_s) / args.steps * 1e3,
                 "traffic": traffic, "traffic_source": traffic_src, "kernels": kernels,
+                "kernels_note": "one bracketed simulated day (36 steps, serial plan); the brackets add a few microseconds between "
+                                "launches, so the rows sum to slightly more than serial_plan_ms_per_step",
             },
         }
-        if overlap_s is not None:
-            # NOT `value`: the same ensemble stepped as two member groups on two HIP streams (PYSPEEDY_AMD_CHUNKS=2, README).
-            # The groups' kernels overlap, so a kernel's duration is no longer its own and the per-kernel roofline above
-            # cannot be stated for this mode; reported because it is how a production run of this size would be configured.
-            ms_o = overlap_s / args.steps * 1e3
-            line["overlapped_member_groups"] = {
-                "member_groups": 2, "ms_per_step": ms_o,
-                "value": E.simulated_years_per_day(total_members, ms_o * 1e-3, STEPS_PER_YEAR), "unit": "simulated-years/day",
-                "note": "same workload, members stepped as 2 groups on 2 HIP streams (PYSPEEDY_AMD_CHUNKS=2); median region",
-            }
+        line.update(legs)
         if baseline is not None:
             line["cpu_baseline"] = baseline
+            if "cfg4_strong" in legs and all_cores:
+                legs["cfg4_strong"]["vs_cpu_all_cores"] = legs["cfg4_strong"]["value"] / all_cores["value"]
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

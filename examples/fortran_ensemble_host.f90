@@ -2,7 +2,11 @@
 !! speedy_driver.f90.j2) under their own names with an spd_ prefix -- modelstate_init, set_<v>, create_datetime,
 !! controlparams_init, init, parallel_step, check, transform_spectral2grid, get_<v> -- driving a 3-member ensemble whose
 !! members are independent containers, exactly as pyspeedy's SpeedyEns holds them.  parallel_step gathers them into one
-!! batched device model on its first call (one set of kernel launches per step for the whole ensemble).
+!! batched device model per GPU on its first call (one set of kernel launches per step and device for the whole ensemble).
+!!
+!! One process, all GPUs of the node: spd_set_device_placement(spd_device_count) spreads the containers over the devices
+!! round-robin; member 1 reads the boundary file, spd_broadcast_boundary hands its fields to the other members device to
+!! device (xGMI); a single parallel_step then drives every device, enqueueing all of them before it waits for any.
 !!
 !!   fortran_ensemble_host <bc.bin> <out.bin> <nsteps>
 !! bc.bin as for fortran_host; member m gets its SST raised by 0.25 (m - 1) K.  out.bin: t_grid (96,48,8) of member 1,
@@ -16,7 +20,7 @@ program fortran_ensemble_host
             "stl12", "snowd12", "soil_wc_l1", "soil_wc_l2", "soil_wc_l3", "sst12", "sea_ice_frac12"]
     integer, parameter :: planes(12) = [1, 1, 1, 1, 1, 12, 12, 12, 12, 12, 12, 12]
     integer(c_int64_t) :: states(n), controls(n), d_start, d_end
-    integer(c_int32_t) :: codes(n), code, alive, members, y, mo, d, h, mi
+    integer(c_int32_t) :: codes(n), code, alive, members, y, mo, d, h, mi, ndev, dev
     real(c_double), allocatable :: field(:, :, :), t_grid(:, :, :)
     character(len=512) :: arg
     integer :: i, m, istep, nsteps, u, uo
@@ -26,19 +30,31 @@ program fortran_ensemble_host
     call check(spd_create_datetime(1982, 1, 1, 0, 0, d_start), "create_datetime")
     call check(spd_create_datetime(1982, 1, 4, 0, 0, d_end), "create_datetime")
     call get_command_argument(1, arg)
+    call check(spd_device_count(ndev), "device_count")
+    call check(spd_set_device_placement(min(ndev, int(n, c_int32_t))), "set_device_placement")
     do m = 1, n
         call check(spd_modelstate_init(states(m)), "modelstate_init")
         call check(spd_controlparams_init(controls(m), d_start, d_end), "controlparams_init")
-        open (newunit=u, file=trim(arg), access="stream", form="unformatted", status="old")
-        do i = 1, 12
-            allocate (field(ix, il, planes(i)))
-            read (u) field
-            if (trim(names(i)) == "sst12") field = field + 0.25d0 * (m - 1)
-            call check(spd_set(states(m), trim(names(i))//c_null_char, field, int(8 * size(field), c_size_t)), &
-                       "set_"//trim(names(i)))
-            deallocate (field)
-        end do
-        close (u)
+    end do
+    ! member 1 reads the file; the others get the fields device to device and then their own SST
+    open (newunit=u, file=trim(arg), access="stream", form="unformatted", status="old")
+    do i = 1, 12
+        allocate (field(ix, il, planes(i)))
+        read (u) field
+        call check(spd_set(states(1), trim(names(i))//c_null_char, field, int(8 * size(field), c_size_t)), &
+                   "set_"//trim(names(i)))
+        deallocate (field)
+    end do
+    close (u)
+    call check(spd_broadcast_boundary(states, int(n, c_int32_t), 0_c_int32_t), "broadcast_boundary")
+    allocate (field(ix, il, 12))
+    do m = 2, n
+        call check(spd_get(states(m), "sst12"//c_null_char, field, int(8 * size(field), c_size_t)), "get_sst12")
+        field = field + 0.25d0 * (m - 1)
+        call check(spd_set(states(m), "sst12"//c_null_char, field, int(8 * size(field), c_size_t)), "set_sst12")
+    end do
+    deallocate (field)
+    do m = 1, n
         call check(spd_init(states(m), controls(m), code), "init")
         if (code /= 0) stop "init failed"
     end do
@@ -61,7 +77,9 @@ program fortran_ensemble_host
         write (uo) t_grid
     end do
     close (uo)
-    print "(a, i0, a, i0, a, i0)", "members in one device model ", members, "  device models alive ", alive, "  start year ", y
+    call check(spd_modelstate_device(states(n), dev), "modelstate_device")
+    print "(a, i0, a, i0, a, i0, a, i0, a, i0)", "members in one device model ", members, "  device models alive ", alive, &
+        "  start year ", y, "  devices ", ndev, "  device of the last member ", dev
     do m = 1, n
         call check(spd_modelstate_close(states(m)), "modelstate_close")
         call check(spd_controlparams_close(controls(m)), "controlparams_close")

@@ -140,8 +140,19 @@ long spd_model_var_bytes(spd_model_handle m, const char *name);
  * spd_model_set broadcasts the same host array to every member.  Synchronous. */
 int spd_model_set(spd_model_handle m, const char *name, int member, const void *host_buf, size_t bytes);
 int spd_model_get(spd_model_handle m, const char *name, int member, void *host_buf, size_t bytes);
-/* device base pointer of a registry array ([nmembers][...]), for zero-copy users */
+/* Device base pointer of a registry array ([nmembers][...]), for zero-copy users.  Contract:
+ *  - the address stays valid (and stays the array of that name) until spd_model_destroy, except "sst_anom" after
+ *    spd_model_init_sst_anom and the SPPT arrays before spd_model_set_sppt;
+ *  - taking the address of "phi" pins the geopotential to one buffer: the model stops alternating between two (the
+ *    look-ahead it otherwise uses for launches of up to 8 members), which costs such ensembles 1-3 % per step;
+ *  - the kernels of a step are stream-ordered on the stream given to spd_model_step: read or write through the pointer
+ *    on that stream, or synchronise first;
+ *  - the call itself drops what the model had derived from the state (look-ahead geopotential, the day's interpolated
+ *    climatologies).  A caller that WRITES through a pointer it obtained earlier -- spectral t / phis, a climatology or
+ *    anomaly field, anything -- must call spd_model_invalidate before the next step, or the step uses the stale values. */
 void *spd_model_device_ptr(spd_model_handle m, const char *name);
+/* the state was changed behind the model's back (a write through a device pointer): drop everything derived from it */
+int spd_model_invalidate(spd_model_handle m);
 int spd_model_set_co2(spd_model_handle m, double air_absortivity_co2);
 /* current value (the daily forcing raises it when increase_co2 is set, forcing.f90:52-57) */
 double spd_model_co2(spd_model_handle m);
@@ -152,10 +163,12 @@ int spd_model_step_dynamics(spd_model_handle m, int j1, int j2, double dt, int c
 /* check_diagnostics (diagnostics.f90:16-76) for every member: error_codes_host[i] = 0 or -2; diag_host may be NULL or
  * receive [nmembers][3][kx] (eddy KE of vor, of div, global-mean T).  Synchronises `stream`. */
 int spd_model_check(spd_model_handle m, int time_level, int32_t *error_codes_host, double *diag_host, void *stream);
-/* The same check without stalling the launch pipeline: _begin enqueues it and returns a slot (0 or 1, at most two in flight),
- * _end waits for that slot only.  Begin the check of step k, launch step k + 1, then end the check of step k. */
+/* The same check without stalling the launch pipeline: _begin enqueues it and returns a slot (0 or 1, at most two in flight:
+ * a third _begin fails with SPD_E_ARG until one of them has been ended), _end waits for that slot only.  Begin the check of
+ * step k, launch step k + 1, then end the check of step k. */
 int spd_model_check_begin(spd_model_handle m, int time_level, void *stream);
 int spd_model_check_end(spd_model_handle m, int slot, int32_t *error_codes_host);
+int spd_model_checks_in_flight(spd_model_handle m); /* 0, 1 or 2: checks begun and not yet ended */
 
 /* initialize_state (initialization.f90:13-91) for every member from the boundary fields stored beforehand with
  * spd_model_set (orog, fmask_orig, alb0, veg_high, veg_low, stl12, snowd12, soil_wc_l1, soil_wc_l2, sst12,
@@ -192,7 +205,9 @@ int spd_model_get_control(spd_model_handle m, spd_model_control *out);
 int spd_model_set_control(spd_model_handle m, const spd_model_control *in);
 /* measurement hook: HIP events recorded on the launch stream around the kernels of every step.  level 0 = off, 1 = the
  * dominant kernel only (the 91*M-field spectral->grid launch; cheap enough for the timed region of bench.py), 2 = every
- * kernel of the step (a separate measurement pass: each bracket adds a few microseconds between launches).
+ * kernel of the step (a separate measurement pass: each bracket adds a few microseconds between launches).  While the level
+ * is not 0 the step is issued as ONE member group on the caller's stream (the serial plan), whatever "member_groups" says:
+ * kernels of overlapping groups share the GPU and their durations would not be their own.
  * _read synchronises the events of the spectral->grid launches and returns their mean time in ms;
  * _read_kernels returns, per kernel id SPD_K_*, mean and minimum bracket time in ms, the number of brackets and the units
  * (fields for the transforms, members otherwise) one bracket processed; all four arrays hold SPD_K_COUNT entries. */
@@ -215,7 +230,7 @@ int spd_model_profile_read_kernels(spd_model_handle m, double *mean_ms, double *
 /* how the step is configured (environment switches read at spd_model_create): cfg[0] = spectral->grid transforms per member
  * and step (77, or the reference's 91 with PYSPEEDY_AMD_PRUNE_DEAD=0), cfg[1] = 1 when every step stores the diagnostics-only
  * physics outputs (PYSPEEDY_AMD_DIAG_EVERY_STEP=1; default 0: only the last step of a multi-step call does), cfg[2] = member
- * groups stepped on separate streams (PYSPEEDY_AMD_CHUNKS), cfg[3] = 1 for separate dynamics / physics launches, cfg[4] = 1
+ * groups stepped on separate streams (PYSPEEDY_AMD_CHUNKS / "member_groups"; the configured number), cfg[3] = 1 for separate dynamics / physics launches, cfg[4] = 1
  * when spectral_step_kernel also computes the next step's geopotential, cfg[5] = 1 when it carries the land / sea-ice coupling */
 int spd_model_get_config(spd_model_handle m, int32_t *cfg /* 6 */);
 /* The launch-plan switches that can change on a live model, by name (the environment variables of README.md set the same
@@ -224,8 +239,10 @@ int spd_model_get_config(spd_model_handle m, int32_t *cfg /* 6 */);
  *   "coupler_in_spectral"  0 / 1   land / sea-ice coupling as tail blocks of spectral_step_kernel or as a launch of its own
  *   "spectral_early"      -1 / 0 / 1   spectral_step_kernel with all loads up front: automatic (up to 8 members) / never / always
  *   "split_dyn"            0 / 1   separate launches for grid-point dynamics and column physics
- * Returns SPD_E_ARG for an unknown name or a value outside the list.  What is fixed at creation (member groups on separate
- * streams, the pruned transform table, the geopotential fold) is read from the environment only. */
+ *   "member_groups"        1 ... 4 the members are stepped in that many groups on separate HIP streams (default 2 from 32
+ *                                  members up, else 1; always 1 while spd_model_profile is on, with SPPT and with split_dyn)
+ * Returns SPD_E_ARG for an unknown name or a value outside the list.  What is fixed at creation (the pruned transform
+ * table, the geopotential fold) is read from the environment only. */
 int spd_model_set_option(spd_model_handle m, const char *name, int32_t value);
 /* BASELINE cfg 5: fp32 != 0 runs the arithmetic of the column physics (physics.f90:107-256 and the schemes it calls) in
  * single precision; the model state, the grid-point dynamics and the tendencies handed to the transforms stay fp64 (the
@@ -249,6 +266,10 @@ int spd_model_init_sst_anom(spd_model_handle m, int n_months);
 int spd_model_set_sppt(spd_model_handle m, int on, uint64_t seed, int64_t first_member_id);
 /* device-to-device copy of every registered variable of one member into a member of another model on the same GPU */
 int spd_model_copy_member(spd_model_handle dst, int dst_member, spd_model_handle src, int src_member, void *stream);
+/* the named registry variables only; the two models may live on different GPUs (device-to-device over xGMI,
+ * hipMemcpyPeerAsync): how one process hands the shared boundary fields to the members it keeps on its other devices */
+int spd_model_copy_vars(spd_model_handle dst, int dst_member, spd_model_handle src, int src_member, const char *const *names,
+                        int n_names, void *stream);
 
 #ifdef __cplusplus
 }

@@ -277,5 +277,29 @@ module pyspeedy_amd_c
             integer(c_int64_t), value :: state_cnt
             integer(c_int32_t), intent(out) :: models_alive, members_in_model
         end function
+        ! ---- one process, several GPUs (extension; the reference's ensemble is one process, speedy_driver.f90.j2:58-79) ----
+        integer(c_int) function spd_device_count(n_devices) bind(C, name="spd_device_count")
+            import :: c_int, c_int32_t
+            integer(c_int32_t), intent(out) :: n_devices
+        end function
+        integer(c_int) function spd_set_device_placement(n_devices) bind(C, name="spd_set_device_placement")
+            import :: c_int, c_int32_t
+            integer(c_int32_t), value :: n_devices   ! 0: current device; k: containers spread over devices 0 .. k-1
+        end function
+        integer(c_int) function spd_modelstate_init_on(state_cnt, device) bind(C, name="spd_modelstate_init_on")
+            import :: c_int, c_int64_t, c_int32_t
+            integer(c_int64_t), intent(out) :: state_cnt
+            integer(c_int32_t), value :: device
+        end function
+        integer(c_int) function spd_modelstate_device(state_cnt, device) bind(C, name="spd_modelstate_device")
+            import :: c_int, c_int64_t, c_int32_t
+            integer(c_int64_t), value :: state_cnt
+            integer(c_int32_t), intent(out) :: device
+        end function
+        integer(c_int) function spd_broadcast_boundary(state_cnts, n, root) bind(C, name="spd_broadcast_boundary")
+            import :: c_int, c_int64_t, c_int32_t
+            integer(c_int64_t), intent(in) :: state_cnts(*)
+            integer(c_int32_t), value :: n, root     ! root: 0-based index into state_cnts
+        end function
     end interface
 end module pyspeedy_amd_c

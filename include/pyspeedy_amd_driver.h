@@ -7,7 +7,9 @@
  * the GPU work it started has finished), exactly like the Fortran routines it replaces.  All functions return SPD_OK or a
  * negative SPD_E_* code (pyspeedy_amd.h) -- that is the status of the CALL; the model's own error code of
  * init / step / check (error_codes.f90:7-9: 0 success, -1 state not initialised, -2 variables out of range) is written
- * to `error_code`, as the reference's `intent(out) :: error_code` arguments are.
+ * to `error_code`, as the reference's `intent(out) :: error_code` arguments are.  One more value exists for parallel_step
+ * over several device models: -3 for the members of a model whose step could not be issued or checked at all (the call then
+ * returns that model's SPD_E_* code after the other models have been stepped; their members have their usual codes).
  *
  * Batching.  The reference steps an ensemble with an OpenMP loop over independent containers (parallel_step, :58-79).
  * Here spd_parallel_step advances all members with ONE set of kernel launches: the first time it is handed n > 1
@@ -33,9 +35,26 @@ extern "C" {
 
 /* ---- ModelState interface (speedy_driver.f90.j2:216-248) ---- */
 int spd_modelstate_init(int64_t *state_cnt);
-int spd_modelstate_init_ensemble(int64_t *state_cnts, int32_t n_members); /* extension: members of one batched model */
+/* extension: n containers that are batched from the start (one device model; with a device placement of k > 1 devices one
+ * device model per device, member e of n on device e k / n) */
+int spd_modelstate_init_ensemble(int64_t *state_cnts, int32_t n_members);
 int spd_modelstate_init_sst_anom(int64_t state_cnt, int32_t n_months);    /* sst_anom(ix, il, 0:n_months+1), zero-filled */
 int spd_modelstate_close(int64_t state_cnt);
+
+/* ---- extension: one process, several GPUs.  The reference's ensemble is ONE process that hands all its containers to
+ *      parallel_step (speedy_driver.f90.j2:58-79, an OpenMP loop over members).  By default a container lives on the HIP
+ *      device that is current in the calling thread.  spd_set_device_placement(k) (or PYSPEEDY_AMD_DEVICES=k|all in the
+ *      environment) makes spd_modelstate_init spread containers over devices 0 .. k-1 round-robin in creation order;
+ *      spd_modelstate_init_on names the device; spd_set_device_placement(0) goes back to the current device.
+ *      spd_parallel_step over containers of several devices gathers and steps them per device and enqueues every device's
+ *      step and range check before it waits for any, so the GPUs work side by side.  spd_broadcast_boundary copies the shared
+ *      boundary fields (orog, fmask_orig, alb0, veg_high, veg_low, stl12, snowd12, soil_wc_l1..3, sst12, sea_ice_frac12 and,
+ *      when the lengths agree, sst_anom) of container `root` into all the others, device to device over xGMI. ---- */
+int spd_device_count(int32_t *n_devices);
+int spd_set_device_placement(int32_t n_devices);
+int spd_modelstate_init_on(int64_t *state_cnt, int32_t device);
+int spd_modelstate_device(int64_t state_cnt, int32_t *device);
+int spd_broadcast_boundary(const int64_t *state_cnts, int32_t n, int32_t root);
 
 /* ---- Datetime interface (:163-210) ---- */
 int spd_create_datetime(int32_t year, int32_t month, int32_t day, int32_t hour, int32_t minute, int64_t *datetime_cnt);
@@ -87,6 +106,11 @@ int spd_registry_entry(int32_t index, char *name /* 32 bytes */, int32_t *dtype,
 int spd_driver_model(int64_t state_cnt, void **model, int32_t *member, int32_t *members_in_model);
 /* how many device models are alive and how many members the container's model holds (tests / diagnostics of batching) */
 int spd_driver_stats(int64_t state_cnt, int32_t *models_alive, int32_t *members_in_model);
+/* Host-side order in which parallel_step (begin / end) handled its device models when there were several: spd_driver_trace(1)
+ * starts recording, _read copies up to `capacity` (kind, group) pairs and returns how many there are; kind 1 = step + check
+ * of the group enqueued, 2 = the host starts waiting for the group, 3 = its codes are back. */
+int spd_driver_trace(int32_t on);
+int spd_driver_trace_read(int32_t *pairs, int32_t capacity);
 
 #ifdef __cplusplus
 }

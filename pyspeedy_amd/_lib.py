@@ -88,6 +88,8 @@ _SIGNATURES = {
     "spd_model_set": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]),
     "spd_model_get": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]),
     "spd_model_device_ptr": (C.c_void_p, [C.c_void_p, C.c_char_p]),
+    "spd_model_invalidate": (C.c_int, [C.c_void_p]),
+    "spd_model_checks_in_flight": (C.c_int, [C.c_void_p]),
     "spd_model_set_co2": (C.c_int, [C.c_void_p, C.c_double]),
     "spd_model_co2": (C.c_double, [C.c_void_p]),
     "spd_model_set_time_step": (C.c_int, [C.c_void_p, C.c_double]),
@@ -113,6 +115,14 @@ _SIGNATURES = {
     "spd_modelstate_init": (C.c_int, [C.POINTER(C.c_int64)]),
     "spd_modelstate_init_ensemble": (C.c_int, [C.POINTER(C.c_int64), C.c_int32]),
     "spd_modelstate_init_sst_anom": (C.c_int, [C.c_int64, C.c_int32]),
+    "spd_device_count": (C.c_int, [C.POINTER(C.c_int32)]),
+    "spd_set_device_placement": (C.c_int, [C.c_int32]),
+    "spd_modelstate_init_on": (C.c_int, [C.POINTER(C.c_int64), C.c_int32]),
+    "spd_modelstate_device": (C.c_int, [C.c_int64, C.POINTER(C.c_int32)]),
+    "spd_broadcast_boundary": (C.c_int, [C.POINTER(C.c_int64), C.c_int32, C.c_int32]),
+    "spd_driver_trace": (C.c_int, [C.c_int32]),
+    "spd_driver_trace_read": (C.c_int, [C.POINTER(C.c_int32), C.c_int32]),
+    "spd_model_copy_vars": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_void_p]),
     "spd_modelstate_close": (C.c_int, [C.c_int64]),
     "spd_create_datetime": (C.c_int, [C.c_int32] * 5 + [C.POINTER(C.c_int64)]),
     "spd_get_datetime": (C.c_int, [C.c_int64] + [C.POINTER(C.c_int32)] * 5),

@@ -119,12 +119,15 @@ struct Batch {  // one device model shared by the containers of its members
     int device = 0, members = 0, n_months = 1;
     bool sst_anom_allocated = false;
     std::vector<char> initialized;
+    // The steps and range checks of this model are issued on a stream of its own, so that the models of one parallel_step --
+    // on different devices, or several on one device -- run side by side.  A blocking stream: everything else the driver does
+    // (initialisation, copies, transforms) stays on the null stream, which orders itself against it.
+    hipStream_t stream = nullptr;
     ~Batch() {
         --g_models_alive;
-        if (model) {
-            (void)hipSetDevice(device);
-            (void)spd_model_destroy(model);
-        }
+        (void)hipSetDevice(device);
+        if (model) (void)spd_model_destroy(model);
+        if (stream) (void)hipStreamDestroy(stream);
     }
 };
 struct State {
@@ -150,9 +153,7 @@ std::map<int, spd_handle> g_contexts;  // one context per device, alive for the 
 
 int fail(int code, const std::string &msg) { return spd_set_error(code, msg); }
 
-int context_for_current_device(spd_handle *out, int *device) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return fail(SPD_E_DEVICE, "speedy driver: no HIP device (there is no CPU fallback)");
+int context_for_device(int dev, spd_handle *out) {
     auto it = g_contexts.find(dev);
     if (it == g_contexts.end()) {
         spd_handle h = nullptr;
@@ -160,14 +161,47 @@ int context_for_current_device(spd_handle *out, int *device) {
         it = g_contexts.emplace(dev, h).first;
     }
     *out = it->second;
-    *device = dev;
     return SPD_OK;
 }
 
-int new_batch(int members, std::shared_ptr<Batch> *out) {
+// Where a new state container lives.  Default: the HIP device that is current in the calling thread (one process per GPU,
+// the torch.distributed layout).  spd_set_device_placement(k) or PYSPEEDY_AMD_DEVICES=k|all makes ONE process spread its
+// containers over devices 0 .. k-1: single containers round-robin in creation order, the members of
+// spd_modelstate_init_ensemble in blocks (member e of n on device e k / n).  parallel_step then drives all
+// devices from the one call (the reference's one-process ensemble, speedy_driver.f90.j2:58-79).
+int g_place_ndev = -1;  // -1: not decided yet (environment), 0: current device, k > 0: devices 0 .. k-1
+long g_place_counter = 0;
+
+int device_count() {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+int placement_devices() {
+    if (g_place_ndev < 0) {
+        g_place_ndev = 0;
+        if (const char *e = getenv("PYSPEEDY_AMD_DEVICES")) {
+            const int have = device_count();
+            int want = std::strcmp(e, "all") == 0 ? have : atoi(e);
+            if (want > have) want = have;
+            g_place_ndev = want > 0 ? want : 0;
+        }
+    }
+    return g_place_ndev;
+}
+
+int current_device(int *dev) {
+    if (hipGetDevice(dev) != hipSuccess) return fail(SPD_E_DEVICE, "speedy driver: no HIP device (there is no CPU fallback)");
+    return SPD_OK;
+}
+
+int new_batch(int members, int device, std::shared_ptr<Batch> *out) {
     auto b = std::make_shared<Batch>();
-    if (int rc = context_for_current_device(&b->ctx, &b->device)) return rc;
+    b->device = device;
+    if (hipSetDevice(device) != hipSuccess) return fail(SPD_E_DEVICE, "speedy driver: hipSetDevice(" + std::to_string(device) + ") failed");
+    if (int rc = context_for_device(device, &b->ctx)) return rc;
     if (int rc = spd_model_create(b->ctx, members, &b->model)) return rc;
+    if (hipStreamCreate(&b->stream) != hipSuccess) return fail(SPD_E_DEVICE, "speedy driver: hipStreamCreate failed");
     b->members = members;
     b->initialized.assign(members, 0);
     *out = b;
@@ -187,6 +221,11 @@ bool same_date(const Control &a, const Control &b) {
 int push_date(Batch &b, const Control &c) {
     spd_model_control mc;
     if (int rc = spd_model_get_control(b.model, &mc)) return rc;
+    // A host with the reference's loop hands the model back the date the model gave it: nothing to do then (setting the
+    // control block drops the day's interpolated climatologies, and every step would interpolate them again).
+    if (mc.year == c.now.ymdhm[0] && mc.month == c.now.ymdhm[1] && mc.day == c.now.ymdhm[2] && mc.hour == c.now.ymdhm[3] &&
+        mc.minute == c.now.ymdhm[4] && mc.month_idx == c.month_idx)
+        return SPD_OK;
     mc.year = c.now.ymdhm[0]; mc.month = c.now.ymdhm[1]; mc.day = c.now.ymdhm[2]; mc.hour = c.now.ymdhm[3];
     mc.minute = c.now.ymdhm[4];
     mc.month_idx = c.month_idx;
@@ -216,16 +255,21 @@ int split_batch(const std::shared_ptr<Batch> &b) {
     if (int rc = spd_model_get_control(b->model, &mc)) return rc;
     for (auto &st : members_of(b)) {
         std::shared_ptr<Batch> single;
-        if (int rc = new_batch(1, &single)) return rc;
+        if (int rc = new_batch(1, b->device, &single)) return rc;
         if (b->sst_anom_allocated) {
             if (int rc = spd_model_init_sst_anom(single->model, b->n_months)) return rc;
             single->n_months = b->n_months;
             single->sst_anom_allocated = true;
         }
+        spd_model_control mine = mc;
+        if (mc.sppt_on) {  // the generator is keyed by global member ids: the single keeps the id its member had in the batch
+            mine.sppt_first_member_id = mc.sppt_first_member_id + st->member;
+            if (int rc = spd_model_set_sppt(single->model, 1, mc.sppt_seed, mine.sppt_first_member_id)) return rc;
+        }
         if (int rc = spd_model_copy_member(single->model, 0, b->model, st->member, nullptr)) return rc;
         single->initialized[0] = b->initialized[st->member];
         if (single->initialized[0]) {
-            if (int rc = spd_model_set_control(single->model, &mc)) return rc;
+            if (int rc = spd_model_set_control(single->model, &mine)) return rc;
             if (int rc = spd_model_set_time_step(single->model, 2 * kDelt)) return rc;
         } else {
             (void)spd_model_set_flags(single->model, mc.land_coupling_flag, mc.sst_anomaly_coupling_flag, mc.increase_co2);
@@ -238,8 +282,23 @@ int split_batch(const std::shared_ptr<Batch> &b) {
     return SPD_OK;  // (`b` dies with the caller's reference)
 }
 
-// Gather n independent, initialised one-member models that agree in their control blocks into one batched model.
-// Returns SPD_OK with *done = false when the states cannot be gathered (then the caller steps them one by one).
+// How many device models the n members that share a device (and a date, and their control flags) are kept in.  From 32
+// members up: two.  parallel_step enqueues the step and range check of every device model before it waits for any, so the
+// kernels of the two share the GPU and fill each other's tails -- the member groups of spd_model_step one level up, where no
+// stream has to be forked and joined around every step of a host that calls once per model step (measured at 64 members:
+// two models 0.28 ms per step through spd_parallel_step_begin / _end, one model 0.30, one model stepped as two stream groups
+// 0.34).  PYSPEEDY_AMD_DRIVER_SPLIT=0 keeps one model; =n splits from n members.
+size_t device_model_parts(size_t n) {
+    static const int split_from = [] {
+        const char *e = getenv("PYSPEEDY_AMD_DRIVER_SPLIT");
+        return e ? atoi(e) : 32;
+    }();
+    return (split_from > 0 && n >= static_cast<size_t>(split_from)) ? 2 : 1;
+}
+
+// Gather independent, initialised one-member models of ONE device that agree in their control blocks (the caller made the
+// class: same device, same n_months, same control container date) into one batched model.  *done = false when they turn out
+// not to be gatherable after all (then they are stepped as they are).
 int gather(const std::vector<std::shared_ptr<State>> &states, bool *done) {
     *done = false;
     const int n = static_cast<int>(states.size());
@@ -250,17 +309,14 @@ int gather(const std::vector<std::shared_ptr<State>> &states, bool *done) {
         if (b.device != states[0]->batch->device || b.n_months != states[0]->batch->n_months ||
             b.sst_anom_allocated != states[0]->batch->sst_anom_allocated)
             return SPD_OK;
-        for (int j = 0; j < i; ++j)
-            if (states[j]->batch == states[i]->batch) return SPD_OK;  // the same container twice
         spd_model_control mc;
         if (int rc = spd_model_get_control(b.model, &mc)) return rc;
         if (i == 0) first = mc;
         else if (std::memcmp(&mc, &first, sizeof(mc)) != 0) return SPD_OK;
     }
     if (first.sppt_on) return SPD_OK;  // (the SPPT generator is keyed by member ids of the model it was set up for)
-    if (hipSetDevice(states[0]->batch->device) != hipSuccess) return fail(SPD_E_DEVICE, "speedy driver: hipSetDevice failed");
     std::shared_ptr<Batch> big;
-    if (int rc = new_batch(n, &big)) return rc;
+    if (int rc = new_batch(n, states[0]->batch->device, &big)) return rc;
     if (states[0]->batch->sst_anom_allocated) {
         if (int rc = spd_model_init_sst_anom(big->model, states[0]->batch->n_months)) return rc;
         big->n_months = states[0]->batch->n_months;
@@ -290,8 +346,8 @@ int step_batch(Batch &b, const Control &c, std::vector<int32_t> &codes) {
         }
     if (hipSetDevice(b.device) != hipSuccess) return fail(SPD_E_DEVICE, "speedy driver: hipSetDevice failed");
     if (int rc = push_date(b, c)) return rc;
-    if (int rc = spd_model_step(b.model, 1, nullptr)) return rc;
-    return spd_model_check(b.model, 2, codes.data(), nullptr, nullptr);
+    if (int rc = spd_model_step(b.model, 1, b.stream)) return rc;
+    return spd_model_check(b.model, 2, codes.data(), nullptr, b.stream);
 }
 
 int table_values(const RegVar &v, spd_handle ctx, std::vector<double> &out64, std::vector<float> &out32) {
@@ -344,23 +400,90 @@ extern "C" {
 // ---------------------------------------------------------------------------------------------------------------------
 // ModelState
 // ---------------------------------------------------------------------------------------------------------------------
-int spd_modelstate_init(int64_t *state_cnt) {
-    if (!state_cnt) return fail(SPD_E_ARG, "spd_modelstate_init: null argument");
-    return spd_modelstate_init_ensemble(state_cnt, 1);
-}
+// the n members that share a device live in one device model up to 31 members and in two from 32 up (plan_step has the why)
+static int make_device_containers(int64_t *state_cnts, int n, int device);
 
-int spd_modelstate_init_ensemble(int64_t *state_cnts, int32_t n_members) {
-    if (!state_cnts || n_members < 1) return fail(SPD_E_ARG, "spd_modelstate_init_ensemble: bad argument");
-    LOCK;
+static int make_containers(int64_t *state_cnts, int n, int device) {
     std::shared_ptr<Batch> b;
-    if (int rc = new_batch(n_members, &b)) return rc;
-    for (int i = 0; i < n_members; ++i) {
+    if (int rc = new_batch(n, device, &b)) return rc;
+    for (int i = 0; i < n; ++i) {
         auto st = std::make_shared<State>();
         st->batch = b;
         st->member = i;
         state_cnts[i] = g_next++;
         g_states[state_cnts[i]] = st;
     }
+    return SPD_OK;
+}
+
+static int make_device_containers(int64_t *state_cnts, int n, int device) {
+    const int parts = static_cast<int>(device_model_parts(static_cast<size_t>(n)));
+    for (int part = 0, first = 0; part < parts; ++part) {
+        const int count = n / parts + (part < n % parts ? 1 : 0);
+        if (int rc = make_containers(state_cnts + first, count, device)) return rc;
+        first += count;
+    }
+    return SPD_OK;
+}
+
+int spd_modelstate_init(int64_t *state_cnt) {
+    if (!state_cnt) return fail(SPD_E_ARG, "spd_modelstate_init: null argument");
+    LOCK;
+    int dev = 0;
+    const int k = placement_devices();
+    if (k > 0) dev = static_cast<int>(g_place_counter++ % k);  // one process over k devices: round-robin in creation order
+    else if (int rc = current_device(&dev)) return rc;
+    return make_containers(state_cnt, 1, dev);
+}
+
+int spd_modelstate_init_on(int64_t *state_cnt, int32_t device) {
+    if (!state_cnt) return fail(SPD_E_ARG, "spd_modelstate_init_on: null argument");
+    if (device < 0 || device >= device_count()) return fail(SPD_E_ARG, "spd_modelstate_init_on: no such HIP device");
+    LOCK;
+    return make_containers(state_cnt, 1, device);
+}
+
+int spd_modelstate_init_ensemble(int64_t *state_cnts, int32_t n_members) {
+    if (!state_cnts || n_members < 1) return fail(SPD_E_ARG, "spd_modelstate_init_ensemble: bad argument");
+    LOCK;
+    const int k = placement_devices();
+    if (k <= 1) {
+        int dev = 0;
+        if (k == 0) {
+            if (int rc = current_device(&dev)) return rc;
+        }
+        return make_device_containers(state_cnts, n_members, dev);
+    }
+    // block partition: member e on device e k / n, one batched model per device
+    for (int d = 0, first = 0; d < k; ++d) {
+        int last = first;
+        while (last < n_members && static_cast<long>(last) * k / n_members == d) ++last;
+        if (last > first)
+            if (int rc = make_device_containers(state_cnts + first, last - first, d)) return rc;
+        first = last;
+    }
+    return SPD_OK;
+}
+
+int spd_device_count(int32_t *n_devices) {
+    if (!n_devices) return fail(SPD_E_ARG, "spd_device_count: null argument");
+    *n_devices = device_count();
+    return SPD_OK;
+}
+
+int spd_set_device_placement(int32_t n_devices) {
+    if (n_devices < 0 || n_devices > device_count()) return fail(SPD_E_ARG, "spd_set_device_placement: more devices than the process can see");
+    LOCK;
+    g_place_ndev = n_devices;
+    g_place_counter = 0;
+    return SPD_OK;
+}
+
+int spd_modelstate_device(int64_t state_cnt, int32_t *device) {
+    LOCK;
+    auto st = state_of(state_cnt);
+    if (!st || !device) return fail(SPD_E_ARG, "spd_modelstate_device: not a live state container");
+    *device = st->batch->device;
     return SPD_OK;
 }
 
@@ -457,13 +580,31 @@ int spd_init(int64_t state_cnt, int64_t control_cnt, int32_t *error_code) {
     std::shared_ptr<Batch> b = st->batch;
     if (hipSetDevice(b->device) != hipSuccess) return fail(SPD_E_DEVICE, "spd_init: hipSetDevice failed");
     const int32_t *d = c.start.ymdhm;
+    if (b->members > 1) {
+        // A member of a batched model.  The batch has ONE date and step counter: it takes them when its last member has been
+        // initialised, and all members must have been given the same start date.  A member that is initialised again after
+        // the batch is complete, or with another start date than the members before it, leaves the batch first.
+        bool any = false, all = true;
+        for (int i = 0; i < b->members; ++i) {
+            any = any || b->initialized[i];
+            all = all && b->initialized[i];
+        }
+        spd_model_control mc;
+        if (int rc = spd_model_get_control(b->model, &mc)) return rc;
+        const bool same_start = !any || (mc.year == d[0] && mc.month == d[1] && mc.day == d[2] && mc.hour == d[3] && mc.minute == d[4] &&
+                                         mc.current_step == 0);
+        if (all || !same_start) {
+            if (int rc = split_batch(b)) return rc;
+            b = st->batch;
+        }
+    }
     if (b->members == 1) {
         if (int rc = spd_model_init(b->model, d[0], d[1], d[2], d[3], d[4], nullptr)) return rc;
     } else {
-        // a member of a batched model: initialise a scratch one-member model from this member's boundary fields and copy the
-        // resulting state into the member's slot; the batch takes its date when its last member has been initialised
+        // initialise a scratch one-member model from this member's boundary fields and copy the resulting state into the
+        // member's slot
         std::shared_ptr<Batch> scratch;
-        if (int rc = new_batch(1, &scratch)) return rc;
+        if (int rc = new_batch(1, b->device, &scratch)) return rc;
         int rc = SPD_OK;
         if (b->sst_anom_allocated) rc = spd_model_init_sst_anom(scratch->model, b->n_months);
         spd_model_control mc;
@@ -474,6 +615,7 @@ int spd_init(int64_t state_cnt, int64_t control_cnt, int32_t *error_code) {
         if (rc == SPD_OK) rc = spd_model_init(scratch->model, d[0], d[1], d[2], d[3], d[4], nullptr);
         if (rc == SPD_OK) rc = spd_model_copy_member(b->model, st->member, scratch->model, 0, nullptr);
         if (rc == SPD_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(SPD_E_DEVICE, "spd_init: device error");
+        // (date, step counter 0 and the CO2 reference: the same values for every member of the batch, see above)
         if (rc == SPD_OK) rc = spd_model_mark_initialized(b->model, 0, d[0], d[1], d[2], d[3], d[4]);
         if (rc == SPD_OK) rc = spd_model_set_time_step(b->model, 2 * kDelt);
         if (rc != SPD_OK) return rc;  // (the scratch model dies at the end of this block)
@@ -490,10 +632,12 @@ struct StepGroup {
     std::shared_ptr<Batch> batch;
     std::vector<int> positions;  // indices into the argument list
     std::vector<int> members;    // member index of each position
-    std::vector<Control *> controls;    // valid during the call that planned the step
-    std::vector<int64_t> control_ids;   // ... and how to find them again later (begin / end form)
+    std::vector<int64_t> control_ids;   // the control containers, looked up again whenever the lock was given up
     Control before;              // model date before the step
-    int slot = -1;               // pending check (begin / end form); -1: the members were not initialised
+    Control advanced;            // ... and after it (valid when slot >= 0)
+    int slot = -1;               // pending check; -1: the members were not initialised; -2: the step could not be issued
+    int rc = SPD_OK;             // status of this group's device calls
+    std::string error;           // ... and its message
 };
 struct PendingStep {
     int n = 0;
@@ -501,8 +645,20 @@ struct PendingStep {
 };
 std::map<int64_t, PendingStep> g_pending;
 
-// resolve the containers, gather independent one-member models into one batch where possible, split batches that are asked
-// for in a different grouping, and return the groups to step
+// Host-side order of the device work of the multi-group paths, for tests: (kind, group) pairs, kind 1 = step + check
+// enqueued, 2 = waiting for the check of that group started, 3 = finished.  Off unless spd_driver_trace(1) was called.
+bool g_trace_on = false;
+std::vector<int32_t> g_trace;
+static void trace(int kind, int group) {
+    if (!g_trace_on) return;
+    std::lock_guard<std::recursive_mutex> lock(g_mutex);
+    g_trace.push_back(kind);
+    g_trace.push_back(group);
+}
+
+// Resolve the containers; gather independent one-member models into batched models -- per device and per set of members that
+// agree in date, control flags and anomaly length, so one odd member or a second device never de-batches the rest --; split
+// batches that are asked for in a different grouping; return the groups to step.
 static int plan_step(const int64_t *state_cnts, const int64_t *control_cnts, int n, std::vector<StepGroup> &groups, const char *who) {
     std::vector<std::shared_ptr<State>> states(n);
     std::vector<Control *> controls(n);
@@ -511,16 +667,38 @@ static int plan_step(const int64_t *state_cnts, const int64_t *control_cnts, int
         auto ci = g_controls.find(control_cnts[i]);
         if (!states[i] || ci == g_controls.end()) return fail(SPD_E_ARG, std::string(who) + ": not a live state / control container");
         controls[i] = &ci->second;
+        for (int j = 0; j < i; ++j)
+            if (states[j] == states[i]) return fail(SPD_E_ARG, std::string(who) + ": the same state container twice");
     }
-    bool dates_agree = true;
-    for (int i = 1; i < n; ++i) dates_agree = dates_agree && same_date(*controls[0], *controls[i]);
-    // n independent one-member models -> one batched model (once; later calls find them batched)
-    if (n > 1 && dates_agree) {
-        bool singles = true;
-        for (int i = 0; i < n; ++i) singles = singles && states[i]->batch->members == 1;
-        if (singles) {
-            bool done = false;
-            if (int rc = gather(states, &done)) return rc;
+    // independent one-member models -> batched models (once; later calls find them batched)
+    std::vector<char> classed(n, 0);
+    for (int i = 0; i < n; ++i) {
+        if (classed[i] || states[i]->batch->members != 1 || !states[i]->batch->initialized[0]) continue;
+        std::vector<std::shared_ptr<State>> cls;
+        for (int j = i; j < n; ++j) {
+            const Batch &bi = *states[i]->batch, &bj = *states[j]->batch;
+            if (classed[j] || bj.members != 1 || !bj.initialized[0] || bj.device != bi.device || bj.n_months != bi.n_months ||
+                bj.sst_anom_allocated != bi.sst_anom_allocated || !same_date(*controls[i], *controls[j]))
+                continue;
+            spd_model_control a, b;
+            if (int rc = spd_model_get_control(bi.model, &a)) return rc;
+            if (int rc = spd_model_get_control(bj.model, &b)) return rc;
+            if (std::memcmp(&a, &b, sizeof(a)) != 0) continue;
+            classed[j] = 1;
+            cls.push_back(states[j]);
+        }
+        // From 32 members up a class becomes TWO device models: the call enqueues both before it waits for either (below), so
+        // their kernels share the GPU and fill each other's tails -- the member groups of spd_model_step, one level up,
+        // where no stream has to be forked and joined at every step of a host that calls once per model step.
+        const size_t parts = device_model_parts(cls.size());
+        for (size_t part = 0, first = 0; part < parts; ++part) {
+            const size_t count = cls.size() / parts + (part < cls.size() % parts ? 1 : 0);
+            std::vector<std::shared_ptr<State>> sub(cls.begin() + first, cls.begin() + first + count);
+            first += count;
+            if (sub.size() > 1) {
+                bool done = false;
+                if (int rc = gather(sub, &done)) return rc;
+            }
         }
     }
     std::vector<char> handled(n, 0);
@@ -531,11 +709,7 @@ static int plan_step(const int64_t *state_cnts, const int64_t *control_cnts, int
         for (int j = i; j < n; ++j)
             if (states[j]->batch == b) mine.push_back(j);
         bool whole = static_cast<int>(mine.size()) == b->members;
-        std::vector<char> seen(b->members, 0);
-        for (int j : mine) {
-            whole = whole && !seen[states[j]->member] && same_date(*controls[i], *controls[j]);
-            seen[states[j]->member] = 1;
-        }
+        for (int j : mine) whole = whole && same_date(*controls[i], *controls[j]);
         if (!whole) {  // a different grouping than the batch: take it apart and step this container on its own
             if (int rc = split_batch(b)) return rc;
             b = states[i]->batch;
@@ -546,11 +720,11 @@ static int plan_step(const int64_t *state_cnts, const int64_t *control_cnts, int
         g.positions = mine;
         for (int j : mine) {
             g.members.push_back(states[j]->member);
-            g.controls.push_back(controls[j]);
             g.control_ids.push_back(control_cnts[j]);
             handled[j] = 1;
         }
         g.before = *controls[i];
+        g.advanced = g.before;
         groups.push_back(g);
     }
     return SPD_OK;
@@ -562,27 +736,104 @@ static bool all_initialized(const Batch &b) {
     return true;
 }
 
+// Model error code of a member whose step could not be issued or checked at all (a device or argument error of the call,
+// not one of the reference's three codes): error_codes.f90 stops at -2.
+constexpr int32_t kStepFailed = -3;
+
+// Enqueue the step and the range check of one group on its model's stream; nothing waits.  (lock held)
+static void issue_group(StepGroup &g) {
+    Batch &b = *g.batch;
+    if (!all_initialized(b)) return;  // slot stays -1: E_STATE_NOT_INITIALIZED
+    int rc = SPD_OK;
+    if (hipSetDevice(b.device) != hipSuccess) rc = fail(SPD_E_DEVICE, "speedy driver: hipSetDevice failed");
+    if (rc == SPD_OK && spd_model_checks_in_flight(b.model) >= 2)  // (refuse BEFORE the step: a step without its check is no step)
+        rc = fail(SPD_E_ARG, "speedy driver: two steps of this device model are in flight already; end one with spd_parallel_step_end first");
+    if (rc == SPD_OK) rc = push_date(b, g.before);
+    if (rc == SPD_OK) rc = spd_model_step(b.model, 1, b.stream);
+    if (rc == SPD_OK) {
+        g.slot = spd_model_check_begin(b.model, 2, b.stream);
+        if (g.slot < 0) rc = g.slot;
+    }
+    if (rc == SPD_OK) rc = pull_date(b, g.advanced);
+    if (rc != SPD_OK) {
+        g.rc = rc;
+        g.error = spd_last_error();
+        if (g.slot >= 0) {  // (the check is in flight: take it back so that the slot is free again)
+            std::vector<int32_t> scratch(b.members);
+            (void)spd_model_check_end(b.model, g.slot, scratch.data());
+        }
+        g.slot = -2;
+    }
+}
+
+// Wait for the check of one group.  (lock NOT held: other host threads may work on other containers meanwhile)
+static void collect_group(StepGroup &g, std::vector<int32_t> &codes) {
+    Batch &b = *g.batch;
+    codes.assign(b.members, g.slot == -2 ? kStepFailed : -1);
+    if (g.slot < 0) return;
+    int rc = SPD_OK;
+    if (hipSetDevice(b.device) != hipSuccess) rc = fail(SPD_E_DEVICE, "speedy driver: hipSetDevice failed");
+    if (rc == SPD_OK) rc = spd_model_check_end(b.model, g.slot, codes.data());
+    if (rc != SPD_OK) {
+        g.rc = rc;
+        g.error = spd_last_error();
+        codes.assign(b.members, kStepFailed);
+    }
+}
+
+// Hand the codes out and settle the dates: speedy.f90:57-71 advances the date only after a successful check.  (lock held)
+// dates_ran_ahead: the begin / end form moved the dates at _begin already (and a later _begin may have moved them again): only
+// a member whose check failed gets the date from before its step back.
+static void settle_group(const StepGroup &g, const std::vector<int32_t> &codes, int32_t *error_codes, bool dates_ran_ahead) {
+    for (size_t k = 0; k < g.positions.size(); ++k) {
+        const int32_t code = codes[g.members[k]];
+        error_codes[g.positions[k]] = code;
+        auto ci = g_controls.find(g.control_ids[k]);
+        if (ci == g_controls.end() || (code == 0 && dates_ran_ahead)) continue;
+        const Control &to = code == 0 ? g.advanced : g.before;
+        ci->second.now = to.now;
+        ci->second.month_idx = to.month_idx;
+    }
+}
+
+// the status of the call: the first group that failed (its message becomes spd_last_error again); the others were stepped
+static int first_failure(const std::vector<StepGroup> &groups) {
+    for (const StepGroup &g : groups)
+        if (g.rc != SPD_OK) return fail(g.rc, g.error);
+    return SPD_OK;
+}
+
 int spd_parallel_step(const int64_t *state_cnts, const int64_t *control_cnts, int32_t *error_codes, int32_t n) {
     if (n < 0 || (n > 0 && (!state_cnts || !control_cnts || !error_codes))) return fail(SPD_E_ARG, "spd_parallel_step: bad argument");
-    LOCK;
+    std::unique_lock<std::recursive_mutex> lock(g_mutex);
     std::vector<StepGroup> groups;
     if (int rc = plan_step(state_cnts, control_cnts, n, groups, "spd_parallel_step")) return rc;
-    for (StepGroup &g : groups) {
+    if (groups.size() == 1) {  // one device model (the usual case): step, check and wait in one go
+        StepGroup &g = groups[0];
         std::vector<int32_t> codes;
         if (int rc = step_batch(*g.batch, g.before, codes)) return rc;
-        Control advanced = g.before;
         if (all_initialized(*g.batch))
-            if (int rc = pull_date(*g.batch, advanced)) return rc;
-        for (size_t k = 0; k < g.positions.size(); ++k) {
-            const int32_t code = codes[g.members[k]];
-            error_codes[g.positions[k]] = code;
-            if (code == 0) {  // speedy.f90:57-71: the date only advances after a successful check
-                g.controls[k]->now = advanced.now;
-                g.controls[k]->month_idx = advanced.month_idx;
-            }
-        }
+            if (int rc = pull_date(*g.batch, g.advanced)) return rc;
+        settle_group(g, codes, error_codes, false);
+        return SPD_OK;
     }
-    return SPD_OK;
+    // Several device models -- one per GPU of a one-process ensemble, or members that could not be batched --: every
+    // group's step and check are enqueued before the host waits for any of them, so the devices (and the models that share
+    // one) work side by side; a group that fails does not keep the others from being stepped.
+    for (size_t i = 0; i < groups.size(); ++i) {
+        issue_group(groups[i]);
+        trace(1, static_cast<int>(i));
+    }
+    lock.unlock();
+    std::vector<std::vector<int32_t>> codes(groups.size());
+    for (size_t i = 0; i < groups.size(); ++i) {
+        trace(2, static_cast<int>(i));
+        collect_group(groups[i], codes[i]);
+        trace(3, static_cast<int>(i));
+    }
+    lock.lock();
+    for (size_t i = 0; i < groups.size(); ++i) settle_group(groups[i], codes[i], error_codes, false);
+    return first_failure(groups);
 }
 
 int spd_parallel_step_begin(const int64_t *state_cnts, const int64_t *control_cnts, int32_t n, int64_t *token) {
@@ -591,19 +842,16 @@ int spd_parallel_step_begin(const int64_t *state_cnts, const int64_t *control_cn
     PendingStep p;
     p.n = n;
     if (int rc = plan_step(state_cnts, control_cnts, n, p.groups, "spd_parallel_step_begin")) return rc;
-    for (StepGroup &g : p.groups) {
-        Batch &b = *g.batch;
-        if (!all_initialized(b)) continue;  // slot stays -1: E_STATE_NOT_INITIALIZED at _end
-        if (hipSetDevice(b.device) != hipSuccess) return fail(SPD_E_DEVICE, "spd_parallel_step_begin: hipSetDevice failed");
-        if (int rc = push_date(b, g.before)) return rc;
-        if (int rc = spd_model_step(b.model, 1, nullptr)) return rc;
-        g.slot = spd_model_check_begin(b.model, 2, nullptr);
-        if (g.slot < 0) return g.slot;
-        Control advanced = g.before;
-        if (int rc = pull_date(b, advanced)) return rc;
-        for (Control *c : g.controls) {
-            c->now = advanced.now;
-            c->month_idx = advanced.month_idx;
+    for (size_t i = 0; i < p.groups.size(); ++i) {
+        StepGroup &g = p.groups[i];
+        issue_group(g);  // (a group that cannot be issued reports at _end; the others go ahead)
+        trace(1, static_cast<int>(i));
+        if (g.slot < 0) continue;
+        for (int64_t id : g.control_ids) {  // the dates run ahead of the check; _end puts a failed member's date back
+            auto ci = g_controls.find(id);
+            if (ci == g_controls.end()) continue;
+            ci->second.now = g.advanced.now;
+            ci->second.month_idx = g.advanced.month_idx;
         }
     }
     *token = g_next++;
@@ -612,26 +860,74 @@ int spd_parallel_step_begin(const int64_t *state_cnts, const int64_t *control_cn
 }
 
 int spd_parallel_step_end(int64_t token, int32_t *error_codes) {
-    LOCK;
+    std::unique_lock<std::recursive_mutex> lock(g_mutex);
     auto it = g_pending.find(token);
     if (it == g_pending.end() || !error_codes) return fail(SPD_E_ARG, "spd_parallel_step_end: not a pending step");
     PendingStep p = std::move(it->second);
     g_pending.erase(it);
-    for (StepGroup &g : p.groups) {
-        std::vector<int32_t> codes(g.batch->members, -1);
-        if (g.slot >= 0)
-            if (int rc = spd_model_check_end(g.batch->model, g.slot, codes.data())) return rc;
-        for (size_t k = 0; k < g.positions.size(); ++k) {
-            const int32_t code = codes[g.members[k]];
-            error_codes[g.positions[k]] = code;
-            auto ci = g_controls.find(g.control_ids[k]);
-            if (code != 0 && g.slot >= 0 && ci != g_controls.end()) {  // the reference would not have advanced this date
-                ci->second.now = g.before.now;
-                ci->second.month_idx = g.before.month_idx;
-            }
-        }
+    lock.unlock();
+    std::vector<std::vector<int32_t>> codes(p.groups.size());
+    for (size_t i = 0; i < p.groups.size(); ++i) {
+        trace(2, static_cast<int>(i));
+        collect_group(p.groups[i], codes[i]);
+        trace(3, static_cast<int>(i));
     }
+    lock.lock();
+    for (size_t i = 0; i < p.groups.size(); ++i) {
+        StepGroup &g = p.groups[i];
+        if (g.slot == -1) {  // not initialised: the dates were never touched
+            for (size_t k = 0; k < g.positions.size(); ++k) error_codes[g.positions[k]] = -1;
+            continue;
+        }
+        settle_group(g, codes[i], error_codes, true);
+    }
+    return first_failure(p.groups);
+}
+
+// The shared boundary fields (orography, masks, albedo, vegetation, the monthly climatologies and -- when both have
+// the same length -- the SST anomalies) of container `root` into every other container of the list, device to device: the
+// one exchange of a sharded ensemble, for a host that keeps all members in one process.  (One process per GPU: the same
+// broadcast is ensemble.broadcast_boundary_conditions over RCCL.)
+int spd_broadcast_boundary(const int64_t *state_cnts, int32_t n, int32_t root) {
+    if (n < 1 || !state_cnts || root < 0 || root >= n) return fail(SPD_E_ARG, "spd_broadcast_boundary: bad argument");
+    static const char *const kBoundary[] = {"orog", "fmask_orig", "alb0", "veg_high", "veg_low", "stl12", "snowd12", "soil_wc_l1",
+                                            "soil_wc_l2", "soil_wc_l3", "sst12", "sea_ice_frac12", "sst_anom"};
+    LOCK;
+    auto src = state_of(state_cnts[root]);
+    if (!src) return fail(SPD_E_ARG, "spd_broadcast_boundary: not a live state container");
+    std::vector<int> devices;
+    for (int i = 0; i < n; ++i) {
+        if (i == root) continue;
+        auto dst = state_of(state_cnts[i]);
+        if (!dst) return fail(SPD_E_ARG, "spd_broadcast_boundary: not a live state container");
+        const bool anom = dst->batch->sst_anom_allocated == src->batch->sst_anom_allocated && dst->batch->n_months == src->batch->n_months;
+        if (int rc = spd_model_copy_vars(dst->batch->model, dst->member, src->batch->model, src->member, kBoundary, anom ? 13 : 12,
+                                         nullptr))
+            return rc;
+        devices.push_back(dst->batch->device);
+    }
+    for (int d : devices)  // (the call is synchronous, like every call of this interface)
+        if (hipSetDevice(d) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+            return fail(SPD_E_DEVICE, "spd_broadcast_boundary: device error");
     return SPD_OK;
+}
+
+int spd_driver_trace(int32_t on) {
+    LOCK;
+    g_trace_on = on != 0;
+    g_trace.clear();
+    return SPD_OK;
+}
+
+int spd_driver_trace_read(int32_t *pairs, int32_t capacity) {
+    LOCK;
+    const int n = static_cast<int>(g_trace.size() / 2);
+    if (pairs)
+        for (int i = 0; i < n && i < capacity; ++i) {
+            pairs[2 * i] = g_trace[2 * i];
+            pairs[2 * i + 1] = g_trace[2 * i + 1];
+        }
+    return n;
 }
 
 int spd_step(int64_t state_cnt, int64_t control_cnt, int32_t *error_code) {

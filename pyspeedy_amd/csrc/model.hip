@@ -95,6 +95,7 @@ struct spd_model {
     int *d_err_slot[2] = {nullptr, nullptr};
     hipEvent_t err_event[2] = {nullptr, nullptr};
     int next_slot = 0;
+    bool slot_busy[2] = {false, false};  // begun and not yet ended
     double air_absortivity_co2 = 6.0;  // model_state_def.py:320 default
     // device copies of the dt-dependent tables (re-uploaded by set_time_step)
     // surface / coupler state, calendar and run control (do_single_step, speedy.f90:20-74)
@@ -308,10 +309,12 @@ int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
     if (const char *env = getenv("PYSPEEDY_AMD_COUPLER_IN_SPECTRAL")) m->coupler_in_spectral = atoi(env) != 0;
     if (const char *env = getenv("PYSPEEDY_AMD_SPECTRAL_EARLY")) m->spectral_early = atoi(env);
     if (const char *env = getenv("PYSPEEDY_AMD_FOLD_GEO")) m->fold_geo = atoi(env) != 0;
-    // PYSPEEDY_AMD_CHUNKS = 2 or 3 steps the members in that many groups on separate streams: measured -6 % / -8 % per step
-    // at 64 members (4 groups: +7 %).  Off by default: with overlapping launches the duration of a single kernel -- what the
-    // roofline accounting of bench.py and the committed rocprof summaries are about -- is no longer attributable to it.
-    m->nchunks = 1;
+    // Member groups on separate streams (spd_model_step): two groups from 32 members up -- measured -7.6 % per step at 64
+    // members, -1 % at 16, +6 % at 8 (nothing to fill there); 3 groups are no better, 4 are slower.  PYSPEEDY_AMD_CHUNKS = 1 ... 4
+    // or spd_model_set_option("member_groups") override.  While spd_model_profile is on the step is issued as ONE group on
+    // the caller's stream: with overlapping launches the duration of a kernel is not its own, and per-kernel durations are
+    // what the profile is for.
+    m->nchunks = nmembers >= 32 ? 2 : 1;
     if (const char *env = getenv("PYSPEEDY_AMD_CHUNKS")) m->nchunks = atoi(env);
     if (m->nchunks < 1) m->nchunks = 1;
     if (m->nchunks > 4) m->nchunks = 4;
@@ -503,11 +506,26 @@ int spd_model_get(spd_model_handle m, const char *name, int member, void *host, 
     return xfer(m, name, member, host, bytes, false);
 }
 
+// The address is that of the array as it stands NOW and stays valid for the life of the model.  Two things follow for a caller
+// that keeps it across steps (include/pyspeedy_amd.h has the contract):
+//  * "phi": with the geopotential fold (launches of up to 8 members) the step alternates between two buffers; handing out the
+//    address pins the geopotential to the buffer in use -- the fold is switched off for this model from here on -- so that
+//    the address keeps showing what the registry's phi is after every later step;
+//  * the model caches what it derived from the state (the look-ahead geopotential, the day's interpolated climatologies):
+//    they are dropped here, and a caller that writes through a pointer it took EARLIER must call spd_model_invalidate.
 void *spd_model_device_ptr(spd_model_handle m, const char *name) {
     if (!m || !name) return nullptr;
     auto it = m->reg.find(name);
+    if (it == m->reg.end()) return nullptr;
     m->surf_cache_valid = m->phi_ahead = false;  // the caller may write through the pointer
-    return it == m->reg.end() ? nullptr : it->second.ptr;
+    if (it->first == "phi") m->fold_geo = false;
+    return it->second.ptr;
+}
+
+int spd_model_invalidate(spd_model_handle m) {
+    if (!m) return m_fail(SPD_E_ARG, "spd_model_invalidate: null model");
+    m->surf_cache_valid = m->phi_ahead = false;
+    return SPD_OK;
 }
 
 int spd_model_set_co2(spd_model_handle m, double air_absortivity_co2) {
@@ -676,6 +694,8 @@ int spd_model_check_begin(spd_model_handle m, int time_level, void *stream) {
     if (time_level < 1 || time_level > 2) return m_fail(SPD_E_ARG, "spd_model_check_begin: time level is 1 or 2");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int slot = m->next_slot;
+    if (m->slot_busy[slot])
+        return m_fail(SPD_E_ARG, "spd_model_check_begin: two checks are in flight already; end one with spd_model_check_end first");
     if (!m->h_err[slot]) {
         void *p = nullptr;
         M_HIP(hipHostMalloc(&p, sizeof(int) * m->M, hipHostMallocDefault));
@@ -689,13 +709,20 @@ int spd_model_check_begin(spd_model_handle m, int time_level, void *stream) {
     if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_check_begin: ") + hipGetErrorString(e));
     M_HIP(hipMemcpyAsync(m->h_err[slot], m->d_err_slot[slot], sizeof(int) * m->M, hipMemcpyDeviceToHost, s));
     M_HIP(hipEventRecord(m->err_event[slot], s));
+    m->slot_busy[slot] = true;
     m->next_slot = 1 - slot;
     return slot;
 }
 
+int spd_model_checks_in_flight(spd_model_handle m) {
+    if (!m) return m_fail(SPD_E_ARG, "spd_model_checks_in_flight: null model");
+    return (m->slot_busy[0] ? 1 : 0) + (m->slot_busy[1] ? 1 : 0);
+}
+
 int spd_model_check_end(spd_model_handle m, int slot, int32_t *error_codes_host) {
     if (!m || !error_codes_host) return m_fail(SPD_E_ARG, "spd_model_check_end: null argument");
-    if (slot < 0 || slot > 1 || !m->err_event[slot]) return m_fail(SPD_E_ARG, "spd_model_check_end: no check was begun in this slot");
+    if (slot < 0 || slot > 1 || !m->slot_busy[slot]) return m_fail(SPD_E_ARG, "spd_model_check_end: no check was begun in this slot");
+    m->slot_busy[slot] = false;
     M_HIP(hipEventSynchronize(m->err_event[slot]));
     std::memcpy(error_codes_host, m->h_err[slot], sizeof(int) * m->M);
     return SPD_OK;
@@ -852,7 +879,9 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
     // Members never exchange data, so the step is issued group by group on separate streams: every group runs the same
     // six launches on its own members, and the groups' kernels overlap on the GPU.  The caller's stream orders the whole call:
     // the group streams start after everything already enqueued on it, and it continues after all of them.
-    const int G = (m->split_dyn_physics || m->sppt_on) ? 1 : m->nchunks;
+    // (a call of ONE step forks and joins the group streams around that step -- two dependent cross-stream hand-overs per
+    // step cost more than the overlap gains: measured +12 % at 64 members through spd_parallel_step -- so it is issued serially)
+    const int G = (m->split_dyn_physics || m->sppt_on || m->profile > 0 || nsteps == 1) ? 1 : m->nchunks;
     hipStream_t gs[4] = {s, nullptr, nullptr, nullptr};
     if (G > 1) {
         M_HIP(hipSetDevice(m->ctx->device));
@@ -867,6 +896,17 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
             M_HIP(hipStreamWaitEvent(gs[g], m->ev_start, 0));
         }
     }
+    // whatever way this function is left, the caller's stream continues behind everything the group streams were given
+    struct Join {
+        hipStream_t s, *gs;
+        hipEvent_t *ev;
+        int G;
+        ~Join() {
+            if (G > 1)
+                for (int g = 0; g < G; ++g)
+                    if (hipEventRecord(ev[g], gs[g]) == hipSuccess) (void)hipStreamWaitEvent(s, ev[g], 0);
+        }
+    } join{s, gs, m->cev, G};
     const int base = m->M / G, extra = m->M % G;
     int rc = SPD_OK;
     for (int it = 0; it < nsteps && rc == SPD_OK; ++it) {
@@ -908,11 +948,6 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
         m->cal = next;
         m->surf_cache_valid = true;
     }
-    if (G > 1)
-        for (int g = 0; g < G; ++g) {
-            M_HIP(hipEventRecord(m->cev[g], gs[g]));
-            M_HIP(hipStreamWaitEvent(s, m->cev[g], 0));
-        }
     return rc;
 }
 
@@ -1052,6 +1087,7 @@ int spd_model_set_option(spd_model_handle m, const char *name, int32_t value) {
     else if (key == "coupler_in_spectral" && flag) m->coupler_in_spectral = value != 0;
     else if (key == "split_dyn" && flag) m->split_dyn_physics = value != 0;
     else if (key == "spectral_early" && value >= -1 && value <= 1) m->spectral_early = value;
+    else if (key == "member_groups" && value >= 1 && value <= 4) m->nchunks = value < m->M ? value : m->M;
     else return m_fail(SPD_E_ARG, "spd_model_set_option: unknown option or value out of range: " + key);
     return SPD_OK;
 }
@@ -1182,6 +1218,38 @@ int spd_model_copy_member(spd_model_handle dst, int di, spd_model_handle src, in
         const size_t b = kv.second.bytes_member;
         M_HIP(hipMemcpyAsync(static_cast<char *>(it->second.ptr) + b * di, static_cast<const char *>(kv.second.ptr) + b * si, b,
                              hipMemcpyDeviceToDevice, s));
+    }
+    return SPD_OK;
+}
+
+// Copy the named registry variables of member `si` of `src` into member `di` of `dst`; the two models may live on different
+// devices (then the bytes travel device to device: hipMemcpyPeerAsync, xGMI between the GPUs of a node).  Asynchronous on
+// `stream` (a stream of the DESTINATION device); both devices are synchronised first, as in spd_model_copy_member.
+int spd_model_copy_vars(spd_model_handle dst, int di, spd_model_handle src, int si, const char *const *names, int nnames,
+                        void *stream) {
+    if (!dst || !src || (nnames > 0 && !names)) return m_fail(SPD_E_ARG, "spd_model_copy_vars: null argument");
+    if (di < 0 || di >= dst->M || si < 0 || si >= src->M) return m_fail(SPD_E_ARG, "spd_model_copy_vars: member index out of range");
+    const int ddev = dst->ctx->device, sdev = src->ctx->device;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (sdev != ddev) {
+        M_HIP(hipSetDevice(sdev));
+        M_HIP(hipDeviceSynchronize());
+    }
+    M_HIP(hipSetDevice(ddev));
+    M_HIP(hipDeviceSynchronize());
+    dst->surf_cache_valid = dst->phi_ahead = false;
+    for (int i = 0; i < nnames; ++i) {
+        auto a = src->reg.find(names[i]), b = dst->reg.find(names[i]);
+        if (a == src->reg.end() || b == dst->reg.end())
+            return m_fail(SPD_E_ARG, std::string("spd_model_copy_vars: unknown variable '") + names[i] + "'");
+        if (a->second.bytes_member != b->second.bytes_member)
+            return m_fail(SPD_E_SIZE, std::string("spd_model_copy_vars: variable '") + names[i] + "' differs between the models");
+        const size_t n = a->second.bytes_member;
+        char *to = static_cast<char *>(b->second.ptr) + n * di;
+        const char *from = static_cast<const char *>(a->second.ptr) + n * si;
+        if (to == from) continue;
+        if (sdev == ddev) M_HIP(hipMemcpyAsync(to, from, n, hipMemcpyDeviceToDevice, s));
+        else M_HIP(hipMemcpyPeerAsync(to, ddev, from, sdev, n, s));
     }
     return SPD_OK;
 }

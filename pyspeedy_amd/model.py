@@ -98,7 +98,12 @@ class EnsembleModel:
 
     def device_view(self, name):
         """Zero-copy torch view [nmembers, *reversed reference shape] of a registry variable in HBM (C order == the
-        reference's Fortran order inside a member).  For on-device post-processing such as ensemble statistics."""
+        reference's Fortran order inside a member).  For on-device post-processing such as ensemble statistics.
+
+        The view stays valid for the life of the model (spd_model_device_ptr, include/pyspeedy_amd.h): after every later
+        step it shows the variable as that step left it.  Taking the view drops what the model had derived from the state;
+        WRITING through a view taken earlier must be followed by `invalidate()` before the next step.  A view of "phi"
+        pins the geopotential to one buffer (small ensembles lose the 1-3 % of the look-ahead geopotential)."""
         dtype, shape = (np.float64, self.WORK_ARRAYS[name]) if name in self.WORK_ARRAYS else self.shape(name)
         ptr = self._lib.spd_model_device_ptr(self._m, name.encode())
         if not ptr:
@@ -108,6 +113,11 @@ class EnsembleModel:
             __cuda_array_interface__ = {"shape": (self.nmembers,) + tuple(reversed(shape)),
                                         "typestr": np.dtype(dtype).str, "data": (int(ptr), False), "version": 2}
         return torch.as_tensor(_Blob(), device=self.sp.device)
+
+    def invalidate(self):
+        """The state was written through a device view taken earlier: drop what the model derived from it (look-ahead
+        geopotential, the day's interpolated climatologies)."""
+        check(self._lib.spd_model_invalidate(self._m), "spd_model_invalidate")
 
     def set_sppt(self, on=True, seed=0, first_member_id=0):
         """Switch the deterministic SPPT scheme (csrc/sppt.hip) on or off; `first_member_id` = global id of member 0 of
@@ -233,7 +243,8 @@ class EnsembleModel:
 
     def set_option(self, name, value):
         """A launch-plan switch of the live model by name (spd_model_set_option: diag_every_step, coupler_in_spectral,
-        spectral_early, split_dyn); none of them changes the state a step leaves behind.  ValueError for an unknown name."""
+        spectral_early, split_dyn, member_groups); none of them changes the state a step leaves behind.  ValueError for an
+        unknown name."""
         rc = self._lib.spd_model_set_option(self._m, name.encode(), int(value))
         if rc == _lib.SPD_E_ARG:
             raise ValueError("unknown option or value out of range: %s = %r" % (name, value))

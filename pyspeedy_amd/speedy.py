@@ -199,17 +199,21 @@ class Speedy:
             raise RuntimeError("The SPEEDY model was not initialized. Call the `set_bc` method to initialize the model.")
         self.current_date = self.start_date
         pending = None  # the range check of a step is collected after the next step has been enqueued (GPU never idles)
-        while self.current_date < self.end_date:
-            token = _speedy.parallel_step_begin([self._state_cnt], [self._control_cnt])
-            self._collect(pending)
-            pending = token
-            self.current_date += _DT_STEP
-            if _callbacks_due(callbacks, self):
-                self._collect(pending)
-                pending = None
-            for callback in callbacks:
-                callback(self)
-        self._collect(pending)
+        try:
+            while self.current_date < self.end_date:
+                token = _speedy.parallel_step_begin([self._state_cnt], [self._control_cnt])
+                previous, pending = pending, token
+                self._collect(previous)
+                self.current_date += _DT_STEP
+                if _callbacks_due(callbacks, self):
+                    previous, pending = pending, None
+                    self._collect(previous)
+                for callback in callbacks:
+                    callback(self)
+            previous, pending = pending, None
+            self._collect(previous)
+        finally:
+            self._drain(pending)  # (a step that was begun behind the one that failed: end it, its code no longer matters)
 
     @staticmethod
     def _collect(token):
@@ -218,6 +222,14 @@ class Speedy:
             if (codes < 0).any():
                 raise RuntimeError("".join("Member%d: %s\n" % (n, ERROR_CODES[int(c)]) for n, c in enumerate(codes))
                                    if len(codes) > 1 else ERROR_CODES[int(codes[0])])
+
+    @staticmethod
+    def _drain(token):
+        if token is not None:
+            try:
+                _speedy.parallel_step_end(token)
+            except Exception:
+                pass
 
     def grid2spectral(self):
         """Transform the grid u, v, t, q, ps and phi fields to the spectral domain."""
@@ -290,11 +302,20 @@ def _build_dataset(model, arrays, members, date):
 
 
 class SpeedyEns:
-    """Ensemble of Speedy members that live in one batched device model."""
+    """Ensemble of Speedy members that live in one batched device model -- or, with `devices=k`, in one batched model on
+    each of the GPUs 0 .. k-1 of this process (members in blocks, member e of n on device e k / n): `run` then drives all
+    devices with one parallel_step per model step.  `devices=None` keeps the process-wide placement
+    (speedy_driver.set_device_placement / PYSPEEDY_AMD_DEVICES; by default the current device)."""
 
-    def __init__(self, num_of_members, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 2)):
+    def __init__(self, num_of_members, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 2), devices=None):
         self.n_members = int(num_of_members)
-        cnts = _speedy.modelstate_init_ensemble(self.n_members)
+        if devices is not None:
+            _speedy.set_device_placement(int(devices))
+        try:
+            cnts = _speedy.modelstate_init_ensemble(self.n_members)
+        finally:
+            if devices is not None:
+                _speedy.set_device_placement(0)
         self.members = [Speedy(start_date=start_date, end_date=end_date, member=i, _state_cnt=c) for i, c in enumerate(cnts)]
         self.current_date = self.members[0].current_date
 
@@ -315,7 +336,7 @@ class SpeedyEns:
         variables = DEFAULT_OUTPUT_VARS if variables is None else variables
         for var in variables:
             _exportable(var)
-        arrays = _speedy.ensemble_grid_arrays(self.members[0]._state_cnt, list(variables))
+        arrays = _speedy.ensemble_grid_arrays([m._state_cnt for m in self], list(variables))
         return _build_dataset(self.members[0], arrays, [m.member_id for m in self], self.current_date)
 
     def run(self, callbacks=None):
@@ -328,19 +349,23 @@ class SpeedyEns:
             if not member._initialized_bc:
                 raise RuntimeError("The SPEEDY model was not initialized. Call the `set_bc` method of every member.")
         pending = None
-        while self.current_date < end_date:
-            token = _speedy.parallel_step_begin(state_cnts, control_cnts)
-            Speedy._collect(pending)
-            pending = token
-            self.current_date += _DT_STEP
-            for member in self:
-                member.current_date = self.current_date
-            if _callbacks_due(callbacks, self):
-                Speedy._collect(pending)
-                pending = None
-            for callback in callbacks:
-                callback(self)
-        Speedy._collect(pending)
+        try:
+            while self.current_date < end_date:
+                token = _speedy.parallel_step_begin(state_cnts, control_cnts)
+                previous, pending = pending, token
+                Speedy._collect(previous)
+                self.current_date += _DT_STEP
+                for member in self:
+                    member.current_date = self.current_date
+                if _callbacks_due(callbacks, self):
+                    previous, pending = pending, None
+                    Speedy._collect(previous)
+                for callback in callbacks:
+                    callback(self)
+            previous, pending = pending, None
+            Speedy._collect(previous)
+        finally:
+            Speedy._drain(pending)
 
     def get_current_step(self):
         return self.members[0]["current_step"]

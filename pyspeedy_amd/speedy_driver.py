@@ -71,6 +71,51 @@ def modelstate_init_ensemble(nmembers):
     return list(arr)
 
 
+# Extension: one process, several GPUs (include/pyspeedy_amd_driver.h).  The reference's ensemble is one process handing all
+# containers to parallel_step; with a placement of k devices the containers are spread over GPUs 0 .. k-1 and one
+# parallel_step drives them all (every device's step is enqueued before the host waits for any).
+def device_count():
+    n = C.c_int32()
+    _ok(_L().spd_device_count(C.byref(n)), "device_count")
+    return n.value
+
+
+def set_device_placement(n_devices):
+    """0: new containers live on the current HIP device (default); k: spread over devices 0 .. k-1 (single containers
+    round-robin in creation order, the members of modelstate_init_ensemble in blocks)."""
+    _ok(_L().spd_set_device_placement(int(n_devices)), "set_device_placement")
+
+
+def modelstate_init_on(device):
+    c = C.c_int64()
+    _ok(_L().spd_modelstate_init_on(C.byref(c), int(device)), "modelstate_init_on")
+    return c.value
+
+
+def modelstate_device(state_cnt):
+    d = C.c_int32()
+    _ok(_L().spd_modelstate_device(int(state_cnt), C.byref(d)), "modelstate_device")
+    return d.value
+
+
+def broadcast_boundary(state_cnts, root=0):
+    """The shared boundary fields of container state_cnts[root] into all the others, device to device."""
+    s, n = _cnts(state_cnts)
+    _ok(_L().spd_broadcast_boundary(s, n, int(root)), "broadcast_boundary")
+
+
+def driver_trace(on=True):
+    _ok(_L().spd_driver_trace(int(bool(on))), "driver_trace")
+
+
+def driver_trace_read():
+    """[(kind, group), ...] in host order: 1 = step + check of a device model enqueued, 2 = waiting for it, 3 = codes back."""
+    n = _L().spd_driver_trace_read(None, 0)
+    buf = (C.c_int32 * (2 * max(n, 1)))()
+    n = _L().spd_driver_trace_read(buf, n)
+    return [(buf[2 * i], buf[2 * i + 1]) for i in range(n)]
+
+
 def modelstate_init_sst_anom(state_cnt, n_months):
     _ok(_L().spd_modelstate_init_sst_anom(int(state_cnt), int(n_months)), "modelstate_init_sst_anom")
 
@@ -192,16 +237,27 @@ def device_model(state_cnt):
     handle, member, members = C.c_void_p(), C.c_int32(), C.c_int32()
     _ok(_L().spd_driver_model(int(state_cnt), C.byref(handle), C.byref(member), C.byref(members)), "device_model")
     n_months = _shape("sst_anom", state_cnt)[2] - 2
-    return EnsembleModel.borrowed(handle, members.value, torch.device("cuda", torch.cuda.current_device()),
+    return EnsembleModel.borrowed(handle, members.value, torch.device("cuda", modelstate_device(state_cnt)),
                                   max(n_months, 1)), member.value
 
 
-def ensemble_grid_arrays(state_cnt, names):
-    """Extension: the grid-space variables `names` of ALL members of the batched model `state_cnt` belongs to, after one
-    batched spectral2grid: dict name -> float64 array [member, (lev,) lat, lon] (one device-to-host copy per variable)."""
-    model, _ = device_model(state_cnt)
-    model.spectral2grid()
-    return {n: model.device_view(n).cpu().numpy() for n in names}
+def ensemble_grid_arrays(state_cnts, names):
+    """Extension: the grid-space variables `names` of the given containers (one container: of ALL members of the batched model
+    it belongs to), after one batched spectral2grid per device model: dict name -> float64 array [member, (lev,) lat, lon]
+    in the order of `state_cnts` (one device-to-host copy per variable and device model)."""
+    if np.ndim(state_cnts) == 0:
+        model, _ = device_model(state_cnts)
+        model.spectral2grid()
+        return {n: model.device_view(n).cpu().numpy() for n in names}
+    models, where = {}, []
+    for cnt in state_cnts:
+        model, member = device_model(cnt)
+        key = model._m.value
+        if key not in models:
+            model.spectral2grid()
+            models[key] = {n: model.device_view(n).cpu().numpy() for n in names}
+        where.append((key, member))
+    return {n: np.stack([models[key][n][member] for key, member in where]) for n in names}
 
 
 def driver_stats(state_cnt=0):

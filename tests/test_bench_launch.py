@@ -32,9 +32,8 @@ def test_workload_partition():
 
 def test_launcher_reports_a_failing_rank():
     """Without a GPU every rank stops with an error: the launcher must return non-zero and print no result line."""
-    import torch
-    if torch.cuda.is_available():
-        pytest.skip("needs a machine without a GPU")
+    if os.path.exists("/dev/kfd"):  # (not torch.cuda.is_available(): that would initialise the GPU in the test process, which
+        pytest.skip("needs a machine without a GPU")  # must stay able to start the other spawning tests)
     run = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
                          capture_output=True, text=True, timeout=300)
     assert run.returncode != 0
@@ -59,14 +58,53 @@ def test_bench_two_ranks_share_the_gpu():
     assert strong["n_gpus"] == 2 and strong["scaling"] == "strong"
     assert strong["config"]["members_per_gpu"] == 3 and strong["config"]["members_total"] == 6
     assert strong["regions"] == 2 and strong["ms_per_step_min"] <= strong["ms_per_step"]
+    assert strong["vs_baseline"] is None and "cpu_baseline" not in strong and "cfg4_strong" not in strong
     weak = _result(subprocess.run([sys.executable, BENCH, "--gpus", "2", "--members", "4"] + common, capture_output=True,
                                   text=True, timeout=900, env=env))
     assert weak["n_gpus"] == 2 and weak["scaling"] == "weak"
     assert weak["config"]["members_per_gpu"] == 4 and weak["config"]["members_total"] == 8
+    assert weak["config"]["plan"].startswith("serial")  # 4 members per GPU: one group
     years = 8 * 86400.0 / (weak["ms_per_step"] * 1e-3 * 13140)
     assert abs(weak["value"] - years) < 1e-6 * years
     names = {k["kernel"] for k in weak["roofline"]["kernels"]}
     assert {"spec2grid", "column_sw", "column", "grid2spec", "spectral_step"} <= names
+    assert weak["roofline"]["serial_plan_ms_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_the_n_rank_line_is_complete():
+    """The driver's own command at N > 1 (default members: the weak headline, 64 per GPU) -- here with 2 ranks sharing the one
+    GPU: the line carries the host baseline with its core count (measured by the launcher before any rank exists), the ratio to
+    it, and BASELINE cfg 4 to the letter (64 members in total, sharded) beside the weak headline."""
+    env = dict(os.environ, PYSPEEDY_AMD_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    res = _result(subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "6", "--warmup", "3", "--regions", "2",
+                                  "--cpu-seconds", "1.5"], capture_output=True, text=True, timeout=1200, env=env))
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["config"]["members_total"] == 128
+    assert res["config"]["plan"].startswith("2 member groups")
+    cores = res["cpu_baseline"]["all_cores"]["cores"]
+    assert cores >= 1 and res["cpu_baseline"]["cores"] == 1 and res["cpu_baseline"]["kind"] in ("reference", "port")
+    assert abs(res["vs_baseline"] - res["value"] / res["cpu_baseline"]["all_cores"]["value"]) < 1e-9 * res["vs_baseline"]
+    strong = res["cfg4_strong"]
+    assert strong["members_total"] == 64 and strong["members_per_gpu"] == 32 and strong["scaling"] == "strong"
+    assert abs(strong["value"] - 64 * 86400.0 / (strong["ms_per_step"] * 1e-3 * 13140)) < 1e-6 * strong["value"]
+    assert strong["vs_cpu_all_cores"] > 0
+    assert "drop_in_step" not in res  # (a leg of the one-GPU line)
+
+
+@pytest.mark.gpu
+def test_the_one_gpu_line_carries_the_drop_in_and_every_store_legs():
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "PYSPEEDY_AMD_BENCH_BACKEND"):
+        env.pop(k, None)
+    res = _result(subprocess.run([sys.executable, BENCH, "--members", "8", "--steps", "6", "--warmup", "3", "--regions", "2",
+                                  "--cpu-seconds", "1.5"], capture_output=True, text=True, timeout=1200, env=env))
+    assert res["n_gpus"] == 1 and res["config"]["members_total"] == 8
+    d = res["drop_in_step"]
+    assert d["containers"] == 8 and 0 < d["begin_end_ms_per_step"] and 0 < d["sync_ms_per_step"]
+    e = res["every_step_stores"]
+    assert e["spec2grid_per_member"] == 91 and e["ms_per_step"] > 0
+    assert res["cpu_baseline"]["all_cores"]["cores"] >= 1 and res["vs_baseline"] > 0
 
 
 @pytest.mark.gpu
@@ -80,3 +118,20 @@ def test_bench_one_rank_world_through_rccl():
                                   "--regions", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env))
     assert res["n_gpus"] == 1 and res["config"]["backend"] == "nccl"
     assert res["config"]["members_total"] == 4 and res["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_measures_the_host_baseline_on_rank_0():
+    """The driver's launch line for N > 1: every process is a rank; rank 0 measures the host baseline before it touches the GPU
+    while the other ranks wait in the rendezvous, and the line is as complete as the launcher's."""
+    sys.path.insert(0, ROOT)
+    import bench
+    env = dict(os.environ, PYSPEEDY_AMD_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(bench.free_port()), BENCH, "--gpus", "2", "--members", "4", "--steps", "6", "--warmup", "3",
+           "--regions", "2", "--cpu-seconds", "1.5"]
+    res = _result(subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env))
+    assert res["n_gpus"] == 2 and res["config"]["members_total"] == 8
+    assert res["cpu_baseline"]["all_cores"]["cores"] >= 1 and res["vs_baseline"] > 0

@@ -169,9 +169,15 @@ def test_parallel_step_gathers_independent_containers_into_one_batched_model(drv
     assert drv.step(batched[1], ctl_b[1]) == 0 and drv.step(alone[1], ctl_a[1]) == 0
     assert drv.stats(batched[1])[1] == 1 and drv.stats(batched[0])[1] == 1
     assert np.array_equal(drv.get(batched[1], "t", np.complex128), drv.get(alone[1], "t", np.complex128))
-    # members 0 and 2 are one step behind member 1 now: parallel_step over all three cannot batch them (dates differ) ...
+    # members 0 and 2 are one step behind member 1 now: parallel_step over all three batches the two that agree (a partial
+    # gather) and steps member 1 as a second device model in the same call -- still on the trajectories of the lone runs
     codes = drv.parallel_step(batched, ctl_b)
-    assert codes == [0, 0, 0] and drv.stats(batched[0])[1] == 1
+    assert codes == [0, 0, 0] and drv.stats(batched[0])[1] == 2 and drv.stats(batched[2])[1] == 2 and drv.stats(batched[1])[1] == 1
+    for s, c in ((alone[0], ctl_a[0]), (alone[2], ctl_a[2]), (alone[1], ctl_a[1])):
+        assert drv.step(s, c) == 0
+    for sb, sa in zip(batched, alone):
+        assert np.array_equal(drv.get(sb, "t", np.complex128), drv.get(sa, "t", np.complex128))
+        assert np.array_equal(drv.get(sb, "sst_am"), drv.get(sa, "sst_am"))
     drv.close(*batched, *alone)
     assert drv.stats(0)[0] == alive0
 
@@ -228,3 +234,158 @@ def test_a_failing_member_keeps_its_date_and_reports_minus_two(drv, bc):
     assert drv.model_date(controls[1]) == before and drv.model_date(controls[0])[0] == (1982, 1, 1, 2, 0)
     assert drv.L.spd_parallel_step_end(token, codes) < 0  # a token is good for one _end
     drv.close(*states)
+
+
+def _trace(drv):
+    n = drv.L.spd_driver_trace_read(None, 0)
+    buf = (C.c_int32 * (2 * max(n, 1)))()
+    drv.L.spd_driver_trace_read(buf, n)
+    return [(buf[2 * i], buf[2 * i + 1]) for i in range(n)]
+
+
+def test_several_device_models_in_one_parallel_step_are_enqueued_before_any_wait(drv, bc):
+    """speedy_driver.f90.j2:58-79 hands ALL containers of a one-process ensemble to one parallel_step.  Here the containers
+    of such a call may live in several device models (one per GPU; on this one-GPU box: members with different SST-anomaly
+    lengths, which cannot share a model).  The call batches what it can -- two 2-member models -- and enqueues the step and
+    range check of every model before it waits for the first; the trajectories are bitwise those of containers stepped alone."""
+    alive0, _ = drv.stats(0)
+    pert = [None, 0.3 * np.ones((96, 48, 12)), -0.2 * np.ones((96, 48, 12)), 0.1 * np.ones((96, 48, 12))]
+    months = [1, 1, 3, 3]
+    together, alone = [drv.state() for _ in range(4)], [drv.state() for _ in range(4)]
+    ctl_t, ctl_a = [drv.control(START, END) for _ in range(4)], [drv.control(START, END) for _ in range(4)]
+    for group, ctls in ((together, ctl_t), (alone, ctl_a)):
+        for s, c, p, nm in zip(group, ctls, pert, months):
+            drv.ok(drv.L.spd_modelstate_init_sst_anom(s, nm))
+            drv.set_bc(s, bc, p)
+            assert drv.init(s, c) == 0
+    drv.ok(drv.L.spd_driver_trace(1))
+    assert drv.parallel_step(together, ctl_t) == [0, 0, 0, 0]
+    assert [drv.stats(s)[1] for s in together] == [2, 2, 2, 2] and drv.stats(0)[0] == alive0 + 2 + 4
+    assert _trace(drv) == [(1, 0), (1, 1), (2, 0), (3, 0), (2, 1), (3, 1)]  # both models enqueued, then the waits
+    for _ in range(38):
+        assert drv.parallel_step(together, ctl_t) == [0, 0, 0, 0]
+    # ... and in the overlapped form
+    drv.ok(drv.L.spd_driver_trace(1))
+    n = 4
+    token, codes = C.c_int64(), (C.c_int32 * n)()
+    drv.ok(drv.L.spd_parallel_step_begin((C.c_int64 * n)(*together), (C.c_int64 * n)(*ctl_t), n, C.byref(token)))
+    assert _trace(drv) == [(1, 0), (1, 1)]
+    drv.ok(drv.L.spd_parallel_step_end(token, codes))
+    assert list(codes) == [0, 0, 0, 0] and _trace(drv)[2:] == [(2, 0), (3, 0), (2, 1), (3, 1)]
+    drv.ok(drv.L.spd_driver_trace(0))
+    for s, c in zip(alone, ctl_a):
+        for _ in range(40):
+            assert drv.step(s, c) == 0
+    assert drv.model_date(ctl_t[3]) == drv.model_date(ctl_a[3])
+    for st, sa in zip(together, alone):
+        for name, dt in (("vor", np.complex128), ("t", np.complex128), ("ps", np.complex128), ("tr", np.complex128)):
+            assert np.array_equal(drv.get(st, name, dt), drv.get(sa, name, dt)), name
+        for name in ("olr", "land_temp", "sst_am", "rad_tau2"):
+            assert np.array_equal(drv.get(st, name), drv.get(sa, name)), name
+    drv.close(*together, *alone)
+    assert drv.stats(0)[0] == alive0
+
+
+def test_a_device_model_that_cannot_be_stepped_does_not_stop_the_others(drv, bc):
+    """Two device models in one call; one of them already has two range checks in flight (two _begin without _end), so a
+    third cannot be issued: its members report -3, the call returns that model's error AFTER the other model has been
+    stepped, dates move only for the members that were stepped."""
+    a, b = drv.state(), drv.state()
+    ca, cb = drv.control(START, END), drv.control(START, END)
+    drv.ok(drv.L.spd_modelstate_init_sst_anom(b, 3))  # (different anomaly length: the two cannot share a model)
+    for s, c in ((a, ca), (b, cb)):
+        drv.set_bc(s, bc)
+        assert drv.init(s, c) == 0
+    one = lambda v: (C.c_int64 * 1)(v)
+    t1, t2, t3 = C.c_int64(), C.c_int64(), C.c_int64()
+    drv.ok(drv.L.spd_parallel_step_begin(one(a), one(ca), 1, C.byref(t1)))
+    drv.ok(drv.L.spd_parallel_step_begin(one(a), one(ca), 1, C.byref(t2)))
+    date_a, date_b = drv.model_date(ca), drv.model_date(cb)
+    drv.ok(drv.L.spd_parallel_step_begin((C.c_int64 * 2)(a, b), (C.c_int64 * 2)(ca, cb), 2, C.byref(t3)))
+    assert drv.model_date(ca) == date_a and drv.model_date(cb)[0] == (1982, 1, 1, 0, 40)
+    codes = (C.c_int32 * 2)()
+    assert drv.L.spd_parallel_step_end(t3, codes) < 0 and b"in flight" in drv.L.spd_last_error()
+    assert list(codes) == [-3, 0]
+    assert drv.model_date(ca) == date_a and drv.model_date(cb)[0] == (1982, 1, 1, 0, 40) and date_b[0] == (1982, 1, 1, 0, 0)
+    c1 = (C.c_int32 * 1)()
+    for t in (t1, t2):
+        drv.ok(drv.L.spd_parallel_step_end(t, c1))
+        assert c1[0] == 0
+    assert drv.parallel_step([a, b], [ca, cb]) == [0, 0]  # everything works again
+    assert drv.get(a, "current_step", np.int32) == 3 and drv.get(b, "current_step", np.int32) == 2
+    drv.close(a, b)
+
+
+def test_device_placement_and_boundary_broadcast(drv, bc):
+    """One process, several GPUs: the placement interface on the one device of this box (device ids, round-robin placement of
+    single containers, block placement of an ensemble, refusal of devices that do not exist) and the device-to-device
+    broadcast of the boundary fields, after which the receiving members run exactly like members that were set field by
+    field."""
+    ndev = C.c_int32()
+    drv.ok(drv.L.spd_device_count(C.byref(ndev)))
+    assert ndev.value >= 1
+    assert drv.L.spd_set_device_placement(ndev.value + 1) < 0
+    bad = C.c_int64()
+    assert drv.L.spd_modelstate_init_on(C.byref(bad), ndev.value) < 0 and b"no such HIP device" in drv.L.spd_last_error()
+    drv.ok(drv.L.spd_set_device_placement(ndev.value))
+    try:
+        root, other = drv.state(), drv.state()
+        ens = (C.c_int64 * 3)()
+        drv.ok(drv.L.spd_modelstate_init_ensemble(ens, 3))
+    finally:
+        drv.ok(drv.L.spd_set_device_placement(0))
+    named = C.c_int64()
+    drv.ok(drv.L.spd_modelstate_init_on(C.byref(named), 0))
+    dev = C.c_int32(-1)
+    for cnt, expect in ((root, 0), (other, 1 % ndev.value), (named.value, 0), (ens[0], 0), (ens[2], 2 * ndev.value // 3)):
+        drv.ok(drv.L.spd_modelstate_device(cnt, C.byref(dev)))
+        assert dev.value == expect
+    cnts = [root, other, named.value] + list(ens)
+    drv.set_bc(root, bc, 0.2 * np.ones((96, 48, 12)))
+    drv.ok(drv.L.spd_broadcast_boundary((C.c_int64 * len(cnts))(*cnts), len(cnts), 0))
+    by_hand = drv.state()
+    drv.set_bc(by_hand, bc, 0.2 * np.ones((96, 48, 12)))
+    for name in ("orog", "sst12", "soil_wc_l3", "sea_ice_frac12", "alb0"):
+        for cnt in cnts[1:]:
+            assert np.array_equal(drv.get(cnt, name), drv.get(by_hand, name)), name
+    controls = [drv.control(START, END) for _ in cnts]
+    ch = drv.control(START, END)
+    for s, c in zip(cnts + [by_hand], controls + [ch]):
+        assert drv.init(s, c) == 0
+    for _ in range(4):
+        assert drv.parallel_step(cnts, controls) == [0] * len(cnts)
+        assert drv.step(by_hand, ch) == 0
+    for cnt in (other, ens[1]):
+        assert np.array_equal(drv.get(cnt, "t", np.complex128), drv.get(by_hand, "t", np.complex128))
+    drv.close(by_hand, *cnts)
+
+
+def test_init_of_a_batched_member_never_resets_the_other_members(drv, bc):
+    """A batched model has one date and one step counter.  Initialising a member again after the batch has stepped, or with
+    another start date than its fellow members, takes that member out of the batch first; the others keep their date."""
+    n = 3
+    ens = (C.c_int64 * n)()
+    drv.ok(drv.L.spd_modelstate_init_ensemble(ens, n))
+    states = list(ens)
+    controls = [drv.control(START, END) for _ in range(n)]
+    for s, c in zip(states, controls):
+        drv.set_bc(s, bc)
+        assert drv.init(s, c) == 0
+    for _ in range(3):
+        assert drv.parallel_step(states, controls) == [0] * n
+    assert drv.stats(states[0])[1] == n
+    assert drv.init(states[1], controls[1]) == 0  # start member 1 over
+    assert drv.stats(states[1])[1] == 1 and drv.stats(states[0])[1] == 1
+    assert drv.get(states[0], "current_step", np.int32) == 3 and drv.get(states[1], "current_step", np.int32) == 0
+    assert drv.model_date(controls[1])[0] == START and drv.model_date(controls[0])[0] == (1982, 1, 1, 2, 0)
+    # a member with its own start date is on its own from the beginning
+    ens2 = (C.c_int64 * 2)()
+    drv.ok(drv.L.spd_modelstate_init_ensemble(ens2, 2))
+    c0, c1 = drv.control(START, END), drv.control((1982, 2, 1, 0, 0), (1982, 2, 4, 0, 0))
+    for s in ens2:
+        drv.set_bc(s, bc)
+    assert drv.init(ens2[0], c0) == 0 and drv.init(ens2[1], c1) == 0
+    assert drv.stats(ens2[0])[1] == 1 and drv.stats(ens2[1])[1] == 1
+    assert drv.parallel_step(list(ens2), [c0, c1]) == [0, 0]
+    assert drv.model_date(c0)[0] == (1982, 1, 1, 0, 40) and drv.model_date(c1)[0] == (1982, 2, 1, 0, 40)
+    drv.close(*states, *ens2)

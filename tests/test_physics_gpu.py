@@ -11,6 +11,8 @@ import torch
 
 from test_physics_oracle import load_snapshot
 
+import physics_helpers as H  # tests/physics_helpers.py
+
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-12
@@ -66,7 +68,7 @@ def test_golden_snapshots(phys, golden_dir, name):
 def test_against_oracle_synthetic_members(phys, oracle, sw):
     """Three different synthetic members in one launch (member-major batching), incl. integer diagnostics."""
     import pyspeedy_amd.physics as P
-    members = [P.synthetic_member(seed=s) for s in (1, 2, 3)]
+    members = [H.synthetic_member(seed=s) for s in (1, 2, 3)]
     refs, pres = [], {k: [] for k in oracle.PHYS_PERSIST_SHAPES}
     rng = np.random.default_rng(0)
     for m in members:
@@ -98,7 +100,7 @@ def test_against_oracle_synthetic_members(phys, oracle, sw):
 def test_member_independence_and_determinism(phys):
     """Columns are independent: permuting members permutes results bit for bit; two runs are identical."""
     import pyspeedy_amd.physics as P
-    members = [P.synthetic_member(seed=s) for s in (4, 5)]
+    members = [H.synthetic_member(seed=s) for s in (4, 5)]
     t1, s1 = run_hip(phys, members, True, 0.3)
     t2, s2 = run_hip(phys, members[::-1], True, 0.3)
     t3, s3 = run_hip(phys, members, True, 0.3)
@@ -111,7 +113,7 @@ def test_member_independence_and_determinism(phys):
 def test_full_ensemble_size_properties(phys):
     """64 members (BASELINE cfg 4 shard on one GPU): all finite, energy-like bounds, and replicated members agree."""
     import pyspeedy_amd.physics as P
-    base = P.synthetic_member(seed=9)
+    base = H.synthetic_member(seed=9)
     M = 64
     dev = lambda n: torch.from_numpy(P.to_device_layout(base[n])).cuda()[None].expand(M, *P.shapes(1)[n][1:]).contiguous()
     fields = {n: dev(n) for n in P.STATE_IN_3D + P.STATE_IN_2D}
@@ -130,7 +132,7 @@ def test_full_ensemble_size_properties(phys):
 
 def test_argument_checking(phys):
     import pyspeedy_amd.physics as P
-    m = P.synthetic_member(seed=1)
+    m = H.synthetic_member(seed=1)
     dev = lambda n: torch.from_numpy(P.to_device_layout(m[n])[None]).cuda()
     fields = {n: dev(n) for n in P.STATE_IN_3D + P.STATE_IN_2D}
     tend = {n: dev(n) for n in P.TENDENCIES}

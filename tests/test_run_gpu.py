@@ -322,3 +322,76 @@ def test_launch_plan_options_by_name(spectral, bc):
             b.set_option(name, value)
     a.close()
     b.close()
+
+
+def test_device_views_held_across_steps_stay_valid(spectral, bc):
+    """include/pyspeedy_amd.h, spd_model_device_ptr: a view taken once shows the variable after every later step -- also `phi`
+    of a small ensemble, which the step otherwise keeps in two alternating buffers (taking its address pins it) --, and a
+    WRITE through a view that was taken earlier takes effect once spd_model_invalidate has been called: the model then
+    equals one whose temperature was set through spd_model_set."""
+    import torch
+    from pyspeedy_amd.model import EnsembleModel
+    a, b = EnsembleModel(spectral, 2), EnsembleModel(spectral, 2)
+    for m in (a, b):
+        m.set_bc(bc)
+        m.run(3)
+    assert a.config()["fold_geo"]
+    phi, t = a.device_view("phi"), a.device_view("t")
+    assert not a.config()["fold_geo"] and b.config()["fold_geo"]  # pinned: the look-ahead geopotential is off for `a` only
+    for _ in range(4):  # the held views follow the model step by step; the pinned model stays bitwise on the other's course
+        a.run(1)
+        b.run(1)
+        torch.cuda.synchronize()
+        for member in (0, 1):
+            assert np.array_equal(phi[member].cpu().numpy(), b.get("phi", member).transpose(2, 1, 0)), "phi"
+            assert np.array_equal(t[member].cpu().numpy(), b.get("t", member).transpose(3, 2, 1, 0)), "t"
+    # a write through the view taken seven steps ago + invalidate == spd_model_set (which invalidates by itself)
+    new_t = b.get("t", 1) * (1.0 + 1e-3)
+    b.set("t", new_t, member=1)
+    t[1].copy_(torch.from_numpy(np.ascontiguousarray(new_t.transpose(3, 2, 1, 0))).to(t.device))
+    a.invalidate()
+    a.run(5)
+    b.run(5)
+    for n in SPEC + ("phi", "sst_am", "olr"):
+        for member in (0, 1):
+            assert np.array_equal(a.get(n, member), b.get(n, member)), n
+    a.close()
+    b.close()
+
+
+def test_the_default_plan_overlaps_two_member_groups_from_32_members_and_profiling_is_serial(spectral, bc):
+    """spd_model_create: two member groups on two streams from 32 members up, one group below; spd_model_set_option
+    ("member_groups") changes it on a live model; the states are bitwise the same whatever the grouping; while
+    spd_model_profile is on the step is issued as one group (per-kernel durations must be the kernel's own)."""
+    from pyspeedy_amd.model import EnsembleModel
+    assert "PYSPEEDY_AMD_CHUNKS" not in os.environ
+    small = EnsembleModel(spectral, 8)
+    assert small.config()["chunks"] == 1
+    small.close()
+    a, b = EnsembleModel(spectral, 33), EnsembleModel(spectral, 33)
+    assert a.config()["chunks"] == 2
+    b.set_option("member_groups", 1)
+    assert b.config()["chunks"] == 1
+    for m in (a, b):
+        m.set_bc(bc)
+        t0 = m.get("t", 0)
+        for i in (1, 16, 17, 32):
+            t = t0 * (1.0 + 1e-4 * np.random.default_rng(i).standard_normal((31, 32, 8, 1)))
+            t[0] = t[0].real
+            m.set("t", t, member=i)
+    a.run(38)
+    b.run(38)
+    a.profile(2)  # (serial plan for the profiled steps: the two models keep agreeing)
+    a.run(3)
+    prof = a.profile_read_kernels()
+    a.profile(0)
+    assert prof["spec2grid"][2] == 3 and prof["spec2grid"][3] == 77 * 33  # ONE launch per step over all members
+    b.run(3)
+    assert (a.check(2) == 0).all()
+    for n in SPEC + ("sst_am", "olr", "land_temp"):
+        for member in (0, 16, 17, 32):
+            assert np.array_equal(a.get(n, member), b.get(n, member)), n
+    with pytest.raises(ValueError):
+        a.set_option("member_groups", 5)
+    a.close()
+    b.close()

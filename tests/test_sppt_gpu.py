@@ -8,6 +8,8 @@ import sys
 import numpy as np
 import pytest
 
+import physics_helpers as H  # tests/physics_helpers.py
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -94,7 +96,7 @@ def test_tendency_formula_through_the_physics_kernel(spectral):
     import sppt_oracle as O
     import pyspeedy_amd.physics as P
     phys = P.ColumnPhysics(spectral)
-    base = P.synthetic_member(seed=11)
+    base = H.synthetic_member(seed=11)
     M = 2
     dev = lambda n: torch.from_numpy(P.to_device_layout(base[n])).cuda()[None].expand(M, *P.shapes(1)[n][1:]).contiguous()
     fields = {n: dev(n) for n in P.STATE_IN_3D + P.STATE_IN_2D}

@@ -1,5 +1,5 @@
 """Cost of the reference-shaped synchronous loop -- spd_parallel_step (step + range check + error codes back) once per model
-step, as an f2py / Fortran host of the reference would call it -- next to the overlapped form and the bare device loop.
+step, as an f2py / Fortran host of the reference would call it -- next to the overlapped form (the bare device loop is bench.py's headline).
 Usage (GPU box): python tools/perf_driver_sync.py [members]"""
 import os
 import sys
@@ -51,14 +51,8 @@ def main():
         per_step.append(time.perf_counter() - t0)
     assert (drv.parallel_step_end(token) == 0).all()
     ovl_ms, stalls = median_ms(per_step), stalls + sum(1 for t in per_step if t > 5e-3)
-    model, _ = drv.device_model(states[0])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    model.run(STEPS)
-    torch.cuda.synchronize()
-    dev_ms = (time.perf_counter() - t0) / STEPS * 1e3
-    print("M=%d  parallel_step (synchronous) %.4f ms/step;  begin / end overlapped %.4f;  device loop %.4f  (medians; %d steps "
-          "longer than 5 ms)" % (M, sync_ms, ovl_ms, dev_ms, stalls))
+    print("M=%d  parallel_step (synchronous) %.4f ms/step;  begin / end overlapped %.4f  (medians; %d steps longer than 5 ms; "
+          "%d device models)" % (M, sync_ms, ovl_ms, stalls, len({drv.device_model(s)[0]._m.value for s in states})))
 
 
 main()

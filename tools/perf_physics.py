@@ -5,10 +5,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import pyspeedy_amd
 import pyspeedy_amd.physics as P
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import physics_helpers as H  # noqa: E402
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 sp = pyspeedy_amd.ModSpectral()
 phys = P.ColumnPhysics(sp)
-base = P.synthetic_member(seed=3)
+base = H.synthetic_member(seed=3)
 dev = lambda n: torch.from_numpy(P.to_device_layout(base[n])).cuda()[None].expand(M, *P.shapes(1)[n][1:]).contiguous()
 fields = {n: dev(n) for n in P.STATE_IN_3D + P.STATE_IN_2D}
 tend = {n: dev(n) for n in P.TENDENCIES}
