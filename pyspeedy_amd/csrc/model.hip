@@ -92,7 +92,6 @@ struct spd_model {
     double *d_diag = nullptr;
     // asynchronous range check (spd_model_check_begin / _end): two pinned result slots with their events
     int *h_err[2] = {nullptr, nullptr}, *h_err_sync = nullptr;  // (h_err_sync: pinned staging of the synchronous check)
-    int *d_err_slot[2] = {nullptr, nullptr};
     hipEvent_t err_event[2] = {nullptr, nullptr};
     int next_slot = 0;
     bool slot_busy[2] = {false, false};  // begun and not yet ended
@@ -668,16 +667,16 @@ int spd_model_check(spd_model_handle m, int time_level, int32_t *error_codes_hos
     if (!m || !error_codes_host) return m_fail(SPD_E_ARG, "spd_model_check: null argument");
     if (time_level < 1 || time_level > 2) return m_fail(SPD_E_ARG, "spd_model_check: time level is 1 or 2");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = run_diagnostics(m->P, m->ctx->dev, m->M, time_level - 1, m->d_err, m->d_diag, s);
-    if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_check: ") + hipGetErrorString(e));
-    // the codes travel through pinned memory: a device-to-host copy into the caller's pageable buffer is staged by the runtime
-    // and costs this synchronous call -- made once per model step by hosts with the reference's loop -- tens of microseconds
+    // The kernel writes the codes straight into pinned, coherent host memory (one 4-byte store per member over the fabric): a
+    // device-to-host copy behind the kernel is a second operation on the stream -- several microseconds for a host that makes
+    // this synchronous call once per model step -- and a copy into the caller's pageable buffer would be staged on top.
     if (!m->h_err_sync) {
         void *p = nullptr;
-        M_HIP(hipHostMalloc(&p, sizeof(int) * m->M, hipHostMallocDefault));
+        M_HIP(hipHostMalloc(&p, sizeof(int) * m->M, hipHostMallocCoherent));
         m->h_err_sync = static_cast<int *>(p);
     }
-    M_HIP(hipMemcpyAsync(m->h_err_sync, m->d_err, sizeof(int) * m->M, hipMemcpyDeviceToHost, s));
+    hipError_t e = run_diagnostics(m->P, m->ctx->dev, m->M, time_level - 1, m->h_err_sync, m->d_diag, s);
+    if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_check: ") + hipGetErrorString(e));
     if (diag_host) M_HIP(hipMemcpyAsync(diag_host, m->d_diag, sizeof(double) * m->M * 24, hipMemcpyDeviceToHost, s));
     M_HIP(hipStreamSynchronize(s));
     std::memcpy(error_codes_host, m->h_err_sync, sizeof(int) * m->M);
@@ -696,18 +695,14 @@ int spd_model_check_begin(spd_model_handle m, int time_level, void *stream) {
     const int slot = m->next_slot;
     if (m->slot_busy[slot])
         return m_fail(SPD_E_ARG, "spd_model_check_begin: two checks are in flight already; end one with spd_model_check_end first");
-    if (!m->h_err[slot]) {
+    if (!m->h_err[slot]) {  // (pinned, coherent: the kernel stores the codes there itself, see spd_model_check)
         void *p = nullptr;
-        M_HIP(hipHostMalloc(&p, sizeof(int) * m->M, hipHostMallocDefault));
+        M_HIP(hipHostMalloc(&p, sizeof(int) * m->M, hipHostMallocCoherent));
         m->h_err[slot] = static_cast<int *>(p);
-        M_HIP(hipMalloc(&p, sizeof(int) * m->M));
-        m->allocs.push_back(p);
-        m->d_err_slot[slot] = static_cast<int *>(p);
         M_HIP(hipEventCreateWithFlags(&m->err_event[slot], hipEventDisableTiming));
     }
-    hipError_t e = run_diagnostics(m->P, m->ctx->dev, m->M, time_level - 1, m->d_err_slot[slot], m->d_diag, s);
+    hipError_t e = run_diagnostics(m->P, m->ctx->dev, m->M, time_level - 1, m->h_err[slot], m->d_diag, s);
     if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_check_begin: ") + hipGetErrorString(e));
-    M_HIP(hipMemcpyAsync(m->h_err[slot], m->d_err_slot[slot], sizeof(int) * m->M, hipMemcpyDeviceToHost, s));
     M_HIP(hipEventRecord(m->err_event[slot], s));
     m->slot_busy[slot] = true;
     m->next_slot = 1 - slot;

@@ -281,7 +281,55 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
     const int wave = wave_id(), lane = tid & 63;
 
     TRACE_BEGIN();
-    if (ST != Stage::LegendreOnly) {
+    if (ST == Stage::Fused) {
+        // ---- load grid rows (16 B per lane, coalesced) and form the symmetric / antisymmetric parts on the way in ----
+        // The direct Legendre transform works on even(j) = (row(il+1-j) + row(j)) wt(j) and odd(j) = (row(il+1-j) - row(j)) wt(j)
+        // of the FOURIER coefficients (legendre.f90:186-197).  The zonal FFT is linear, so the two combinations are formed here
+        // from the grid rows themselves -- a lane loads the same 16 bytes of the northern and of the southern row of a latitude
+        // pair -- and the FFT transforms them: the pass over the Fourier buffer that formed them after the FFT (13 % of a
+        // workgroup's lifetime, and a barrier) is gone.  Rounding-level reordering: (a + b) w transformed instead of the
+        // transforms added, inside the 1e-13 tolerance of tests/test_transforms_gpu.py.  The northern row of the pair takes the
+        // symmetric part, the southern row the antisymmetric one, as the Legendre loop below expects.
+        // (all loads of a lane are issued before the first LDS store: a rolled loop would wait for each one in turn)
+        gd2_in g = (gd2_in)src;
+        constexpr int kPairTasks = IY * (IX / 2);                              // 24 latitude pairs x 48 16-byte pieces
+        constexpr int kPairPerLane = (kPairTasks + kThreads - 1) / kThreads;  // 3
+        d2 gn[kPairPerLane], gs[kPairPerLane];
+        double wj[kPairPerLane], cn[kPairPerLane], cs[kPairPerLane];
+        const double *ctab = (prescale == 1) ? T.cosgr : T.cosgr2;
+#pragma unroll
+        for (int it = 0; it < kPairPerLane; ++it) {
+            const int idx = tid + it * kThreads;
+            if (idx < kPairTasks) {
+                const int j = idx / (IX / 2), ip = idx - j * (IX / 2);
+                gn[it] = __builtin_nontemporal_load(&g[(kRows - 1 - j) * (IX / 2) + ip]);  // read once, by this workgroup only
+                gs[it] = __builtin_nontemporal_load(&g[j * (IX / 2) + ip]);
+                wj[it] = T.wt[j];
+                cn[it] = (prescale != 0) ? ctab[kRows - 1 - j] : 1.0;
+                cs[it] = (prescale != 0) ? ctab[j] : 1.0;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < kPairPerLane; ++it) {
+            const int idx = tid + it * kThreads;
+            if (idx < kPairTasks) {
+                const int j = idx / (IX / 2), ip = idx - j * (IX / 2);
+                d2 n = gn[it], so = gs[it];
+                if (prescale != 0) {  // rows times cosgr / cosgr2 first (spectral.f90:229-243), then the pair's Gaussian weight
+                    n.x *= cn[it];
+                    n.y *= cn[it];
+                    so.x *= cs[it];
+                    so.y *= cs[it];
+                }
+                const double w = wj[it];
+                double *an = rows + (kRows - 1 - j) * kRowStride + 2 * ip, *as = rows + j * kRowStride + 2 * ip;
+                an[0] = (n.x + so.x) * w;
+                an[1] = (n.y + so.y) * w;
+                as[0] = (n.x - so.x) * w;
+                as[1] = (n.y - so.y) * w;
+            }
+        }
+    } else if (ST == Stage::FourierOnly) {
         // ---- load grid rows (16 B per lane, coalesced) ----
         // (all loads of a lane are issued before the first LDS store: a rolled loop would wait for each one in turn)
         gd2_in g = (gd2_in)src;
@@ -309,6 +357,8 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
                 a[1] = v.y;
             }
         }
+    }
+    if (ST != Stage::LegendreOnly) {
         __syncthreads();
         TRACE_MARK(1, 0);
         double *row = rows + lane * kRowStride;
@@ -338,6 +388,10 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
                     fft::fwd_group_last_r(row, T.work, T.fft_scale, q);
             }
             __syncthreads();
+            // (the FFT rows are dead from here on: the output staging area, which aliases their tail, can be cleared -- the
+            // Legendre loop only writes the coefficients the reference fills)
+            if (ST == Stage::Fused)
+                for (int idx = tid; idx < NSPEC; idx += kThreads) s[idx] = d2{0.0, 0.0};
             double *crow = cbuf + lane * kCStride;  // R -> registers -> barrier -> C
             if (active && wave < fft::kNumGroups) {
                 if (wave < 5) {
@@ -373,22 +427,24 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
     }
 
     // ---- direct Legendre (legendre.f90:175-221) ----
-    // step 1, in place: north row <- symmetric part, south row <- antisymmetric part, both times the Gaussian weight;
-    // the output staging area (free now: the FFT rows are dead) is cleared, step 2 only writes the coefficients the
-    // reference fills
-    for (int idx = tid; idx < NSPEC; idx += kThreads) s[idx] = d2{0.0, 0.0};
-    for (int idx = tid; idx < MX * IY; idx += kThreads) {
-        const int j = idx / MX, m = idx - j * MX;
-        const int pr = pos_re(m), pi = pos_im(m);
-        double *rn = cbuf + (kRows - 1 - j) * kCStride, *rs = cbuf + j * kCStride;
-        const double w = T.wt[j];
-        const double nr = rn[pr], sr = rs[pr], ni = rn[pi], si = rs[pi];
-        rn[pr] = (nr + sr) * w;
-        rs[pr] = (nr - sr) * w;
-        rn[pi] = (ni + si) * w;
-        rs[pi] = (ni - si) * w;
+    // step 1 (Legendre stage on its own only; the fused kernel formed the two parts while it loaded the grid), in place:
+    // north row <- symmetric part, south row <- antisymmetric part, both times the Gaussian weight; the output staging area is
+    // cleared, step 2 only writes the coefficients the reference fills
+    if (ST == Stage::LegendreOnly) {
+        for (int idx = tid; idx < NSPEC; idx += kThreads) s[idx] = d2{0.0, 0.0};
+        for (int idx = tid; idx < MX * IY; idx += kThreads) {
+            const int j = idx / MX, m = idx - j * MX;
+            const int pr = pos_re(m), pi = pos_im(m);
+            double *rn = cbuf + (kRows - 1 - j) * kCStride, *rs = cbuf + j * kCStride;
+            const double w = T.wt[j];
+            const double nr = rn[pr], sr = rs[pr], ni = rn[pi], si = rs[pi];
+            rn[pr] = (nr + sr) * w;
+            rs[pr] = (nr - sr) * w;
+            rn[pi] = (ni + si) * w;
+            rs[pi] = (ni - si) * w;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     TRACE_MARK(1, 3);
     // step 2: lane = (m, parity, two valid n of that parity) from the work list of the context (capi.hip: dir_lanes);
     // sum over the 24 latitude pairs in reference order
