@@ -511,7 +511,7 @@ def run_rank(args):
         model.set_option("member_groups", 1)
     cfg = model.config()
     sppt = args.config == "cfg5"
-    plan = "serial: one member group on one stream (SPPT steps are not grouped)" if sppt else plan_name(cfg, M)
+    plan = plan_name(cfg, M)
     model.run(args.warmup)
     budget = MAX_STEPS - args.warmup - 36  # model steps this ensemble may still take (36: the bracketed one-day pass)
     # ---- headline: the library's default plan

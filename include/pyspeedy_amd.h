@@ -239,8 +239,8 @@ int spd_model_get_config(spd_model_handle m, int32_t *cfg /* 6 */);
  *   "coupler_in_spectral"  0 / 1   land / sea-ice coupling as tail blocks of spectral_step_kernel or as a launch of its own
  *   "spectral_early"      -1 / 0 / 1   spectral_step_kernel with all loads up front: automatic (up to 8 members) / never / always
  *   "split_dyn"            0 / 1   separate launches for grid-point dynamics and column physics
- *   "member_groups"        1 ... 4 the members are stepped in that many groups on separate HIP streams (default 2 from 32
- *                                  members up, else 1; always 1 while spd_model_profile is on, with SPPT and with split_dyn)
+ *   "member_groups"        1 ... 4 the members are stepped in that many groups on separate HIP streams (default: 1 below 20
+ *                                  members, 2 for 20 ... 23 and from 64 up, 3 for 24 ... 63; always 1 while spd_model_profile is on, for calls of a single step and with split_dyn)
  * Returns SPD_E_ARG for an unknown name or a value outside the list.  What is fixed at creation (the pruned transform
  * table, the geopotential fold) is read from the environment only. */
 int spd_model_set_option(spd_model_handle m, const char *name, int32_t value);

@@ -308,12 +308,13 @@ int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
     if (const char *env = getenv("PYSPEEDY_AMD_COUPLER_IN_SPECTRAL")) m->coupler_in_spectral = atoi(env) != 0;
     if (const char *env = getenv("PYSPEEDY_AMD_SPECTRAL_EARLY")) m->spectral_early = atoi(env);
     if (const char *env = getenv("PYSPEEDY_AMD_FOLD_GEO")) m->fold_geo = atoi(env) != 0;
-    // Member groups on separate streams (spd_model_step): two groups from 32 members up -- measured -7.6 % per step at 64
-    // members, -1 % at 16, +6 % at 8 (nothing to fill there); 3 groups are no better, 4 are slower.  PYSPEEDY_AMD_CHUNKS = 1 ... 4
-    // or spd_model_set_option("member_groups") override.  While spd_model_profile is on the step is issued as ONE group on
-    // the caller's stream: with overlapping launches the duration of a kernel is not its own, and per-kernel durations are
-    // what the profile is for.
-    m->nchunks = nmembers >= 32 ? 2 : 1;
+    // Member groups on separate streams (spd_model_step).  Measured per step against one group (profiles/r03_member_groups.txt):
+    // 16 members and fewer: nothing to fill, 0 ... +10 %; 20 members: 2 groups -3 %; 24 ... 48: 3 groups -9 ... -12 % (2 groups
+    // -7 ... -10 %); 64: 2 groups -10 %, 3 groups -9.5 %; 96 / 128: -4 % / -3 % either way; 4 groups are slower everywhere.
+    // PYSPEEDY_AMD_CHUNKS = 1 ... 4 or spd_model_set_option("member_groups") override.  While spd_model_profile is on the step
+    // is issued as ONE group on the caller's stream: with overlapping launches the duration of a kernel is not its own, and
+    // per-kernel durations are what the profile is for.
+    m->nchunks = nmembers >= 64 ? 2 : (nmembers >= 24 ? 3 : (nmembers >= 20 ? 2 : 1));
     if (const char *env = getenv("PYSPEEDY_AMD_CHUNKS")) m->nchunks = atoi(env);
     if (m->nchunks < 1) m->nchunks = 1;
     if (m->nchunks > 4) m->nchunks = 4;
@@ -591,32 +592,38 @@ static bool begin_step_geopotential(spd_model *m) {
     return !ahead;
 }
 
+// the SPPT generator moves on once per model step (not per member group)
+static void sppt_advance(spd_model *m) {
+    if (!m->sppt_on) return;
+    m->sppt_first = false;
+    m->sppt_step += 1;
+}
+
 // cpl != nullptr: the coupling that follows the step is part of the last launch
 static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int compute_shortwave, int first, int count, int diag,
                              bool run_geo, const CouplerArgs *cpl, hipStream_t s) {
     const DeviceTables &T = m->ctx->dev;
     const int M = m->M;
     hipError_t e = hipSuccess;
-    // physics.f90:234-236: a new SPPT pattern for every call of the physics (whole model: SPPT steps are never chunked).  Its
-    // AR(1) update rides in the geopotential launch when there is one (both open the step, neither needs the other)
+    // physics.f90:234-236: a new SPPT pattern for every call of the physics, here for the members of this launch (the generator
+    // is keyed by the global member id, so a group of members advances exactly its own part of the pattern; the caller moves
+    // the generator's step counter once per model step, after all groups have been issued).  The AR(1) update rides in the
+    // geopotential launch when there is one (both open the step, neither needs the other)
     SpptArgs sp{};
-    if (m->sppt_on) sp = sppt_args(m->sppt_spec, T, M, m->sppt_seed, m->sppt_member_base, m->sppt_step, m->sppt_first ? 1 : 0);
+    if (m->sppt_on)
+        sp = sppt_args(m->sppt_spec + static_cast<size_t>(first) * 8 * NSPEC * C, T, count, m->sppt_seed, m->sppt_member_base + first,
+                       m->sppt_step, m->sppt_first ? 1 : 0);
     if (run_geo) {
         ProfScope ps(m, SPD_K_GEOPOTENTIAL, count, s);
         e = run_geopotential(m->P, m->D, first, count, 0, m->sppt_on ? &sp : nullptr, s);  // tendencies.f90:229
     } else if (m->sppt_on) {
-        ProfScope ps(m, SPD_K_SPPT, 8 * M, s);
+        ProfScope ps(m, SPD_K_SPPT, 8 * count, s);
         e = run_sppt_update(sp, s);
     }
     spd_physics_args pa = m->pa;
     pa.compute_shortwave = compute_shortwave ? 1 : 0;
     pa.air_absortivity_co2 = m->air_absortivity_co2;
-    pa.sppt_pattern = nullptr;
-    if (e == hipSuccess && m->sppt_on) {
-        m->sppt_first = false;
-        m->sppt_step += 1;
-        pa.sppt_pattern = m->sppt_grid;  // its 8 transforms per member ride in the spectral -> grid launch below
-    }
+    pa.sppt_pattern = m->sppt_on ? m->sppt_grid : nullptr;  // its 8 transforms per member ride in the spectral -> grid launch below
     if (e == hipSuccess) {                                                                // :109-146, physics.f90:89-101
         const int per = m->inv_per_member + (m->sppt_on ? 8 : 0);
         FieldDesc *table = (m->sppt_on ? m->inv_table_sppt : m->inv_table)[j2 - 1][m->phi_cur];
@@ -659,6 +666,7 @@ int spd_model_step_dynamics(spd_model_handle m, int j1, int j2, double dt, int c
     const bool run_geo = begin_step_geopotential(m);
     const hipError_t e = step_range(m, j1, j2, dt, compute_shortwave, 0, m->M, 1, run_geo, nullptr, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_step_dynamics: ") + hipGetErrorString(e));
+    sppt_advance(m);
     return SPD_OK;
 }
 
@@ -876,7 +884,7 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
     // the group streams start after everything already enqueued on it, and it continues after all of them.
     // (a call of ONE step forks and joins the group streams around that step -- two dependent cross-stream hand-overs per
     // step cost more than the overlap gains: measured +12 % at 64 members through spd_parallel_step -- so it is issued serially)
-    const int G = (m->split_dyn_physics || m->sppt_on || m->profile > 0 || nsteps == 1) ? 1 : m->nchunks;
+    const int G = (m->split_dyn_physics || m->profile > 0 || nsteps == 1) ? 1 : m->nchunks;
     hipStream_t gs[4] = {s, nullptr, nullptr, nullptr};
     if (G > 1) {
         M_HIP(hipSetDevice(m->ctx->device));
@@ -939,6 +947,7 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
             first += count;
         }
         if (rc != SPD_OK) break;
+        sppt_advance(m);
         m->current_step += 1;
         m->cal = next;
         m->surf_cache_valid = true;

@@ -359,8 +359,9 @@ def test_device_views_held_across_steps_stay_valid(spectral, bc):
     b.close()
 
 
-def test_the_default_plan_overlaps_two_member_groups_from_32_members_and_profiling_is_serial(spectral, bc):
-    """spd_model_create: two member groups on two streams from 32 members up, one group below; spd_model_set_option
+def test_the_default_plan_overlaps_member_groups_and_profiling_is_serial(spectral, bc):
+    """spd_model_create: member groups on separate streams from 20 members up (3 groups at 33 members, 2 at 64), one group
+    below; spd_model_set_option
     ("member_groups") changes it on a live model; the states are bitwise the same whatever the grouping; while
     spd_model_profile is on the step is issued as one group (per-kernel durations must be the kernel's own)."""
     from pyspeedy_amd.model import EnsembleModel
@@ -369,7 +370,7 @@ def test_the_default_plan_overlaps_two_member_groups_from_32_members_and_profili
     assert small.config()["chunks"] == 1
     small.close()
     a, b = EnsembleModel(spectral, 33), EnsembleModel(spectral, 33)
-    assert a.config()["chunks"] == 2
+    assert a.config()["chunks"] == 3
     b.set_option("member_groups", 1)
     assert b.config()["chunks"] == 1
     for m in (a, b):

@@ -1,8 +1,10 @@
 #!/bin/bash
 # Collects the round's final evidence in ONE session on an MI355X box (boxes differ by up to 10 %: numbers that are quoted
 # together must come from the same box).  Run through gpurun from the repository root:
-#     gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r02 > gpurun_out/collect.log 2>&1'
+#     gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r03 > gpurun_out/collect.log 2>&1'
 # and copy gpurun_out/final/* into profiles/ afterwards.
+# The per-kernel evidence (rocprofv3 kernel stats, PMC traffic) is taken with `--serial-plan --no-legs`: every launch of a kernel
+# then has one size and shares the GPU with nothing, which is also how bench.py itself measures its `roofline` object.
 set -e
 TAG=${1:-rXX}
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -10,24 +12,25 @@ OUT=$R/gpurun_out/final
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
-python3 $R/bench.py --overlap-leg --no-cpu-baseline > $OUT/${TAG}_bench_overlap_leg.json 2>> $OUT/bench.err
-python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_20.json 2>> $OUT/bench.err
+python3 $R/bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_20.json 2>> $OUT/bench.err
+python3 $R/bench.py --serial-plan --no-legs --no-cpu-baseline > $OUT/${TAG}_bench_serial_plan.json 2>> $OUT/bench.err
 python3 $R/bench.py --config cfg5 --no-cpu-baseline > $OUT/${TAG}_bench_cfg5.json 2>> $OUT/bench.err
 python3 $R/bench.py --scaling strong --members 8 --no-cpu-baseline > $OUT/${TAG}_bench_m8.json 2>> $OUT/bench.err
 python3 $R/bench.py --scaling strong --members 1 --no-cpu-baseline > $OUT/${TAG}_bench_m1.json 2>> $OUT/bench.err
-PYSPEEDY_AMD_PRUNE_DEAD=0 PYSPEEDY_AMD_DIAG_EVERY_STEP=1 python3 $R/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_fidelity.json 2>> $OUT/bench.err
 echo "bench lines done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k64 -o run -- python3 $R/bench.py --no-cpu-baseline > $OUT/k64.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k8 -o run -- python3 $R/bench.py --scaling strong --members 8 --no-cpu-baseline > $OUT/k8.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k1 -o run -- python3 $R/bench.py --scaling strong --members 1 --no-cpu-baseline > $OUT/k1.log 2>&1
+SER="--serial-plan --no-legs --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k64 -o run -- python3 $R/bench.py $SER > $OUT/k64.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k8 -o run -- python3 $R/bench.py --scaling strong --members 8 $SER > $OUT/k8.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k1 -o run -- python3 $R/bench.py --scaling strong --members 1 $SER > $OUT/k1.log 2>&1
 cp $OUT/k64/run_kernel_stats.csv $OUT/${TAG}_model_bench_kernel_stats.csv
 cp $OUT/k8/run_kernel_stats.csv $OUT/${TAG}_model_bench_kernel_stats_8members.csv
 cp $OUT/k1/run_kernel_stats.csv $OUT/${TAG}_model_bench_kernel_stats_1member.csv
 echo "kernel traces done"
 # PMC passes, each on its own (never together with a trace domain other than --kernel-trace)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc/fetch -o run -- python3 $R/bench.py --steps 36 --warmup 6 --regions 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc/write -o run -- python3 $R/bench.py --steps 36 --warmup 6 --regions 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
-python3 $R/tools/pmc_summary.py $OUT/pmc $OUT/${TAG}_pmc_model_step.json "python3 bench.py --steps 36 --warmup 6 --regions 1 --no-cpu-baseline (64 members)" 8
+PMC="--steps 36 --warmup 6 --regions 1 $SER"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc/fetch -o run -- python3 $R/bench.py $PMC > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc/write -o run -- python3 $R/bench.py $PMC > $OUT/pmc_write.log 2>&1
+python3 $R/tools/pmc_summary.py $OUT/pmc $OUT/${TAG}_pmc_model_step.json "python3 bench.py $PMC (64 members)" 8
 rm -rf $OUT/k64/run_kernel_trace.csv $OUT/k8/run_kernel_trace.csv $OUT/k1/run_kernel_trace.csv $OUT/pmc/fetch $OUT/pmc/write
 python3 $R/tools/copy_rate.py > $OUT/${TAG}_device_copy_rate.txt 2>&1 || true
 echo "all done"

@@ -1,5 +1,5 @@
 """Per-kernel times of the bench workload with an experimental build of the library (results may be WRONG on purpose:
-bounding experiments).  PYSPEEDY_AMD_LIB=build_variants/lib_<x>.so python tools/exp_bound.py [members] [steps]
+bounding experiments).  PYSPEEDY_AMD_LIB=build_variants/lib_<x>.so python tools/exp_bound.py [members] [steps] [cfg4|cfg5]
 Prints ms/step (one call of `steps` steps, median of 5) and the level-2 per-kernel HIP-event table of one simulated day."""
 import os
 import sys
@@ -17,7 +17,7 @@ def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 360
     tag = os.path.basename(os.environ.get("PYSPEEDY_AMD_LIB", "committed"))
-    args = types.SimpleNamespace(config="cfg4")
+    args = types.SimpleNamespace(config=sys.argv[3] if len(sys.argv) > 3 else "cfg4")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     sp, model = bench.build_ensemble(args, M, 0, dev, None, 0, dev)
