@@ -400,33 +400,55 @@ def drop_in_leg(M, steps):
     ens = SpeedyEns(M, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 3, 1))
     for member in ens:
         member.set_bc()
-    states = [m._state_cnt for m in ens.members]
-    controls = [m._control_cnt for m in ens.members]
+    # the calls below are the C entry points themselves, on argument arrays built once: what a Fortran / C host of the
+    # reference's loop pays per step (the Python veneer would add its own list -> array conversions to every call)
+    import ctypes as C
+    L = pyspeedy_amd_lib()
+    n = len(ens.members)
+    states = (C.c_int64 * n)(*[m._state_cnt for m in ens.members])
+    controls = (C.c_int64 * n)(*[m._control_cnt for m in ens.members])
+    codes = (C.c_int32 * n)()
+
+    def ok(rc):
+        if rc != 0:
+            raise SystemExit("bench.py: drop-in leg: " + L.spd_last_error().decode())
+
     for _ in range(12):
-        assert (drv.parallel_step(states, controls) == 0).all()
+        ok(L.spd_parallel_step(states, controls, codes, n))
+    assert not any(codes)
     torch.cuda.synchronize()
     sync = []
     for _ in range(steps):
         t0 = time.perf_counter()
-        codes = drv.parallel_step(states, controls)
+        ok(L.spd_parallel_step(states, controls, codes, n))
         sync.append(time.perf_counter() - t0)
-    assert (codes == 0).all()
-    ovl = []
-    token = drv.parallel_step_begin(states, controls)
+    assert not any(codes)
+    ovl, worst = [], 0
+    token, nxt = C.c_int64(), C.c_int64()
+    ok(L.spd_parallel_step_begin(states, controls, n, C.byref(token)))
     for _ in range(steps):
         t0 = time.perf_counter()
-        nxt = drv.parallel_step_begin(states, controls)
-        assert (drv.parallel_step_end(token) == 0).all()
-        token = nxt
+        ok(L.spd_parallel_step_begin(states, controls, n, C.byref(nxt)))
+        ok(L.spd_parallel_step_end(token, codes))
+        token.value = nxt.value
         ovl.append(time.perf_counter() - t0)
-    assert (drv.parallel_step_end(token) == 0).all()
+        worst |= int(any(codes))
+    ok(L.spd_parallel_step_end(token, codes))
+    assert not worst and not any(codes)
+    models = len({drv.device_model(m._state_cnt)[0]._m.value for m in ens.members})
     del ens
-    return {"containers": M, "steps_timed": steps, "sync_ms_per_step": median(sync) * 1e3,
+    return {"containers": M, "device_models": models, "steps_timed": steps, "sync_ms_per_step": median(sync) * 1e3,
             "begin_end_ms_per_step": median(ovl) * 1e3,
             "note": "spd_parallel_step(state_cnts, control_cnts, error_codes, n) once per model step over independent containers "
-                    "(gathered into one device model on the first call): every step stores all diagnostics and runs the range "
+                    "(one device model up to 31 containers, two from 32 up, both enqueued before either is waited for): every "
+                    "step stores all diagnostics and runs the range "
                     "check as a launch of its own; sync = the call returns the codes, begin_end = the check of step k is "
                     "collected after step k + 1 has been enqueued; medians of per-step wall times"}
+
+
+def pyspeedy_amd_lib():
+    import pyspeedy_amd
+    return pyspeedy_amd.lib()
 
 
 def plan_name(cfg, M):
@@ -592,11 +614,12 @@ def run_rank(args):
                 "algorithmic_bytes_per_field": S_BYTES + G_BYTES, "avg_launch_ms": kern_ms, "launches_timed": launches,
                 "measured_in": "%d further regions of %d steps issued in the serial plan (one member group on one stream: the "
                                "duration of a kernel that shares the GPU with another group's kernels is not its own); HIP events "
-                               "on the launch stream around every spec2grid launch" % (len(serial_s), args.steps),
+                               "attached to the dispatch of every spec2grid launch of those regions" % (len(serial_s), args.steps),
                 "serial_plan_ms_per_step": median(serial_s) / args.steps * 1e3,
                 "traffic": traffic, "traffic_source": traffic_src, "kernels": kernels,
-                "kernels_note": "one bracketed simulated day (36 steps, serial plan); the brackets add a few microseconds between "
-                                "launches, so the rows sum to slightly more than serial_plan_ms_per_step",
+                "kernels_note": "one simulated day (36 steps, serial plan) with events attached to every kernel's dispatch (the "
+                                "kernels' own begin / end time stamps, as in rocprofv3's kernel trace); the rows sum to less than "
+                                "serial_plan_ms_per_step by the gaps between dependent launches",
             },
         }
         line.update(legs)

@@ -203,9 +203,10 @@ typedef struct spd_model_control {
 } spd_model_control;
 int spd_model_get_control(spd_model_handle m, spd_model_control *out);
 int spd_model_set_control(spd_model_handle m, const spd_model_control *in);
-/* measurement hook: HIP events recorded on the launch stream around the kernels of every step.  level 0 = off, 1 = the
- * dominant kernel only (the 91*M-field spectral->grid launch; cheap enough for the timed region of bench.py), 2 = every
- * kernel of the step (a separate measurement pass: each bracket adds a few microseconds between launches).  While the level
+/* measurement hook: HIP events on the launch stream for the kernels of every step.  level 0 = off, 1 = the dominant kernel
+ * only (the 77*M-field spectral->grid launch), 2 = every kernel of the step.  The events of a step kernel are attached to its
+ * dispatch (hipExtLaunchKernel): they hold the kernel's own begin / end time stamps, as rocprofv3's kernel trace does, and no
+ * marker packets sit between the launches (only the daily forcing, three launches, is bracketed by recorded events).  While the level
  * is not 0 the step is issued as ONE member group on the caller's stream (the serial plan), whatever "member_groups" says:
  * kernels of overlapping groups share the GPU and their durations would not be their own.
  * _read synchronises the events of the spectral->grid launches and returns their mean time in ms;

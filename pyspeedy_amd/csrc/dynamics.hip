@@ -20,6 +20,7 @@
 #include "coupler_point.hpp"
 #include "device_tables.hpp"
 #include "dyn_column.hpp"
+#include "launch_events.hpp"
 #include "model.hpp"
 #include "sppt_point.hpp"
 
@@ -423,13 +424,29 @@ __global__ __launch_bounds__(64 * KX) void diagnostics_kernel(ModelPtrs P, Devic
     const size_t so = ((static_cast<size_t>(mem) * 2 + tl) * 8 + l) * NSPEC;
     const d2 *vor = reinterpret_cast<const d2 *>(P.vor) + so, *div = reinterpret_cast<const d2 *>(P.div) + so;
     double d1 = 0.0, d2s = 0.0;
-    for (int k = lane; k < NSPEC; k += 64) {
-        if (k % MX == 0) continue;  // m = 1 (zonal mean) is excluded: only the eddies count
-        const double e = T.elm2[k];
-        const d2 a = vor[k], b = div[k];
-        // temp = -x * elm2 ; diag -= real(temp * conjg(x))
-        d1 = d1 - ((-a.x * e) * a.x + (-a.y * e) * a.y);
-        d2s = d2s - ((-b.x * e) * b.x + (-b.y * e) * b.y);
+    // (the 16 rounds of a lane are requested in two batches of 8 before anything is summed: the kernel is one dependent chain per
+    // wavefront, launched once per model step by hosts with the reference's loop; the order of the sum is unchanged)
+    constexpr int kRounds = (NSPEC + 63) / 64, kBatch = 8;
+    static_assert(kRounds % kBatch == 0, "two full batches");
+#pragma unroll
+    for (int r0 = 0; r0 < kRounds; r0 += kBatch) {
+        d2 a[kBatch], b[kBatch];
+        double e[kBatch];
+#pragma unroll
+        for (int r = 0; r < kBatch; ++r) {
+            const int k = lane + 64 * (r0 + r), kc = k < NSPEC ? k : NSPEC - 1;
+            e[r] = T.elm2[kc];
+            a[r] = vor[kc];
+            b[r] = div[kc];
+        }
+#pragma unroll
+        for (int r = 0; r < kBatch; ++r) {
+            const int k = lane + 64 * (r0 + r);
+            if (k >= NSPEC || k % MX == 0) continue;  // m = 1 (zonal mean) is excluded: only the eddies count
+            // temp = -x * elm2 ; diag -= real(temp * conjg(x))
+            d1 = d1 - ((-a[r].x * e[r]) * a[r].x + (-a[r].y * e[r]) * a[r].y);
+            d2s = d2s - ((-b[r].x * e[r]) * b[r].x + (-b[r].y * e[r]) * b[r].y);
+        }
     }
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) {
@@ -465,15 +482,15 @@ hipError_t run_geopotential(const ModelPtrs &P, const DynDeviceTables &D, int fi
     const int ngeo = (count * NSPEC + kT - 1) / kT;
     if (sppt) {
         const long n = static_cast<long>(sppt->M) * KX * NSPEC;
-        hipLaunchKernelGGL(geopotential_kernel<true>, dim3(ngeo + static_cast<unsigned>((n + kT - 1) / kT)), dim3(kT), 0, s, P, D,
+        launch(geopotential_kernel<true>, dim3(ngeo + static_cast<unsigned>((n + kT - 1) / kT)), dim3(kT), 0, s, P, D,
                            first, count, tl, *sppt);
     } else {
-        hipLaunchKernelGGL(geopotential_kernel<false>, dim3(ngeo), dim3(kT), 0, s, P, D, first, count, tl, SpptArgs{});
+        launch(geopotential_kernel<false>, dim3(ngeo), dim3(kT), 0, s, P, D, first, count, tl, SpptArgs{});
     }
     return hipGetLastError();
 }
 hipError_t run_dyn_grid(const ModelPtrs &P, const DynDeviceTables &D, int M, hipStream_t s) {
-    hipLaunchKernelGGL(dyn_grid_kernel, dim3((M * NG + kT - 1) / kT), dim3(kT), 0, s, P, D, M);
+    launch(dyn_grid_kernel, dim3((M * NG + kT - 1) / kT), dim3(kT), 0, s, P, D, M);
     return hipGetLastError();
 }
 // cpl != nullptr: the coupling of the step rides in the same launch (tail blocks).  Small launches use the form of the kernel
@@ -482,7 +499,7 @@ namespace {
 template <bool FOLD, bool EARLY, typename CA>
 void launch_spectral_step(dim3 grid, hipStream_t s, const ModelPtrs &P, const DeviceTables &T, const DynDeviceTables &D, int M,
                           int first, int count, int j1, double dt, double eps, const CA &cpl) {
-    hipLaunchKernelGGL((spectral_step_kernel<FOLD, EARLY, CA>), grid, dim3(kT), 0, s, P, T, D, M, first, count, j1, dt, eps, cpl);
+    launch(spectral_step_kernel<FOLD, EARLY, CA>, grid, dim3(kT), 0, s, P, T, D, M, first, count, j1, dt, eps, cpl);
 }
 template <typename CA>
 void dispatch_spectral_step(bool fold, bool early, dim3 grid, hipStream_t s, const ModelPtrs &P, const DeviceTables &T,

@@ -14,6 +14,7 @@
 #include "context.hpp"
 #include "model.hpp"
 #include "coupler_point.hpp"
+#include "launch_events.hpp"
 #include "sppt_point.hpp"
 #include "surface.hpp"
 
@@ -147,6 +148,13 @@ struct spd_model {
     double *d_dmp1 = nullptr, *d_dmp1d = nullptr, *d_dmp1s = nullptr, *d_elz = nullptr, *d_xj = nullptr, *d_xc = nullptr,
            *d_xd = nullptr;
 };
+
+namespace spd {
+LaunchEvents &pending_launch_events() {
+    static thread_local LaunchEvents ev;
+    return ev;
+}
+}  // namespace spd
 
 static int m_fail(int code, const std::string &msg) { return spd_set_error(code, msg); }
 
@@ -554,11 +562,15 @@ int spd_model_set_time_step(spd_model_handle m, double dt) {
 }
 
 // HIP-event bracket around one launch (or a short group of launches) of the step when profiling asks for it
+// attach = true (a scope around exactly ONE launch of a step kernel): the events are not recorded here but announced to the
+// launch (launch_events.hpp), which attaches them to its dispatch packet: the pair then holds the kernel's own begin / end time
+// stamps.  attach = false: recorded around whatever the scope holds (the daily forcing: three launches).
 struct ProfScope {
     spd_model *m;
     hipStream_t s;
-    hipEvent_t stop = nullptr;
-    ProfScope(spd_model *m_, int kernel, int fields, hipStream_t s_) : m(m_), s(s_) {
+    hipEvent_t start = nullptr, stop = nullptr;
+    bool attach;
+    ProfScope(spd_model *m_, int kernel, int fields, hipStream_t s_, bool attach_ = true) : m(m_), s(s_), attach(attach_) {
         if (m->profile == 0 || (m->profile == 1 && kernel != SPD_K_SPEC2GRID)) return;
         if (m->prof_used == m->prof_events.size()) {
             hipEvent_t a = nullptr, b = nullptr;
@@ -570,11 +582,20 @@ struct ProfScope {
         const size_t i = m->prof_used++;
         m->prof_fields[i] = fields;
         m->prof_kernel[i] = kernel;
-        (void)hipEventRecord(m->prof_events[i].first, s);
+        start = m->prof_events[i].first;
         stop = m->prof_events[i].second;
+        if (attach) pending_launch_events() = LaunchEvents{start, stop};
+        else (void)hipEventRecord(start, s);
     }
     ~ProfScope() {
-        if (stop) (void)hipEventRecord(stop, s);
+        if (!stop) return;
+        if (!attach) {
+            (void)hipEventRecord(stop, s);
+        } else if (pending_launch_events().start == start) {  // no launch picked the events up (nothing was launched): record
+            pending_launch_events() = LaunchEvents{};        // them, so that reading the pair does not wait for ever
+            (void)hipEventRecord(start, s);
+            (void)hipEventRecord(stop, s);
+        }
     }
 };
 
@@ -755,7 +776,7 @@ static ZonalDevice forcing_host(spd_model *m, int imode) {
 static int forcing_range(spd_model *m, const ZonalDevice &zd, int first, int count, hipStream_t s) {
     const double gamlat = static_cast<double>(6.0f) / (1000.f * static_cast<double>(9.81f));  // setgam, forcing.f90:105-117
     const size_t og = static_cast<size_t>(first) * NG, os = static_cast<size_t>(first) * NSPEC * C;
-    ProfScope ps(m, SPD_K_FORCING, count, s);
+    ProfScope ps(m, SPD_K_FORCING, count, s, false);
     hipError_t e = run_forcing(m->S, first, count, zd, gamlat, m->corh_t, m->corh_q, s);
     if (e == hipSuccess) e = run_grid2spec(m->ctx->dev, 0, m->corh_t + og, m->P.tcorh + os, 0, count, s);
     if (e == hipSuccess) e = run_grid2spec(m->ctx->dev, 0, m->corh_q + og, m->P.qcorh + os, 0, count, s);

@@ -25,6 +25,7 @@
 #include "../../include/pyspeedy_amd.h"
 #include "device_tables.hpp"
 #include "dyn_column.hpp"
+#include "launch_events.hpp"
 #include "stream_store.hpp"
 
 namespace spd {
@@ -861,7 +862,7 @@ static hipError_t launch_physics(const DeviceTables &T, const spd_physics_args &
                                  const DynDeviceTables &D, int diag, hipStream_t s) {
     const long total = static_cast<long>(nmembers) * NG;
     const unsigned blocks = static_cast<unsigned>((total + kPhysThreads - 1) / kPhysThreads);
-    hipLaunchKernelGGL((physics_kernel<W, FUSED, KEEP, R>), dim3(blocks), dim3(kPhysThreads), 0, s, a, col_tables<R>(T), first,
+    launch(physics_kernel<W, FUSED, KEEP, R>, dim3(blocks), dim3(kPhysThreads), 0, s, a, col_tables<R>(T), first,
                        nmembers, P, D, diag);
     return hipGetLastError();
 }

@@ -20,6 +20,7 @@
 
 #include "device_tables.hpp"
 #include "sppt_point.hpp"
+#include "launch_events.hpp"
 
 namespace spd {
 
@@ -54,7 +55,7 @@ SpptArgs sppt_args(double *spec, const DeviceTables &T, int M, unsigned long lon
 
 hipError_t run_sppt_update(const SpptArgs &a, hipStream_t s) {
     const long n = static_cast<long>(a.M) * KX * NSPEC;
-    hipLaunchKernelGGL(sppt_update_kernel, dim3(static_cast<unsigned>((n + kT - 1) / kT)), dim3(kT), 0, s, a);
+    launch(sppt_update_kernel, dim3(static_cast<unsigned>((n + kT - 1) / kT)), dim3(kT), 0, s, a);
     return hipGetLastError();
 }
 

@@ -9,6 +9,7 @@
 
 #include "coupler_point.hpp"
 #include "surface.hpp"
+#include "launch_events.hpp"
 #include "stream_store.hpp"
 
 namespace spd {
@@ -144,7 +145,7 @@ hipError_t run_rest_surface(const double *phis0, double *forog, double *surf_ps,
 // members [first, first + count)
 hipError_t run_coupler(const SurfacePtrs &S, int first, int count, const TimeInterp &w, int day, int land_coupling,
                        int sst_anomaly, int anom_planes, int fresh, hipStream_t s) {
-    hipLaunchKernelGGL(coupler_kernel, dim3((count * NG + kT - 1) / kT), dim3(kT), 0, s, S, first, count, w, day, land_coupling,
+    launch(coupler_kernel, dim3((count * NG + kT - 1) / kT), dim3(kT), 0, s, S, first, count, w, day, land_coupling,
                        sst_anomaly, anom_planes, fresh);
     return hipGetLastError();
 }

@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_tables.hpp"
+#include "launch_events.hpp"
 #include "fft96.hpp"
 
 namespace spd {
@@ -543,7 +544,7 @@ hipError_t run_spec2grid_table(const DeviceTables &T, const FieldDesc *table, in
     if (nfields == 0) return hipSuccess;
     const hipError_t cfg = SPD_CONFIGURE(&spec2grid_table_kernel);
     if (cfg != hipSuccess) return cfg;
-    hipLaunchKernelGGL(spec2grid_table_kernel, dim3(nfields), dim3(kThreads), kLdsBytes, st, table, T);
+    launch(spec2grid_table_kernel, dim3(nfields), dim3(kThreads), kLdsBytes, st, table, T);
     return hipGetLastError();
 }
 
@@ -551,7 +552,7 @@ hipError_t run_grid2spec_table(const DeviceTables &T, const FieldDesc *table, in
     if (nfields == 0) return hipSuccess;
     const hipError_t cfg = SPD_CONFIGURE(&grid2spec_table_kernel);
     if (cfg != hipSuccess) return cfg;
-    hipLaunchKernelGGL(grid2spec_table_kernel, dim3(nfields), dim3(kThreads), kLdsBytes, st, table, T);
+    launch(grid2spec_table_kernel, dim3(nfields), dim3(kThreads), kLdsBytes, st, table, T);
     return hipGetLastError();
 }
 
