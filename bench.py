@@ -481,6 +481,14 @@ def wait_for_ranks(rank, world, what):
     deadline = time.time() + 600.0
     while time.time() < deadline:
         if all(os.path.exists("%s.%d" % (base, r)) for r in range(world)):
+            if rank != 0:  # (rank 0 reads the files last: it is the one that waits for all of them)
+                return True
+            time.sleep(0.5)
+            for r in range(world):
+                try:
+                    os.unlink("%s.%d" % (base, r))
+                except OSError:
+                    pass
             return True
         time.sleep(0.05)
     return False

@@ -978,9 +978,9 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
 
 int spd_model_current_step(spd_model_handle m) { return m ? m->current_step : SPD_E_ARG; }
 
-// Profiling with HIP events on the launch stream.  Level 1: every step brackets its 91*M-field spec2grid launch (the
-// roofline kernel of bench.py); level 2: every kernel of the step is bracketed (the events serialise nothing, but each
-// bracket adds a few microseconds between launches, so level 2 is for a separate measurement pass, not for the timed region).
+// Profiling with HIP events on the launch stream.  Level 1: the spec2grid launch of every step (the roofline kernel of
+// bench.py); level 2: every kernel of the step.  The events are attached to the kernels' dispatch packets (launch_events.hpp),
+// and while the level is not 0 the step is issued as one member group (spd_model_step).
 int spd_model_profile(spd_model_handle m, int level) {
     if (!m) return m_fail(SPD_E_ARG, "spd_model_profile: null model");
     if (level < 0 || level > 2) return m_fail(SPD_E_ARG, "spd_model_profile: level is 0, 1 or 2");
