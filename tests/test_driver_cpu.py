@@ -65,3 +65,29 @@ def test_calls_on_dead_containers_fail_cleanly(hip_lib):
     assert L.spd_get(12345, b"olr", buf.ctypes.data_as(C.c_void_p), buf.nbytes) < 0
     assert L.spd_modelstate_close(12345) == 0  # closing twice is harmless, as deallocate on a freed container is not tested upstream
     assert b"container" in L.spd_last_error()
+
+
+def test_multi_device_interface_without_a_device(hip_lib):
+    """The one-process-several-GPUs extension on a machine that has no GPU: the device count is 0, no placement beyond it is
+    accepted, naming a device fails with a message (never a CPU fallback), and the trace / broadcast entry points check their
+    arguments.  (The machine with a GPU runs tests/test_driver_gpu.py::test_device_placement_and_boundary_broadcast.)"""
+    import os
+    import pytest
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("needs a machine without a GPU")
+    L = hip_lib
+    n = C.c_int32(-1)
+    assert L.spd_device_count(C.byref(n)) == 0 and n.value == 0
+    assert L.spd_device_count(None) < 0
+    assert L.spd_set_device_placement(0) == 0 and L.spd_set_device_placement(1) < 0 and L.spd_set_device_placement(-1) < 0
+    cnt = C.c_int64(0)
+    assert L.spd_modelstate_init_on(C.byref(cnt), 0) < 0 and b"no such HIP device" in L.spd_last_error()
+    assert L.spd_modelstate_init(C.byref(cnt)) < 0  # no device, no state: there is no CPU fallback
+    dev = C.c_int32()
+    assert L.spd_modelstate_device(4242, C.byref(dev)) < 0
+    ids = (C.c_int64 * 2)(4242, 4243)
+    assert L.spd_broadcast_boundary(ids, 2, 5) < 0 and L.spd_broadcast_boundary(ids, 2, 0) < 0
+    assert L.spd_driver_trace(1) == 0 and L.spd_driver_trace_read(None, 0) == 0 and L.spd_driver_trace(0) == 0
+    codes = (C.c_int32 * 2)()
+    assert L.spd_parallel_step(ids, ids, codes, 2) < 0 and b"container" in L.spd_last_error()
+    assert L.spd_parallel_step(ids, ids, codes, 0) == 0  # an empty ensemble steps trivially
