@@ -336,20 +336,6 @@ int gather(const std::vector<std::shared_ptr<State>> &states, bool *done) {
     return SPD_OK;
 }
 
-// do_single_step + check_diagnostics for all members of `b` at the date of `c`
-int step_batch(Batch &b, const Control &c, std::vector<int32_t> &codes) {
-    codes.assign(b.members, 0);
-    for (int i = 0; i < b.members; ++i)
-        if (!b.initialized[i]) {
-            codes.assign(b.members, -1);  // E_STATE_NOT_INITIALIZED
-            return SPD_OK;
-        }
-    if (hipSetDevice(b.device) != hipSuccess) return fail(SPD_E_DEVICE, "speedy driver: hipSetDevice failed");
-    if (int rc = push_date(b, c)) return rc;
-    if (int rc = spd_model_step(b.model, 1, b.stream)) return rc;
-    return spd_model_check(b.model, 2, codes.data(), nullptr, b.stream);
-}
-
 int table_values(const RegVar &v, spd_handle ctx, std::vector<double> &out64, std::vector<float> &out32) {
     auto tab = [&](const char *name, std::vector<double> &dst) -> int {
         const long n = spd_get_table_host(ctx, name, nullptr, 0);
@@ -808,18 +794,11 @@ int spd_parallel_step(const int64_t *state_cnts, const int64_t *control_cnts, in
     std::unique_lock<std::recursive_mutex> lock(g_mutex);
     std::vector<StepGroup> groups;
     if (int rc = plan_step(state_cnts, control_cnts, n, groups, "spd_parallel_step")) return rc;
-    if (groups.size() == 1) {  // one device model (the usual case): step, check and wait in one go
-        StepGroup &g = groups[0];
-        std::vector<int32_t> codes;
-        if (int rc = step_batch(*g.batch, g.before, codes)) return rc;
-        if (all_initialized(*g.batch))
-            if (int rc = pull_date(*g.batch, g.advanced)) return rc;
-        settle_group(g, codes, error_codes, false);
-        return SPD_OK;
-    }
-    // Several device models -- one per GPU of a one-process ensemble, or members that could not be batched --: every
-    // group's step and check are enqueued before the host waits for any of them, so the devices (and the models that share
-    // one) work side by side; a group that fails does not keep the others from being stepped.
+    // One device model, or several -- one per GPU of a one-process ensemble, the two models 32 or more containers of a device
+    // are kept in, members that could not be batched --: every model's step and check are enqueued before the host waits for
+    // any of them, so the devices (and the models that share one) work side by side; a model that fails does not keep the
+    // others from being stepped; and the lock is given up while the host waits, so that other host threads can step THEIR
+    // containers meanwhile (the reference's parallel_step is `!f2py threadsafe`).
     for (size_t i = 0; i < groups.size(); ++i) {
         issue_group(groups[i]);
         trace(1, static_cast<int>(i));
