@@ -657,19 +657,22 @@ static int plan_step(const int64_t *state_cnts, const int64_t *control_cnts, int
             if (states[j] == states[i]) return fail(SPD_E_ARG, std::string(who) + ": the same state container twice");
     }
     // independent one-member models -> batched models (once; later calls find them batched)
-    std::vector<char> classed(n, 0);
+    std::vector<char> classed(n, 1);
+    std::vector<spd_model_control> own(n);  // the control block of every initialised one-member model, read once
     for (int i = 0; i < n; ++i) {
-        if (classed[i] || states[i]->batch->members != 1 || !states[i]->batch->initialized[0]) continue;
+        const Batch &b = *states[i]->batch;
+        if (b.members != 1 || !b.initialized[0]) continue;
+        if (int rc = spd_model_get_control(b.model, &own[i])) return rc;
+        classed[i] = own[i].sppt_on ? 1 : 0;  // (an SPPT member keeps its own model: gather() has the why)
+    }
+    for (int i = 0; i < n; ++i) {
+        if (classed[i]) continue;
         std::vector<std::shared_ptr<State>> cls;
         for (int j = i; j < n; ++j) {
             const Batch &bi = *states[i]->batch, &bj = *states[j]->batch;
-            if (classed[j] || bj.members != 1 || !bj.initialized[0] || bj.device != bi.device || bj.n_months != bi.n_months ||
-                bj.sst_anom_allocated != bi.sst_anom_allocated || !same_date(*controls[i], *controls[j]))
+            if (classed[j] || bj.device != bi.device || bj.n_months != bi.n_months || bj.sst_anom_allocated != bi.sst_anom_allocated ||
+                !same_date(*controls[i], *controls[j]) || std::memcmp(&own[i], &own[j], sizeof(own[i])) != 0)
                 continue;
-            spd_model_control a, b;
-            if (int rc = spd_model_get_control(bi.model, &a)) return rc;
-            if (int rc = spd_model_get_control(bj.model, &b)) return rc;
-            if (std::memcmp(&a, &b, sizeof(a)) != 0) continue;
             classed[j] = 1;
             cls.push_back(states[j]);
         }

@@ -33,7 +33,8 @@ from . import registry as R
 
 ERROR_CODES = {0: "Run successful.",
                -1: "The model state was not initialized. Initialize it (init) before running the model.",
-               -2: "Model variables out of the accepted range (diagnostics.f90)."}
+               -2: "Model variables out of the accepted range (diagnostics.f90).",
+               -3: "The step of this member's device model could not be issued or checked (see the error of the call)."}
 
 
 def _L():
