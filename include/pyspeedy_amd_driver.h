@@ -12,12 +12,18 @@
  * returns that model's SPD_E_* code after the other models have been stepped; their members have their usual codes).
  *
  * Batching.  The reference steps an ensemble with an OpenMP loop over independent containers (parallel_step, :58-79).
- * Here spd_parallel_step advances all members with ONE set of kernel launches: the first time it is handed n > 1
- * independent, initialised containers that agree in date, step counter and control flags, it gathers their states into one
- * batched device model (device-to-device copies, once) and rebinds the containers to the members of that model; get / set /
- * check / transforms keep working per container.  spd_step on a single member of such a batch, or a parallel_step over a
- * different grouping, takes the members apart again first (correct, but it gives the batching up).
+ * Here spd_parallel_step advances the members with one set of kernel launches per DEVICE MODEL: the first time it is handed
+ * independent, initialised containers it gathers them (device-to-device copies, once) into batched device models -- per
+ * device, and per set of containers that agree in date, step counter, control flags and anomaly length; 32 or more of them
+ * on one device become two models -- and rebinds the containers to the members of those models; get / set / check / transforms
+ * keep working per container.  A call over several models enqueues the step and range check of every model (each on a stream
+ * of its own) before it waits for any, and does not hold the library's lock while it waits: devices, models and host threads
+ * that step other containers work side by side.  spd_step on a single member of a batch, or a parallel_step over a different
+ * grouping, takes that batch apart again first (correct, but it gives the batching up).
  * spd_modelstate_init_ensemble creates n containers that are batched from the start.
+ *
+ * Threads.  Every entry point may be called from any host thread; calls on the SAME container (or on containers that share a
+ * device model) must not overlap in time -- the reference's `!f2py threadsafe` contract.
  *
  * Date: as in the reference the CONTROL container owns the model date (ControlParams_t%model_datetime, month_idx,
  * model_control.f90:38-47): step / parallel_step take the date from it and advance it; a member whose step fails keeps its
