@@ -116,7 +116,7 @@ struct spd_model {
     int inv_per_member = 77;
     int nchunks = 1;
     hipStream_t cstream[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t cev[4] = {nullptr, nullptr, nullptr, nullptr}, ev_start = nullptr;
+    hipEvent_t cev[4] = {nullptr, nullptr, nullptr, nullptr}, ev_start = nullptr, ev_offset = nullptr;
     bool split_dyn_physics = false;  // PYSPEEDY_AMD_SPLIT_DYN=1: separate dynamics and physics launches (for measurements)
     int phys_fp32 = 0;               // spd_model_set_physics_precision: column physics arithmetic in fp32 (BASELINE cfg 5)
     // Dead-store elimination inside multi-step calls (PYSPEEDY_AMD_DIAG_EVERY_STEP=1 switches it off): only the LAST step
@@ -459,6 +459,7 @@ int spd_model_destroy(spd_model_handle m) {
         if (m->cev[i]) (void)hipEventDestroy(m->cev[i]);
     }
     if (m->ev_start) (void)hipEventDestroy(m->ev_start);
+    if (m->ev_offset) (void)hipEventDestroy(m->ev_offset);
     if (m->h_err_sync) (void)hipHostFree(m->h_err_sync);
     for (int i = 0; i < 2; ++i) {
         if (m->h_err[i]) (void)hipHostFree(m->h_err[i]);
@@ -622,7 +623,7 @@ static void sppt_advance(spd_model *m) {
 
 // cpl != nullptr: the coupling that follows the step is part of the last launch
 static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int compute_shortwave, int first, int count, int diag,
-                             bool run_geo, const CouplerArgs *cpl, hipStream_t s) {
+                             bool run_geo, const CouplerArgs *cpl, hipStream_t s, hipEvent_t after_grid2spec = nullptr) {
     const DeviceTables &T = m->ctx->dev;
     const int M = m->M;
     hipError_t e = hipSuccess;
@@ -670,6 +671,7 @@ static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int comput
         ProfScope ps(m, SPD_K_GRID2SPEC, 73 * count, s);
         e = run_grid2spec_table(T, m->fwd_table + static_cast<size_t>(first) * 73, 73 * count, s);
     }
+    if (after_grid2spec && e == hipSuccess) e = hipEventRecord(after_grid2spec, s);
     const double eps = (j1 == 1) ? 0.0 : static_cast<double>(0.05f);                      // rob, time_stepping.f90:130-134
     if (e == hipSuccess) {
         ProfScope ps(m, SPD_K_SPECTRAL_STEP, count, s);
@@ -931,6 +933,16 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
                     if (hipEventRecord(ev[g], gs[g]) == hipSuccess) (void)hipStreamWaitEvent(s, ev[g], 0);
         }
     } join{s, gs, m->cev, G};
+    // Two groups that start together stay together: they have the same work, so both run their transform launches at the same
+    // time and their column launches at the same time, and only the tails overlap.  The second group therefore starts when the
+    // first has issued three quarters of its first step (behind its grid -> spectral launch): from then on one group's
+    // latency-bound transforms run beside the other's streaming column / spectral kernels.  Measured at 64 members: 0.241 ms
+    // per step every time, against 0.243 ... 0.250 when left to chance (profiles/r03_member_groups.txt); 96 members -2.8 %;
+    // nothing at 32 / 48 members or with 3 groups.  The offset costs the call three quarters of a step once, so it is applied to
+    // calls of at least 72 steps (PYSPEEDY_AMD_GROUP_OFFSET=0 switches it off).
+    static const bool offset_allowed = !(getenv("PYSPEEDY_AMD_GROUP_OFFSET") && atoi(getenv("PYSPEEDY_AMD_GROUP_OFFSET")) == 0);
+    const bool offset = offset_allowed && G == 2 && nsteps >= 72;
+    if (offset && !m->ev_offset) M_HIP(hipEventCreateWithFlags(&m->ev_offset, hipEventDisableTiming));
     const int base = m->M / G, extra = m->M % G;
     int rc = SPD_OK;
     for (int it = 0; it < nsteps && rc == SPD_OK; ++it) {
@@ -956,7 +968,9 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
                             m->anom_planes, fresh};
             const bool ride = m->coupler_in_spectral;
             if (rc == SPD_OK) {
-                const hipError_t e = step_range(m, 2, 2, 2 * delt, sw, first, count, diag, run_geo, ride ? &cpl : nullptr, gs[g]);
+                if (offset && it == 0 && g == 1) M_HIP(hipStreamWaitEvent(gs[1], m->ev_offset, 0));
+                const hipError_t e = step_range(m, 2, 2, 2 * delt, sw, first, count, diag, run_geo, ride ? &cpl : nullptr, gs[g],
+                                                (offset && it == 0 && g == 0) ? m->ev_offset : nullptr);
                 if (e != hipSuccess) rc = m_fail(SPD_E_DEVICE, std::string("spd_model_step: ") + hipGetErrorString(e));
             }
             if (rc == SPD_OK && !ride) {
