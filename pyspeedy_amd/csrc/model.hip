@@ -938,10 +938,11 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
     // first has issued three quarters of its first step (behind its grid -> spectral launch): from then on one group's
     // latency-bound transforms run beside the other's streaming column / spectral kernels.  Measured at 64 members: 0.241 ms
     // per step every time, against 0.243 ... 0.250 when left to chance (profiles/r03_member_groups.txt); 96 members -2.8 %;
-    // nothing at 32 / 48 members or with 3 groups.  The offset costs the call three quarters of a step once, so it is applied to
-    // calls of at least 72 steps (PYSPEEDY_AMD_GROUP_OFFSET=0 switches it off).
-    static const bool offset_allowed = !(getenv("PYSPEEDY_AMD_GROUP_OFFSET") && atoi(getenv("PYSPEEDY_AMD_GROUP_OFFSET")) == 0);
-    const bool offset = offset_allowed && G == 2 && nsteps >= 72;
+    // nothing at 32 / 48 members or with 3 groups.  It costs a call the time its first and last three quarters of a step run
+    // alone; applied to calls of at least 72 steps (PYSPEEDY_AMD_GROUP_OFFSET=n: from n steps, 0: never -- in 20-step calls it
+    // measured 0 ... +1.5 %).
+    static const int offset_from = getenv("PYSPEEDY_AMD_GROUP_OFFSET") ? atoi(getenv("PYSPEEDY_AMD_GROUP_OFFSET")) : 72;
+    const bool offset = offset_from > 0 && G == 2 && nsteps >= offset_from;
     if (offset && !m->ev_offset) M_HIP(hipEventCreateWithFlags(&m->ev_offset, hipEventDisableTiming));
     const int base = m->M / G, extra = m->M % G;
     int rc = SPD_OK;
