@@ -36,14 +36,21 @@ struct share {
     int64_t *states, *controls;
     int32_t *codes;
     int n, nsteps, failed;
+    char msg[256]; /* spd_last_error() is per thread: the worker keeps its own message */
 };
 
 static void *step_share(void *arg) {
     struct share *s = (struct share *)arg;
     for (int it = 0; it < s->nsteps && !s->failed; ++it) {
-        if (spd_parallel_step(s->states, s->controls, s->codes, s->n) != SPD_OK) s->failed = 1;
-        for (int i = 0; i < s->n; ++i)
-            if (s->codes[i] != 0) s->failed = 1;
+        if (spd_parallel_step(s->states, s->controls, s->codes, s->n) != SPD_OK) {
+            s->failed = 1;
+            snprintf(s->msg, sizeof(s->msg), "%s", spd_last_error());
+        }
+        for (int i = 0; i < s->n && !s->failed; ++i)
+            if (s->codes[i] != 0) {
+                s->failed = 1;
+                snprintf(s->msg, sizeof(s->msg), "member %d left the accepted range (code %d) at step %d", i, (int)s->codes[i], it);
+            }
     }
     return NULL;
 }
@@ -101,6 +108,7 @@ int main(int argc, char **argv) {
         sh[t].n = count;
         sh[t].nsteps = nsteps;
         sh[t].failed = 0;
+        sh[t].msg[0] = 0;
         first += count;
         if (threads == 1) step_share(&sh[t]);
         else if (pthread_create(&tid[t], NULL, step_share, &sh[t]) != 0) return 1;
@@ -108,7 +116,7 @@ int main(int argc, char **argv) {
     for (int t = 0; t < threads; ++t) {
         if (threads > 1) pthread_join(tid[t], NULL);
         if (sh[t].failed) {
-            fprintf(stderr, "c_host: a step failed (%s)\n", spd_last_error());
+            fprintf(stderr, "c_host: a step failed (%s)\n", sh[t].msg);
             return 1;
         }
     }
