@@ -60,13 +60,10 @@ def main():
         member["t_grid"] = t + rng.normal(0.0, 0.01, t.shape)
         member.grid2spectral()
 
-    model = drv.device_model(ens.members[0]._state_cnt)[0]  # the batched device model of this rank
-
     def write_statistics(_ens):
         if _ens.get_current_step() % 36:
             return
-        model.spectral2grid()
-        view = model.device_view("t_grid")  # [local members, lev, lat, lon] in HBM
+        view = _ens.device_view("t_grid", spectral2grid=True)  # [local members, lev, lat, lon] in HBM
         if backend != "nccl":
             view = view.cpu()
         mean, spread = E.ensemble_mean_spread(view, dist)

@@ -339,6 +339,12 @@ class SpeedyEns:
         arrays = _speedy.ensemble_grid_arrays([m._state_cnt for m in self], list(variables))
         return _build_dataset(self.members[0], arrays, [m.member_id for m in self], self.current_date)
 
+    def device_view(self, name, spectral2grid=False):
+        """The registry variable `name` of all members as one device tensor [member, ...] (speedy_driver.ensemble_device_view):
+        zero-copy while the ensemble lives in one device model, gathered on the device otherwise (32 or more members are kept
+        as two models, `devices=k` as one or two per GPU)."""
+        return _speedy.ensemble_device_view([m._state_cnt for m in self], name, spectral2grid)
+
     def run(self, callbacks=None):
         """Advance every member from the start to the end date; all members step together (parallel_step)."""
         callbacks = list(callbacks or [])

@@ -22,7 +22,8 @@ of kernel launches per step for all of them afterwards) -- see include/pyspeedy_
 
 Extensions (no counterpart in the reference): `modelstate_init_ensemble(n)` (containers batched from the start),
 `parallel_step_begin / parallel_step_end` (range check overlapped with the next step), `device_model(state_cnt)` (the batched
-device model behind a container, for zero-copy access to the state), `ensemble_grid_arrays`.
+device model behind a container, for zero-copy access to the state), `ensemble_device_view`, `ensemble_grid_arrays`, the
+one-process-several-GPUs placement functions.
 """
 import ctypes as C
 
@@ -240,6 +241,28 @@ def device_model(state_cnt):
     n_months = _shape("sst_anom", state_cnt)[2] - 2
     return EnsembleModel.borrowed(handle, members.value, torch.device("cuda", modelstate_device(state_cnt)),
                                   max(n_months, 1)), member.value
+
+
+def ensemble_device_view(state_cnts, name, spectral2grid=False):
+    """Extension: the registry variable `name` of the given containers as ONE device tensor [member, *reversed reference
+    shape] in the order of `state_cnts`.  Zero-copy when the containers are, in that order, all the members of one device
+    model; otherwise (the two models of 32 or more containers, several GPUs, a subset) the views of the models are gathered
+    into a new tensor on the device of the first container.  `spectral2grid=True` refreshes the grid-space variables of every
+    model involved first (one batched transform per model).  For on-device post-processing such as ensemble statistics."""
+    import torch
+    models, where = {}, []
+    for cnt in state_cnts:
+        model, member = device_model(cnt)
+        key = model._m.value
+        if key not in models:
+            if spectral2grid:
+                model.spectral2grid()
+            models[key] = model.device_view(name)
+        where.append((key, member))
+    if len(models) == 1 and [m for _, m in where] == list(range(next(iter(models.values())).shape[0])):
+        return next(iter(models.values()))
+    device = models[where[0][0]].device
+    return torch.stack([models[key][member].to(device) for key, member in where])
 
 
 def ensemble_grid_arrays(state_cnts, names):

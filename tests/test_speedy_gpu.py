@@ -229,15 +229,27 @@ def test_ensemble_statistics_on_device():
         member["t_grid"] = t + rng.normal(0.0, 0.01, t.shape)
         member.grid2spectral()
     ens.run()
-    model = drv.device_model(ens.members[0]._state_cnt)[0]
-    model.spectral2grid()
-    view = model.device_view("t_grid")
+    view = ens.device_view("t_grid", spectral2grid=True)
     assert tuple(view.shape) == (4, 8, 48, 96) and view.is_cuda
+    assert view.data_ptr() == drv.device_model(ens.members[0]._state_cnt)[0].device_view("t_grid").data_ptr()  # zero-copy
     mean, spread = E.ensemble_mean_spread(view, None)
     host = np.stack([m["t_grid"] for m in ens])  # [member, lon, lat, lev]
     np.testing.assert_allclose(mean.cpu().numpy().transpose(2, 1, 0), host.mean(axis=0), rtol=1e-14)
     np.testing.assert_allclose(spread.cpu().numpy().transpose(2, 1, 0), host.std(axis=0, ddof=1), rtol=1e-9, atol=1e-14)
     assert float(spread.max()) > 1e-4
+    # 32 members and more live in two device models: the view is gathered, the statistics are those of all members
+    big = SpeedyEns(33, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 1, 0, 40))
+    for member in big:
+        member.set_bc()
+    big.members[32]["t_grid"] = big.members[32]["t_grid"] + 1.0
+    big.members[32].grid2spectral()
+    assert len({drv.device_model(m._state_cnt)[0]._m.value for m in big}) == 2
+    view = big.device_view("t_grid", spectral2grid=True)
+    assert tuple(view.shape) == (33, 8, 48, 96)
+    mean, _ = E.ensemble_mean_spread(view, None)
+    host = np.stack([m["t_grid"] for m in big])
+    np.testing.assert_allclose(mean.cpu().numpy().transpose(2, 1, 0), host.mean(axis=0), rtol=1e-14)
+    assert 0.5 / 33 < float((mean - view[0]).mean()) < 2.0 / 33  # (the grid <-> spectral round trip of the reference is not exact)
 
 
 def test_month_crossing_with_sst_anomaly_and_co2_trend():
