@@ -339,6 +339,29 @@ class SpeedyEns:
         arrays = _speedy.ensemble_grid_arrays([m._state_cnt for m in self], list(variables))
         return _build_dataset(self.members[0], arrays, [m.member_id for m in self], self.current_date)
 
+    def _device_models(self):
+        """[(EnsembleModel view, member_id of the container that is member 0 of that model)] for the device models the
+        ensemble lives in (one; two from 32 members up; per GPU with `devices=k`)."""
+        found = {}
+        for m in self.members:
+            model, index = _speedy.device_model(m._state_cnt)
+            entry = found.setdefault(model._m.value, [model, None])
+            if index == 0:
+                entry[1] = m.member_id
+        return [(model, first) for model, first in found.values()]
+
+    def set_sppt(self, on=True, seed=0):
+        """BASELINE cfg 5: switch the deterministic SPPT scheme (csrc/sppt.hip; compile-time off and non-functional in the
+        reference, parity unpinned) on or off for every member.  The noise of a member is keyed by its `member_id`, so it does
+        not depend on how the ensemble is grouped into device models or sharded over GPUs."""
+        for model, first in self._device_models():
+            model.set_sppt(on, seed=seed, first_member_id=0 if first is None else first)
+
+    def set_physics_precision(self, fp32):
+        """BASELINE cfg 5: fp32 arithmetic in the column physics of every member (state and dynamics stay fp64)."""
+        for model, _ in self._device_models():
+            model.set_physics_precision(fp32)
+
     def device_view(self, name, spectral2grid=False):
         """The registry variable `name` of all members as one device tensor [member, ...] (speedy_driver.ensemble_device_view):
         zero-copy while the ensemble lives in one device model, gathered on the device otherwise (32 or more members are kept

@@ -151,3 +151,34 @@ def test_fp32_physics_ensemble_stays_inside_the_fp64_envelope(spectral, members)
         assert r_mean <= 0.1, (v, r_mean)
         assert abs(r_spread - 1.0) <= 0.03, (v, r_spread)
         assert local <= 1.0, (v, local)
+
+
+def test_cfg5_through_the_ensemble_facade_equals_the_batched_model(spectral):
+    """SpeedyEns.set_sppt / set_physics_precision reach every device model the ensemble lives in (34 members: two models of 17)
+    with the members' global ids: after six steps every member equals, bit for bit, the same member of ONE 34-member model
+    stepped with the same seed -- the noise does not depend on the grouping."""
+    from datetime import datetime
+    import pyspeedy_amd
+    from pyspeedy_amd import speedy_driver as drv
+    from pyspeedy_amd.model import EnsembleModel
+    from pyspeedy_amd.speedy import SpeedyEns
+    M = 34
+    ens = SpeedyEns(M, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 1, 4, 0))
+    for member in ens:
+        member.set_bc()
+    assert len({drv.device_model(m._state_cnt)[0]._m.value for m in ens}) == 2
+    ens.set_sppt(True, seed=11)
+    ens.set_physics_precision(True)
+    ens.run()
+    one = EnsembleModel(spectral, M)
+    one.init_sst_anom(1)
+    with np.load(pyspeedy_amd.example_bc_file()) as z:
+        one.set_bc({k: z[k] for k in z.files})
+    one.set_sppt(True, seed=11, first_member_id=0)
+    one.set_physics_precision(True)
+    one.run(6)
+    for i in (0, 16, 17, 33):
+        for name in ("t", "vor", "tr", "ps"):
+            assert np.array_equal(ens.members[i][name], one.get(name, i)), (i, name)
+    assert np.abs(ens.members[0]["t"] - ens.members[17]["t"]).max() > 0  # different noise for different members
+    one.close()
