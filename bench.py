@@ -43,7 +43,7 @@ relays rank 0's JSON line and fails if any rank fails.  Under `python -m torch.d
 process is one rank.  PYSPEEDY_AMD_BENCH_BACKEND=gloo rehearses the N-rank control flow when the ranks share one GPU.
 
 Timing: W warm-up steps, then regions of EXACTLY K steps, each bracketed by barrier + synchronize on both sides and reduced
-with MAX over ranks.  Regions are repeated until `--min-seconds` (default 3) of timed GPU work have accumulated (the run
+with MAX over ranks.  Regions are repeated until `--min-seconds` (default 5) of timed GPU work have accumulated (the run
 stays inside the SST-anomaly months it allocates) and `ms_per_step` is the MEDIAN region (minimum and count beside it): a
 20-step run is then several hundred 5-ms samples, and the GPU is busy for seconds, not milliseconds.
 """
@@ -61,8 +61,8 @@ sys.path.insert(0, ROOT)
 
 STEPS_PER_YEAR = 36 * 365  # model_control.f90:57-60, params.f90:32
 S_BYTES, G_BYTES = 15872, 36864  # one spectral / one grid field
-ANOM_MONTHS = 26                  # sst_anom(ix, il, 0:27), zero: December 1981 ... January 1984
-MAX_STEPS = 2 * STEPS_PER_YEAR    # the run stays inside the months of (zero) SST anomalies the bench allocates
+ANOM_MONTHS = 38                  # sst_anom(ix, il, 0:39), zero: December 1981 ... January 1985
+MAX_STEPS = 3 * STEPS_PER_YEAR    # the run stays inside the months of (zero) SST anomalies the bench allocates
 NG = 96 * 48
 
 # Algorithmic HBM bytes of each step kernel PER MEMBER, counted from the kernels' argument lists (DESIGN.md section 5 has
@@ -87,7 +87,7 @@ def parse(argv=None):
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--members", type=int, default=None, help="members per GPU (weak) or in total (strong)")
     ap.add_argument("--regions", type=int, default=0, help="timed regions of `steps` steps (0 = automatic)")
-    ap.add_argument("--min-seconds", type=float, default=3.0, help="timed regions are repeated until this much GPU time")
+    ap.add_argument("--min-seconds", type=float, default=5.0, help="timed regions are repeated until this much GPU time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true",
                     help="headline and roofline only: no drop_in_step / every_step_stores / cfg4_strong objects (profiles of "
