@@ -23,6 +23,11 @@ def compile_module(workdir):
                    cwd=workdir, check=True, capture_output=True, text=True)
 
 
+def compile_reference_named_module(workdir):
+    subprocess.run([FLANG, "-c", "-I.", os.path.join(ROOT, "include", "speedy_driver_amd.f90"), "-o", "speedy_driver_amd.o"],
+                   cwd=workdir, check=True, capture_output=True, text=True)
+
+
 @needs_flang
 def test_interface_module_and_example_compile(tmp_path):
     compile_module(tmp_path)
@@ -30,6 +35,38 @@ def test_interface_module_and_example_compile(tmp_path):
     for prog in ("fortran_host", "fortran_ensemble_host"):
         subprocess.run([FLANG, "-c", "-I.", os.path.join(ROOT, "examples", prog + ".f90"), "-o", prog + ".o"],
                        cwd=tmp_path, check=True, capture_output=True, text=True)
+
+
+def test_the_reference_named_module_is_current_and_complete():
+    """include/speedy_driver_amd.f90 (module `speedy_driver`, the reference's own procedure names forwarding to the C ABI) is
+    what tools/gen_fortran_driver.py generates from the registry, fits gfortran's 132-column free form, and declares every
+    procedure of registry/templates/speedy_driver.f90.j2: the fixed ones by name, and get_ / set_ / get_<v>_shape / is_array_
+    for every registry variable."""
+    import re
+    import sys
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_fortran_driver.py"), "--check"], check=True)
+    text = open(os.path.join(ROOT, "include", "speedy_driver_amd.f90")).read()
+    assert max(len(ln) for ln in text.splitlines()) <= 132
+    subs = set(re.findall(r"^\s*subroutine\s+(\w+)\s*\(", text, flags=re.M))
+    fixed = {"init", "step", "parallel_step", "check", "transform_spectral2grid", "transform_grid2spectral", "apply_grid_filter",
+             "controlparams_init", "controlparams_close", "create_datetime", "get_datetime", "close_datetime", "modelstate_init",
+             "modelstate_init_sst_anom", "modelstate_close"}
+    assert fixed <= subs
+    sys.path.insert(0, ROOT)
+    import pyspeedy_amd.registry as R
+    for name, v in R.REGISTRY.items():
+        want = {"get_" + name, "set_" + name, "is_array_" + name} | ({"get_%s_shape" % name} if v.shape is not None else set())
+        assert want <= subs, name
+    assert "!f2py threadsafe" in text
+
+
+@needs_flang
+def test_reference_named_module_and_its_host_compile(tmp_path):
+    compile_module(tmp_path)
+    compile_reference_named_module(tmp_path)
+    assert (tmp_path / "speedy_driver.mod").exists()
+    subprocess.run([FLANG, "-c", "-I.", os.path.join(ROOT, "examples", "fortran_reference_api_host.f90"), "-o", "host.o"],
+                   cwd=tmp_path, check=True, capture_output=True, text=True)
 
 
 @needs_flang
@@ -81,3 +118,31 @@ def test_fortran_host_with_the_reference_call_sites_steps_three_containers_as_on
     ref = np.load(os.path.join(ROOT, "tests", "golden", "export.npz"))["d1_t_grid"]
     assert np.abs(t1 - ref).max() <= 1e-10 * np.abs(ref).max()
     assert np.abs(t3 - ref).max() > 1e-3
+
+
+@needs_flang
+@pytest.mark.gpu
+def test_a_host_written_against_the_references_own_module_runs_unchanged(tmp_path, hip_lib):
+    """examples/fortran_reference_api_host.f90 uses `speedy_driver` and nothing but the reference's procedure names
+    (modelstate_init, set_orog ..., init, parallel_step, check, transform_spectral2grid, get_t_grid, get_current_step,
+    get_sst_anom_shape, is_array_t_grid).  Linked against include/speedy_driver_amd.f90 it steps two members for a day on the
+    GPU: member 1 equals the reference-generated golden, member 2 (SST + 0.5 K) differs."""
+    import pyspeedy_amd
+    compile_module(tmp_path)
+    compile_reference_named_module(tmp_path)
+    libdir = os.path.join(ROOT, "pyspeedy_amd")
+    subprocess.run([FLANG, "-I.", os.path.join(ROOT, "examples", "fortran_reference_api_host.f90"), "speedy_driver_amd.o",
+                    "pyspeedy_amd_c.o", "-L" + libdir, "-lpyspeedy_amd", "-Wl,-rpath," + libdir, "-o", "ref_api_host"],
+                   cwd=tmp_path, check=True, capture_output=True, text=True)
+    with np.load(pyspeedy_amd.example_bc_file()) as bc, open(tmp_path / "bc.bin", "wb") as fh:
+        for n in NAMES:
+            fh.write(np.asarray(bc[n], dtype=np.float64).tobytes(order="F"))
+    run = subprocess.run([str(tmp_path / "ref_api_host"), "bc.bin", "out.bin", "36"], cwd=tmp_path, capture_output=True,
+                         text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "steps 36  t_grid is an array T  end year 1982" in run.stdout, run.stdout
+    out = np.fromfile(tmp_path / "out.bin", dtype=np.float64).reshape((2, 96 * 48 * 8))
+    t1, t2 = (o.reshape((96, 48, 8), order="F") for o in out)
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "export.npz"))["d1_t_grid"]
+    assert np.abs(t1 - ref).max() <= 1e-10 * np.abs(ref).max()
+    assert np.abs(t2 - ref).max() > 1e-3
