@@ -77,6 +77,13 @@ class Dataset:
             idx[d] = int(hits[0])
         return self.isel(**idx)
 
+    def to_xarray(self):
+        """The same data as an `xarray.Dataset` -- what the reference's `to_dataframe()` returns (pyspeedy/speedy.py:415-477) --
+        for hosts that have xarray installed (it is not a dependency of this package; ImportError otherwise)."""
+        import xarray as xr
+        return xr.Dataset({k: (v.dims, v.values, v.attrs) for k, v in self.data_vars.items()},
+                          coords={k: (v.dims, v.values, v.attrs) for k, v in self.coords.items()}, attrs=dict(self.attrs))
+
     def to_netcdf(self, path):
         write_netcdf(self, path)
 
