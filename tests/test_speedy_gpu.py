@@ -284,3 +284,25 @@ def test_month_crossing_with_sst_anomaly_and_co2_trend():
         close(model[v], g[v], v)
     with pytest.raises(RuntimeError):  # anomalies must cover the run (speedy.py:349-362)
         Speedy(start_date=datetime(1982, 1, 29), end_date=datetime(1982, 4, 3)).set_bc(sst_anomaly={"ssta": ssta, "time": times})
+
+
+def test_ens_speedy_across_two_device_models(gold):
+    """33 members live in two device models (17 + 16): `run` steps both with one parallel_step per model step, the exporter
+    gathers all members in member order, and every member still reproduces the reference's one-day run."""
+    from pyspeedy_amd import speedy_driver as drv
+    from pyspeedy_amd.callbacks import XarrayExporter
+    from pyspeedy_amd.dataset import open_dataset
+    from pyspeedy_amd.speedy import SpeedyEns
+    start, end = datetime(1982, 1, 1), datetime(1982, 1, 2)
+    ens = SpeedyEns(33, start_date=start, end_date=end)
+    for member in ens:
+        member.set_bc()
+    assert len({drv.device_model(m._state_cnt)[0]._m.value for m in ens}) == 2
+    exp = expected(gold, 1)
+    with tempfile.TemporaryDirectory() as tmp:
+        ens.run(callbacks=[XarrayExporter(output_dir=tmp)])
+        ens_ds = open_dataset(os.path.join(tmp, end.strftime("%Y-%m-%d_%H%M.nc")))
+    assert ens_ds["u"].shape[:2] == (1, 33) and list(ens_ds["ens"].values) == list(range(33))
+    for m in (0, 16, 17, 32):
+        assert_matches(ens_ds.sel(ens=m), exp)
+    assert ens.get_current_step() == 36 and ens.members[32].get_current_step() == 36
