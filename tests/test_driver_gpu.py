@@ -389,3 +389,69 @@ def test_init_of_a_batched_member_never_resets_the_other_members(drv, bc):
     assert drv.parallel_step(list(ens2), [c0, c1]) == [0, 0]
     assert drv.model_date(c0)[0] == (1982, 1, 1, 0, 40) and drv.model_date(c1)[0] == (1982, 2, 1, 0, 40)
     drv.close(*states, *ens2)
+
+
+def test_random_groupings_keep_every_container_on_the_trajectory_of_a_lone_container(drv, bc):
+    """A randomised sequence (fixed seed) of parallel_step / begin-end over changing subsets of six containers, state writes and
+    a scalar change -- gathers, partial gathers, splits and two-model calls in whatever order they come -- against six twin
+    containers that are only ever stepped alone with step(): every container ends bitwise on its twin's trajectory, with its
+    twin's date and step counter."""
+    rng = np.random.default_rng(20260410)
+    n = 6
+    world = [drv.state() for _ in range(n)]
+    twins = [drv.state() for _ in range(n)]
+    cw = [drv.control(START, END) for _ in range(n)]
+    ct = [drv.control(START, END) for _ in range(n)]
+    for i in range(n):
+        for s, c in ((world[i], cw[i]), (twins[i], ct[i])):
+            drv.set_bc(s, bc, 0.05 * i * np.ones((96, 48, 12)))
+            assert drv.init(s, c) == 0
+    steps, largest = [0] * n, 0
+    for op in range(60):
+        kind = rng.integers(0, 10)
+        # mostly subsets of the containers that stand at the same date (they can share a device model: gathers, then splits when
+        # the next subset differs), sometimes any subset (several dates, hence several device models in one call)
+        counts = {c: steps.count(c) for c in steps}
+        modal = max(counts, key=lambda c: (counts[c], -c))
+        pool = [i for i in range(n) if steps[i] == modal] if rng.random() < 0.75 else list(range(n))
+        k = int(rng.integers(1, len(pool) + 1))
+        subset = sorted(rng.choice(pool, size=k, replace=False).tolist())
+        if kind <= 7:
+            for i in subset:
+                steps[i] += 1 if kind <= 5 else 2
+        if kind <= 5:  # synchronous parallel_step over a subset
+            assert drv.parallel_step([world[i] for i in subset], [cw[i] for i in subset]) == [0] * k
+            for i in subset:
+                assert drv.step(twins[i], ct[i]) == 0
+        elif kind <= 7:  # the overlapped form, two steps deep
+            ids, ctl = (C.c_int64 * k)(*[world[i] for i in subset]), (C.c_int64 * k)(*[cw[i] for i in subset])
+            t1, t2, codes = C.c_int64(), C.c_int64(), (C.c_int32 * k)()
+            drv.ok(drv.L.spd_parallel_step_begin(ids, ctl, k, C.byref(t1)))
+            drv.ok(drv.L.spd_parallel_step_begin(ids, ctl, k, C.byref(t2)))
+            for t in (t1, t2):
+                drv.ok(drv.L.spd_parallel_step_end(t, codes))
+                assert list(codes) == [0] * k
+            for i in subset:
+                assert drv.step(twins[i], ct[i]) == 0 and drv.step(twins[i], ct[i]) == 0
+        elif kind == 8:  # the host writes a member's temperature
+            i = subset[0]
+            t = drv.get(world[i], "t", np.complex128)
+            t[1:4, 1:4] *= 1.0 + 1e-6 * (op + 1)
+            drv.set(world[i], "t", t)
+            drv.set(twins[i], "t", t)
+        else:  # a scalar of its own takes a member out of its batch
+            i, one = subset[0], np.array([op % 2], dtype=np.int32)
+            for s in (world[i], twins[i]):
+                drv.ok(drv.L.spd_set(s, b"land_coupling_flag", one.ctypes.data_as(C.c_void_p), 4))
+        largest = max(largest, max(drv.stats(s)[1] for s in world))
+    sizes = sorted(drv.stats(s)[1] for s in world)
+    print("device models of the six containers at the end:", sizes, "; largest model on the way:", largest)
+    assert largest >= 3
+    for i in range(n):
+        assert drv.model_date(cw[i]) == drv.model_date(ct[i]), i
+        assert drv.get(world[i], "current_step", np.int32) == drv.get(twins[i], "current_step", np.int32)
+        for name, dt in (("vor", np.complex128), ("t", np.complex128), ("ps", np.complex128), ("tr", np.complex128)):
+            assert np.array_equal(drv.get(world[i], name, dt), drv.get(twins[i], name, dt)), (i, name)
+        for name in ("olr", "land_temp", "sst_am", "rad_tau2", "hfluxn"):
+            assert np.array_equal(drv.get(world[i], name), drv.get(twins[i], name)), (i, name)
+    drv.close(*world, *twins)
