@@ -37,6 +37,12 @@ What the ONE JSON line of rank 0 holds:
                         back), synchronous and in the overlapped begin / end form, over independent containers.
   every_step_stores (N = 1)  the step with every store of the reference restored (all 91 spectral->grid transforms, the
                         diagnostics-only physics outputs on every step).
+  cfg3, cfg4_shard8, cfg5 (N = 1)  the other BASELINE configs on the same clock: 1 member fp64; 8 members fp64 (one GPU's share
+                        of cfg 4 as worded); 32 members with SPPT + fp32 column physics (one GPU's share of cfg 5) -- ms_per_step,
+                        launch plan, the step's own roofline fraction (algorithmic bytes of all its launches / time / 8 TB/s)
+                        and per-kernel microseconds.
+  cfg2_transforms (N = 1)  BASELINE cfg 2: spec2grid / grid2spec alone over batches of B = 1 ... 16 384 fields: ns per field and
+                        fraction of the HBM peak.
 
 Launching: with N > 1 and no torchrun environment, this process only starts N rank processes (before touching the GPU),
 relays rank 0's JSON line and fails if any rank fails.  Under `python -m torch.distributed.run ... bench.py --gpus N` each
@@ -64,6 +70,7 @@ S_BYTES, G_BYTES = 15872, 36864  # one spectral / one grid field
 ANOM_MONTHS = 38                  # sst_anom(ix, il, 0:39), zero: December 1981 ... January 1985
 MAX_STEPS = 3 * STEPS_PER_YEAR    # the run stays inside the months of (zero) SST anomalies the bench allocates
 NG = 96 * 48
+CFG2_SIZES = (1, 8, 64, 512, 4096, 16384)  # fields per launch of the cfg2_transforms leg (cfg 2)
 
 # Algorithmic HBM bytes of each step kernel PER MEMBER, counted from the kernels' argument lists (DESIGN.md section 5 has
 # the itemised lists).  Transforms: SURVEY 8d's contract figure S + G per field.
@@ -94,6 +101,9 @@ def parse(argv=None):
                          "this command then hold launches of one size and one plan per region kind)")
     ap.add_argument("--serial-plan", action="store_true", help="headline in the serial plan too (one member group)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--leg-seconds", type=float, default=0.6,
+                    help="GPU time of each of the cfg3 / cfg4_shard8 / cfg5 / cfg2_transforms legs of the one-GPU line")
+    ap.add_argument("--cfg2-sizes", type=int, nargs="+", default=list(CFG2_SIZES), help="batch sizes of the cfg2_transforms leg")
     ap.add_argument("--cpu-worker", type=float, nargs=2, default=None, metavar=("T_START", "SECONDS"), help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
@@ -388,6 +398,105 @@ def fidelity_leg(args, M, first_id, device, dist, rank, coll_device, barrier):
                     "diagnostics-only physics outputs per column stored on every step of the call"}
 
 
+LEG_REGION_STEPS = 360  # the legs time regions of ten simulated days whatever --steps the headline was given
+
+
+def config_leg(args, config, members, what, device, dist, rank, coll_device, barrier):
+    """One more BASELINE config on the same clock as the headline: the ensemble of `config` with `members` members on this GPU,
+    built, perturbed and spun up exactly like the headline's, timed in regions of LEG_REGION_STEPS steps between barrier +
+    synchronize (default plan of the library for that size) until --leg-seconds of GPU work, median region; then one simulated
+    day in the serial plan with events attached to every dispatch for the per-kernel durations.  `step_roofline` prices the
+    WHOLE step: the algorithmic bytes of all its launches / ms_per_step against the 8 TB/s HBM peak."""
+    from pyspeedy_amd import ensemble as E
+    leg = argparse.Namespace(**dict(vars(args), config=config, scaling="strong", members=members, steps=LEG_REGION_STEPS, regions=0))
+    sp, model = build_ensemble(leg, members, 0, device, dist, rank, coll_device)
+    cfg = model.config()
+    model.run(leg.warmup)
+    secs = timed_regions(model, leg, barrier, dist, coll_device, MAX_STEPS - leg.warmup - 72, args.leg_seconds, 500)
+    rows = kernel_table(model, members, cfg["inv_per_member"], config == "cfg5")
+    ok = (model.check(2) == 0).all()
+    model.close()
+    sp.close()
+    if not ok:
+        raise SystemExit("bench.py: members left the accepted range in the %s leg" % what)
+    ms = median(secs) / leg.steps * 1e3
+    step_bytes = sum(r["algorithmic_bytes_per_launch"] * r["launches_timed"] for r in rows) / 36.0
+    gbs = step_bytes / (ms * 1e-3) / 1e9
+    out = {
+        "workload": what, "members": members, "ms_per_step": ms, "us_per_member_step": ms * 1e3 / members,
+        "ms_per_step_min": min(secs) / leg.steps * 1e3, "regions": len(secs), "steps_per_region": leg.steps,
+        "timed_seconds": sum(secs), "plan": plan_name(cfg, members),
+        "value": E.simulated_years_per_day(members, ms * 1e-3, STEPS_PER_YEAR), "unit": "simulated-years/day",
+        "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_step": int(round(step_bytes)), "achieved": gbs, "peak": 8000.0,
+                          "unit": "GB/s", "frac": gbs / 8000.0},
+        "kernel_us": {r["kernel"]: round(r["avg_launch_us"], 3) for r in rows},
+        "kernel_us_min": {r["kernel"]: round(r["min_launch_us"], 3) for r in rows},
+        "kernel_frac": {r["kernel"]: round(r["frac"], 4) for r in rows},
+        "kernel_us_sum_per_step": sum(r["avg_launch_us"] * r["launches_timed"] for r in rows) / 36.0,
+    }
+    return out
+
+
+def transforms_leg(args, device):
+    """BASELINE cfg 2: the two fused transform kernels on their own through the operator-level C ABI (spd_spec2grid /
+    spd_grid2spec, include/pyspeedy_amd.h) over contiguous batches of B fields.  Inputs as SURVEY 8d words them: spectra =
+    triangular-truncated complex normal(0, 1) / (1 + l), Im(m = 0) = 0, numpy default_rng(1234); grids = spec2grid of those
+    spectra (band-limited).  Per (kernel, B): back-to-back launches on one stream between two HIP events, repeated until
+    --leg-seconds / 12 of GPU time; ns per field and the fraction of 8 TB/s at 52 736 algorithmic bytes per field."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    import pyspeedy_amd
+    sp = pyspeedy_amd.ModSpectral(device.index)
+    L, h = sp._lib, sp.handle
+    bmax = max(args.cfg2_sizes)
+    rng = np.random.default_rng(1234)
+    nn, mm = np.meshgrid(np.arange(32), np.arange(31), indexing="ij")  # [n][m]; total wavenumber l = m + n
+    spec = (rng.standard_normal((bmax, 32, 31)) + 1j * rng.standard_normal((bmax, 32, 31))) / (1.0 + nn + mm)
+    spec[:, (nn + mm) > 30] = 0
+    spec[:, :, 0] = spec[:, :, 0].real
+    spec_d = torch.from_numpy(spec).to(device)
+    grid_d = torch.empty((bmax, 48, 96), dtype=torch.float64, device=device)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    if L.spd_spec2grid(h, p(spec_d), p(grid_d), 1, bmax, st) != 0:
+        raise SystemExit("bench.py: cfg2 leg: " + L.spd_last_error().decode())
+    out_spec, out_grid = torch.empty_like(spec_d), torch.empty_like(grid_d)
+    torch.cuda.synchronize()
+    share = max(args.leg_seconds / (2.0 * len(args.cfg2_sizes)), 1e-3)
+    rows, total = [], 0.0
+    for B in args.cfg2_sizes:
+        calls = {"spec2grid": lambda: L.spd_spec2grid(h, p(spec_d), p(out_grid), 1, B, st),
+                 "grid2spec": lambda: L.spd_grid2spec(h, p(grid_d), p(out_spec), B, st)}
+        for name, fn in calls.items():
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            n, elapsed, a, b = 8, 0.0, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            while True:
+                a.record()
+                for _ in range(n):
+                    if fn() != 0:
+                        raise SystemExit("bench.py: cfg2 leg: " + L.spd_last_error().decode())
+                b.record()
+                b.synchronize()
+                elapsed = a.elapsed_time(b) * 1e-3
+                total += elapsed
+                if elapsed >= share or n >= (1 << 20):
+                    break
+                n = min(1 << 20, max(2 * n, int(1.2 * n * share / max(elapsed, 1e-6))))
+            per_launch = elapsed / n
+            gbs = (S_BYTES + G_BYTES) * B / per_launch / 1e9
+            rows.append({"kernel": name, "fields": B, "launches_timed": n, "us_per_launch": per_launch * 1e6,
+                         "ns_per_field": per_launch / B * 1e9, "achieved": gbs, "frac": gbs / 8000.0})
+    sp.close()
+    return {"workload": "BASELINE cfg 2: the fused transform kernels alone, contiguous batches of B fields (spd_spec2grid / "
+                        "spd_grid2spec), SURVEY 8d inputs (seed 1234, band-limited grids)",
+            "algorithmic_bytes_per_field": S_BYTES + G_BYTES, "peak": 8000.0, "unit": "GB/s", "timed_seconds": total, "rows": rows,
+            "note": "back-to-back launches on one stream between two HIP events; at B = 1 and 8 a launch is one dependent chain of "
+                    "one workgroup (load, Legendre, FFT, store) and the figure is that latency, not a bandwidth"}
+
+
 def drop_in_leg(M, steps):
     """The reference-shaped host loop over M independent containers through the outer C boundary (include/pyspeedy_amd_driver.h):
     spd_parallel_step once per model step -- step, range check, error codes back -- synchronously and in the overlapped
@@ -565,6 +674,14 @@ def run_rank(args):
         if n_gpus == 1 and args.config == "cfg4":
             legs["every_step_stores"] = fidelity_leg(args, M, first_id, device, dist, rank, coll_device, barrier)
             legs["drop_in_step"] = drop_in_leg(M, 360)
+            # the other BASELINE configs on the same clock (SURVEY 8d "Configs as concrete inputs")
+            legs["cfg2_transforms"] = transforms_leg(args, device)
+            legs["cfg3"] = config_leg(args, "cfg4", 1, "BASELINE cfg 3: one member, fp64, the full step on the GPU", device, dist, rank,
+                                      coll_device, barrier)
+            legs["cfg4_shard8"] = config_leg(args, "cfg4", 8, "BASELINE cfg 4 as worded: one GPU's share of 64 members on 8 GPUs = 8 "
+                                             "members, fp64", device, dist, rank, coll_device, barrier)
+            legs["cfg5"] = config_leg(args, "cfg5", 32, "BASELINE cfg 5: one GPU's share of 256 members on 8 GPUs = 32 members, SPPT "
+                                      "on, fp32 arithmetic in the column physics (fp64 state)", device, dist, rank, coll_device, barrier)
         if n_gpus > 1 and args.scaling == "weak" and args.config == "cfg4" and args.members is None:
             # BASELINE cfg 4 to the letter next to the weak headline: 64 members in total, block-sharded over the ranks
             strong = argparse.Namespace(**dict(vars(args), scaling="strong", members=None))

@@ -163,8 +163,8 @@ int spd_model_step_dynamics(spd_model_handle m, int j1, int j2, double dt, int c
 /* check_diagnostics (diagnostics.f90:16-76) for every member: error_codes_host[i] = 0 or -2; diag_host may be NULL or
  * receive [nmembers][3][kx] (eddy KE of vor, of div, global-mean T).  Synchronises `stream`. */
 int spd_model_check(spd_model_handle m, int time_level, int32_t *error_codes_host, double *diag_host, void *stream);
-/* The same check without stalling the launch pipeline: _begin enqueues it and returns a slot (0 or 1, at most two in flight:
- * a third _begin fails with SPD_E_ARG until one of them has been ended), _end waits for that slot only.  Begin the check of
+/* The same check without stalling the launch pipeline: _begin enqueues it and returns a slot (0 or 1, whichever is
+ * free; at most two in flight: a third _begin fails with SPD_E_ARG until one has been ended), _end waits for that slot only.  Begin the check of
  * step k, launch step k + 1, then end the check of step k. */
 int spd_model_check_begin(spd_model_handle m, int time_level, void *stream);
 int spd_model_check_end(spd_model_handle m, int slot, int32_t *error_codes_host);
@@ -271,6 +271,11 @@ int spd_model_copy_member(spd_model_handle dst, int dst_member, spd_model_handle
  * hipMemcpyPeerAsync): how one process hands the shared boundary fields to the members it keeps on its other devices */
 int spd_model_copy_vars(spd_model_handle dst, int dst_member, spd_model_handle src, int src_member, const char *const *names,
                         int n_names, void *stream);
+/* the same copies enqueued only: no device is synchronised first, so the caller must have made sure that nothing in flight on
+ * either device still uses the arrays (spd_broadcast_boundary synchronises every device once, then enqueues all its copies);
+ * `stream` is a stream of the DESTINATION device, which is the current device when the call returns */
+int spd_model_copy_vars_enqueue(spd_model_handle dst, int dst_member, spd_model_handle src, int src_member,
+                                const char *const *names, int n_names, void *stream);
 
 #ifdef __cplusplus
 }

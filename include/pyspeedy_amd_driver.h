@@ -22,6 +22,17 @@
  * grouping, takes that batch apart again first (correct, but it gives the batching up).
  * spd_modelstate_init_ensemble creates n containers that are batched from the start.
  *
+ * Current device.  Entry points that touch a container living on another GPU switch the calling thread's HIP device while
+ * they work and restore the device that was current when they were called before they return: the caller's current device
+ * (and with it e.g. torch.cuda.current_device()) never changes under it, whatever devices an ensemble is spread over.
+ *
+ * A step that went out without its check.  Everything that can refuse a step (a free check slot, the control block) is asked
+ * before the step is enqueued.  If a DEVICE error strikes between the enqueue of the step and the hand-over of its codes, the
+ * members get -3, their dates stay, and the device model is marked: its state has moved on while date and codes say it has not,
+ * and every later step of it fails (SPD_E_ARG, code -3) until its members are initialised again (spd_init).  In the begin / end
+ * form a member whose check of step k fails (-2) gets the date from before step k back even if step k + 1 has been begun on
+ * it meanwhile: after -2 the state is outside the model's accepted range, and the only defined continuation is a new spd_init.
+ *
  * Threads.  Every entry point may be called from any host thread; calls on the SAME container (or on containers that share a
  * device model) must not overlap in time -- the reference's `!f2py threadsafe` contract.
  *
@@ -41,9 +52,15 @@ extern "C" {
 
 /* ---- ModelState interface (speedy_driver.f90.j2:216-248) ---- */
 int spd_modelstate_init(int64_t *state_cnt);
-/* extension: n containers that are batched from the start (one device model; with a device placement of k > 1 devices one
- * device model per device, member e of n on device e k / n) */
+/* extension: n containers that are batched from the start.  Up to 31 members of a device form ONE device model; from 32 up they
+ * are kept as TWO (first half / second half; parallel_step enqueues both before it waits for either, which is worth 8 % per step
+ * at 64 members; PYSPEEDY_AMD_DRIVER_SPLIT=0 keeps one model, =n splits from n members).  With a device placement of k > 1
+ * devices: member e of n on device e k / n, one or two device models per device.  A host that reaches for the device arrays
+ * (spd_driver_model) must therefore go through the containers, not assume that the first container's model holds everybody. */
 int spd_modelstate_init_ensemble(int64_t *state_cnts, int32_t n_members);
+/* the same with the number of devices as an argument (0: the calling thread's current device; k: devices 0 .. k-1 in blocks):
+ * the process-wide placement below is neither read nor changed */
+int spd_modelstate_init_ensemble_on(int64_t *state_cnts, int32_t n_members, int32_t n_devices);
 int spd_modelstate_init_sst_anom(int64_t state_cnt, int32_t n_months);    /* sst_anom(ix, il, 0:n_months+1), zero-filled */
 int spd_modelstate_close(int64_t state_cnt);
 
@@ -61,6 +78,9 @@ int spd_set_device_placement(int32_t n_devices);
 int spd_modelstate_init_on(int64_t *state_cnt, int32_t device);
 int spd_modelstate_device(int64_t state_cnt, int32_t *device);
 int spd_broadcast_boundary(const int64_t *state_cnts, int32_t n, int32_t root);
+/* what the last spd_broadcast_boundary did: copies that crossed to another device (one per device that holds a destination:
+ * the first container there receives from the root, the others from that container) and copies that stayed on a device */
+int spd_broadcast_boundary_stats(int32_t *peer_copies, int32_t *local_copies);
 
 /* ---- Datetime interface (:163-210) ---- */
 int spd_create_datetime(int32_t year, int32_t month, int32_t day, int32_t hour, int32_t minute, int64_t *datetime_cnt);
@@ -107,7 +127,8 @@ int spd_is_array(const char *name, int32_t *is_array);
 int spd_registry_entry(int32_t index, char *name /* 32 bytes */, int32_t *dtype, int32_t *ndim, int32_t *shape /* 5 */,
                        int32_t *is_read_only);
 /* the batched device model behind a container (spd_model_handle of pyspeedy_amd.h, owned by the driver: do not destroy it)
- * and the container's member index in it -- for zero-copy access to the state (spd_model_device_ptr) and the extensions of
+ * and the container's member index in it (an ensemble of 32 or more containers of one device lives in TWO device models, see
+ * spd_modelstate_init_ensemble: ask per container) -- for zero-copy access to the state (spd_model_device_ptr) and the extensions of
  * the model level (SPPT, physics precision, profiling).  The binding changes when parallel_step gathers or splits. */
 int spd_driver_model(int64_t state_cnt, void **model, int32_t *member, int32_t *members_in_model);
 /* how many device models are alive and how many members the container's model holds (tests / diagnostics of batching) */

@@ -1,9 +1,10 @@
 // Outer boundary (include/pyspeedy_amd_driver.h): the procedures of the reference's f2py module speedy_driver
 // (registry/templates/speedy_driver.f90.j2) on top of the batched device model (spd_model_*, model.hip).  Host code only:
 // containers, the name-driven registry, and the gathering of independent one-member models into one batched model so that
-// parallel_step is one set of kernel launches for the whole ensemble.
-#include <hip/hip_runtime.h>
-
+// parallel_step is one set of kernel launches for the whole ensemble.  Plain C++: the GPU runtime is reached through the
+// spd_model_* functions and the few calls of driver_backend.hpp, so that this file also builds against a stub of both and runs
+// under the sanitizers on a machine without a GPU (tests/test_sanitizers.py, tests/sanitize/driver_stub.cpp).
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstring>
@@ -15,7 +16,7 @@
 
 #include "../../include/pyspeedy_amd.h"
 #include "../../include/pyspeedy_amd_driver.h"
-#include "context.hpp"
+#include "driver_backend.hpp"
 
 namespace {
 
@@ -122,12 +123,16 @@ struct Batch {  // one device model shared by the containers of its members
     // The steps and range checks of this model are issued on a stream of its own, so that the models of one parallel_step --
     // on different devices, or several on one device -- run side by side.  A blocking stream: everything else the driver does
     // (initialisation, copies, transforms) stays on the null stream, which orders itself against it.
-    hipStream_t stream = nullptr;
+    void *stream = nullptr;
+    // A step was enqueued and its range check (or anything else that had to follow it) could not be: the device state has
+    // moved on while date and codes say it has not.  Nothing steps such a model again until it is initialised anew.
+    bool advanced_without_check = false;
     ~Batch() {
         --g_models_alive;
-        (void)hipSetDevice(device);
+        drvdev::DeviceGuard guard;  // (may run from any entry point that drops the last reference, or from a host's garbage collector)
+        (void)drvdev::set_device(device);
         if (model) (void)spd_model_destroy(model);
-        if (stream) (void)hipStreamDestroy(stream);
+        drvdev::stream_destroy(stream);
     }
 };
 struct State {
@@ -150,6 +155,37 @@ std::map<int64_t, std::shared_ptr<State>> g_states;
 std::map<int64_t, Date> g_dates;
 std::map<int64_t, Control> g_controls;
 std::map<int, spd_handle> g_contexts;  // one context per device, alive for the life of the process
+// Counts every event after which the grouping of an argument list may come out differently: containers created or closed,
+// batches gathered or split, a member initialised, a step that left members with different dates.  parallel_step keeps the
+// plan of its last argument list and re-uses it while this has not moved (plan_step).
+uint64_t g_epoch = 1;
+struct BroadcastStats {
+    int peer_copies, local_copies;
+} g_broadcast_stats{0, 0};  // of the last spd_broadcast_boundary
+
+// The plan of an argument list: which of its containers are (all) the members of which device model.  Made by plan_step,
+// never changed afterwards, shared by the calls that use it.
+struct GroupPlan {
+    std::shared_ptr<Batch> batch;
+    std::vector<int> positions;        // indices into the argument list
+    std::vector<int> members;          // member index of each position
+    std::vector<int64_t> control_ids;  // the control containers, looked up again whenever the lock was given up
+};
+struct Plan {
+    std::vector<int64_t> states, controls;  // the argument list it was made for
+    std::vector<GroupPlan> groups;
+    uint64_t epoch = 0;
+};
+// A host with the reference's loop hands parallel_step the same two lists at every model step: the plan of the last call is
+// kept and used again while nothing has happened that could change it (g_epoch) -- the per-step host work of the call is then
+// one comparison of the lists and one control-container look-up per device model, whatever the number of containers.
+std::shared_ptr<const Plan> g_last_plan;
+
+void regrouped() {  // (lock held) something happened after which an argument list may group differently
+    ++g_epoch;
+    g_last_plan.reset();   // (the plan holds references to device models: they must be free to die with their containers)
+}
+
 
 int fail(int code, const std::string &msg) { return spd_set_error(code, msg); }
 
@@ -172,10 +208,7 @@ int context_for_device(int dev, spd_handle *out) {
 int g_place_ndev = -1;  // -1: not decided yet (environment), 0: current device, k > 0: devices 0 .. k-1
 long g_place_counter = 0;
 
-int device_count() {
-    int n = 0;
-    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
-}
+int device_count() { return drvdev::device_count(); }
 
 int placement_devices() {
     if (g_place_ndev < 0) {
@@ -191,17 +224,17 @@ int placement_devices() {
 }
 
 int current_device(int *dev) {
-    if (hipGetDevice(dev) != hipSuccess) return fail(SPD_E_DEVICE, "speedy driver: no HIP device (there is no CPU fallback)");
+    if (!drvdev::get_device(dev)) return fail(SPD_E_DEVICE, "speedy driver: no HIP device (there is no CPU fallback)");
     return SPD_OK;
 }
 
 int new_batch(int members, int device, std::shared_ptr<Batch> *out) {
     auto b = std::make_shared<Batch>();
     b->device = device;
-    if (hipSetDevice(device) != hipSuccess) return fail(SPD_E_DEVICE, "speedy driver: hipSetDevice(" + std::to_string(device) + ") failed");
+    if (!drvdev::set_device(device)) return fail(SPD_E_DEVICE, "speedy driver: hipSetDevice(" + std::to_string(device) + ") failed");
     if (int rc = context_for_device(device, &b->ctx)) return rc;
     if (int rc = spd_model_create(b->ctx, members, &b->model)) return rc;
-    if (hipStreamCreate(&b->stream) != hipSuccess) return fail(SPD_E_DEVICE, "speedy driver: hipStreamCreate failed");
+    if (!drvdev::stream_create(&b->stream)) return fail(SPD_E_DEVICE, "speedy driver: hipStreamCreate failed");
     b->members = members;
     b->initialized.assign(members, 0);
     *out = b;
@@ -268,6 +301,7 @@ int split_batch(const std::shared_ptr<Batch> &b) {
         }
         if (int rc = spd_model_copy_member(single->model, 0, b->model, st->member, nullptr)) return rc;
         single->initialized[0] = b->initialized[st->member];
+        single->advanced_without_check = b->advanced_without_check;
         if (single->initialized[0]) {
             if (int rc = spd_model_set_control(single->model, &mine)) return rc;
             if (int rc = spd_model_set_time_step(single->model, 2 * kDelt)) return rc;
@@ -278,7 +312,8 @@ int split_batch(const std::shared_ptr<Batch> &b) {
         st->batch = single;
         st->member = 0;
     }
-    if (hipDeviceSynchronize() != hipSuccess) return fail(SPD_E_DEVICE, "speedy driver: device error while splitting a batch");
+    regrouped();
+    if (!drvdev::device_synchronize()) return fail(SPD_E_DEVICE, "speedy driver: device error while splitting a batch");
     return SPD_OK;  // (`b` dies with the caller's reference)
 }
 
@@ -324,7 +359,7 @@ int gather(const std::vector<std::shared_ptr<State>> &states, bool *done) {
     }
     for (int i = 0; i < n; ++i)
         if (int rc = spd_model_copy_member(big->model, i, states[i]->batch->model, 0, nullptr)) return rc;
-    if (hipDeviceSynchronize() != hipSuccess) return fail(SPD_E_DEVICE, "speedy driver: device error while gathering a batch");
+    if (!drvdev::device_synchronize()) return fail(SPD_E_DEVICE, "speedy driver: device error while gathering a batch");
     if (int rc = spd_model_set_control(big->model, &first)) return rc;
     if (int rc = spd_model_set_time_step(big->model, 2 * kDelt)) return rc;
     for (int i = 0; i < n; ++i) {
@@ -332,6 +367,7 @@ int gather(const std::vector<std::shared_ptr<State>> &states, bool *done) {
         states[i]->member = i;
         big->initialized[i] = 1;
     }
+    regrouped();
     *done = true;
     return SPD_OK;
 }
@@ -399,6 +435,7 @@ static int make_containers(int64_t *state_cnts, int n, int device) {
         state_cnts[i] = g_next++;
         g_states[state_cnts[i]] = st;
     }
+    regrouped();
     return SPD_OK;
 }
 
@@ -414,6 +451,7 @@ static int make_device_containers(int64_t *state_cnts, int n, int device) {
 
 int spd_modelstate_init(int64_t *state_cnt) {
     if (!state_cnt) return fail(SPD_E_ARG, "spd_modelstate_init: null argument");
+    drvdev::DeviceGuard guard;
     LOCK;
     int dev = 0;
     const int k = placement_devices();
@@ -425,14 +463,13 @@ int spd_modelstate_init(int64_t *state_cnt) {
 int spd_modelstate_init_on(int64_t *state_cnt, int32_t device) {
     if (!state_cnt) return fail(SPD_E_ARG, "spd_modelstate_init_on: null argument");
     if (device < 0 || device >= device_count()) return fail(SPD_E_ARG, "spd_modelstate_init_on: no such HIP device");
+    drvdev::DeviceGuard guard;
     LOCK;
     return make_containers(state_cnt, 1, device);
 }
 
-int spd_modelstate_init_ensemble(int64_t *state_cnts, int32_t n_members) {
-    if (!state_cnts || n_members < 1) return fail(SPD_E_ARG, "spd_modelstate_init_ensemble: bad argument");
-    LOCK;
-    const int k = placement_devices();
+// n containers batched from the start over k devices (k = 0: the current device); (lock held)
+static int init_ensemble(int64_t *state_cnts, int32_t n_members, int k) {
     if (k <= 1) {
         int dev = 0;
         if (k == 0) {
@@ -449,6 +486,23 @@ int spd_modelstate_init_ensemble(int64_t *state_cnts, int32_t n_members) {
         first = last;
     }
     return SPD_OK;
+}
+
+int spd_modelstate_init_ensemble(int64_t *state_cnts, int32_t n_members) {
+    if (!state_cnts || n_members < 1) return fail(SPD_E_ARG, "spd_modelstate_init_ensemble: bad argument");
+    drvdev::DeviceGuard guard;
+    LOCK;
+    return init_ensemble(state_cnts, n_members, placement_devices());
+}
+
+// the same with the number of devices as an argument: the process-wide placement is neither read nor changed
+int spd_modelstate_init_ensemble_on(int64_t *state_cnts, int32_t n_members, int32_t n_devices) {
+    if (!state_cnts || n_members < 1) return fail(SPD_E_ARG, "spd_modelstate_init_ensemble_on: bad argument");
+    if (n_devices < 0 || n_devices > device_count())
+        return fail(SPD_E_ARG, "spd_modelstate_init_ensemble_on: more devices than the process can see");
+    drvdev::DeviceGuard guard;
+    LOCK;
+    return init_ensemble(state_cnts, n_members, n_devices);
 }
 
 int spd_device_count(int32_t *n_devices) {
@@ -474,6 +528,7 @@ int spd_modelstate_device(int64_t state_cnt, int32_t *device) {
 }
 
 int spd_modelstate_init_sst_anom(int64_t state_cnt, int32_t n_months) {
+    drvdev::DeviceGuard guard;
     LOCK;
     auto st = state_of(state_cnt);
     if (!st) return fail(SPD_E_ARG, "spd_modelstate_init_sst_anom: not a live state container");
@@ -482,13 +537,16 @@ int spd_modelstate_init_sst_anom(int64_t state_cnt, int32_t n_months) {
     if (int rc = spd_model_init_sst_anom(b.model, n_months)) return rc;
     b.n_months = n_months;
     b.sst_anom_allocated = true;
+    regrouped();
     return SPD_OK;
 }
 
 int spd_modelstate_close(int64_t state_cnt) {
+    drvdev::DeviceGuard guard;  // (the device model's destructor switches to its device)
     LOCK;
     auto it = g_states.find(state_cnt);
     if (it == g_states.end()) return SPD_OK;
+    regrouped();         // (drops the kept plan's references first)
     g_states.erase(it);  // the device model goes with its last container
     return SPD_OK;
 }
@@ -540,7 +598,7 @@ int spd_controlparams_init(int64_t *control_cnt, int64_t start_cnt, int64_t end_
 
 int spd_controlparams_close(int64_t cnt) {
     LOCK;
-    g_controls.erase(cnt);
+    if (g_controls.erase(cnt)) regrouped();
     return SPD_OK;
 }
 
@@ -558,13 +616,14 @@ int spd_controlparams_get_model_datetime(int64_t cnt, int32_t *ymdhm, int32_t *m
 // ---------------------------------------------------------------------------------------------------------------------
 int spd_init(int64_t state_cnt, int64_t control_cnt, int32_t *error_code) {
     if (!error_code) return fail(SPD_E_ARG, "spd_init: null argument");
+    drvdev::DeviceGuard guard;
     LOCK;
     auto st = state_of(state_cnt);
     auto ci = g_controls.find(control_cnt);
     if (!st || ci == g_controls.end()) return fail(SPD_E_ARG, "spd_init: not a live state / control container");
     Control &c = ci->second;
     std::shared_ptr<Batch> b = st->batch;
-    if (hipSetDevice(b->device) != hipSuccess) return fail(SPD_E_DEVICE, "spd_init: hipSetDevice failed");
+    if (!drvdev::set_device(b->device)) return fail(SPD_E_DEVICE, "spd_init: hipSetDevice failed");
     const int32_t *d = c.start.ymdhm;
     if (b->members > 1) {
         // A member of a batched model.  The batch has ONE date and step counter: it takes them when its last member has been
@@ -584,8 +643,10 @@ int spd_init(int64_t state_cnt, int64_t control_cnt, int32_t *error_code) {
             b = st->batch;
         }
     }
+    regrouped();
     if (b->members == 1) {
         if (int rc = spd_model_init(b->model, d[0], d[1], d[2], d[3], d[4], nullptr)) return rc;
+        b->advanced_without_check = false;
     } else {
         // initialise a scratch one-member model from this member's boundary fields and copy the resulting state into the
         // member's slot
@@ -600,7 +661,7 @@ int spd_init(int64_t state_cnt, int64_t control_cnt, int32_t *error_code) {
         if (rc == SPD_OK) rc = spd_model_set_co2(scratch->model, mc.air_absortivity_co2);
         if (rc == SPD_OK) rc = spd_model_init(scratch->model, d[0], d[1], d[2], d[3], d[4], nullptr);
         if (rc == SPD_OK) rc = spd_model_copy_member(b->model, st->member, scratch->model, 0, nullptr);
-        if (rc == SPD_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(SPD_E_DEVICE, "spd_init: device error");
+        if (rc == SPD_OK && !drvdev::device_synchronize()) rc = fail(SPD_E_DEVICE, "spd_init: device error");
         // (date, step counter 0 and the CO2 reference: the same values for every member of the batch, see above)
         if (rc == SPD_OK) rc = spd_model_mark_initialized(b->model, 0, d[0], d[1], d[2], d[3], d[4]);
         if (rc == SPD_OK) rc = spd_model_set_time_step(b->model, 2 * kDelt);
@@ -613,30 +674,28 @@ int spd_init(int64_t state_cnt, int64_t control_cnt, int32_t *error_code) {
     return SPD_OK;
 }
 
-// One group of a parallel step: the containers of the argument list that are (all) the members of one device model.
-struct StepGroup {
-    std::shared_ptr<Batch> batch;
-    std::vector<int> positions;  // indices into the argument list
-    std::vector<int> members;    // member index of each position
-    std::vector<int64_t> control_ids;   // the control containers, looked up again whenever the lock was given up
-    Control before;              // model date before the step
-    Control advanced;            // ... and after it (valid when slot >= 0)
-    int slot = -1;               // pending check; -1: the members were not initialised; -2: the step could not be issued
-    int rc = SPD_OK;             // status of this group's device calls
-    std::string error;           // ... and its message
+// ---------------------------------------------------------------------------------------------------------------------
+// parallel_step
+// ---------------------------------------------------------------------------------------------------------------------
+// what ONE call does with one group of its plan
+struct GroupRun {
+    Control before;    // model date before the step
+    Control advanced;  // ... and after it (valid when slot >= 0)
+    int slot = -1;     // pending check; -1: the members were not initialised; -2: the step could not be issued
+    int rc = SPD_OK;   // status of this group's device calls
+    std::string error; // ... and its message
 };
 struct PendingStep {
-    int n = 0;
-    std::vector<StepGroup> groups;
+    std::shared_ptr<const Plan> plan;
+    std::vector<GroupRun> run;
 };
 std::map<int64_t, PendingStep> g_pending;
-
 // Host-side order of the device work of the multi-group paths, for tests: (kind, group) pairs, kind 1 = step + check
 // enqueued, 2 = waiting for the check of that group started, 3 = finished.  Off unless spd_driver_trace(1) was called.
-bool g_trace_on = false;
+std::atomic<bool> g_trace_on{false};
 std::vector<int32_t> g_trace;
 static void trace(int kind, int group) {
-    if (!g_trace_on) return;
+    if (!g_trace_on.load(std::memory_order_relaxed)) return;
     std::lock_guard<std::recursive_mutex> lock(g_mutex);
     g_trace.push_back(kind);
     g_trace.push_back(group);
@@ -644,24 +703,28 @@ static void trace(int kind, int group) {
 
 // Resolve the containers; gather independent one-member models into batched models -- per device and per set of members that
 // agree in date, control flags and anomaly length, so one odd member or a second device never de-batches the rest --; split
-// batches that are asked for in a different grouping; return the groups to step.
-static int plan_step(const int64_t *state_cnts, const int64_t *control_cnts, int n, std::vector<StepGroup> &groups, const char *who) {
+// batches that are asked for in a different grouping; make the groups to step.
+static int make_plan(const int64_t *state_cnts, const int64_t *control_cnts, int n, std::shared_ptr<const Plan> &out, const char *who) {
     std::vector<std::shared_ptr<State>> states(n);
     std::vector<Control *> controls(n);
+    {
+        std::vector<int64_t> seen(state_cnts, state_cnts + n);
+        std::sort(seen.begin(), seen.end());
+        if (std::adjacent_find(seen.begin(), seen.end()) != seen.end())
+            return fail(SPD_E_ARG, std::string(who) + ": the same state container twice");
+    }
     for (int i = 0; i < n; ++i) {
         states[i] = state_of(state_cnts[i]);
         auto ci = g_controls.find(control_cnts[i]);
         if (!states[i] || ci == g_controls.end()) return fail(SPD_E_ARG, std::string(who) + ": not a live state / control container");
         controls[i] = &ci->second;
-        for (int j = 0; j < i; ++j)
-            if (states[j] == states[i]) return fail(SPD_E_ARG, std::string(who) + ": the same state container twice");
     }
     // independent one-member models -> batched models (once; later calls find them batched)
     std::vector<char> classed(n, 1);
     std::vector<spd_model_control> own(n);  // the control block of every initialised one-member model, read once
     for (int i = 0; i < n; ++i) {
         const Batch &b = *states[i]->batch;
-        if (b.members != 1 || !b.initialized[0]) continue;
+        if (b.members != 1 || !b.initialized[0] || b.advanced_without_check) continue;
         if (int rc = spd_model_get_control(b.model, &own[i])) return rc;
         classed[i] = own[i].sppt_on ? 1 : 0;  // (an SPPT member keeps its own model: gather() has the why)
     }
@@ -690,21 +753,26 @@ static int plan_step(const int64_t *state_cnts, const int64_t *control_cnts, int
             }
         }
     }
+    auto plan = std::make_shared<Plan>();
+    plan->states.assign(state_cnts, state_cnts + n);
+    plan->controls.assign(control_cnts, control_cnts + n);
+    // (containers of one device model are found through a map from the model to its group: linear in n)
+    std::map<const Batch *, std::vector<int>> positions_of;
+    for (int i = 0; i < n; ++i) positions_of[states[i]->batch.get()].push_back(i);
     std::vector<char> handled(n, 0);
     for (int i = 0; i < n; ++i) {
         if (handled[i]) continue;
         std::shared_ptr<Batch> b = states[i]->batch;
-        std::vector<int> mine;  // positions of the argument list that belong to this model
-        for (int j = i; j < n; ++j)
-            if (states[j]->batch == b) mine.push_back(j);
+        std::vector<int> mine = positions_of[b.get()];  // positions of the argument list that belong to this model
         bool whole = static_cast<int>(mine.size()) == b->members;
         for (int j : mine) whole = whole && same_date(*controls[i], *controls[j]);
         if (!whole) {  // a different grouping than the batch: take it apart and step this container on its own
             if (int rc = split_batch(b)) return rc;
+            for (int j : mine) positions_of[states[j]->batch.get()].assign(1, j);
             b = states[i]->batch;
             mine.assign(1, i);
         }
-        StepGroup g;
+        GroupPlan g;
         g.batch = b;
         g.positions = mine;
         for (int j : mine) {
@@ -712,9 +780,30 @@ static int plan_step(const int64_t *state_cnts, const int64_t *control_cnts, int
             g.control_ids.push_back(control_cnts[j]);
             handled[j] = 1;
         }
-        g.before = *controls[i];
-        g.advanced = g.before;
-        groups.push_back(g);
+        plan->groups.push_back(std::move(g));
+    }
+    plan->epoch = g_epoch;  // (after the gathers and splits above, which moved it)
+    out = plan;
+    return SPD_OK;
+}
+
+// The plan of this argument list (the last call's, when it still holds) and a fresh run record per group.  (lock held)
+static int plan_step(const int64_t *state_cnts, const int64_t *control_cnts, int n, std::shared_ptr<const Plan> &plan,
+                     std::vector<GroupRun> &run, const char *who) {
+    const size_t bytes = static_cast<size_t>(n) * sizeof(int64_t);
+    if (g_last_plan && g_last_plan->epoch == g_epoch && static_cast<int>(g_last_plan->states.size()) == n &&
+        (n == 0 || (std::memcmp(g_last_plan->states.data(), state_cnts, bytes) == 0 &&
+                    std::memcmp(g_last_plan->controls.data(), control_cnts, bytes) == 0))) {
+        plan = g_last_plan;
+    } else {
+        if (int rc = make_plan(state_cnts, control_cnts, n, plan, who)) return rc;
+        g_last_plan = plan;
+    }
+    run.assign(plan->groups.size(), GroupRun{});
+    for (size_t i = 0; i < run.size(); ++i) {
+        auto ci = g_controls.find(plan->groups[i].control_ids[0]);
+        if (ci == g_controls.end()) return fail(SPD_E_ARG, std::string(who) + ": not a live control container");
+        run[i].before = run[i].advanced = ci->second;
     }
     return SPD_OK;
 }
@@ -730,42 +819,52 @@ static bool all_initialized(const Batch &b) {
 constexpr int32_t kStepFailed = -3;
 
 // Enqueue the step and the range check of one group on its model's stream; nothing waits.  (lock held)
-static void issue_group(StepGroup &g) {
+// Everything that can refuse is asked BEFORE the step is enqueued (a free check slot, the control block); what fails from the
+// step on is a device error, and it leaves the model marked: its state has moved while its date and codes say it has not, and
+// it is not stepped again until its members are initialised anew.
+static void issue_group(const GroupPlan &g, GroupRun &r) {
     Batch &b = *g.batch;
     if (!all_initialized(b)) return;  // slot stays -1: E_STATE_NOT_INITIALIZED
     int rc = SPD_OK;
-    if (hipSetDevice(b.device) != hipSuccess) rc = fail(SPD_E_DEVICE, "speedy driver: hipSetDevice failed");
-    if (rc == SPD_OK && spd_model_checks_in_flight(b.model) >= 2)  // (refuse BEFORE the step: a step without its check is no step)
+    bool step_enqueued = false;
+    if (b.advanced_without_check)
+        rc = fail(SPD_E_ARG, "speedy driver: an earlier step of this device model was enqueued but could not be checked; initialise its members again");
+    if (rc == SPD_OK && !drvdev::set_device(b.device)) rc = fail(SPD_E_DEVICE, "speedy driver: hipSetDevice failed");
+    if (rc == SPD_OK && spd_model_checks_in_flight(b.model) >= 2)  // (a step without its check is no step)
         rc = fail(SPD_E_ARG, "speedy driver: two steps of this device model are in flight already; end one with spd_parallel_step_end first");
-    if (rc == SPD_OK) rc = push_date(b, g.before);
-    if (rc == SPD_OK) rc = spd_model_step(b.model, 1, b.stream);
+    if (rc == SPD_OK) rc = push_date(b, r.before);
     if (rc == SPD_OK) {
-        g.slot = spd_model_check_begin(b.model, 2, b.stream);
-        if (g.slot < 0) rc = g.slot;
+        step_enqueued = true;
+        rc = spd_model_step(b.model, 1, b.stream);
     }
-    if (rc == SPD_OK) rc = pull_date(b, g.advanced);
+    if (rc == SPD_OK) {
+        r.slot = spd_model_check_begin(b.model, 2, b.stream);
+        if (r.slot < 0) rc = r.slot;
+    }
+    if (rc == SPD_OK) rc = pull_date(b, r.advanced);
     if (rc != SPD_OK) {
-        g.rc = rc;
-        g.error = spd_last_error();
-        if (g.slot >= 0) {  // (the check is in flight: take it back so that the slot is free again)
+        r.rc = rc;
+        r.error = spd_last_error();
+        if (r.slot >= 0) {  // (the check is in flight: take it back so that the slot is free again)
             std::vector<int32_t> scratch(b.members);
-            (void)spd_model_check_end(b.model, g.slot, scratch.data());
+            (void)spd_model_check_end(b.model, r.slot, scratch.data());
         }
-        g.slot = -2;
+        r.slot = -2;
+        if (step_enqueued) b.advanced_without_check = true;
     }
 }
 
 // Wait for the check of one group.  (lock NOT held: other host threads may work on other containers meanwhile)
-static void collect_group(StepGroup &g, std::vector<int32_t> &codes) {
+static void collect_group(const GroupPlan &g, GroupRun &r, std::vector<int32_t> &codes) {
     Batch &b = *g.batch;
-    codes.assign(b.members, g.slot == -2 ? kStepFailed : -1);
-    if (g.slot < 0) return;
+    codes.assign(b.members, r.slot == -2 ? kStepFailed : -1);
+    if (r.slot < 0) return;
     int rc = SPD_OK;
-    if (hipSetDevice(b.device) != hipSuccess) rc = fail(SPD_E_DEVICE, "speedy driver: hipSetDevice failed");
-    if (rc == SPD_OK) rc = spd_model_check_end(b.model, g.slot, codes.data());
+    if (!drvdev::set_device(b.device)) rc = fail(SPD_E_DEVICE, "speedy driver: hipSetDevice failed");
+    if (rc == SPD_OK) rc = spd_model_check_end(b.model, r.slot, codes.data());
     if (rc != SPD_OK) {
-        g.rc = rc;
-        g.error = spd_last_error();
+        r.rc = rc;
+        r.error = spd_last_error();
         codes.assign(b.members, kStepFailed);
     }
 }
@@ -773,67 +872,76 @@ static void collect_group(StepGroup &g, std::vector<int32_t> &codes) {
 // Hand the codes out and settle the dates: speedy.f90:57-71 advances the date only after a successful check.  (lock held)
 // dates_ran_ahead: the begin / end form moved the dates at _begin already (and a later _begin may have moved them again): only
 // a member whose check failed gets the date from before its step back.
-static void settle_group(const StepGroup &g, const std::vector<int32_t> &codes, int32_t *error_codes, bool dates_ran_ahead) {
+static void settle_group(const GroupPlan &g, const GroupRun &r, const std::vector<int32_t> &codes, int32_t *error_codes,
+                         bool dates_ran_ahead) {
+    bool any_failed = false;
     for (size_t k = 0; k < g.positions.size(); ++k) {
         const int32_t code = codes[g.members[k]];
         error_codes[g.positions[k]] = code;
+        any_failed = any_failed || code != 0;
         auto ci = g_controls.find(g.control_ids[k]);
         if (ci == g_controls.end() || (code == 0 && dates_ran_ahead)) continue;
-        const Control &to = code == 0 ? g.advanced : g.before;
+        const Control &to = code == 0 ? r.advanced : r.before;
         ci->second.now = to.now;
         ci->second.month_idx = to.month_idx;
     }
+    if (r.rc != SPD_OK && r.slot >= 0) g.batch->advanced_without_check = true;  // (stepped, and the check could not be collected)
+    if (any_failed) regrouped();  // the members of a model may now disagree about the date
 }
 
 // the status of the call: the first group that failed (its message becomes spd_last_error again); the others were stepped
-static int first_failure(const std::vector<StepGroup> &groups) {
-    for (const StepGroup &g : groups)
-        if (g.rc != SPD_OK) return fail(g.rc, g.error);
+static int first_failure(const std::vector<GroupRun> &run) {
+    for (const GroupRun &r : run)
+        if (r.rc != SPD_OK) return fail(r.rc, r.error);
     return SPD_OK;
 }
 
 int spd_parallel_step(const int64_t *state_cnts, const int64_t *control_cnts, int32_t *error_codes, int32_t n) {
     if (n < 0 || (n > 0 && (!state_cnts || !control_cnts || !error_codes))) return fail(SPD_E_ARG, "spd_parallel_step: bad argument");
+    drvdev::DeviceGuard guard;
     std::unique_lock<std::recursive_mutex> lock(g_mutex);
-    std::vector<StepGroup> groups;
-    if (int rc = plan_step(state_cnts, control_cnts, n, groups, "spd_parallel_step")) return rc;
+    std::shared_ptr<const Plan> plan;
+    std::vector<GroupRun> run;
+    if (int rc = plan_step(state_cnts, control_cnts, n, plan, run, "spd_parallel_step")) return rc;
+    const std::vector<GroupPlan> &groups = plan->groups;
     // One device model, or several -- one per GPU of a one-process ensemble, the two models 32 or more containers of a device
     // are kept in, members that could not be batched --: every model's step and check are enqueued before the host waits for
     // any of them, so the devices (and the models that share one) work side by side; a model that fails does not keep the
     // others from being stepped; and the lock is given up while the host waits, so that other host threads can step THEIR
     // containers meanwhile (the reference's parallel_step is `!f2py threadsafe`).
     for (size_t i = 0; i < groups.size(); ++i) {
-        issue_group(groups[i]);
+        issue_group(groups[i], run[i]);
         trace(1, static_cast<int>(i));
     }
     lock.unlock();
     std::vector<std::vector<int32_t>> codes(groups.size());
     for (size_t i = 0; i < groups.size(); ++i) {
         trace(2, static_cast<int>(i));
-        collect_group(groups[i], codes[i]);
+        collect_group(groups[i], run[i], codes[i]);
         trace(3, static_cast<int>(i));
     }
     lock.lock();
-    for (size_t i = 0; i < groups.size(); ++i) settle_group(groups[i], codes[i], error_codes, false);
-    return first_failure(groups);
+    for (size_t i = 0; i < groups.size(); ++i) settle_group(groups[i], run[i], codes[i], error_codes, false);
+    return first_failure(run);
 }
 
 int spd_parallel_step_begin(const int64_t *state_cnts, const int64_t *control_cnts, int32_t n, int64_t *token) {
     if (n < 0 || !token || (n > 0 && (!state_cnts || !control_cnts))) return fail(SPD_E_ARG, "spd_parallel_step_begin: bad argument");
+    drvdev::DeviceGuard guard;
     LOCK;
     PendingStep p;
-    p.n = n;
-    if (int rc = plan_step(state_cnts, control_cnts, n, p.groups, "spd_parallel_step_begin")) return rc;
-    for (size_t i = 0; i < p.groups.size(); ++i) {
-        StepGroup &g = p.groups[i];
-        issue_group(g);  // (a group that cannot be issued reports at _end; the others go ahead)
+    if (int rc = plan_step(state_cnts, control_cnts, n, p.plan, p.run, "spd_parallel_step_begin")) return rc;
+    for (size_t i = 0; i < p.run.size(); ++i) {
+        const GroupPlan &g = p.plan->groups[i];
+        GroupRun &r = p.run[i];
+        issue_group(g, r);  // (a group that cannot be issued reports at _end; the others go ahead)
         trace(1, static_cast<int>(i));
-        if (g.slot < 0) continue;
+        if (r.slot < 0) continue;
         for (int64_t id : g.control_ids) {  // the dates run ahead of the check; _end puts a failed member's date back
             auto ci = g_controls.find(id);
             if (ci == g_controls.end()) continue;
-            ci->second.now = g.advanced.now;
-            ci->second.month_idx = g.advanced.month_idx;
+            ci->second.now = r.advanced.now;
+            ci->second.month_idx = r.advanced.month_idx;
         }
     }
     *token = g_next++;
@@ -842,55 +950,88 @@ int spd_parallel_step_begin(const int64_t *state_cnts, const int64_t *control_cn
 }
 
 int spd_parallel_step_end(int64_t token, int32_t *error_codes) {
+    drvdev::DeviceGuard guard;
     std::unique_lock<std::recursive_mutex> lock(g_mutex);
     auto it = g_pending.find(token);
     if (it == g_pending.end() || !error_codes) return fail(SPD_E_ARG, "spd_parallel_step_end: not a pending step");
     PendingStep p = std::move(it->second);
     g_pending.erase(it);
     lock.unlock();
-    std::vector<std::vector<int32_t>> codes(p.groups.size());
-    for (size_t i = 0; i < p.groups.size(); ++i) {
+    const std::vector<GroupPlan> &groups = p.plan->groups;
+    std::vector<std::vector<int32_t>> codes(groups.size());
+    for (size_t i = 0; i < groups.size(); ++i) {
         trace(2, static_cast<int>(i));
-        collect_group(p.groups[i], codes[i]);
+        collect_group(groups[i], p.run[i], codes[i]);
         trace(3, static_cast<int>(i));
     }
     lock.lock();
-    for (size_t i = 0; i < p.groups.size(); ++i) {
-        StepGroup &g = p.groups[i];
-        if (g.slot == -1) {  // not initialised: the dates were never touched
+    for (size_t i = 0; i < groups.size(); ++i) {
+        const GroupPlan &g = groups[i];
+        if (p.run[i].slot == -1) {  // not initialised: the dates were never touched
             for (size_t k = 0; k < g.positions.size(); ++k) error_codes[g.positions[k]] = -1;
             continue;
         }
-        settle_group(g, codes[i], error_codes, true);
+        settle_group(g, p.run[i], codes[i], error_codes, true);
     }
-    return first_failure(p.groups);
+    return first_failure(p.run);
 }
 
 // The shared boundary fields (orography, masks, albedo, vegetation, the monthly climatologies and -- when both have
 // the same length -- the SST anomalies) of container `root` into every other container of the list, device to device: the
 // one exchange of a sharded ensemble, for a host that keeps all members in one process.  (One process per GPU: the same
-// broadcast is ensemble.broadcast_boundary_conditions over RCCL.)
+// broadcast is ensemble.broadcast_boundary_conditions over RCCL.)  The fields cross to another GPU ONCE: into the first
+// container of the list that lives there (hipMemcpyPeerAsync, xGMI); the other containers of that GPU take them from it with
+// local copies queued behind it on the same stream.  Devices are synchronised once before (the copies run on the null stream
+// of the destination device, which must not overtake what the models' own streams still hold) and once after the call.
 int spd_broadcast_boundary(const int64_t *state_cnts, int32_t n, int32_t root) {
     if (n < 1 || !state_cnts || root < 0 || root >= n) return fail(SPD_E_ARG, "spd_broadcast_boundary: bad argument");
     static const char *const kBoundary[] = {"orog", "fmask_orig", "alb0", "veg_high", "veg_low", "stl12", "snowd12", "soil_wc_l1",
                                             "soil_wc_l2", "soil_wc_l3", "sst12", "sea_ice_frac12", "sst_anom"};
+    drvdev::DeviceGuard guard;
     LOCK;
     auto src = state_of(state_cnts[root]);
     if (!src) return fail(SPD_E_ARG, "spd_broadcast_boundary: not a live state container");
-    std::vector<int> devices;
+    std::vector<std::shared_ptr<State>> dst(n);
+    std::map<int, std::vector<int>> on_device;  // device -> positions of the list (root excluded), in list order
     for (int i = 0; i < n; ++i) {
         if (i == root) continue;
-        auto dst = state_of(state_cnts[i]);
-        if (!dst) return fail(SPD_E_ARG, "spd_broadcast_boundary: not a live state container");
-        const bool anom = dst->batch->sst_anom_allocated == src->batch->sst_anom_allocated && dst->batch->n_months == src->batch->n_months;
-        if (int rc = spd_model_copy_vars(dst->batch->model, dst->member, src->batch->model, src->member, kBoundary, anom ? 13 : 12,
-                                         nullptr))
-            return rc;
-        devices.push_back(dst->batch->device);
+        dst[i] = state_of(state_cnts[i]);
+        if (!dst[i]) return fail(SPD_E_ARG, "spd_broadcast_boundary: not a live state container");
+        on_device[dst[i]->batch->device].push_back(i);
     }
-    for (int d : devices)  // (the call is synchronous, like every call of this interface)
-        if (hipSetDevice(d) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
-            return fail(SPD_E_DEVICE, "spd_broadcast_boundary: device error");
+    const int src_device = src->batch->device;
+    auto sync_device = [](int d) { return drvdev::set_device(d) && drvdev::device_synchronize(); };
+    if (!sync_device(src_device)) return fail(SPD_E_DEVICE, "spd_broadcast_boundary: device error");
+    for (auto &kv : on_device)
+        if (kv.first != src_device && !sync_device(kv.first)) return fail(SPD_E_DEVICE, "spd_broadcast_boundary: device error");
+    g_broadcast_stats = {0, 0};
+    int rc = SPD_OK;
+    for (auto &kv : on_device) {
+        // the source of this device's copies: the root itself on its own device, elsewhere the first container that has
+        // received everything (a container whose anomaly length differs from the root's receives 12 fields and cannot pass 13 on)
+        std::shared_ptr<State> local = kv.first == src_device ? src : nullptr;
+        for (int i : kv.second) {
+            const Batch &d = *dst[i]->batch, &s = *src->batch;
+            const bool anom = d.sst_anom_allocated == s.sst_anom_allocated && d.n_months == s.n_months;
+            const std::shared_ptr<State> &from = local ? local : src;
+            const bool crosses = from->batch->device != d.device;
+            rc = spd_model_copy_vars_enqueue(d.model, dst[i]->member, from->batch->model, from->member, kBoundary, anom ? 13 : 12, nullptr);
+            if (rc != SPD_OK) break;
+            ++(crosses ? g_broadcast_stats.peer_copies : g_broadcast_stats.local_copies);
+            if (!local && anom) local = dst[i];
+        }
+        if (rc != SPD_OK) break;
+    }
+    // (the call is synchronous, like every call of this interface)
+    for (auto &kv : on_device)
+        if (!sync_device(kv.first) && rc == SPD_OK) rc = fail(SPD_E_DEVICE, "spd_broadcast_boundary: device error");
+    return rc;
+}
+
+int spd_broadcast_boundary_stats(int32_t *peer_copies, int32_t *local_copies) {
+    LOCK;
+    if (peer_copies) *peer_copies = g_broadcast_stats.peer_copies;
+    if (local_copies) *local_copies = g_broadcast_stats.local_copies;
     return SPD_OK;
 }
 
@@ -919,6 +1060,7 @@ int spd_step(int64_t state_cnt, int64_t control_cnt, int32_t *error_code) {
 
 int spd_check(int64_t state_cnt, int32_t *error_code) {
     if (!error_code) return fail(SPD_E_ARG, "spd_check: null argument");
+    drvdev::DeviceGuard guard;
     LOCK;
     auto st = state_of(state_cnt);
     if (!st) return fail(SPD_E_ARG, "spd_check: not a live state container");
@@ -927,7 +1069,7 @@ int spd_check(int64_t state_cnt, int32_t *error_code) {
         *error_code = -1;
         return SPD_OK;
     }
-    if (hipSetDevice(b.device) != hipSuccess) return fail(SPD_E_DEVICE, "spd_check: hipSetDevice failed");
+    if (!drvdev::set_device(b.device)) return fail(SPD_E_DEVICE, "spd_check: hipSetDevice failed");
     std::vector<int32_t> codes(b.members, 0);
     if (int rc = spd_model_check(b.model, 1, codes.data(), nullptr, nullptr)) return rc;
     *error_code = codes[st->member];
@@ -935,16 +1077,17 @@ int spd_check(int64_t state_cnt, int32_t *error_code) {
 }
 
 static int transform(int64_t state_cnt, int which, const char *who) {
+    drvdev::DeviceGuard guard;
     LOCK;
     auto st = state_of(state_cnt);
     if (!st) return fail(SPD_E_ARG, std::string(who) + ": not a live state container");
     Batch &b = *st->batch;
-    if (hipSetDevice(b.device) != hipSuccess) return fail(SPD_E_DEVICE, std::string(who) + ": hipSetDevice failed");
+    if (!drvdev::set_device(b.device)) return fail(SPD_E_DEVICE, std::string(who) + ": hipSetDevice failed");
     int rc;
     if (which == 0) rc = spd_model_spectral2grid(b.model, st->member, 1, nullptr);
     else if (which == 1) rc = spd_model_grid2spectral(b.model, st->member, 1, nullptr);
     else rc = spd_model_grid_filter(b.model, st->member, 1, nullptr);
-    if (rc == SPD_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = fail(SPD_E_DEVICE, std::string(who) + ": device error");
+    if (rc == SPD_OK && !drvdev::null_stream_synchronize()) rc = fail(SPD_E_DEVICE, std::string(who) + ": device error");
     return rc;
 }
 int spd_transform_spectral2grid(int64_t state_cnt) { return transform(state_cnt, 0, "spd_transform_spectral2grid"); }
@@ -956,6 +1099,7 @@ int spd_apply_grid_filter(int64_t state_cnt) { return transform(state_cnt, 2, "s
 // ---------------------------------------------------------------------------------------------------------------------
 static int access(int64_t state_cnt, const char *name, void *buf, size_t bytes, bool set) {
     const char *who = set ? "spd_set" : "spd_get";
+    drvdev::DeviceGuard guard;
     LOCK;
     auto st = state_of(state_cnt);
     const RegVar *v = find_var(name);
@@ -965,7 +1109,7 @@ static int access(int64_t state_cnt, const char *name, void *buf, size_t bytes, 
     const size_t need = var_bytes(*v, *b);
     if (bytes != need)
         return fail(SPD_E_SIZE, std::string(who) + ": '" + name + "' is " + std::to_string(need) + " bytes (Array shape missmatch)");
-    if (hipSetDevice(b->device) != hipSuccess) return fail(SPD_E_DEVICE, std::string(who) + ": hipSetDevice failed");
+    if (!drvdev::set_device(b->device)) return fail(SPD_E_DEVICE, std::string(who) + ": hipSetDevice failed");
     switch (v->where) {
         case Device:
             return set ? spd_model_set(b->model, name, st->member, buf, bytes) : spd_model_get(b->model, name, st->member, buf, bytes);

@@ -1,0 +1,24 @@
+// HIP side of driver_backend.hpp.
+#include <hip/hip_runtime.h>
+
+#include "driver_backend.hpp"
+
+namespace drvdev {
+int device_count() {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+bool get_device(int *device) { return hipGetDevice(device) == hipSuccess; }
+bool set_device(int device) { return hipSetDevice(device) == hipSuccess; }
+bool stream_create(void **stream) {
+    hipStream_t s = nullptr;
+    if (hipStreamCreate(&s) != hipSuccess) return false;
+    *stream = s;
+    return true;
+}
+void stream_destroy(void *stream) {
+    if (stream) (void)hipStreamDestroy(static_cast<hipStream_t>(stream));
+}
+bool device_synchronize() { return hipDeviceSynchronize() == hipSuccess; }
+bool null_stream_synchronize() { return hipStreamSynchronize(nullptr) == hipSuccess; }
+}  // namespace drvdev

@@ -723,7 +723,9 @@ int spd_model_check_begin(spd_model_handle m, int time_level, void *stream) {
     if (!m) return m_fail(SPD_E_ARG, "spd_model_check_begin: null model");
     if (time_level < 1 || time_level > 2) return m_fail(SPD_E_ARG, "spd_model_check_begin: time level is 1 or 2");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int slot = m->next_slot;
+    // any free slot (alternating while both are free): the condition for refusing is exactly "two in flight", which is what
+    // spd_model_checks_in_flight lets a caller ask BEFORE it enqueues the step this check belongs to
+    const int slot = m->slot_busy[m->next_slot] ? 1 - m->next_slot : m->next_slot;
     if (m->slot_busy[slot])
         return m_fail(SPD_E_ARG, "spd_model_check_begin: two checks are in flight already; end one with spd_model_check_end first");
     if (!m->h_err[slot]) {  // (pinned, coherent: the kernel stores the codes there itself, see spd_model_check)
@@ -1268,15 +1270,25 @@ int spd_model_copy_member(spd_model_handle dst, int di, spd_model_handle src, in
 int spd_model_copy_vars(spd_model_handle dst, int di, spd_model_handle src, int si, const char *const *names, int nnames,
                         void *stream) {
     if (!dst || !src || (nnames > 0 && !names)) return m_fail(SPD_E_ARG, "spd_model_copy_vars: null argument");
-    if (di < 0 || di >= dst->M || si < 0 || si >= src->M) return m_fail(SPD_E_ARG, "spd_model_copy_vars: member index out of range");
     const int ddev = dst->ctx->device, sdev = src->ctx->device;
-    hipStream_t s = static_cast<hipStream_t>(stream);
     if (sdev != ddev) {
         M_HIP(hipSetDevice(sdev));
         M_HIP(hipDeviceSynchronize());
     }
     M_HIP(hipSetDevice(ddev));
     M_HIP(hipDeviceSynchronize());
+    return spd_model_copy_vars_enqueue(dst, di, src, si, names, nnames, stream);
+}
+
+// The same copies without the two device synchronisations in front: for a caller that hands the same fields to many members and
+// has synchronised the devices once itself (spd_broadcast_boundary).  Leaves the DESTINATION device current.
+int spd_model_copy_vars_enqueue(spd_model_handle dst, int di, spd_model_handle src, int si, const char *const *names, int nnames,
+                                void *stream) {
+    if (!dst || !src || (nnames > 0 && !names)) return m_fail(SPD_E_ARG, "spd_model_copy_vars: null argument");
+    if (di < 0 || di >= dst->M || si < 0 || si >= src->M) return m_fail(SPD_E_ARG, "spd_model_copy_vars: member index out of range");
+    const int ddev = dst->ctx->device, sdev = src->ctx->device;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    M_HIP(hipSetDevice(ddev));
     dst->surf_cache_valid = dst->phi_ahead = false;
     for (int i = 0; i < nnames; ++i) {
         auto a = src->reg.find(names[i]), b = dst->reg.find(names[i]);

@@ -309,13 +309,7 @@ class SpeedyEns:
 
     def __init__(self, num_of_members, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 2), devices=None):
         self.n_members = int(num_of_members)
-        if devices is not None:
-            _speedy.set_device_placement(int(devices))
-        try:
-            cnts = _speedy.modelstate_init_ensemble(self.n_members)
-        finally:
-            if devices is not None:
-                _speedy.set_device_placement(0)
+        cnts = _speedy.modelstate_init_ensemble(self.n_members, devices=None if devices is None else int(devices))
         self.members = [Speedy(start_date=start_date, end_date=end_date, member=i, _state_cnt=c) for i, c in enumerate(cnts)]
         self.current_date = self.members[0].current_date
 

@@ -1,6 +1,6 @@
 """The function set of the reference's f2py module `pyspeedy.speedy_driver.speedy_driver` (imported there as
 `_speedy`; generated from registry/templates/speedy_driver.f90.j2), bound to the C entry points of the same names in
-libpyspeedy_amd.so (include/pyspeedy_amd_driver.h, csrc/driver.hip).
+libpyspeedy_amd.so (include/pyspeedy_amd_driver.h, csrc/driver.cpp).
 
 Same names, argument order and return conventions, so that `pyspeedy/speedy.py`-style host code runs unchanged:
 
@@ -67,9 +67,15 @@ def modelstate_init():
     return c.value
 
 
-def modelstate_init_ensemble(nmembers):
+def modelstate_init_ensemble(nmembers, devices=None):
+    """n containers batched from the start.  devices=None: the process-wide placement (set_device_placement /
+    PYSPEEDY_AMD_DEVICES; by default the current device); devices=k: blocks over GPUs 0 .. k-1 (0: the current device)
+    without touching that placement."""
     arr = (C.c_int64 * int(nmembers))()
-    _ok(_L().spd_modelstate_init_ensemble(arr, int(nmembers)), "modelstate_init_ensemble")
+    if devices is None:
+        _ok(_L().spd_modelstate_init_ensemble(arr, int(nmembers)), "modelstate_init_ensemble")
+    else:
+        _ok(_L().spd_modelstate_init_ensemble_on(arr, int(nmembers), int(devices)), "modelstate_init_ensemble_on")
     return list(arr)
 
 
@@ -104,6 +110,13 @@ def broadcast_boundary(state_cnts, root=0):
     """The shared boundary fields of container state_cnts[root] into all the others, device to device."""
     s, n = _cnts(state_cnts)
     _ok(_L().spd_broadcast_boundary(s, n, int(root)), "broadcast_boundary")
+
+
+def broadcast_boundary_stats():
+    """(copies of the last broadcast_boundary that crossed to another device, copies that stayed on one)"""
+    peer, local = C.c_int32(), C.c_int32()
+    _ok(_L().spd_broadcast_boundary_stats(C.byref(peer), C.byref(local)), "broadcast_boundary_stats")
+    return peer.value, local.value
 
 
 def driver_trace(on=True):

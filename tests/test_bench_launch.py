@@ -98,13 +98,35 @@ def test_the_one_gpu_line_carries_the_drop_in_and_every_store_legs():
     for k in ("WORLD_SIZE", "PYSPEEDY_AMD_BENCH_BACKEND"):
         env.pop(k, None)
     res = _result(subprocess.run([sys.executable, BENCH, "--members", "8", "--steps", "6", "--warmup", "3", "--regions", "2",
-                                  "--cpu-seconds", "1.5"], capture_output=True, text=True, timeout=1200, env=env))
+                                  "--cpu-seconds", "1.5", "--leg-seconds", "0.05"], capture_output=True, text=True, timeout=1200,
+                                 env=env))
     assert res["n_gpus"] == 1 and res["config"]["members_total"] == 8
     d = res["drop_in_step"]
     assert d["containers"] == 8 and 0 < d["begin_end_ms_per_step"] and 0 < d["sync_ms_per_step"]
     e = res["every_step_stores"]
     assert e["spec2grid_per_member"] == 91 and e["ms_per_step"] > 0
     assert res["cpu_baseline"]["all_cores"]["cores"] >= 1 and res["vs_baseline"] > 0
+    # every BASELINE config on the same clock (SURVEY 8d "Configs as concrete inputs")
+    for key, members in (("cfg3", 1), ("cfg4_shard8", 8), ("cfg5", 32)):
+        leg = res[key]
+        assert leg["members"] == members and leg["ms_per_step"] > 0 and leg["steps_per_region"] == 360 and leg["regions"] >= 1
+        assert abs(leg["us_per_member_step"] - leg["ms_per_step"] * 1e3 / members) < 1e-9
+        assert abs(leg["value"] - members * 86400.0 / (leg["ms_per_step"] * 1e-3 * 13140)) < 1e-6 * leg["value"]
+        r = leg["step_roofline"]
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1
+        assert abs(r["achieved"] - r["algorithmic_bytes_per_step"] / (leg["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+        assert {"spec2grid", "column_sw", "column", "grid2spec", "spectral_step"} <= set(leg["kernel_us"])
+        assert set(leg["kernel_frac"]) == set(leg["kernel_us"]) and leg["plan"]
+    # a member-step moves ~20 MB: the legs' byte counts must scale with the members
+    per_member = [res[k]["step_roofline"]["algorithmic_bytes_per_step"] / res[k]["members"] for k in ("cfg3", "cfg4_shard8", "cfg5")]
+    assert all(1.8e7 < b < 2.4e7 for b in per_member), per_member
+    assert "sppt" in res["cfg5"]["workload"].lower() and res["cfg5"]["plan"].startswith("3 member groups")
+    t = res["cfg2_transforms"]
+    assert t["algorithmic_bytes_per_field"] == 52736
+    assert sorted({r["fields"] for r in t["rows"]}) == [1, 8, 64, 512, 4096, 16384]
+    assert {r["kernel"] for r in t["rows"]} == {"spec2grid", "grid2spec"} and len(t["rows"]) == 12
+    for r in t["rows"]:
+        assert r["ns_per_field"] > 0 and abs(r["frac"] - 52736 / r["ns_per_field"] / 8000.0) < 1e-6
 
 
 @pytest.mark.gpu
