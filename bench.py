@@ -33,6 +33,12 @@ What the ONE JSON line of rank 0 holds:
   vs_baseline           value / cpu_baseline.all_cores.value: BASELINE.md holds no published number; north_star's target is
                         stated against the host-CPU reference ("core count stated"), so that is the ratio given (+ note).
   cfg4_strong (N > 1)   BASELINE cfg 4 to the letter beside the weak headline: 64 members in total, block-sharded.
+  collective            what the collective layer saw, gathered through it (RCCL on the GPU box): ranks_seen, device_of_rank[],
+                        the checksum of the boundary fields every rank received in the start-up broadcast and whether they agree.
+  one_process (N > 1)   the reference's own shape beside the process-per-GPU headline: rank 0 ALONE drives all N GPUs -- containers
+                        in blocks per device, boundary fields device to device, spd_parallel_step[_begin / _end] once per model
+                        step over all containers -- while the other ranks sit idle on the host.  `--one-process` runs only this,
+                        in one process, and makes it the line's value.
   drop_in_step (N = 1)  the reference-shaped host loop: spd_parallel_step once per model step (step + range check + codes
                         back), synchronous and in the overlapped begin / end form, over independent containers.
   every_step_stores (N = 1)  the step with every store of the reference restored (all 91 spectral->grid transforms, the
@@ -104,6 +110,9 @@ def parse(argv=None):
     ap.add_argument("--leg-seconds", type=float, default=0.6,
                     help="GPU time of each of the cfg3 / cfg4_shard8 / cfg5 / cfg2_transforms legs of the one-GPU line")
     ap.add_argument("--cfg2-sizes", type=int, nargs="+", default=list(CFG2_SIZES), help="batch sizes of the cfg2_transforms leg")
+    ap.add_argument("--one-process", action="store_true",
+                    help="ONE process drives all --gpus devices through spd_parallel_step (the reference's own shape) and that is the "
+                         "line's value; without it, an N > 1 line carries the same measurement as its `one_process` object")
     ap.add_argument("--cpu-worker", type=float, nargs=2, default=None, metavar=("T_START", "SECONDS"), help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
@@ -299,6 +308,7 @@ def build_ensemble(args, M, first_id, device, dist, rank, coll_device):
     model.init_sst_anom(ANOM_MONTHS)  # zero anomalies over the whole run (speedy.py:338-372)
     # rank 0 reads the boundary file; one RCCL broadcast (~3.4 MB over xGMI) hands it to the other GPUs
     bc = E.broadcast_boundary_conditions(dict(load_bc()) if rank == 0 else None, dist, coll_device)
+    model.bc_checksum, model.bc_bytes = boundary_checksum(bc)  # (of what THIS rank received)
     model.set_bc(bc, start_date=(1982, 1, 1, 0, 0))
     # cfg 4 perturbation (examples/Ensemble_forecast.ipynb): t_grid += N(0, 0.01), then grid2spectral;
     # the generator is seeded with the GLOBAL member id, so the ensemble does not depend on how it is sharded
@@ -311,6 +321,49 @@ def build_ensemble(args, M, first_id, device, dist, rank, coll_device):
         model.set_sppt(True, seed=2024, first_member_id=first_id)
         model.set_physics_precision(True)
     return sp, model
+
+
+def boundary_checksum(bc):
+    """(60-bit checksum, bytes) of a set of boundary fields: sha256 over names, shapes and fp64 values in name order."""
+    import hashlib
+    import numpy as np
+    h, n = hashlib.sha256(), 0
+    for k in sorted(bc):
+        a = np.ascontiguousarray(np.asarray(bc[k], dtype=np.float64))
+        h.update(k.encode())
+        h.update(repr(a.shape).encode())
+        h.update(a.tobytes())
+        n += a.nbytes
+    return int(h.hexdigest()[:15], 16), n
+
+
+def collective_record(dist, backend, device, coll_device, rank, checksum, nbytes):
+    """What the collective layer actually saw, gathered THROUGH it: every rank contributes (rank, HIP device index, checksum of
+    the boundary fields it received in the start-up broadcast) as an int64 tensor to one all_gather -- RCCL on device buffers on
+    the GPU box -- and its GPU's identity to one all_gather_object.  A line that holds this object proves that N ranks met, which
+    device each one computed on, and that the broadcast delivered the same bytes everywhere."""
+    import torch
+    props = torch.cuda.get_device_properties(device)
+    ident = {"rank": rank, "pid": os.getpid(), "device": device.index, "name": props.name,
+             "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None)}
+    mine = torch.tensor([rank, device.index, checksum], dtype=torch.int64, device=coll_device)
+    if dist is None:
+        rows, idents, world = [mine.tolist()], [ident], 1
+    else:
+        world = dist.get_world_size()
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        rows = [p.tolist() for p in parts]
+        idents = [None] * world
+        try:
+            dist.all_gather_object(idents, ident)
+        except Exception as exc:  # (the tensor path above is the proof; the identities are an extra)
+            idents = [{"error": repr(exc)}]
+    gpus = {(i.get("uuid") or "", i.get("pci_bus_id"), i.get("device")) for i in idents if i and "rank" in i}
+    return {"backend": backend if dist is not None else "none (single process)", "world_size": world,
+            "ranks_seen": len({r[0] for r in rows}), "device_of_rank": [r[1] for r in sorted(rows)],
+            "boundary_bytes": nbytes, "boundary_checksum_of_rank": ["%015x" % r[2] for r in sorted(rows)],
+            "boundary_checksum_equal": len({r[2] for r in rows}) == 1, "distinct_gpus": len(gpus), "gpu_of_rank": idents}
 
 
 def kernel_table(model, M, inv_per_member, sppt):
@@ -413,6 +466,9 @@ def config_leg(args, config, members, what, device, dist, rank, coll_device, bar
     cfg = model.config()
     model.run(leg.warmup)
     secs = timed_regions(model, leg, barrier, dist, coll_device, MAX_STEPS - leg.warmup - 72, args.leg_seconds, 500)
+    model.profile(2)  # a first bracketed day that is not read: it creates the events and takes the one-off costs of the
+    model.run(36)     # profiling path (the headline's table comes behind its serial-plan regions, which do the same for it)
+    model.sync()
     rows = kernel_table(model, members, cfg["inv_per_member"], config == "cfg5")
     ok = (model.check(2) == 0).all()
     model.close()
@@ -497,21 +553,12 @@ def transforms_leg(args, device):
                     "one workgroup (load, Legendre, FFT, store) and the figure is that latency, not a bandwidth"}
 
 
-def drop_in_leg(M, steps):
-    """The reference-shaped host loop over M independent containers through the outer C boundary (include/pyspeedy_amd_driver.h):
-    spd_parallel_step once per model step -- step, range check, error codes back -- synchronously and in the overlapped
-    begin / end form.  Per-step wall times, medians (the runtime stalls once per process for ~40 ms shortly after the first
-    launches; a median keeps that out)."""
-    import torch
-    from datetime import datetime
-    from pyspeedy_amd import speedy_driver as drv
-    from pyspeedy_amd.speedy import SpeedyEns
-    ens = SpeedyEns(M, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 3, 1))
-    for member in ens:
-        member.set_bc()
-    # the calls below are the C entry points themselves, on argument arrays built once: what a Fortran / C host of the
-    # reference's loop pays per step (the Python veneer would add its own list -> array conversions to every call)
+def _time_container_loop(ens, steps):
+    """Per-step wall times of spd_parallel_step over all containers of `ens`, synchronous and begin / end (medians and means).
+    The calls are the C entry points themselves, on argument arrays built once: what a Fortran / C host of the reference's loop
+    pays per step (the Python veneer would add its own list -> array conversions to every call)."""
     import ctypes as C
+    import torch
     L = pyspeedy_amd_lib()
     n = len(ens.members)
     states = (C.c_int64 * n)(*[m._state_cnt for m in ens.members])
@@ -520,12 +567,16 @@ def drop_in_leg(M, steps):
 
     def ok(rc):
         if rc != 0:
-            raise SystemExit("bench.py: drop-in leg: " + L.spd_last_error().decode())
+            raise SystemExit("bench.py: parallel_step loop: " + L.spd_last_error().decode())
+
+    def sync_all():
+        for d in range(torch.cuda.device_count()):
+            torch.cuda.synchronize(d)
 
     for _ in range(12):
         ok(L.spd_parallel_step(states, controls, codes, n))
     assert not any(codes)
-    torch.cuda.synchronize()
+    sync_all()
     sync = []
     for _ in range(steps):
         t0 = time.perf_counter()
@@ -544,15 +595,84 @@ def drop_in_leg(M, steps):
         worst |= int(any(codes))
     ok(L.spd_parallel_step_end(token, codes))
     assert not worst and not any(codes)
-    models = len({drv.device_model(m._state_cnt)[0]._m.value for m in ens.members})
+    return {"steps_timed": steps, "sync_ms_per_step": median(sync) * 1e3, "begin_end_ms_per_step": median(ovl) * 1e3,
+            "sync_ms_per_step_mean": sum(sync) / len(sync) * 1e3, "begin_end_ms_per_step_mean": sum(ovl) / len(ovl) * 1e3}
+
+
+def drop_in_leg(M, steps):
+    """The reference-shaped host loop over M independent containers through the outer C boundary (include/pyspeedy_amd_driver.h):
+    spd_parallel_step once per model step -- step, range check, error codes back -- synchronously and in the overlapped
+    begin / end form.  Per-step wall times, medians (the runtime stalls once per process for ~40 ms shortly after the first
+    launches; a median keeps that out)."""
+    from datetime import datetime
+    from pyspeedy_amd import speedy_driver as drv
+    from pyspeedy_amd.speedy import SpeedyEns
+    ens = SpeedyEns(M, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 3, 1))
+    for member in ens:
+        member.set_bc()
+    out = {"containers": M, "device_models": len({drv.device_model(m._state_cnt)[0]._m.value for m in ens.members})}
+    out.update(_time_container_loop(ens, steps))
     del ens
-    return {"containers": M, "device_models": models, "steps_timed": steps, "sync_ms_per_step": median(sync) * 1e3,
-            "begin_end_ms_per_step": median(ovl) * 1e3,
-            "note": "spd_parallel_step(state_cnts, control_cnts, error_codes, n) once per model step over independent containers "
-                    "(one device model up to 31 containers, two from 32 up, both enqueued before either is waited for): every "
-                    "step stores all diagnostics and runs the range "
-                    "check as a launch of its own; sync = the call returns the codes, begin_end = the check of step k is "
-                    "collected after step k + 1 has been enqueued; medians of per-step wall times"}
+    out["note"] = ("spd_parallel_step(state_cnts, control_cnts, error_codes, n) once per model step over independent containers "
+                   "(one device model up to 31 containers, two from 32 up, both enqueued before either is waited for): every "
+                   "step stores all diagnostics and runs the range check as a launch of its own; sync = the call returns the codes, "
+                   "begin_end = the check of step k is collected after step k + 1 has been enqueued; medians of per-step wall times")
+    return out
+
+
+def one_process_leg(n_devices, members_total, steps, what):
+    """The reference's own shape (speedy_driver.f90.j2:58-79, SpeedyEns.run): ONE process owns every container and hands them all
+    to parallel_step.  The containers are placed in blocks on the first `n_devices` GPUs this process can see
+    (spd_modelstate_init_ensemble_on: member e of n on device e k / n), the boundary fields are set on container 0 only and
+    handed to the others device to device (spd_broadcast_boundary: one crossing per GPU), every member is initialised and
+    perturbed like the headline's (t_grid += N(0, 0.01 K), seed = member id), and spd_parallel_step[_begin / _end] is called
+    once per model step over ALL containers: every GPU's step and range check are enqueued before the host waits for any."""
+    import numpy as np
+    import torch
+    from datetime import datetime
+    from pyspeedy_amd import speedy_driver as drv
+    from pyspeedy_amd import speedy as S
+    before = torch.cuda.current_device()
+    used = max(1, min(n_devices, drv.device_count()))
+    t0 = time.perf_counter()
+    ens = S.SpeedyEns(members_total, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 3, 1), devices=used)
+    root = ens.members[0]
+    for member in ens:
+        member._set_sst_anomalies(None)  # (zero anomalies of the run's length in every container: they travel with the rest)
+    bc = load_bc()
+    for state_name, file_name in S._BC_FIELDS:
+        root[state_name] = np.asarray(bc[file_name], dtype=np.float64)
+    cnts = [m._state_cnt for m in ens.members]
+    drv.broadcast_boundary(cnts, 0)
+    peer, local = drv.broadcast_boundary_stats()
+    probe = ens.members[-1]["sst12"]  # what arrived in the last container (on the last device) is what the root holds
+    arrived = bool(np.array_equal(probe, np.asarray(bc["sst"], dtype=np.float64)))
+    for i, member in enumerate(ens.members):
+        code = drv.init(member._state_cnt, member._control_cnt)
+        if code < 0:
+            raise SystemExit("bench.py: one-process leg: init of member %d returned %d" % (i, code))
+        member._initialized_bc = True
+        member.spectral2grid()
+        noise = np.random.default_rng(i).normal(0.0, 0.01, (96, 48, 8))
+        member["t_grid"] = member["t_grid"] + noise
+        member.grid2spectral()
+    t_setup = time.perf_counter() - t0
+    devices = sorted({drv.modelstate_device(c) for c in cnts})
+    models = len({drv.device_model(c)[0]._m.value for c in cnts})
+    timing = _time_container_loop(ens, steps)
+    ms = timing["begin_end_ms_per_step"]
+    out = {"workload": what, "processes": 1, "devices_asked": n_devices, "devices_used": len(devices), "containers": members_total,
+           "members_per_device": [sum(1 for c in cnts if drv.modelstate_device(c) == d) for d in devices],
+           "device_models": models, "boundary_broadcast": {"peer_copies": peer, "local_copies": local, "arrived_intact": arrived},
+           "setup_seconds": t_setup, "ms_per_step": ms,
+           "value": members_total * 86400.0 / (ms * 1e-3 * STEPS_PER_YEAR), "unit": "simulated-years/day",
+           "current_device_preserved": torch.cuda.current_device() == before}
+    out.update(timing)
+    out["note"] = ("one process, spd_parallel_step_begin / _end once per model step over all containers (ms_per_step, value) and the "
+                   "synchronous spd_parallel_step (sync_ms_per_step); per-step wall times, medians; every step stores all diagnostics "
+                   "and runs the range check")
+    del ens
+    return out
 
 
 def pyspeedy_amd_lib():
@@ -603,6 +723,55 @@ def wait_for_ranks(rank, world, what):
     return False
 
 
+def file_flag(what, set_it=False, wait_seconds=0.0):
+    """A flag file shared by the ranks of one job (keyed like wait_for_ranks): set it, or wait on the HOST until it is there."""
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), "pyspeedy_bench_%s_%d_%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid(), what))
+    if set_it:
+        open(path, "w").close()
+        return True
+    deadline = time.time() + wait_seconds
+    while time.time() < deadline:
+        if os.path.exists(path):
+            return True
+        time.sleep(0.05)
+    return False
+
+
+def run_one_process(args):
+    """`--one-process`: this process alone drives --gpus devices; the line's value is the begin / end loop over all containers."""
+    baseline = None if args.no_cpu_baseline else cpu_baseline(args.cpu_seconds)  # (before the GPU is touched)
+    import torch
+    import pyspeedy_amd
+    pyspeedy_amd.lib()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
+    torch.cuda.set_device(0)
+    per_gpu_default, total_default = (64, 64)
+    if args.config != "cfg4":
+        raise SystemExit("bench.py: --one-process measures cfg4")
+    if args.scaling == "weak":
+        per = args.members if args.members is not None else per_gpu_default
+        total = per * args.gpus
+    else:
+        total = args.members if args.members is not None else total_default
+    op = one_process_leg(args.gpus, total, max(args.steps, 20), "BASELINE cfg4 (%s scaling), %d members, ONE process over %d GPUs"
+                         % (args.scaling, total, args.gpus))
+    all_cores = (baseline or {}).get("all_cores")
+    line = {"metric": "simulated-years/day (whole node), T30L8", "value": op["value"], "unit": "simulated-years/day",
+            "n_gpus": args.gpus, "steps": op["steps_timed"], "warmup": 12, "ms_per_step": op["ms_per_step"],
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": (op["value"] / all_cores["value"]) if all_cores else None,
+            "dtype": "f64", "data": "reference example_bc boundary fields (committed fixture); members perturbed with t_grid += "
+                                    "N(0, 0.01 K), seed = member id",
+            "config": {"workload": op["workload"], "members_total": total, "parallelism": "one process, spd_parallel_step over all "
+                       "containers, members in blocks per GPU, no collective in the step", "backend": "none (one process; boundary "
+                       "fields device to device, hipMemcpyPeerAsync)"},
+            "one_process": op}
+    if baseline is not None:
+        line["cpu_baseline"] = baseline
+    print(json.dumps(line), flush=True)
+
+
 def run_rank(args):
     baseline = None
     world_env, rank_env = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -646,6 +815,9 @@ def run_rank(args):
 
     M, first_id, total_members = workload(args, world, rank)
     sp, model = build_ensemble(args, M, first_id, device, dist, rank, coll_device)
+    collective = collective_record(dist, backend, device, coll_device, rank, model.bc_checksum, model.bc_bytes)
+    if not collective["boundary_checksum_equal"] or collective["ranks_seen"] != n_gpus:
+        raise SystemExit("bench.py: the start-up broadcast did not deliver the same boundary fields to %d ranks: %r" % (n_gpus, collective))
     if args.serial_plan:
         model.set_option("member_groups", 1)
     cfg = model.config()
@@ -701,6 +873,24 @@ def run_rank(args):
                 "value": E.simulated_years_per_day(total_s, ms_s * 1e-3, STEPS_PER_YEAR), "unit": "simulated-years/day",
                 "plan": plan_name(scfg, Ms),
                 "note": "BASELINE cfg 4 as worded: 64 members sharded %d per GPU over %d GPUs, same timing rules" % (Ms, n_gpus)}
+        if n_gpus > 1 and args.config == "cfg4":
+            # The reference's own shape beside the process-per-GPU headline: ONE process (rank 0) drives every GPU through
+            # spd_parallel_step.  The other ranks have released their models and wait on the host (a file, not a collective: a
+            # pending RCCL barrier would keep a kernel spinning on the very GPUs that are being measured).
+            barrier()
+            if rank == 0:
+                try:
+                    op = one_process_leg(n_gpus, total_members, 200, "the headline's ensemble (%d members, %d per GPU) driven by ONE "
+                                         "process over %d GPUs" % (total_members, M, n_gpus))
+                    if args.scaling == "weak" and args.members is None:
+                        op["cfg4_strong"] = one_process_leg(n_gpus, 64, 200, "BASELINE cfg 4 as worded: 64 members, %d per GPU, ONE "
+                                                            "process over %d GPUs" % (max(1, 64 // n_gpus), n_gpus))
+                except (Exception, SystemExit) as exc:  # first contact with a second GPU must not cost the line its headline
+                    op = {"error": "%s: %s" % (type(exc).__name__, exc)}
+                legs["one_process"] = op
+                file_flag("one_process_done", set_it=True)
+            else:
+                file_flag("one_process_done", wait_seconds=900.0)
 
     if rank == 0:
         ms_step, ms_min = median(region_s) / args.steps * 1e3, min(region_s) / args.steps * 1e3
@@ -732,6 +922,7 @@ def run_rank(args):
                 "parallelism": "ensemble members sharded per GPU, no collective in the step",
                 "backend": backend if dist is not None else "none (single process)",
             },
+            "collective": collective,
             "roofline": {
                 "kernel": "spec2grid_table_kernel (inverse Legendre + inverse FFT-96, with vort2vel / gradient applied while "
                           "staging the wind and pressure-gradient fields of each member), %d fields/launch" % nfields,
@@ -765,6 +956,8 @@ def main():
         return cpu_worker(*args.cpu_worker)
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be at least 1")
+    if args.one_process:
+        return run_one_process(args)  # one process whatever --gpus says: no ranks are started
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args, argv)  # this process never touches the GPU
     run_rank(args)

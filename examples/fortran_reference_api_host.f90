@@ -5,13 +5,15 @@
 !! library.  This is the file the reference's f2py build would wrap instead of its generated speedy_driver.f90; not one
 !! call site above it changes.
 !!
-!!   fortran_reference_api_host <bc.bin> <out.bin> <nsteps>
+!!   fortran_reference_api_host <bc.bin> <out.bin> <nsteps> [overlapped]
+!! (`overlapped`: the time loop uses parallel_step_begin / parallel_step_end, the library's extension of parallel_step)
 !! bc.bin as for fortran_host; two members, member 2 with its SST raised by 0.5 K.  out.bin: t_grid (96,48,8) of both members.
 program fortran_reference_api_host
     use speedy_driver
     implicit none
     integer, parameter :: ix = 96, il = 48, kx = 8, n = 2
-    integer(8) :: states(n), controls(n), d_start, d_end
+    integer(8) :: states(n), controls(n), d_start, d_end, token, next_token
+    logical :: overlapped
     integer :: codes(n), code, istep, nsteps, m, u, uo, shp(3), y, mo, d, h, mi
     logical :: flag
     real(8) :: f2(ix, il), f12(ix, il, 12), bc2(ix, il, 5), bc12(ix, il, 12, 7), t_grid(ix, il, kx)
@@ -19,6 +21,8 @@ program fortran_reference_api_host
 
     call get_command_argument(3, arg)
     read (arg, *) nsteps
+    call get_command_argument(4, arg)
+    overlapped = trim(arg) == "overlapped"
     call get_command_argument(1, arg)
     open (newunit=u, file=trim(arg), access="stream", form="unformatted", status="old")
     read (u) bc2      ! orog, fmask_orig, alb0, veg_high, veg_low
@@ -48,10 +52,23 @@ program fortran_reference_api_host
         if (code /= 0) stop "init failed"
     end do
 
-    do istep = 1, nsteps
-        call parallel_step(states, controls, codes, n)
+    if (overlapped) then
+        ! the library's extension of the same call: the check of step k is collected after step k + 1 has been enqueued
+        call parallel_step_begin(states, controls, n, token)
+        do istep = 2, nsteps
+            call parallel_step_begin(states, controls, n, next_token)
+            call parallel_step_end(token, codes, n)
+            if (any(codes /= 0)) stop "model variables out of range"
+            token = next_token
+        end do
+        call parallel_step_end(token, codes, n)
         if (any(codes /= 0)) stop "model variables out of range"
-    end do
+    else
+        do istep = 1, nsteps
+            call parallel_step(states, controls, codes, n)
+            if (any(codes /= 0)) stop "model variables out of range"
+        end do
+    end if
     call get_current_step(states(2), istep)
     call get_land_coupling_flag(states(1), flag)
     call is_array_t_grid(flag)

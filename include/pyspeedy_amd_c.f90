@@ -272,6 +272,12 @@ module pyspeedy_amd_c
             integer(c_int64_t), intent(out) :: state_cnts(*)
             integer(c_int32_t), value :: n_members
         end function
+        integer(c_int) function spd_modelstate_init_ensemble_on(state_cnts, n_members, n_devices) &
+                bind(C, name="spd_modelstate_init_ensemble_on")
+            import :: c_int, c_int64_t, c_int32_t
+            integer(c_int64_t), intent(out) :: state_cnts(*)
+            integer(c_int32_t), value :: n_members, n_devices   ! n_devices 0: the current device; k: blocks on devices 0 .. k-1
+        end function
         integer(c_int) function spd_driver_stats(state_cnt, models_alive, members_in_model) bind(C, name="spd_driver_stats")
             import :: c_int, c_int64_t, c_int32_t
             integer(c_int64_t), value :: state_cnt
@@ -300,6 +306,10 @@ module pyspeedy_amd_c
             import :: c_int, c_int64_t, c_int32_t
             integer(c_int64_t), intent(in) :: state_cnts(*)
             integer(c_int32_t), value :: n, root     ! root: 0-based index into state_cnts
+        end function
+        integer(c_int) function spd_broadcast_boundary_stats(peer_copies, local_copies) bind(C, name="spd_broadcast_boundary_stats")
+            import :: c_int, c_int32_t
+            integer(c_int32_t), intent(out) :: peer_copies, local_copies
         end function
     end interface
 end module pyspeedy_amd_c

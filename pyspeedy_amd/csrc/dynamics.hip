@@ -415,10 +415,13 @@ __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTa
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// diagnostics (diagnostics.f90:16-76): one workgroup per member, one wavefront per level; writes err[member] = 0 or -2 (out of
-// range) -- always, so that the caller does not have to clear it first
+// diagnostics (diagnostics.f90:16-76): one workgroup per member, one wavefront per level; writes err[member] = 4 * ticket + (1 if
+// out of range) -- always, so that the caller does not have to clear it first.  `err` is pinned host memory: the ticket of the
+// launch travels with every code, so the host can tell a fresh code from what an earlier launch left there by looking at the
+// memory alone, the moment the store lands (model.hip: wait_codes), instead of waiting for a completion event behind the kernel.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * KX) void diagnostics_kernel(ModelPtrs P, DeviceTables T, int M, int tl, int *err, double *diag) {
+__global__ __launch_bounds__(64 * KX) void diagnostics_kernel(ModelPtrs P, DeviceTables T, int M, int tl, int *err, double *diag,
+                                                              int ticket) {
     __shared__ int bad[KX];
     const int mem = blockIdx.x, l = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t so = ((static_cast<size_t>(mem) * 2 + tl) * 8 + l) * NSPEC;
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(64 * KX) void diagnostics_kernel(ModelPtrs P, Devic
         int any = 0;
 #pragma unroll
         for (int k = 0; k < KX; ++k) any |= bad[k];
-        err[mem] = any ? -2 : 0;
+        __hip_atomic_store(err + mem, 4 * ticket + (any ? 1 : 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -521,8 +524,9 @@ hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const Dy
         dispatch_spectral_step(fold, early, dim3(nspec), s, P, T, D, M, first, count, j1, dt, eps, NoCoupler{});
     return hipGetLastError();
 }
-hipError_t run_diagnostics(const ModelPtrs &P, const DeviceTables &T, int M, int tl, int *err, double *diag, hipStream_t s) {
-    hipLaunchKernelGGL(diagnostics_kernel, dim3(M), dim3(64 * KX), 0, s, P, T, M, tl, err, diag);
+hipError_t run_diagnostics(const ModelPtrs &P, const DeviceTables &T, int M, int tl, int *err, double *diag, int ticket,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(diagnostics_kernel, dim3(M), dim3(64 * KX), 0, s, P, T, M, tl, err, diag, ticket);
     return hipGetLastError();
 }
 

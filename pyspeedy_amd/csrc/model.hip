@@ -3,6 +3,8 @@
 // C ABI: the spd_model_* functions of include/pyspeedy_amd.h.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -29,7 +31,8 @@ hipError_t run_geopotential(const ModelPtrs &P, const DynDeviceTables &D, int fi
 hipError_t run_dyn_grid(const ModelPtrs &P, const DynDeviceTables &D, int M, hipStream_t s);
 hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const DynDeviceTables &D, int M, int first, int count,
                              int j1, double dt, double eps, const CouplerArgs *cpl, bool early, hipStream_t s);
-hipError_t run_diagnostics(const ModelPtrs &P, const DeviceTables &T, int M, int tl, int *err, double *diag, hipStream_t s);
+hipError_t run_diagnostics(const ModelPtrs &P, const DeviceTables &T, int M, int tl, int *err, double *diag, int ticket,
+                           hipStream_t s);
 hipError_t run_coupler(const SurfacePtrs &S, int first, int count, const TimeInterp &w, int day, int land_coupling,
                        int sst_anomaly, int anom_planes, int fresh, hipStream_t s);
 hipError_t run_forcing(const SurfacePtrs &S, int first, int count, const ZonalDevice &Z, double gamlat, double *corh_t,
@@ -96,6 +99,7 @@ struct spd_model {
     hipEvent_t err_event[2] = {nullptr, nullptr};
     int next_slot = 0;
     bool slot_busy[2] = {false, false};  // begun and not yet ended
+    int check_ticket = 0, slot_ticket[2] = {0, 0};  // every range-check launch publishes its codes under a ticket of its own
     double air_absortivity_co2 = 6.0;  // model_state_def.py:320 default
     // device copies of the dt-dependent tables (re-uploaded by set_time_step)
     // surface / coupler state, calendar and run control (do_single_step, speedy.f90:20-74)
@@ -693,6 +697,45 @@ int spd_model_step_dynamics(spd_model_handle m, int j1, int j2, double dt, int c
     return SPD_OK;
 }
 
+static int next_ticket(spd_model *m) {
+    m->check_ticket = m->check_ticket % 0x0fffffff + 1;  // 1 ... 2^28 - 1: never 0 (fresh pinned memory), 4 * ticket + 1 fits an int
+    return m->check_ticket;
+}
+
+// Wait for the codes of the range-check launch that carries `ticket` by watching the pinned memory it writes them to: the host
+// sees each code the moment its store lands (a system-scope release store of 4 * ticket + flag), a few microseconds before a
+// completion event behind the kernel would have been signalled and noticed -- for a host that makes one synchronous call per
+// model step that wait is on the critical path of every step (PYSPEEDY_AMD_POLL_CODES=0: wait for the event / the stream
+// instead).  The event (or the stream) is still asked every few thousand looks, so that a device fault ends the wait.
+static int wait_codes(spd_model *m, const int *pinned, int ticket, hipEvent_t ev, hipStream_t s, int32_t *out, const char *who) {
+    static const bool poll = !(getenv("PYSPEEDY_AMD_POLL_CODES") && atoi(getenv("PYSPEEDY_AMD_POLL_CODES")) == 0);
+    const volatile int *codes = pinned;
+    const int M = m->M;
+    auto all_there = [&]() {
+        for (int i = 0; i < M; ++i)
+            if ((codes[i] >> 2) != ticket) return false;
+        return true;
+    };
+    bool there = false;
+    if (poll) {
+        for (unsigned spin = 1; !(there = all_there()); ++spin) {
+            if ((spin & 0xfff) == 0) {
+                const hipError_t q = ev ? hipEventQuery(ev) : hipStreamQuery(s);
+                if (q == hipSuccess) break;  // the launch is over: its stores are visible now if they ever will be
+                if (q != hipErrorNotReady) return m_fail(SPD_E_DEVICE, std::string(who) + ": " + hipGetErrorString(q));
+            }
+            __builtin_ia32_pause();
+        }
+    } else {
+        if (ev) M_HIP(hipEventSynchronize(ev));
+        else M_HIP(hipStreamSynchronize(s));
+    }
+    if (!there && !all_there()) return m_fail(SPD_E_DEVICE, std::string(who) + ": the range check finished without publishing its codes");
+    std::atomic_thread_fence(std::memory_order_acquire);
+    for (int i = 0; i < M; ++i) out[i] = (codes[i] & 1) ? -2 : 0;
+    return SPD_OK;
+}
+
 // diagnostics.f90 check_diagnostics for every member; synchronises the stream and returns the reference's codes.
 int spd_model_check(spd_model_handle m, int time_level, int32_t *error_codes_host, double *diag_host, void *stream) {
     if (!m || !error_codes_host) return m_fail(SPD_E_ARG, "spd_model_check: null argument");
@@ -706,12 +749,14 @@ int spd_model_check(spd_model_handle m, int time_level, int32_t *error_codes_hos
         M_HIP(hipHostMalloc(&p, sizeof(int) * m->M, hipHostMallocCoherent));
         m->h_err_sync = static_cast<int *>(p);
     }
-    hipError_t e = run_diagnostics(m->P, m->ctx->dev, m->M, time_level - 1, m->h_err_sync, m->d_diag, s);
+    const int ticket = next_ticket(m);
+    hipError_t e = run_diagnostics(m->P, m->ctx->dev, m->M, time_level - 1, m->h_err_sync, m->d_diag, ticket, s);
     if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_check: ") + hipGetErrorString(e));
-    if (diag_host) M_HIP(hipMemcpyAsync(diag_host, m->d_diag, sizeof(double) * m->M * 24, hipMemcpyDeviceToHost, s));
-    M_HIP(hipStreamSynchronize(s));
-    std::memcpy(error_codes_host, m->h_err_sync, sizeof(int) * m->M);
-    return SPD_OK;
+    if (diag_host) {
+        M_HIP(hipMemcpyAsync(diag_host, m->d_diag, sizeof(double) * m->M * 24, hipMemcpyDeviceToHost, s));
+        M_HIP(hipStreamSynchronize(s));
+    }
+    return wait_codes(m, m->h_err_sync, ticket, nullptr, s, error_codes_host, "spd_model_check");
 }
 
 
@@ -734,9 +779,11 @@ int spd_model_check_begin(spd_model_handle m, int time_level, void *stream) {
         m->h_err[slot] = static_cast<int *>(p);
         M_HIP(hipEventCreateWithFlags(&m->err_event[slot], hipEventDisableTiming));
     }
-    hipError_t e = run_diagnostics(m->P, m->ctx->dev, m->M, time_level - 1, m->h_err[slot], m->d_diag, s);
+    const int ticket = next_ticket(m);
+    hipError_t e = run_diagnostics(m->P, m->ctx->dev, m->M, time_level - 1, m->h_err[slot], m->d_diag, ticket, s);
     if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_check_begin: ") + hipGetErrorString(e));
     M_HIP(hipEventRecord(m->err_event[slot], s));
+    m->slot_ticket[slot] = ticket;
     m->slot_busy[slot] = true;
     m->next_slot = 1 - slot;
     return slot;
@@ -751,9 +798,7 @@ int spd_model_check_end(spd_model_handle m, int slot, int32_t *error_codes_host)
     if (!m || !error_codes_host) return m_fail(SPD_E_ARG, "spd_model_check_end: null argument");
     if (slot < 0 || slot > 1 || !m->slot_busy[slot]) return m_fail(SPD_E_ARG, "spd_model_check_end: no check was begun in this slot");
     m->slot_busy[slot] = false;
-    M_HIP(hipEventSynchronize(m->err_event[slot]));
-    std::memcpy(error_codes_host, m->h_err[slot], sizeof(int) * m->M);
-    return SPD_OK;
+    return wait_codes(m, m->h_err[slot], m->slot_ticket[slot], m->err_event[slot], nullptr, error_codes_host, "spd_model_check_end");
 }
 
 
@@ -818,33 +863,67 @@ int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, i
     m->cal.set(year, month, day, hour, minute);
     m->current_step = 0;
     m->surf_cache_valid = m->phi_ahead = false;
-    // ---- land_model_init / sea_model_init on the host, member by member (runs once)
-    const size_t G12 = static_cast<size_t>(12) * NG;
-    auto down = [&](const double *dev, size_t n, int i, std::vector<double> &v) {
-        v.resize(n);
-        return hipMemcpy(v.data(), dev + static_cast<size_t>(i) * n, n * sizeof(double), hipMemcpyDeviceToHost);
-    };
-    auto up = [&](double *dev, size_t n, int i, const std::vector<double> &v) {
-        return hipMemcpy(dev + static_cast<size_t>(i) * n, v.data(), n * sizeof(double), hipMemcpyHostToDevice);
-    };
-    for (int i = 0; i < M; ++i) {
-        SurfaceFields sf;
-        M_HIP(down(m->fmask_orig, NG, i, sf.fmask_orig)); M_HIP(down(m->S.alb0, NG, i, sf.alb0));
-        M_HIP(down(m->veg_high, NG, i, sf.veg_high)); M_HIP(down(m->veg_low, NG, i, sf.veg_low));
-        M_HIP(down(m->S.stl12, G12, i, sf.stl12)); M_HIP(down(m->S.snowd12, G12, i, sf.snowd12));
-        M_HIP(down(m->soil_wc_l1, G12, i, sf.soil_wc_l1)); M_HIP(down(m->soil_wc_l2, G12, i, sf.soil_wc_l2));
-        M_HIP(down(m->S.sst12, G12, i, sf.sst12)); M_HIP(down(m->S.sea_ice_frac12, G12, i, sf.sea_ice_frac12));
-        M_HIP(down(m->S.sst_anom, static_cast<size_t>(m->anom_planes) * NG, i, sf.sst_anom));
-        land_sea_init(m->ctx->host, sf);
-        M_HIP(up(const_cast<double *>(m->pa.fmask_land), NG, i, sf.fmask_land)); M_HIP(up(m->bmask_land, NG, i, sf.bmask_land));
-        M_HIP(up(m->S.fmask_sea, NG, i, sf.fmask_sea)); M_HIP(up(m->bmask_sea, NG, i, sf.bmask_sea));
-        M_HIP(up(m->S.stl12, G12, i, sf.stl12)); M_HIP(up(m->S.snowd12, G12, i, sf.snowd12));
-        M_HIP(up(m->S.soilw12, G12, i, sf.soilw12)); M_HIP(up(m->S.sst12, G12, i, sf.sst12));
-        M_HIP(up(m->S.sea_ice_frac12, G12, i, sf.sea_ice_frac12));
-        M_HIP(up(m->S.sst_anom, static_cast<size_t>(m->anom_planes) * NG, i, sf.sst_anom));
-        M_HIP(up(m->S.rhcapl, NG, i, sf.rhcapl)); M_HIP(up(m->S.cdland, NG, i, sf.cdland));
-        M_HIP(up(m->S.rhcaps, NG, i, sf.rhcaps)); M_HIP(up(m->S.rhcapi, NG, i, sf.rhcapi));
-        M_HIP(up(m->S.cdsea, NG, i, sf.cdsea)); M_HIP(up(m->S.cdice, NG, i, sf.cdice));
+    // ---- land_model_init / sea_model_init on the host (runs once).  The members come down in blocks of up to 64 -- ONE copy per
+    // variable and block, not per member --, a set of boundary fields that several members share (the usual ensemble: all of
+    // them) is preprocessed once, and the results go up with one copy per variable and block again: 27 blocking copies per 64
+    // members instead of 27 per member (a 256-member model: 108 instead of 6912).
+    const size_t G12 = static_cast<size_t>(12) * NG, GA = static_cast<size_t>(m->anom_planes) * NG;
+    constexpr int kBlock = 64;
+    for (int first = 0; first < M; first += kBlock) {
+        const int count = std::min(kBlock, M - first);
+        struct Var {
+            double *dev;
+            size_t n;
+            std::vector<double> SurfaceFields::*field;
+            std::vector<double> host;
+        };
+        Var in[] = {{m->fmask_orig, NG, &SurfaceFields::fmask_orig, {}}, {const_cast<double *>(m->S.alb0), NG, &SurfaceFields::alb0, {}},
+                    {m->veg_high, NG, &SurfaceFields::veg_high, {}}, {m->veg_low, NG, &SurfaceFields::veg_low, {}},
+                    {m->S.stl12, G12, &SurfaceFields::stl12, {}}, {m->S.snowd12, G12, &SurfaceFields::snowd12, {}},
+                    {m->soil_wc_l1, G12, &SurfaceFields::soil_wc_l1, {}}, {m->soil_wc_l2, G12, &SurfaceFields::soil_wc_l2, {}},
+                    {m->S.sst12, G12, &SurfaceFields::sst12, {}}, {m->S.sea_ice_frac12, G12, &SurfaceFields::sea_ice_frac12, {}},
+                    {m->S.sst_anom, GA, &SurfaceFields::sst_anom, {}}};
+        Var out[] = {{const_cast<double *>(m->pa.fmask_land), NG, &SurfaceFields::fmask_land, {}},
+                     {m->bmask_land, NG, &SurfaceFields::bmask_land, {}}, {m->S.fmask_sea, NG, &SurfaceFields::fmask_sea, {}},
+                     {m->bmask_sea, NG, &SurfaceFields::bmask_sea, {}}, {m->S.stl12, G12, &SurfaceFields::stl12, {}},
+                     {m->S.snowd12, G12, &SurfaceFields::snowd12, {}}, {m->S.soilw12, G12, &SurfaceFields::soilw12, {}},
+                     {m->S.sst12, G12, &SurfaceFields::sst12, {}}, {m->S.sea_ice_frac12, G12, &SurfaceFields::sea_ice_frac12, {}},
+                     {m->S.sst_anom, GA, &SurfaceFields::sst_anom, {}}, {m->S.rhcapl, NG, &SurfaceFields::rhcapl, {}},
+                     {m->S.cdland, NG, &SurfaceFields::cdland, {}}, {m->S.rhcaps, NG, &SurfaceFields::rhcaps, {}},
+                     {m->S.rhcapi, NG, &SurfaceFields::rhcapi, {}}, {m->S.cdsea, NG, &SurfaceFields::cdsea, {}},
+                     {m->S.cdice, NG, &SurfaceFields::cdice, {}}};
+        for (Var &v : in) {
+            v.host.resize(v.n * count);
+            M_HIP(hipMemcpy(v.host.data(), v.dev + v.n * first, v.n * count * sizeof(double), hipMemcpyDeviceToHost));
+        }
+        for (Var &v : out) v.host.resize(v.n * count);
+        std::vector<int> done;  // members of this block whose boundary set has been preprocessed (one per distinct set)
+        for (int i = 0; i < count; ++i) {
+            int same = -1;
+            for (int j : done) {
+                bool eq = true;
+                for (const Var &v : in)
+                    if (std::memcmp(v.host.data() + v.n * i, v.host.data() + v.n * j, v.n * sizeof(double)) != 0) {
+                        eq = false;
+                        break;
+                    }
+                if (eq) {
+                    same = j;
+                    break;
+                }
+            }
+            if (same >= 0) {
+                for (Var &v : out) std::memcpy(v.host.data() + v.n * i, v.host.data() + v.n * same, v.n * sizeof(double));
+                continue;
+            }
+            SurfaceFields sf;
+            for (const Var &v : in) (sf.*(v.field)).assign(v.host.begin() + v.n * i, v.host.begin() + v.n * (i + 1));
+            land_sea_init(m->ctx->host, sf);
+            for (Var &v : out) std::memcpy(v.host.data() + v.n * i, (sf.*(v.field)).data(), v.n * sizeof(double));
+            done.push_back(i);
+        }
+        for (const Var &v : out)
+            M_HIP(hipMemcpy(v.dev + v.n * first, v.host.data(), v.n * count * sizeof(double), hipMemcpyHostToDevice));
     }
     // ---- initialize_boundaries (boundaries.f90:22-37): phi0 = g * orog, phis0 = spectrally truncated phi0
     double *phis0 = const_cast<double *>(m->pa.phis0);

@@ -59,6 +59,9 @@ def test_bench_two_ranks_share_the_gpu():
     assert strong["config"]["members_per_gpu"] == 3 and strong["config"]["members_total"] == 6
     assert strong["regions"] == 2 and strong["ms_per_step_min"] <= strong["ms_per_step"]
     assert strong["vs_baseline"] is None and "cpu_baseline" not in strong and "cfg4_strong" not in strong
+    assert strong["collective"]["ranks_seen"] == 2 and strong["collective"]["boundary_checksum_equal"] is True
+    assert strong["one_process"]["containers"] == 6 and strong["one_process"]["device_models"] == 1
+    assert "cfg4_strong" not in strong["one_process"]
     weak = _result(subprocess.run([sys.executable, BENCH, "--gpus", "2", "--members", "4"] + common, capture_output=True,
                                   text=True, timeout=900, env=env))
     assert weak["n_gpus"] == 2 and weak["scaling"] == "weak"
@@ -90,6 +93,20 @@ def test_the_n_rank_line_is_complete():
     assert abs(strong["value"] - 64 * 86400.0 / (strong["ms_per_step"] * 1e-3 * 13140)) < 1e-6 * strong["value"]
     assert strong["vs_cpu_all_cores"] > 0
     assert "drop_in_step" not in res  # (a leg of the one-GPU line)
+    # the line proves what the collective layer saw: two ranks, the device of each, the same boundary fields on both
+    c = res["collective"]
+    assert c["backend"] == "gloo" and c["world_size"] == 2 and c["ranks_seen"] == 2 and c["device_of_rank"] == [0, 0]
+    assert c["boundary_checksum_equal"] is True and len(set(c["boundary_checksum_of_rank"])) == 1 and c["boundary_bytes"] > 3.0e6
+    assert [g["rank"] for g in c["gpu_of_rank"]] == [0, 1] and c["distinct_gpus"] == 1  # (the rehearsal shares one card)
+    # ... and carries the reference's own shape, one process over all devices, measured by rank 0 while rank 1 idles
+    op = res["one_process"]
+    assert "error" not in op, op
+    assert op["processes"] == 1 and op["devices_asked"] == 2 and op["devices_used"] == 1 and op["containers"] == 128
+    assert op["device_models"] == 2 and op["members_per_device"] == [128] and op["current_device_preserved"] is True
+    assert op["boundary_broadcast"] == {"peer_copies": 0, "local_copies": 127, "arrived_intact": True}
+    assert 0 < op["begin_end_ms_per_step"] == op["ms_per_step"] and 0 < op["sync_ms_per_step"]
+    assert abs(op["value"] - 128 * 86400.0 / (op["ms_per_step"] * 1e-3 * 13140)) < 1e-6 * op["value"]
+    assert op["cfg4_strong"]["containers"] == 64 and op["cfg4_strong"]["device_models"] == 2
 
 
 @pytest.mark.gpu
@@ -140,6 +157,24 @@ def test_bench_one_rank_world_through_rccl():
                                   "--regions", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env))
     assert res["n_gpus"] == 1 and res["config"]["backend"] == "nccl"
     assert res["config"]["members_total"] == 4 and res["value"] > 0
+    c = res["collective"]  # gathered through RCCL, on device buffers
+    assert c["backend"] == "nccl" and c["ranks_seen"] == 1 and c["device_of_rank"] == [0] and c["boundary_checksum_equal"] is True
+
+
+@pytest.mark.gpu
+def test_bench_one_process_mode():
+    """`--one-process`: no ranks, this process drives the devices through spd_parallel_step -- rehearsed on the one GPU of the
+    box, where 40 containers are kept as two device models (both enqueued before either is waited for)."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "PYSPEEDY_AMD_BENCH_BACKEND"):
+        env.pop(k, None)
+    res = _result(subprocess.run([sys.executable, BENCH, "--one-process", "--gpus", "1", "--members", "40", "--steps", "30",
+                                  "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env))
+    op = res["one_process"]
+    assert res["n_gpus"] == 1 and res["value"] == op["value"] and res["ms_per_step"] == op["begin_end_ms_per_step"]
+    assert op["containers"] == 40 and op["device_models"] == 2 and op["devices_used"] == 1 and op["steps_timed"] == 30
+    assert op["boundary_broadcast"] == {"peer_copies": 0, "local_copies": 39, "arrived_intact": True}
+    assert op["current_device_preserved"] is True and res["vs_baseline"] is None
 
 
 @pytest.mark.gpu

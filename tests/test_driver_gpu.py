@@ -343,6 +343,10 @@ def test_device_placement_and_boundary_broadcast(drv, bc):
     cnts = [root, other, named.value] + list(ens)
     drv.set_bc(root, bc, 0.2 * np.ones((96, 48, 12)))
     drv.ok(drv.L.spd_broadcast_boundary((C.c_int64 * len(cnts))(*cnts), len(cnts), 0))
+    peer, local = C.c_int32(-1), C.c_int32(-1)
+    drv.ok(drv.L.spd_broadcast_boundary_stats(C.byref(peer), C.byref(local)))
+    # the fields cross to another GPU once per GPU, whatever the number of containers there (here: one GPU, nothing crosses)
+    assert peer.value == (0 if ndev.value == 1 else ndev.value - 1) and peer.value + local.value == len(cnts) - 1
     by_hand = drv.state()
     drv.set_bc(by_hand, bc, 0.2 * np.ones((96, 48, 12)))
     for name in ("orog", "sst12", "soil_wc_l3", "sea_ice_frac12", "alb0"):
@@ -455,3 +459,55 @@ def test_random_groupings_keep_every_container_on_the_trajectory_of_a_lone_conta
         for name in ("olr", "land_temp", "sst_am", "rad_tau2", "hfluxn"):
             assert np.array_equal(drv.get(world[i], name), drv.get(twins[i], name)), (i, name)
     drv.close(*world, *twins)
+
+
+def test_a_synchronous_step_beside_a_pending_one_takes_the_free_check_slot(drv, bc):
+    """(advisor, round 3) A pending begin holds one of a model's two check slots; synchronous steps beside it must take the OTHER
+    slot every time, not alternate into the busy one -- a step that had been enqueued when its check was refused left state and
+    date out of step.  Three synchronous steps between a begin and its end, against a twin stepped alone."""
+    a, twin = drv.state(), drv.state()
+    ca, ct = drv.control(START, END), drv.control(START, END)
+    for s, c in ((a, ca), (twin, ct)):
+        drv.set_bc(s, bc)
+        assert drv.init(s, c) == 0
+    ids, ctl, token, codes = (C.c_int64 * 1)(a), (C.c_int64 * 1)(ca), C.c_int64(), (C.c_int32 * 1)(99)
+    drv.ok(drv.L.spd_parallel_step_begin(ids, ctl, 1, C.byref(token)))
+    for _ in range(3):
+        assert drv.parallel_step([a], [ca]) == [0]
+    drv.ok(drv.L.spd_parallel_step_end(token, codes))
+    assert list(codes) == [0]
+    for _ in range(4):
+        assert drv.step(twin, ct) == 0
+    assert drv.model_date(ca) == drv.model_date(ct) == ((1982, 1, 1, 2, 40), 1)
+    assert drv.get(a, "current_step", np.int32) == 4
+    for name in ("vor", "t", "ps"):
+        assert np.array_equal(drv.get(a, name, np.complex128), drv.get(twin, name, np.complex128)), name
+    drv.close(a, twin)
+
+
+def test_ensemble_placement_by_argument_leaves_the_process_placement_alone(drv):
+    """spd_modelstate_init_ensemble_on(cnts, n, k) takes the number of devices as an argument: the process-wide placement
+    (spd_set_device_placement / PYSPEEDY_AMD_DEVICES) is neither read nor reset by it -- SpeedyEns(devices=k) used to switch it to
+    k and back to 0, losing whatever the host had set.  Every call leaves the caller's current HIP device what it was."""
+    import torch
+    from pyspeedy_amd.speedy import SpeedyEns
+    ndev = C.c_int32()
+    drv.ok(drv.L.spd_device_count(C.byref(ndev)))
+    before = torch.cuda.current_device()
+    drv.ok(drv.L.spd_set_device_placement(ndev.value))
+    try:
+        ens = SpeedyEns(5, devices=1)
+        assert [m._state_cnt > 0 for m in ens.members] == [True] * 5
+        first, second = drv.state(), drv.state()  # the placement set above still rules single containers: round-robin
+        dev = C.c_int32(-1)
+        drv.ok(drv.L.spd_modelstate_device(second, C.byref(dev)))
+        assert dev.value == 1 % ndev.value
+        cnts = (C.c_int64 * 40)()
+        assert drv.L.spd_modelstate_init_ensemble_on(cnts, 40, ndev.value + 1) < 0
+        drv.ok(drv.L.spd_modelstate_init_ensemble_on(cnts, 40, 0))
+        assert drv.stats(cnts[0])[1] == 20 and drv.stats(cnts[39])[1] == 20  # 32 or more on one device: two device models
+        drv.close(first, second, *cnts)
+        del ens
+    finally:
+        drv.ok(drv.L.spd_set_device_placement(0))
+    assert torch.cuda.current_device() == before

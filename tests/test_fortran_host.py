@@ -52,6 +52,7 @@ def test_the_reference_named_module_is_current_and_complete():
              "controlparams_init", "controlparams_close", "create_datetime", "get_datetime", "close_datetime", "modelstate_init",
              "modelstate_init_sst_anom", "modelstate_close"}
     assert fixed <= subs
+    assert {"parallel_step_begin", "parallel_step_end", "modelstate_init_ensemble", "broadcast_boundary"} <= subs  # extensions
     sys.path.insert(0, ROOT)
     import pyspeedy_amd.registry as R
     for name, v in R.REGISTRY.items():
@@ -146,3 +147,10 @@ def test_a_host_written_against_the_references_own_module_runs_unchanged(tmp_pat
     ref = np.load(os.path.join(ROOT, "tests", "golden", "export.npz"))["d1_t_grid"]
     assert np.abs(t1 - ref).max() <= 1e-10 * np.abs(ref).max()
     assert np.abs(t2 - ref).max() > 1e-3
+    # the same host with its time loop in the overlapped form (parallel_step_begin / parallel_step_end of the same module):
+    # the same bits
+    run = subprocess.run([str(tmp_path / "ref_api_host"), "bc.bin", "out2.bin", "36", "overlapped"], cwd=tmp_path,
+                         capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "steps 36" in run.stdout
+    assert np.array_equal(np.fromfile(tmp_path / "out2.bin", dtype=np.float64), out.ravel())

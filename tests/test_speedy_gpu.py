@@ -191,19 +191,25 @@ def test_grid2spectral_and_filter(gold):
         close(model[v], gold["gf_" + v], "filtered " + v)
 
 
-def test_reference_fixture_format_and_envelope():
-    """The reference's own 1-day fixture: identical file layout; values inside the SST-anomaly envelope (it was produced
-    with the observed anomalies, which are not distributed; SURVEY 8c measured rms 0.15 m/s, 0.12 K, 40 Pa)."""
+@pytest.mark.parametrize("end, envelope", [
+    (datetime(1982, 1, 2), {"u": 0.4, "v": 0.4, "t": 0.3, "ps": 100.0}),
+    (datetime(1982, 1, 4), {"u": 0.85, "v": 0.75, "t": 0.45, "ps": 150.0})])
+def test_reference_fixture_format_and_envelope(end, envelope):
+    """The reference's own 1-day and 3-day fixtures (pyspeedy/tests/test_speedy.py:27-50 runs to exactly these dates and
+    compares with rtol 1e-6): identical file layout; values inside the SST-anomaly envelope -- the fixtures were produced with
+    the observed anomalies, which are not distributed.  The reference Fortran itself, run here with zero anomalies, stands at
+    rms 0.15 m/s, 0.12 K, 40 Pa from the first and 0.34 m/s, 0.18 K, 60 Pa from the second (reference_fixtures/README.md); the
+    GPU run must stay within 2.5 times that.  Bit-level parity of the same runs is pinned by export.npz (test_speedy_run)."""
     from pyspeedy_amd.callbacks import XarrayExporter
     from pyspeedy_amd.dataset import open_dataset
     from pyspeedy_amd.speedy import Speedy
-    ref = open_dataset(os.path.join(GOLD, "reference_fixtures", "1982-01-02_0000.nc"))
-    end = datetime(1982, 1, 2)
+    file_name = end.strftime("%Y-%m-%d_%H%M.nc")
+    ref = open_dataset(os.path.join(GOLD, "reference_fixtures", file_name))
     with tempfile.TemporaryDirectory() as tmp:
         model = Speedy(start_date=datetime(1982, 1, 1), end_date=end)
         model.set_bc()
         model.run(callbacks=[XarrayExporter(output_dir=tmp)])
-        ds = open_dataset(os.path.join(tmp, "1982-01-02_0000.nc"))
+        ds = open_dataset(os.path.join(tmp, file_name))
     assert set(ds.keys()) == set(ref.keys())
     for name in list(ref.keys()) + ["lon", "lat", "lev", "time"]:
         assert ds[name].dims == ref[name].dims, name
@@ -213,7 +219,8 @@ def test_reference_fixture_format_and_envelope():
     for c in ("lon", "lat", "lev", "time"):
         np.testing.assert_array_equal(ds[c].values, ref[c].values)
     rms = lambda v: float(np.sqrt(np.mean((ds[v].values.astype(np.float64) - ref[v].values) ** 2)))
-    assert rms("u") < 0.4 and rms("v") < 0.4 and rms("t") < 0.3 and rms("ps") < 100.0
+    for v, limit in envelope.items():
+        assert rms(v) < limit, (v, rms(v), limit)
 
 
 def test_ensemble_statistics_on_device():
