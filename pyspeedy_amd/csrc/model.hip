@@ -39,6 +39,8 @@ hipError_t run_forcing(const SurfacePtrs &S, int first, int count, const ZonalDe
                        double *corh_q, hipStream_t s);
 hipError_t run_rest_state(const RestPtrs &R, int M, const RestConsts &c, hipStream_t s);
 hipError_t run_scale_orog(const double *orog, double *phi0, long n, hipStream_t s);
+hipError_t run_differs_from_first(const double *v, long n, int M, int *flags, hipStream_t s);
+hipError_t run_copy_from_first(double *v, long n, int M, const int *flags, hipStream_t s);
 hipError_t run_rest_surface(const double *phis0, double *forog, double *surf_ps, double *surf_q, const RestConsts &c, long n,
                             hipStream_t s);
 hipError_t run_grid2spec(const DeviceTables &T, int stage, const double *src, double *dst, int prescale, int nfields,
@@ -863,67 +865,53 @@ int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, i
     m->cal.set(year, month, day, hour, minute);
     m->current_step = 0;
     m->surf_cache_valid = m->phi_ahead = false;
-    // ---- land_model_init / sea_model_init on the host (runs once).  The members come down in blocks of up to 64 -- ONE copy per
-    // variable and block, not per member --, a set of boundary fields that several members share (the usual ensemble: all of
-    // them) is preprocessed once, and the results go up with one copy per variable and block again: 27 blocking copies per 64
-    // members instead of 27 per member (a 256-member model: 108 instead of 6912).
+    // ---- land_model_init / sea_model_init on the host (runs once): 11 fields down, 16 up, per DISTINCT set of boundary fields.
+    // The members of an ensemble normally share one set: the device compares every member's inputs with member 0's (bit for
+    // bit), member 0 is preprocessed on the host, and the members that hold the same inputs take its results with device-to-device
+    // copies; only a member whose fields differ goes through the host itself.  (A 256-member model with shared boundary fields:
+    // 27 blocking copies and 27 small launches instead of 6912 blocking copies.)
     const size_t G12 = static_cast<size_t>(12) * NG, GA = static_cast<size_t>(m->anom_planes) * NG;
-    constexpr int kBlock = 64;
-    for (int first = 0; first < M; first += kBlock) {
-        const int count = std::min(kBlock, M - first);
-        struct Var {
-            double *dev;
-            size_t n;
-            std::vector<double> SurfaceFields::*field;
-            std::vector<double> host;
-        };
-        Var in[] = {{m->fmask_orig, NG, &SurfaceFields::fmask_orig, {}}, {const_cast<double *>(m->S.alb0), NG, &SurfaceFields::alb0, {}},
-                    {m->veg_high, NG, &SurfaceFields::veg_high, {}}, {m->veg_low, NG, &SurfaceFields::veg_low, {}},
-                    {m->S.stl12, G12, &SurfaceFields::stl12, {}}, {m->S.snowd12, G12, &SurfaceFields::snowd12, {}},
-                    {m->soil_wc_l1, G12, &SurfaceFields::soil_wc_l1, {}}, {m->soil_wc_l2, G12, &SurfaceFields::soil_wc_l2, {}},
-                    {m->S.sst12, G12, &SurfaceFields::sst12, {}}, {m->S.sea_ice_frac12, G12, &SurfaceFields::sea_ice_frac12, {}},
-                    {m->S.sst_anom, GA, &SurfaceFields::sst_anom, {}}};
-        Var out[] = {{const_cast<double *>(m->pa.fmask_land), NG, &SurfaceFields::fmask_land, {}},
-                     {m->bmask_land, NG, &SurfaceFields::bmask_land, {}}, {m->S.fmask_sea, NG, &SurfaceFields::fmask_sea, {}},
-                     {m->bmask_sea, NG, &SurfaceFields::bmask_sea, {}}, {m->S.stl12, G12, &SurfaceFields::stl12, {}},
-                     {m->S.snowd12, G12, &SurfaceFields::snowd12, {}}, {m->S.soilw12, G12, &SurfaceFields::soilw12, {}},
-                     {m->S.sst12, G12, &SurfaceFields::sst12, {}}, {m->S.sea_ice_frac12, G12, &SurfaceFields::sea_ice_frac12, {}},
-                     {m->S.sst_anom, GA, &SurfaceFields::sst_anom, {}}, {m->S.rhcapl, NG, &SurfaceFields::rhcapl, {}},
-                     {m->S.cdland, NG, &SurfaceFields::cdland, {}}, {m->S.rhcaps, NG, &SurfaceFields::rhcaps, {}},
-                     {m->S.rhcapi, NG, &SurfaceFields::rhcapi, {}}, {m->S.cdsea, NG, &SurfaceFields::cdsea, {}},
-                     {m->S.cdice, NG, &SurfaceFields::cdice, {}}};
-        for (Var &v : in) {
-            v.host.resize(v.n * count);
-            M_HIP(hipMemcpy(v.host.data(), v.dev + v.n * first, v.n * count * sizeof(double), hipMemcpyDeviceToHost));
+    struct Var {
+        double *dev;
+        size_t n;
+        std::vector<double> SurfaceFields::*field;
+    };
+    const Var in[] = {{m->fmask_orig, NG, &SurfaceFields::fmask_orig}, {const_cast<double *>(m->S.alb0), NG, &SurfaceFields::alb0},
+                      {m->veg_high, NG, &SurfaceFields::veg_high}, {m->veg_low, NG, &SurfaceFields::veg_low},
+                      {m->S.stl12, G12, &SurfaceFields::stl12}, {m->S.snowd12, G12, &SurfaceFields::snowd12},
+                      {m->soil_wc_l1, G12, &SurfaceFields::soil_wc_l1}, {m->soil_wc_l2, G12, &SurfaceFields::soil_wc_l2},
+                      {m->S.sst12, G12, &SurfaceFields::sst12}, {m->S.sea_ice_frac12, G12, &SurfaceFields::sea_ice_frac12},
+                      {m->S.sst_anom, GA, &SurfaceFields::sst_anom}};
+    const Var out[] = {{const_cast<double *>(m->pa.fmask_land), NG, &SurfaceFields::fmask_land},
+                       {m->bmask_land, NG, &SurfaceFields::bmask_land}, {m->S.fmask_sea, NG, &SurfaceFields::fmask_sea},
+                       {m->bmask_sea, NG, &SurfaceFields::bmask_sea}, {m->S.stl12, G12, &SurfaceFields::stl12},
+                       {m->S.snowd12, G12, &SurfaceFields::snowd12}, {m->S.soilw12, G12, &SurfaceFields::soilw12},
+                       {m->S.sst12, G12, &SurfaceFields::sst12}, {m->S.sea_ice_frac12, G12, &SurfaceFields::sea_ice_frac12},
+                       {m->S.sst_anom, GA, &SurfaceFields::sst_anom}, {m->S.rhcapl, NG, &SurfaceFields::rhcapl},
+                       {m->S.cdland, NG, &SurfaceFields::cdland}, {m->S.rhcaps, NG, &SurfaceFields::rhcaps},
+                       {m->S.rhcapi, NG, &SurfaceFields::rhcapi}, {m->S.cdsea, NG, &SurfaceFields::cdsea},
+                       {m->S.cdice, NG, &SurfaceFields::cdice}};
+    std::vector<int> differs(M, 0);
+    if (M > 1) {  // (before member 0's inputs are cleaned in place below)
+        M_HIP(hipMemsetAsync(m->d_err, 0, sizeof(int) * M, s));
+        for (const Var &v : in) M_HIP(run_differs_from_first(v.dev, static_cast<long>(v.n), M, m->d_err, s));
+        M_HIP(hipMemcpyAsync(differs.data(), m->d_err, sizeof(int) * M, hipMemcpyDeviceToHost, s));
+        M_HIP(hipStreamSynchronize(s));
+    }
+    for (int i = 0; i < M; ++i) {
+        if (i > 0 && !differs[i]) continue;
+        SurfaceFields sf;
+        for (const Var &v : in) {
+            (sf.*(v.field)).resize(v.n);
+            M_HIP(hipMemcpy((sf.*(v.field)).data(), v.dev + v.n * i, v.n * sizeof(double), hipMemcpyDeviceToHost));
         }
-        for (Var &v : out) v.host.resize(v.n * count);
-        std::vector<int> done;  // members of this block whose boundary set has been preprocessed (one per distinct set)
-        for (int i = 0; i < count; ++i) {
-            int same = -1;
-            for (int j : done) {
-                bool eq = true;
-                for (const Var &v : in)
-                    if (std::memcmp(v.host.data() + v.n * i, v.host.data() + v.n * j, v.n * sizeof(double)) != 0) {
-                        eq = false;
-                        break;
-                    }
-                if (eq) {
-                    same = j;
-                    break;
-                }
-            }
-            if (same >= 0) {
-                for (Var &v : out) std::memcpy(v.host.data() + v.n * i, v.host.data() + v.n * same, v.n * sizeof(double));
-                continue;
-            }
-            SurfaceFields sf;
-            for (const Var &v : in) (sf.*(v.field)).assign(v.host.begin() + v.n * i, v.host.begin() + v.n * (i + 1));
-            land_sea_init(m->ctx->host, sf);
-            for (Var &v : out) std::memcpy(v.host.data() + v.n * i, (sf.*(v.field)).data(), v.n * sizeof(double));
-            done.push_back(i);
-        }
+        land_sea_init(m->ctx->host, sf);
         for (const Var &v : out)
-            M_HIP(hipMemcpy(v.dev + v.n * first, v.host.data(), v.n * count * sizeof(double), hipMemcpyHostToDevice));
+            M_HIP(hipMemcpy(v.dev + v.n * i, (sf.*(v.field)).data(), v.n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (M > 1) {
+        M_HIP(hipMemcpy(m->d_err, differs.data(), sizeof(int) * M, hipMemcpyHostToDevice));
+        for (const Var &v : out) M_HIP(run_copy_from_first(v.dev, static_cast<long>(v.n), M, m->d_err, s));
     }
     // ---- initialize_boundaries (boundaries.f90:22-37): phi0 = g * orog, phis0 = spectrally truncated phi0
     double *phis0 = const_cast<double *>(m->pa.phis0);

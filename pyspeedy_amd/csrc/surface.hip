@@ -132,6 +132,36 @@ __global__ __launch_bounds__(kT) void rest_surface_kernel(const double *phis0, d
     surf_q[i] = qref * exp(qexp * sg);
 }
 
+// spd_model_init: which members hold, bit for bit, the boundary fields of member 0 (flags[i] = 1 when member i differs in this
+// variable), and the hand-over of member 0's preprocessed fields to the members that do
+__global__ void differs_from_first_kernel(const unsigned long long *v, long n, int *flags) {
+    const int mem = blockIdx.y + 1;
+    const unsigned long long *mine = v + static_cast<size_t>(mem) * n;
+    int differs = 0;
+    for (long i = static_cast<long>(blockIdx.x) * kT + threadIdx.x; i < n; i += static_cast<long>(gridDim.x) * kT)
+        differs |= mine[i] != v[i];
+    if (differs) flags[mem] = 1;  // (every writer writes the same value)
+}
+__global__ void copy_from_first_kernel(double *v, long n, const int *flags) {
+    const int mem = blockIdx.y + 1;
+    if (flags[mem]) return;
+    double *mine = v + static_cast<size_t>(mem) * n;
+    for (long i = static_cast<long>(blockIdx.x) * kT + threadIdx.x; i < n; i += static_cast<long>(gridDim.x) * kT) mine[i] = v[i];
+}
+hipError_t run_differs_from_first(const double *v, long n, int M, int *flags, hipStream_t s) {
+    if (M < 2) return hipSuccess;
+    const long blocks = (n + kT - 1) / kT;
+    hipLaunchKernelGGL(differs_from_first_kernel, dim3(blocks < 64 ? blocks : 64, M - 1), dim3(kT), 0, s,
+                       reinterpret_cast<const unsigned long long *>(v), n, flags);
+    return hipGetLastError();
+}
+hipError_t run_copy_from_first(double *v, long n, int M, const int *flags, hipStream_t s) {
+    if (M < 2) return hipSuccess;
+    const long blocks = (n + kT - 1) / kT;
+    hipLaunchKernelGGL(copy_from_first_kernel, dim3(blocks < 64 ? blocks : 64, M - 1), dim3(kT), 0, s, v, n, flags);
+    return hipGetLastError();
+}
+
 hipError_t run_scale_orog(const double *orog, double *phi0, long n, hipStream_t s) {
     hipLaunchKernelGGL(scale_orog_kernel, dim3((n + kT - 1) / kT), dim3(kT), 0, s, orog, phi0, n);
     return hipGetLastError();

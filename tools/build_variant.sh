@@ -16,7 +16,7 @@ while [ $# -gt 0 ]; do
 done
 BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=on"
 pids=()
-for f in capi transforms specops physics dynamics model surface sppt driver; do
+for f in capi transforms specops physics dynamics model surface sppt driver_backend_hip; do
   extra="${FLAGS[*]}"
   if [ ${#ONLY[@]} -gt 0 ]; then
     extra=""
@@ -28,7 +28,7 @@ for f in capi transforms specops physics dynamics model surface sppt driver; do
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-cp $SRC/tables.o $SRC/surface_host.o $OBJ/
+cp $SRC/tables.o $SRC/surface_host.o $SRC/driver.o $OBJ/   # (host-only C++: always the main build's objects)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $ROOT/build_variants/lib_$NAME.so $OBJ/*.o
 rm -rf $OBJ
 echo "built build_variants/lib_$NAME.so"
