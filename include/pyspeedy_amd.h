@@ -242,14 +242,27 @@ int spd_model_get_config(spd_model_handle m, int32_t *cfg /* 6 */);
  *   "split_dyn"            0 / 1   separate launches for grid-point dynamics and column physics
  *   "member_groups"        1 ... 4 the members are stepped in that many groups on separate HIP streams (default: 1 below 20
  *                                  members, 2 for 20 ... 23 and from 64 up, 3 for 24 ... 63; always 1 while spd_model_profile is on, for calls of a single step and with split_dyn)
+ *   "physics_storage32"    0 / 1   (default 1, PYSPEEDY_AMD_PHYS_STORE32) with spd_model_set_physics_precision(m, 1): keep the arrays
+ *                                  only the column physics reads back as fp32 in memory (1) or as fp64 (0: same arithmetic, same
+ *                                  bits in the state, 13 % more bytes in the column kernel); converts the arrays when it changes
  * Returns SPD_E_ARG for an unknown name or a value outside the list.  What is fixed at creation (the pruned transform
  * table, the geopotential fold) is read from the environment only. */
 int spd_model_set_option(spd_model_handle m, const char *name, int32_t value);
 /* BASELINE cfg 5: fp32 != 0 runs the arithmetic of the column physics (physics.f90:107-256 and the schemes it calls) in
  * single precision; the model state, the grid-point dynamics and the tendencies handed to the transforms stay fp64 (the
  * physics increment is formed in fp32 and added to the fp64 dynamics tendency).  Not bitwise comparable with the reference:
- * tests/test_cfg5_gpu.py states the error bounds.  Default 0. */
+ * tests/test_cfg5_gpu.py states the error bounds.  Default 0.
+ * The arrays that only the column physics reads back change their STORAGE with it: its grid-point inputs at the physics' time
+ * level (the work arrays t/q/phi/u/v_grid_phys, pslg_phys), the radiation state a shortwave step leaves for the next two steps
+ * (tt_rsw, rad_tau2, rad_strat_corr) and the diagnostics-only outputs rad_st4a, rad_flux, precnv, precls, cbmf, slrd, slr, olr,
+ * slru, ustr, vstr are kept as fp32 in the first half of their allocations (the fp32 kernel narrows each of these values before
+ * it uses it and computes each one it stores in fp32: nothing is lost, 13 % of the column kernel's and 11 % of the
+ * spectral -> grid launch's bytes are).  spd_model_get / _set (and the driver's spd_get / spd_set) keep speaking fp64 and
+ * convert; spd_model_device_ptr hands out the array as stored: ask spd_model_var_storage (8 or 4 bytes per element).
+ * Switching converts the arrays in place (synchronises the device); spd_model_set_control with another physics_fp32 and
+ * spd_model_copy_member from a model with another setting switch the receiving model first. */
 int spd_model_set_physics_precision(spd_model_handle m, int fp32);
+int spd_model_var_storage(spd_model_handle m, const char *name);
 /* registry scalars land_coupling_flag, sst_anomaly_coupling_flag, increase_co2 (model_state_def.py:305-418) */
 int spd_model_set_flags(spd_model_handle m, int land_coupling_flag, int sst_anomaly_coupling_flag, int increase_co2);
 

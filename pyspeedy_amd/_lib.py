@@ -85,6 +85,7 @@ _SIGNATURES = {
     "spd_model_destroy": (C.c_int, [C.c_void_p]),
     "spd_model_members": (C.c_int, [C.c_void_p]),
     "spd_model_var_bytes": (C.c_long, [C.c_void_p, C.c_char_p]),
+    "spd_model_var_storage": (C.c_int, [C.c_void_p, C.c_char_p]),
     "spd_model_set": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]),
     "spd_model_get": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]),
     "spd_model_device_ptr": (C.c_void_p, [C.c_void_p, C.c_char_p]),

@@ -32,6 +32,9 @@ struct DeviceTables {
 // transform to be applied while the coefficients are staged (`mode`), so that u, v and grad ln ps never exist as spectral
 // arrays in memory: 0 = transform src as it is; 1 / 2 = ucos / vcos of vort2vel(vor = src, div = src2)
 // (spectral.f90:190-214); 3 / 4 = x / y component of gradient(src) (spectral.f90:275-296).
+// flag of a spectral -> grid entry: kcos (1: none, 2: rows times 1 / cos(lat)) [| kGridAsFloat: dst receives the field as
+// fp32, 96 x 48 floats from dst on -- fields that only the fp32 column physics of cfg 5 reads].  grid -> spectral: the prescale.
+constexpr int kGridAsFloat = 0x100;
 struct FieldDesc {
     const double *src;
     double *dst;

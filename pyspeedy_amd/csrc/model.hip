@@ -25,7 +25,7 @@ hipError_t run_spec2grid_table(const DeviceTables &T, const FieldDesc *table, in
 hipError_t run_grid2spec_table(const DeviceTables &T, const FieldDesc *table, int nfields, hipStream_t st);
 hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nmembers, int fp32, hipStream_t s);
 hipError_t run_dyn_physics(const ModelPtrs &P, const DynDeviceTables &D, const DeviceTables &T, const spd_physics_args &a,
-                           int first, int nmembers, int fp32, int diag, hipStream_t s);
+                           int first, int nmembers, int fp32, int store32, int diag, hipStream_t s);
 hipError_t run_geopotential(const ModelPtrs &P, const DynDeviceTables &D, int first, int count, int tl, const SpptArgs *sppt,
                             hipStream_t s);
 hipError_t run_dyn_grid(const ModelPtrs &P, const DynDeviceTables &D, int M, hipStream_t s);
@@ -39,6 +39,7 @@ hipError_t run_forcing(const SurfacePtrs &S, int first, int count, const ZonalDe
                        double *corh_q, hipStream_t s);
 hipError_t run_rest_state(const RestPtrs &R, int M, const RestConsts &c, hipStream_t s);
 hipError_t run_scale_orog(const double *orog, double *phi0, long n, hipStream_t s);
+hipError_t run_change_storage(double *array, long n, bool to_float, void *scratch, hipStream_t s);
 hipError_t run_differs_from_first(const double *v, long n, int M, int *flags, hipStream_t s);
 hipError_t run_copy_from_first(double *v, long n, int M, const int *flags, hipStream_t s);
 hipError_t run_rest_surface(const double *phis0, double *forog, double *surf_ps, double *surf_q, const RestConsts &c, long n,
@@ -68,7 +69,8 @@ constexpr size_t C = 2;  // doubles per complex
 
 struct RegEntry {
     void *ptr;            // device base
-    size_t bytes_member;  // bytes per member
+    size_t bytes_member;  // bytes per member (as fp64: the size the registry and the C boundary speak of)
+    bool f32 = false;     // stored as fp32 (in the first half of the allocation) while the model's physics precision is fp32
 };
 }  // namespace
 
@@ -83,6 +85,8 @@ struct spd_model {
     std::map<std::string, RegEntry> reg;
     FieldDesc *inv_table[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [dynamics time level j2 (0-based)][phi buffer]
     FieldDesc *inv_table_sppt[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // the same + 8 SPPT pattern transforms per member
+    // ... and both with the physics-only outputs (time-level-1 T, q, phi, ln ps, lowest-level u, v) stored as fp32 (cfg 5)
+    FieldDesc *inv_table32[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *inv_table_sppt32[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     FieldDesc *fwd_table = nullptr;
     // Geopotential, double-buffered.  spectral_step_kernel ends by computing the geopotential the NEXT step needs (from the
     // temperature it has just advanced) into the buffer that is not in use; the next step switches to it instead of running
@@ -124,7 +128,11 @@ struct spd_model {
     hipStream_t cstream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t cev[4] = {nullptr, nullptr, nullptr, nullptr}, ev_start = nullptr, ev_offset = nullptr;
     bool split_dyn_physics = false;  // PYSPEEDY_AMD_SPLIT_DYN=1: separate dynamics and physics launches (for measurements)
-    int phys_fp32 = 0;               // spd_model_set_physics_precision: column physics arithmetic in fp32 (BASELINE cfg 5)
+    // spd_model_set_physics_precision (BASELINE cfg 5): column physics arithmetic in fp32 AND fp32 storage of what only the
+    // column physics reads back (RegEntry::f32: its time-level-1 inputs, the persisted radiation state, diagnostics-only outputs)
+    int phys_fp32 = 0;
+    bool phys_store32 = true;  // option physics_storage32 / PYSPEEDY_AMD_PHYS_STORE32: 0 keeps fp64 storage under the fp32 physics
+    bool stored32 = false;     // how the RegEntry::f32 arrays are stored right now (= phys_fp32 && phys_store32)
     // Dead-store elimination inside multi-step calls (PYSPEEDY_AMD_DIAG_EVERY_STEP=1 switches it off): only the LAST step
     // of a spd_model_step call stores the physics outputs that no later kernel reads -- the host can only look at the
     // state between calls, and every earlier value would be overwritten before that.
@@ -163,6 +171,7 @@ LaunchEvents &pending_launch_events() {
 }  // namespace spd
 
 static int m_fail(int code, const std::string &msg) { return spd_set_error(code, msg); }
+static int apply_storage(spd_model *m, bool want32);  // (with spd_model_set_physics_precision)
 
 #define M_HIP(call)                                                                   \
     do {                                                                              \
@@ -191,12 +200,18 @@ static int upload_const(spd_model *m, const double *src, size_t n, const double 
 // The four spectral -> grid descriptor tables ([dynamics time level][phi buffer]) of the step.  with_sppt: every member's
 // entries are followed by the 8 transforms of its SPPT pattern (spectral AR(1) state -> grid, kcos = 1), so that they ride
 // in the same launch instead of being a launch of their own.
-static int build_inverse_tables(spd_model *m, bool with_sppt, FieldDesc *(&out)[2][2]) {
+static int build_inverse_tables(spd_model *m, bool with_sppt, bool phys_as_float, FieldDesc *(&out)[2][2]) {
     const int M = m->M;
     const ModelPtrs &P = m->P;
     const spd_physics_args &pa = m->pa;
     auto spec = [](double *base, size_t field) { return base + field * NSPEC * C; };
     auto grid = [](double *base, size_t field) { return base + field * NG; };
+    // an output of the physics' time level: fp32 in the first half of its array when the column physics wants it so
+    const int pf = phys_as_float ? kGridAsFloat : 0;
+    auto pgrid = [&](const double *base, size_t field) {
+        double *b = const_cast<double *>(base);
+        return phys_as_float ? reinterpret_cast<double *>(reinterpret_cast<float *>(b) + field * NG) : b + field * NG;
+    };
     for (int j2 = 0; j2 < 4; ++j2) {
         const int par = j2 >> 1;  // (j2 & 1) = dynamics time level, par = phi buffer
         std::vector<FieldDesc> t;
@@ -214,13 +229,13 @@ static int build_inverse_tables(spd_model *m, bool with_sppt, FieldDesc *(&out)[
                 // level and at time level 1 for the physics (tendencies.f90:109-118, physics.f90:89-94)
                 e[2][k] = {spec(P.vor, st + k), grid(P.ug2, w + k), 2, 1, spec(P.div, st + k)};
                 e[3][k] = {spec(P.vor, st + k), grid(P.vg2, w + k), 2, 2, spec(P.div, st + k)};
-                e[4][k] = {spec(P.vor, s1 + k), grid(const_cast<double *>(pa.ug), w + k), 2, 1, spec(P.div, s1 + k)};
-                e[5][k] = {spec(P.vor, s1 + k), grid(const_cast<double *>(pa.vg), w + k), 2, 2, spec(P.div, s1 + k)};
+                e[4][k] = {spec(P.vor, s1 + k), pgrid(pa.ug, w + k), 2 | pf, 1, spec(P.div, s1 + k)};
+                e[5][k] = {spec(P.vor, s1 + k), pgrid(pa.vg, w + k), 2 | pf, 2, spec(P.div, s1 + k)};
                 e[6][k] = {spec(P.t, st + k), grid(P.tg2, w + k), 1, 0};
                 e[7][k] = {spec(P.tr, st + k), grid(P.trg2, w + k), 1, 0};
-                e[8][k] = {spec(P.t, s1 + k), grid(const_cast<double *>(pa.tg), w + k), 1, 0};
-                e[9][k] = {spec(P.tr, s1 + k), grid(const_cast<double *>(pa.qg), w + k), 1, 0};
-                e[10][k] = {spec(m->phi_buf[par], w + k), grid(const_cast<double *>(pa.phig), w + k), 1, 0};
+                e[8][k] = {spec(P.t, s1 + k), pgrid(pa.tg, w + k), 1 | pf, 0};
+                e[9][k] = {spec(P.tr, s1 + k), pgrid(pa.qg, w + k), 1 | pf, 0};
+                e[10][k] = {spec(m->phi_buf[par], w + k), pgrid(pa.phig, w + k), 1 | pf, 0};
             }
             const bool prune = m->inv_per_member == 77;
             for (int v = 0; v < 11; ++v)
@@ -229,7 +244,7 @@ static int build_inverse_tables(spd_model *m, bool with_sppt, FieldDesc *(&out)[
             // grad ln ps at the dynamics' time level (tendencies.f90:144-146): gradient applied while staging (mode 3 / 4)
             t.push_back({spec(P.ps, static_cast<size_t>(i) * 2 + (j2 & 1)), grid(P.px, i), 2, 3, nullptr});
             t.push_back({spec(P.ps, static_cast<size_t>(i) * 2 + (j2 & 1)), grid(P.py, i), 2, 4, nullptr});
-            t.push_back({spec(P.ps, static_cast<size_t>(i) * 2), grid(const_cast<double *>(pa.pslg), i), 1, 0});
+            t.push_back({spec(P.ps, static_cast<size_t>(i) * 2), pgrid(pa.pslg, i), 1 | pf, 0});
             if (with_sppt)
                 for (int k = 0; k < 8; ++k) t.push_back({spec(m->sppt_spec, w + k), grid(m->sppt_grid, w + k), 1, 0});
         }
@@ -242,12 +257,21 @@ static int build_inverse_tables(spd_model *m, bool with_sppt, FieldDesc *(&out)[
     return SPD_OK;
 }
 
+// the descriptor tables of the cfg 5 step (physics-only outputs as fp32), built when they are first needed
+static int ensure_tables32(spd_model *m) {
+    if (!m->inv_table32[0][0])
+        if (int rc = build_inverse_tables(m, false, true, m->inv_table32)) return rc;
+    if (m->sppt_spec && !m->inv_table_sppt32[0][0])
+        if (int rc = build_inverse_tables(m, true, true, m->inv_table_sppt32)) return rc;
+    return SPD_OK;
+}
+
 static int build_tables(spd_model *m) {
     const int M = m->M;
     const ModelPtrs &P = m->P;
     auto spec = [](double *base, size_t field) { return base + field * NSPEC * C; };
     auto grid = [](double *base, size_t field) { return base + field * NG; };
-    if (int rc = build_inverse_tables(m, false, m->inv_table)) return rc;
+    if (int rc = build_inverse_tables(m, false, false, m->inv_table)) return rc;
     std::vector<FieldDesc> t;
     t.reserve(static_cast<size_t>(M) * 73);
     const size_t pair = static_cast<size_t>(M) * 8;
@@ -322,6 +346,7 @@ int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
     if (const char *env = getenv("PYSPEEDY_AMD_COUPLER_IN_SPECTRAL")) m->coupler_in_spectral = atoi(env) != 0;
     if (const char *env = getenv("PYSPEEDY_AMD_SPECTRAL_EARLY")) m->spectral_early = atoi(env);
     if (const char *env = getenv("PYSPEEDY_AMD_FOLD_GEO")) m->fold_geo = atoi(env) != 0;
+    if (const char *env = getenv("PYSPEEDY_AMD_PHYS_STORE32")) m->phys_store32 = atoi(env) != 0;
     // Member groups on separate streams (spd_model_step).  Measured per step against one group (profiles/r03_member_groups.txt):
     // 16 members and fewer: nothing to fill, 0 ... +10 %; 20 members: 2 groups -3 %; 24 ... 48: 3 groups -9 ... -12 % (2 groups
     // -7 ... -10 %); 64: 2 groups -10 %, 3 groups -9.5 %; 96 / 128: -4 % / -3 % either way; 4 groups are slower everywhere.
@@ -419,6 +444,10 @@ int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
         spd_model_destroy(m);
         return rc;
     }
+    for (const char *name : {"t_grid_phys", "q_grid_phys", "phi_grid_phys", "pslg_phys", "u_grid_phys", "v_grid_phys",  // inputs
+                             "tt_rsw", "rad_tau2", "rad_strat_corr",                                                 // persisted
+                             "rad_st4a", "rad_flux", "precnv", "precls", "cbmf", "slrd", "slr", "olr", "slru", "ustr", "vstr"})
+        m->reg[name].f32 = true;
     // dynamics tables
     m->dynh = new DynHostTables(h->host);
     const DynHostTables &dh = *m->dynh;
@@ -489,6 +518,15 @@ long spd_model_var_bytes(spd_model_handle m, const char *name) {
     return static_cast<long>(it->second.bytes_member);
 }
 
+// bytes of one real element of the variable as it is stored on the device NOW: 8, or 4 for the arrays only the column physics
+// reads back while the model's physics precision is fp32 (their values then occupy the first half of the allocation)
+int spd_model_var_storage(spd_model_handle m, const char *name) {
+    if (!m || !name) return m_fail(SPD_E_ARG, "spd_model_var_storage: null argument");
+    auto it = m->reg.find(name);
+    if (it == m->reg.end()) return m_fail(SPD_E_ARG, std::string("spd_model_var_storage: unknown variable '") + name + "'");
+    return (it->second.f32 && m->stored32) ? 4 : 8;
+}
+
 static int xfer(spd_model_handle m, const char *name, int member, void *host, size_t bytes, bool to_device) {
     if (!m || !name || !host) return m_fail(SPD_E_ARG, "spd_model_get/set: null argument");
     auto it = m->reg.find(name);
@@ -504,6 +542,23 @@ static int xfer(spd_model_handle m, const char *name, int member, void *host, si
     M_HIP(hipDeviceSynchronize());
     if (to_device) m->surf_cache_valid = m->phi_ahead = false;
     const int first = member < 0 ? 0 : member, last = member < 0 ? m->M - 1 : member;
+    if (e.f32 && m->stored32) {  // stored as fp32 (the first half of the allocation): the boundary speaks fp64
+        const size_t n = bytes / sizeof(double);
+        std::vector<float> narrow(n);
+        double *wide = static_cast<double *>(host);
+        if (to_device)
+            for (size_t k = 0; k < n; ++k) narrow[k] = static_cast<float>(wide[k]);
+        for (int i = first; i <= last; ++i) {
+            float *dev = static_cast<float *>(e.ptr) + static_cast<size_t>(i) * n;
+            if (to_device) {
+                M_HIP(hipMemcpy(dev, narrow.data(), n * sizeof(float), hipMemcpyHostToDevice));
+            } else {
+                M_HIP(hipMemcpy(narrow.data(), dev, n * sizeof(float), hipMemcpyDeviceToHost));
+                for (size_t k = 0; k < n; ++k) wide[k] = static_cast<double>(narrow[k]);
+            }
+        }
+        return SPD_OK;
+    }
     for (int i = first; i <= last; ++i) {
         char *dev = static_cast<char *>(e.ptr) + static_cast<size_t>(i) * e.bytes_member;
         if (to_device)
@@ -654,12 +709,13 @@ static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int comput
     pa.sppt_pattern = m->sppt_on ? m->sppt_grid : nullptr;  // its 8 transforms per member ride in the spectral -> grid launch below
     if (e == hipSuccess) {                                                                // :109-146, physics.f90:89-101
         const int per = m->inv_per_member + (m->sppt_on ? 8 : 0);
-        FieldDesc *table = (m->sppt_on ? m->inv_table_sppt : m->inv_table)[j2 - 1][m->phi_cur];
+        FieldDesc *table = (m->stored32 ? (m->sppt_on ? m->inv_table_sppt32 : m->inv_table32)
+                                         : (m->sppt_on ? m->inv_table_sppt : m->inv_table))[j2 - 1][m->phi_cur];
         ProfScope ps(m, SPD_K_SPEC2GRID, per * count, s);
         e = run_spec2grid_table(T, table + static_cast<size_t>(first) * per, per * count, s);
     }
     if (e == hipSuccess) {
-        if (m->split_dyn_physics) {  // whole model only; the default is the fused launch (with SPPT: its KEEP variant)
+        if (m->split_dyn_physics && !m->phys_fp32) {  // whole model, fp64 only; the default is the fused launch (with SPPT: KEEP)
             {
                 ProfScope ps(m, SPD_K_DYN_GRID, M, s);
                 e = run_dyn_grid(m->P, m->D, M, s);                                       // :151-224
@@ -670,7 +726,7 @@ static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int comput
             }
         } else {
             ProfScope ps(m, compute_shortwave ? SPD_K_COLUMN_SW : SPD_K_COLUMN, count, s);
-            e = run_dyn_physics(m->P, m->D, T, pa, first, count, m->phys_fp32, diag, s);        // both in one launch
+            e = run_dyn_physics(m->P, m->D, T, pa, first, count, m->phys_fp32, m->stored32 ? 1 : 0, diag, s);  // both in one launch
         }
     }
     if (e == hipSuccess) {                                                                // :238-268
@@ -1152,6 +1208,8 @@ int spd_model_set_control(spd_model_handle m, const spd_model_control *in) {
         return m_fail(SPD_E_ARG, "spd_model_set_control: bad date, month index or step counter");
     if (in->sppt_on && !m->sppt_spec)
         return m_fail(SPD_E_ARG, "spd_model_set_control: SPPT is on in the control block: call spd_model_set_sppt and load sppt_spec first");
+    // (the precision of the column physics carries a storage format with it: spd_model_set_physics_precision converts)
+    if (int rc = spd_model_set_physics_precision(m, in->physics_fp32)) return rc;
     m->cal.set(in->year, in->month, in->day, in->hour, in->minute);
     m->cal.month_idx = in->month_idx;
     m->surf_cache_valid = false;
@@ -1161,7 +1219,6 @@ int spd_model_set_control(spd_model_handle m, const spd_model_control *in) {
     m->increase_co2 = in->increase_co2 ? 1 : 0;
     m->sppt_on = in->sppt_on != 0;
     m->sppt_first = in->sppt_first != 0;
-    m->phys_fp32 = in->physics_fp32 ? 1 : 0;
     m->sppt_step = in->sppt_step;
     m->sppt_member_base = in->sppt_first_member_id;
     m->sppt_seed = in->sppt_seed;
@@ -1197,14 +1254,47 @@ int spd_model_set_option(spd_model_handle m, const char *name, int32_t value) {
     else if (key == "split_dyn" && flag) m->split_dyn_physics = value != 0;
     else if (key == "spectral_early" && value >= -1 && value <= 1) m->spectral_early = value;
     else if (key == "member_groups" && value >= 1 && value <= 4) m->nchunks = value < m->M ? value : m->M;
+    else if (key == "physics_storage32" && flag) {
+        m->phys_store32 = value != 0;
+        return apply_storage(m, m->phys_fp32 && m->phys_store32);
+    }
     else return m_fail(SPD_E_ARG, "spd_model_set_option: unknown option or value out of range: " + key);
+    return SPD_OK;
+}
+
+// bring the storage of the RegEntry::f32 arrays in line with what the model's settings ask for
+static int apply_storage(spd_model *m, bool want32) {
+    if (want32 == m->stored32) return SPD_OK;
+    const int fp32 = want32 ? 1 : 0;
+    // the arrays only the column physics reads back change their storage with its arithmetic: converted here, once (values
+    // that came out of the fp32 physics are fp32 numbers already; what the fp64 physics left is rounded as that kernel's loads
+    // would have rounded it)
+    M_HIP(hipSetDevice(m->ctx->device));
+    M_HIP(hipDeviceSynchronize());
+    size_t largest = 0;
+    for (const auto &kv : m->reg)
+        if (kv.second.f32) largest = std::max(largest, kv.second.bytes_member * static_cast<size_t>(m->M));
+    void *scratch = nullptr;
+    M_HIP(hipMalloc(&scratch, largest));
+    hipError_t e = hipSuccess;
+    for (const auto &kv : m->reg) {
+        if (!kv.second.f32 || e != hipSuccess) continue;
+        const long n = static_cast<long>(kv.second.bytes_member / sizeof(double)) * m->M;
+        e = run_change_storage(static_cast<double *>(kv.second.ptr), n, fp32 != 0, scratch, nullptr);
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(scratch);
+    if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_set_physics_precision: ") + hipGetErrorString(e));
+    m->stored32 = want32;
+    if (want32)
+        if (int rc = ensure_tables32(m)) return rc;
     return SPD_OK;
 }
 
 int spd_model_set_physics_precision(spd_model_handle m, int fp32) {
     if (!m) return m_fail(SPD_E_ARG, "spd_model_set_physics_precision: null model");
     m->phys_fp32 = fp32 ? 1 : 0;
-    return SPD_OK;
+    return apply_storage(m, m->phys_fp32 && m->phys_store32);
 }
 
 int spd_model_set_flags(spd_model_handle m, int land_coupling_flag, int sst_anomaly_coupling_flag, int increase_co2) {
@@ -1287,7 +1377,9 @@ int spd_model_set_sppt(spd_model_handle m, int on, uint64_t seed, int64_t first_
         const size_t M = m->M;
         if (int rc = dalloc(m, M * 8 * NSPEC * C, &m->sppt_spec, "sppt_spec", 8 * NSPEC * C * sizeof(double))) return rc;
         if (int rc = dalloc(m, M * 8 * NG, &m->sppt_grid, "sppt_pattern", static_cast<size_t>(8) * NG * sizeof(double))) return rc;
-        if (int rc = build_inverse_tables(m, true, m->inv_table_sppt)) return rc;
+        if (int rc = build_inverse_tables(m, true, false, m->inv_table_sppt)) return rc;
+        if (m->stored32)
+            if (int rc = ensure_tables32(m)) return rc;
     }
     m->sppt_on = on != 0;
     m->sppt_seed = seed;
@@ -1319,6 +1411,8 @@ int spd_model_copy_member(spd_model_handle dst, int di, spd_model_handle src, in
     hipStream_t s = static_cast<hipStream_t>(stream);
     M_HIP(hipSetDevice(dst->ctx->device));
     M_HIP(hipDeviceSynchronize());  // the two models may have been driven on different streams
+    // whole allocations are copied as they are: both models must store them the same way
+    if (int rc = apply_storage(dst, src->stored32)) return rc;
     dst->surf_cache_valid = dst->phi_ahead = false;
     for (const auto &kv : src->reg) {
         auto it = dst->reg.find(kv.first);

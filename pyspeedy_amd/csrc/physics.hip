@@ -120,11 +120,35 @@ ColTables<R> col_tables(const DeviceTables &T) {
 // KEEP (FUSED only): the dynamics' temperature tendencies stay in LDS until the end of the kernel -- needed when the result is
 // not simply "dynamics + physics summed in R": mixed precision (R = float) and SPPT both combine the fp64 dynamics
 // tendency with the physics increment at the end.
-template <int W, bool FUSED, bool KEEP, typename R>
+template <int W, bool FUSED, bool KEEP, typename R, bool S32 = false>
 __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_args a, ColTables<R> CT, int first, int nmembers,
                                                                   ModelPtrs MP, DynDeviceTables MD, int diag) {
     using C = PhysConst<R>;
     constexpr bool MIXED = !std::is_same<R, double>::value;
+    // S32 (the model's cfg 5 step: fp32 arithmetic, fused; model option physics_storage32, default on): what only this kernel ever reads back -- its grid-point inputs at the
+    // physics' time level (written by the spectral -> grid launch), the radiation state a shortwave step leaves for the next
+    // two steps, the diagnostics-only outputs -- lives in memory as fp32, in the first half of the same arrays.  The kernel
+    // narrows every one of those values to fp32 before it uses it and computes every one it stores in fp32, so nothing is lost
+    // against fp64 storage: only the bytes are (13 % of this kernel's, 11 % of the spectral -> grid launch's).  State, dynamics
+    // and the tendencies handed to the forward transforms stay fp64.
+    static_assert(!S32 || (MIXED && FUSED), "fp32 storage belongs to the fused mixed-precision kernel");
+    using IN = typename std::conditional<S32, float, double>::type;
+    auto ld = [](const double *base, size_t i) -> IN {  // (streamed in: read once, by this lane only)
+        if constexpr (S32) return stream_load(reinterpret_cast<const float *>(base) + i);
+        else return stream_load(base + i);
+    };
+    auto ld_plain = [](const double *base, size_t i) -> IN {
+        if constexpr (S32) return reinterpret_cast<const float *>(base)[i];
+        else return base[i];
+    };
+    auto st_stream = [](double *base, size_t i, R v) {
+        if constexpr (S32) stream_store(reinterpret_cast<float *>(base) + i, v);
+        else stream_store(base + i, v);
+    };
+    auto st_plain = [](double *base, size_t i, R v) {
+        if constexpr (S32) reinterpret_cast<float *>(base)[i] = v;
+        else base[i] = v;
+    };
     static_assert(!KEEP || FUSED, "KEEP is a variant of the fused kernel");
     static_assert(!(MIXED && FUSED) || KEEP, "the fused mixed-precision kernel keeps the fp64 dynamics tendencies");
     // LDS of the wavefront.  tau: rad_tau2 of this lane's column while the two longwave sweeps run, [band * 8 + level][lane].
@@ -157,15 +181,15 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
     // kept in registers they are spilled to scratch memory by the allocator, 16 bytes out and back per lane)
     __shared__ double park_uv[2][kPhysThreads];
     // (FUSED, fp64: the physics' first inputs are requested by the dynamics phase, in front of its product stores)
-    double in_t[KX], in_q[KX], in_phi[KX], in_ps;
+    IN in_t[KX], in_q[KX], in_phi[KX], in_ps;
     auto load_column = [&]() {
 #pragma unroll
         for (int k = 0; k < KX; ++k) {
-            in_t[k] = stream_load(&a.tg[o3 + NG * k]);
-            in_q[k] = stream_load(&a.qg[o3 + NG * k]);
-            in_phi[k] = stream_load(&a.phig[o3 + NG * k]);
+            in_t[k] = ld(a.tg, o3 + NG * k);
+            in_q[k] = ld(a.qg, o3 + NG * k);
+            in_phi[k] = ld(a.phig, o3 + NG * k);
         }
-        in_ps = a.pslg[o2];
+        in_ps = ld_plain(a.pslg, o2);
         __builtin_amdgcn_sched_barrier(0);
     };
     if (FUSED) {
@@ -319,8 +343,8 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
             }
     }
     if (diag) {
-        stream_store(&a.cbmf[o2], cbmf);
-        stream_store(&a.precnv[o2], precnv);
+        st_stream(a.cbmf, o2, cbmf);
+        st_stream(a.precnv, o2, precnv);
     }
     const int icnv = KX - itop;  // physics.f90:132
     int iptop = itop;
@@ -360,7 +384,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         qtend[0] = qtend[0] + dfqa[0] + R(0.0f);
         precls = precls * psa;
     }
-    if (diag) stream_store(&a.precls[o2], precls);
+    if (diag) st_stream(a.precls, o2, precls);
 
     const R gse = (se[nl1 - 1] - se[KX - 1]) / (phi[nl1 - 1] - phi[KX - 1]);  // physics.f90:152 (used on shortwave steps)
     const R phi_kx = phi[KX - 1];
@@ -553,7 +577,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
 #pragma unroll
         for (int k = 0; k < KX; ++k) {
             tt_rsw[k] = tt_rsw[k] * rps * CT.grdscp[k];
-            stream_store(&a.tt_rsw[o3 + NG * k], tt_rsw[k]);
+            st_stream(a.tt_rsw, o3 + NG * k, tt_rsw[k]);
             ttend[k] = ttend[k] + tt_rsw[k];
         }
 
@@ -562,10 +586,10 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         const size_t NGs = static_cast<size_t>(NG);
         tau_s[0][lane] = rexp(-psa * CT.dhs[0] * ablwin);
         tau_s[KX][lane] = rexp(-psa * CT.dhs[0] * co2);
-        stream_store(&a.rad_tau2[ot + NGs * (0 + KX * 0)], tau_s[0][lane]);
-        stream_store(&a.rad_tau2[ot + NGs * (0 + KX * 1)], tau_s[KX][lane]);
-        stream_store(&a.rad_tau2[ot + NGs * (0 + KX * 2)], R(1.0f));
-        stream_store(&a.rad_tau2[ot + NGs * (0 + KX * 3)], R(1.0f));
+        st_stream(a.rad_tau2, ot + NGs * (0 + KX * 0), tau_s[0][lane]);
+        st_stream(a.rad_tau2, ot + NGs * (0 + KX * 1), tau_s[KX][lane]);
+        st_stream(a.rad_tau2, ot + NGs * (0 + KX * 2), R(1.0f));
+        st_stream(a.rad_tau2, ot + NGs * (0 + KX * 3), R(1.0f));
         acloud = cloudc * ablcl2;
 #pragma unroll
         for (int k = 2; k <= KX; ++k) {
@@ -583,10 +607,10 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
                 t2 = rexp(-deltap * rmax<R>(ablwv1 * qa[k - 1], acloud));
                 t3 = rexp(-deltap * rmax<R>(ablwv2 * qa[k - 1], acloud));
             }
-            stream_store(&a.rad_tau2[ot + NGs * (k - 1 + KX * 0)], t0);
-            stream_store(&a.rad_tau2[ot + NGs * (k - 1 + KX * 1)], t1);
-            stream_store(&a.rad_tau2[ot + NGs * (k - 1 + KX * 2)], t2);
-            stream_store(&a.rad_tau2[ot + NGs * (k - 1 + KX * 3)], t3);
+            st_stream(a.rad_tau2, ot + NGs * (k - 1 + KX * 0), t0);
+            st_stream(a.rad_tau2, ot + NGs * (k - 1 + KX * 1), t1);
+            st_stream(a.rad_tau2, ot + NGs * (k - 1 + KX * 2), t2);
+            st_stream(a.rad_tau2, ot + NGs * (k - 1 + KX * 3), t3);
             tau_s[k - 1 + KX * 0][lane] = t0;
             tau_s[k - 1 + KX * 1][lane] = t1;
             tau_s[k - 1 + KX * 2][lane] = t2;
@@ -595,19 +619,19 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         const R eps1 = C::EPSLW / (CT.dhs[0] + CT.dhs[1]);
         strat1 = R(a.stratospheric_correction[o2]) * psa;  // (requested here: one more live value above costs the kernel scratch)
         strat2 = eps1 * psa;
-        stream_store(&a.rad_strat_corr[oc], strat1);
-        stream_store(&a.rad_strat_corr[oc + NG], strat2);
+        st_stream(a.rad_strat_corr, oc, strat1);
+        st_stream(a.rad_strat_corr, oc + NG, strat2);
     } else {
 #pragma unroll
-        for (int k = 0; k < KX; ++k) ttend[k] = ttend[k] + R(a.tt_rsw[o3 + NG * k]);
+        for (int k = 0; k < KX; ++k) ttend[k] = ttend[k] + R(ld_plain(a.tt_rsw, o3 + NG * k));
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int k = (b < 2 ? 0 : 1); k < KX; ++k)  // bands 3-4 do not use the top level
-                tau_s[k + KX * b][lane] = R(a.rad_tau2[ot + static_cast<size_t>(NG) * (k + KX * b)]);
+                tau_s[k + KX * b][lane] = R(ld_plain(a.rad_tau2, ot + static_cast<size_t>(NG) * (k + KX * b)));
         ssrd = R(a.ssrd[o2]);
-        strat1 = R(a.rad_strat_corr[oc]);
-        strat2 = R(a.rad_strat_corr[oc + NG]);
+        strat1 = R(ld_plain(a.rad_strat_corr, oc));
+        strat2 = R(ld_plain(a.rad_strat_corr, oc + NG));
     }
 
     // ------------------------------------------------------------------ longwave, downward sweep
@@ -672,11 +696,11 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         dfabs[KX - 1] = dfabs[KX - 1] - corlw;
         slrd = slrd + corlw;
         if (diag) {
-            stream_store(&a.slrd[o2], slrd);
+            st_stream(a.slrd, o2, slrd);
 #pragma unroll
             for (int k = 0; k < KX; ++k) {
-                stream_store(&a.rad_st4a[os + static_cast<size_t>(NG) * k], st4a[k][0]);
-                stream_store(&a.rad_st4a[os + static_cast<size_t>(NG) * (k + KX)], st4a[k][1]);
+                st_stream(a.rad_st4a, os + static_cast<size_t>(NG) * k, st4a[k][0]);
+                st_stream(a.rad_st4a, os + static_cast<size_t>(NG) * (k + KX), st4a[k][1]);
             }
         }
 
@@ -684,7 +708,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         const R fwind0 = 0.95f, ftemp0 = 1.0f, cdl = 2.4e-3f, cds = 1.0e-3f, chl = 1.2e-3f, chs = 0.9e-3f,
                      vgust = 5.0f, ctday = 1.0e-2f, dtheta = 3.0f, fstab = 0.67f, clambda = 7.0f, clambsn = 7.0f;
         const R esbc = C::EMISFC * C::SBC;
-        const R ua = R(a.ug[o3 + NG * (KX - 1)]), va = R(a.vg[o3 + NG * (KX - 1)]);
+        const R ua = R(ld_plain(a.ug, o3 + NG * (KX - 1))), va = R(ld_plain(a.vg, o3 + NG * (KX - 1)));
         const R fmask = R(a.fmask_land[o2]), phi0 = R(a.phis0[o2]), tsea = R(a.sst_am[o2]), land_temp = R(a.land_temp[o2]);
         const R alb_land = R(a.alb_land[o2]), swav = R(a.soil_avail_water[o2]);
         // (every input of the block is requested here, in one batch: a load issued where its value is first needed costs the
@@ -750,11 +774,11 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         a.evap[oa + NG] = evap2;
         stream_store(&a.hfluxn[oa], hfl1); a.hfluxn[oa + NG] = hfl2;
         if (diag) {
-            stream_store(&a.ustr[oa], ustr1); a.ustr[oa + NG] = ustr2; a.ustr[oa + 2 * NG] = ustr3;
-            stream_store(&a.vstr[oa], vstr1); a.vstr[oa + NG] = vstr2; a.vstr[oa + 2 * NG] = vstr3;
+            st_stream(a.ustr, oa, ustr1); st_plain(a.ustr, oa + NG, ustr2); st_plain(a.ustr, oa + 2 * NG, ustr3);
+            st_stream(a.vstr, oa, vstr1); st_plain(a.vstr, oa + NG, vstr2); st_plain(a.vstr, oa + 2 * NG, vstr3);
             stream_store(&a.shf[oa], shf1);   a.shf[oa + 2 * NG] = shf3;
             stream_store(&a.evap[oa], evap1); a.evap[oa + 2 * NG] = evap3;
-            stream_store(&a.slru[oa], slru1); a.slru[oa + NG] = slru2; a.slru[oa + 2 * NG] = slru3;
+            st_stream(a.slru, oa, slru1); st_plain(a.slru, oa + NG, slru2); st_plain(a.slru, oa + 2 * NG, slru3);
         }
         if (a.ts) stream_store(&a.ts[o2], tsfc);
         if (a.tskin) stream_store(&a.tskin[o2], tskin_avg);
@@ -764,7 +788,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
 
         // -------------------------------------------------------------- longwave, upward sweep (:124-205)
         const R refsfc = 1.0f - C::EMISFC;
-        if (diag) stream_store(&a.slr[o2], slru3 - slrd);
+        if (diag) st_stream(a.slr, o2, slru3 - slrd);
         R fsfc[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) fsfc[b] = fband_at(CT.fband, tsfc, b);
@@ -804,9 +828,9 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
 #pragma unroll
         for (int b = 0; b < 4; ++b) olr = olr + flux[b];
         if (diag) {
-            stream_store(&a.olr[o2], olr);
+            st_stream(a.olr, o2, olr);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) a.rad_flux[of4 + static_cast<size_t>(NG) * b] = flux[b];
+            for (int b = 0; b < 4; ++b) st_plain(a.rad_flux, of4 + static_cast<size_t>(NG) * b, flux[b]);
         }
         // physics.f90:207-211: ttend = ttend + tt_rsw + tt_rlw
 #pragma unroll
@@ -857,12 +881,12 @@ static int physics_waves32() {
     return waves;
 }
 
-template <int W, bool FUSED, bool KEEP, typename R>
+template <int W, bool FUSED, bool KEEP, typename R, bool S32 = false>
 static hipError_t launch_physics(const DeviceTables &T, const spd_physics_args &a, int first, int nmembers, const ModelPtrs &P,
                                  const DynDeviceTables &D, int diag, hipStream_t s) {
     const long total = static_cast<long>(nmembers) * NG;
     const unsigned blocks = static_cast<unsigned>((total + kPhysThreads - 1) / kPhysThreads);
-    launch(physics_kernel<W, FUSED, KEEP, R>, dim3(blocks), dim3(kPhysThreads), 0, s, a, col_tables<R>(T), first,
+    launch(physics_kernel<W, FUSED, KEEP, R, S32>, dim3(blocks), dim3(kPhysThreads), 0, s, a, col_tables<R>(T), first,
                        nmembers, P, D, diag);
     return hipGetLastError();
 }
@@ -889,8 +913,14 @@ hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nme
 // computed as always but NOT stored (what a shortwave step leaves for the following steps is always stored).  The model passes 0 for every step of a multi-step call except
 // the last one: such a value would be overwritten by the next step before anything could read it (model.hip).
 hipError_t run_dyn_physics(const ModelPtrs &P, const DynDeviceTables &D, const DeviceTables &T, const spd_physics_args &a,
-                           int first, int nmembers, int fp32, int diag, hipStream_t s) {
-    if (fp32) {
+                           int first, int nmembers, int fp32, int store32, int diag, hipStream_t s) {
+    if (fp32 && store32) {  // cfg 5: fp32 arithmetic, physics-only arrays stored as fp32
+        switch (physics_waves32()) {
+            case 2: return launch_physics<2, true, true, float, true>(T, a, first, nmembers, P, D, diag, s);
+            default: return launch_physics<3, true, true, float, true>(T, a, first, nmembers, P, D, diag, s);
+        }
+    }
+    if (fp32) {  // (model option physics_storage32 = 0: the same arithmetic over fp64 storage, for comparison)
         switch (physics_waves32()) {
             case 2: return launch_physics<2, true, true, float>(T, a, first, nmembers, P, D, diag, s);
             default: return launch_physics<3, true, true, float>(T, a, first, nmembers, P, D, diag, s);

@@ -162,6 +162,25 @@ hipError_t run_copy_from_first(double *v, long n, int M, const int *flags, hipSt
     return hipGetLastError();
 }
 
+// spd_model_set_physics_precision: an array changes between fp64 storage and fp32 storage in the first half of the same
+// allocation.  Through a scratch array: in place the narrow writes of one lane would land on the wide values other lanes read.
+__global__ void narrow_kernel(const double *in, float *out, long n) {
+    const long i = static_cast<long>(blockIdx.x) * kT + threadIdx.x;
+    if (i < n) out[i] = static_cast<float>(in[i]);
+}
+__global__ void widen_kernel(const float *in, double *out, long n) {
+    const long i = static_cast<long>(blockIdx.x) * kT + threadIdx.x;
+    if (i < n) out[i] = static_cast<double>(in[i]);
+}
+hipError_t run_change_storage(double *array, long n, bool to_float, void *scratch, hipStream_t s) {
+    const dim3 grid(static_cast<unsigned>((n + kT - 1) / kT));
+    if (to_float) hipLaunchKernelGGL(narrow_kernel, grid, dim3(kT), 0, s, array, static_cast<float *>(scratch), n);
+    else hipLaunchKernelGGL(widen_kernel, grid, dim3(kT), 0, s, reinterpret_cast<const float *>(array), static_cast<double *>(scratch), n);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return hipMemcpyAsync(array, scratch, static_cast<size_t>(n) * (to_float ? sizeof(float) : sizeof(double)), hipMemcpyDeviceToDevice, s);
+}
+
 hipError_t run_scale_orog(const double *orog, double *phi0, long n, hipStream_t s) {
     hipLaunchKernelGGL(scale_orog_kernel, dim3((n + kT - 1) / kT), dim3(kT), 0, s, orog, phi0, n);
     return hipGetLastError();

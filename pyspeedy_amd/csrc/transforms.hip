@@ -55,6 +55,8 @@ using d2 = double __attribute__((ext_vector_type(2)));
 // instead of flat accesses where the pointer comes out of a descriptor table
 using gd2_in = const __attribute__((address_space(1))) d2 *;
 using gd2_out = __attribute__((address_space(1))) d2 *;
+typedef float f2 __attribute__((ext_vector_type(2)));
+using gf2_out = __attribute__((address_space(1))) f2 *;
 
 // position of coefficient (m, re|im) in an unpacked FFT row (fourier.f90:74-81): re(m) -> 2m-1, im(m) -> 2m,
 // re(0) -> 0.  im(0) has no slot in the transform; it is parked at position 61 where a stage needs it.
@@ -243,6 +245,10 @@ __device__ __forceinline__ void spec2grid_body(const double *__restrict__ src, d
 
     // ---- store grid rows: 16 B per lane, coalesced; optional 1/cos(lat) scaling (fourier.f90:87-91) ----
     // (the scale factors are fetched first: on this ISA a wait for a load also waits for the stores issued before it)
+    // kGridAsFloat (descriptor-table launches of the cfg 5 model step): the field is wanted by the fp32 column physics only,
+    // which narrows every value it reads -- it is narrowed here instead and takes half the bytes (8 B per lane)
+    const bool as_float = (kcos & kGridAsFloat) != 0;
+    kcos &= ~kGridAsFloat;
     gd2_out g = (gd2_out)dst;
     double cs[kGridPerLane];
 #pragma unroll
@@ -260,6 +266,11 @@ __device__ __forceinline__ void spec2grid_body(const double *__restrict__ src, d
             if (kcos != 1) {
                 v.x *= cs[it];
                 v.y *= cs[it];
+            }
+            if (as_float) {
+                const f2 w{static_cast<float>(v.x), static_cast<float>(v.y)};
+                __builtin_nontemporal_store(w, &((gf2_out)dst)[idx]);
+                continue;
             }
             __builtin_nontemporal_store(v, &g[idx]);  // streamed out once: do not let it displace L2 lines
         }

@@ -108,6 +108,10 @@ class EnsembleModel:
         ptr = self._lib.spd_model_device_ptr(self._m, name.encode())
         if not ptr:
             raise KeyError(name)
+        if self._lib.spd_model_var_storage(self._m, name.encode()) == 4:
+            # cfg 5 (set_physics_precision(True)): what only the column physics reads back is STORED as float32; the view shows the
+            # array as it is in memory (a view taken before the precision was switched shows bytes that no longer mean anything)
+            dtype = np.float32
 
         class _Blob:  # CUDA array interface v2 (understood by torch.as_tensor on ROCm builds as well)
             __cuda_array_interface__ = {"shape": (self.nmembers,) + tuple(reversed(shape)),
@@ -231,7 +235,12 @@ class EnsembleModel:
         return tuple(buf)
 
     def set_physics_precision(self, fp32):
-        """BASELINE cfg 5: run the arithmetic of the column physics in single precision (state and dynamics stay fp64)."""
+        """BASELINE cfg 5: run the arithmetic of the column physics in single precision AND keep what only the column physics
+        reads back -- its grid-point inputs at the physics' time level, the radiation state persisted between shortwave steps
+        (tt_rsw, rad_tau2, rad_strat_corr), the diagnostics-only outputs (rad_st4a, rad_flux, precnv, precls, cbmf, slrd, slr,
+        olr, slru, ustr, vstr) -- in memory as float32.  State, dynamics and tendencies stay fp64; get / set of the narrowed
+        variables still speak float64 (converted on the way); device_view shows them as float32.  Switching converts the
+        arrays in place."""
         check(self._lib.spd_model_set_physics_precision(self._m, int(bool(fp32))), "spd_model_set_physics_precision")
 
     def config(self):
@@ -243,8 +252,8 @@ class EnsembleModel:
 
     def set_option(self, name, value):
         """A launch-plan switch of the live model by name (spd_model_set_option: diag_every_step, coupler_in_spectral,
-        spectral_early, split_dyn, member_groups); none of them changes the state a step leaves behind.  ValueError for an
-        unknown name."""
+        spectral_early, split_dyn, member_groups, physics_storage32); none of them changes the state a step leaves behind.
+        ValueError for an unknown name."""
         rc = self._lib.spd_model_set_option(self._m, name.encode(), int(value))
         if rc == _lib.SPD_E_ARG:
             raise ValueError("unknown option or value out of range: %s = %r" % (name, value))

@@ -182,3 +182,40 @@ def test_cfg5_through_the_ensemble_facade_equals_the_batched_model(spectral):
             assert np.array_equal(ens.members[i][name], one.get(name, i)), (i, name)
     assert np.abs(ens.members[0]["t"] - ens.members[17]["t"]).max() > 0  # different noise for different members
     one.close()
+
+
+def test_fp32_storage_of_the_physics_only_arrays_loses_nothing(spectral):
+    """cfg 5 keeps what only the column physics reads back (its time-level-1 inputs, tt_rsw / rad_tau2 / rad_strat_corr, the
+    diagnostics-only outputs) as float32 in memory.  The fp32 kernel narrows each of those values before it uses it anyway, so
+    the trajectory must be BITWISE the one of the same arithmetic over fp64 storage (model option physics_storage32 = 0) --
+    across shortwave and other steps, multi-step calls and a precision switch in mid-run -- while the arrays themselves are
+    float32 on the device and float64 at the boundary."""
+    a = make_ensemble(spectral, 4, False, True)   # fp64 physics first: the switch below converts what IT left in memory
+    b = make_ensemble(spectral, 4, False, True)
+    b.set_option("physics_storage32", 0)
+    for m in (a, b):
+        m.run(4)
+        m.set_physics_precision(True)
+        m.run(1)
+        m.run(40)
+    assert a.device_view("rad_tau2").dtype == torch.float32 and b.device_view("rad_tau2").dtype == torch.float64
+    assert a.device_view("t_grid_phys").dtype == torch.float32 and a.device_view("t_grid").dtype == torch.float64
+    assert a.device_view("ssrd").dtype == torch.float64  # (the coupler reads it too: stays fp64)
+    for name in a.variables():
+        x, y = a.get(name, 2), b.get(name, 2)
+        assert x.dtype == y.dtype and np.array_equal(x, y), name
+    # the boundary converts: what get() returns is the float32 array on the device, widened
+    tau = a.device_view("rad_tau2")[2].cpu().numpy().astype(np.float64)      # [4][8][48][96]
+    assert np.array_equal(tau.transpose(3, 2, 1, 0), a.get("rad_tau2", 2))
+    # ... in both directions, and back to fp64 storage without a change of value
+    olr = a.get("olr", 1)
+    a.set("olr", olr, 3)
+    assert np.array_equal(a.get("olr", 3), olr)
+    a.set_option("physics_storage32", 0)
+    assert a.device_view("rad_tau2").dtype == torch.float64 and np.array_equal(a.get("rad_tau2", 2), b.get("rad_tau2", 2))
+    for m in (a, b):
+        m.run(5)
+    for name in ("vor", "div", "t", "tr", "ps", "tt_rsw", "precnv"):
+        assert np.array_equal(a.get(name, 0), b.get(name, 0)), name
+    a.close()
+    b.close()
