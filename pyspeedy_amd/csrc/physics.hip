@@ -872,13 +872,18 @@ static int physics_waves(int) {
     return waves;
 }
 // launch-bounds variant of the fp32 kernels (waves per SIMD the register allocator leaves room for: 2 or 3; a 4-wave build
-// spilled 368 bytes per lane and was 40 % slower): profiles/r02_cfg5_fp32_vs_fp64.txt
-static int physics_waves32() {
-    static const int waves = [] {
+// spilled 368 bytes per lane and was 40 % slower): profiles/r02_cfg5_fp32_vs_fp64.txt.  By the size of the launch since round 4
+// (profiles/r04_cfg5_fp32_storage.txt): the 3-wave build (168 VGPRs, 100 bytes of scratch) wins when the launch brings more than
+// two wavefronts to a SIMD -- 32 members in one launch: 48 against 59 us --, the 2-wave build (205 VGPRs, no scratch) when it
+// does not -- the 10 / 11-member launches of the default grouped plan at 32 members: 0.144 against 0.150 ms per step.  Same
+// bits either way (-ffp-contract=on; tests/test_variants_spawn.py).  PYSPEEDY_AMD_PHYS_WAVES32=2|3 forces one.
+static int physics_waves32(int nmembers) {
+    static const int forced = [] {
         const char *e = getenv("PYSPEEDY_AMD_PHYS_WAVES32");
-        return e ? atoi(e) : 3;
+        return e ? atoi(e) : 0;
     }();
-    return waves;
+    if (forced) return forced;
+    return nmembers * (NG / kPhysThreads) <= 2 * 1024 ? 2 : 3;  // wavefronts of the launch against two per SIMD of the GPU
 }
 
 template <int W, bool FUSED, bool KEEP, typename R, bool S32 = false>
@@ -896,7 +901,7 @@ hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nme
     const ModelPtrs mp{};
     const DynDeviceTables md{};
     if (fp32) {
-        switch (physics_waves32()) {
+        switch (physics_waves32(nmembers)) {
             case 2: return launch_physics<2, false, false, float>(T, a, 0, nmembers, mp, md, 1, s);
             default: return launch_physics<3, false, false, float>(T, a, 0, nmembers, mp, md, 1, s);
         }
@@ -915,13 +920,13 @@ hipError_t run_physics(const DeviceTables &T, const spd_physics_args &a, int nme
 hipError_t run_dyn_physics(const ModelPtrs &P, const DynDeviceTables &D, const DeviceTables &T, const spd_physics_args &a,
                            int first, int nmembers, int fp32, int store32, int diag, hipStream_t s) {
     if (fp32 && store32) {  // cfg 5: fp32 arithmetic, physics-only arrays stored as fp32
-        switch (physics_waves32()) {
+        switch (physics_waves32(nmembers)) {
             case 2: return launch_physics<2, true, true, float, true>(T, a, first, nmembers, P, D, diag, s);
             default: return launch_physics<3, true, true, float, true>(T, a, first, nmembers, P, D, diag, s);
         }
     }
     if (fp32) {  // (model option physics_storage32 = 0: the same arithmetic over fp64 storage, for comparison)
-        switch (physics_waves32()) {
+        switch (physics_waves32(nmembers)) {
             case 2: return launch_physics<2, true, true, float>(T, a, first, nmembers, P, D, diag, s);
             default: return launch_physics<3, true, true, float>(T, a, first, nmembers, P, D, diag, s);
         }

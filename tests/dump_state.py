@@ -15,6 +15,9 @@ def main():
     bc = np.load(os.path.join(ROOT, "pyspeedy_amd", "data", "example_bc.npz"))
     model = EnsembleModel(pyspeedy_amd.ModSpectral(), 3)
     model.set_bc({k: bc[k] for k in bc.files})
+    if os.environ.get("DUMP_STATE_CFG5"):  # BASELINE cfg 5: SPPT on, fp32 column physics (with its fp32 storage)
+        model.set_sppt(True, seed=5, first_member_id=0)
+        model.set_physics_precision(True)
     model.run(40)
     np.savez(sys.argv[1], **{n: model.get(n, 1) for n in SHAPES})
 
