@@ -35,10 +35,12 @@ What the ONE JSON line of rank 0 holds:
   cfg4_strong (N > 1)   BASELINE cfg 4 to the letter beside the weak headline: 64 members in total, block-sharded.
   collective            what the collective layer saw, gathered through it (RCCL on the GPU box): ranks_seen, device_of_rank[],
                         the checksum of the boundary fields every rank received in the start-up broadcast and whether they agree.
-  one_process (N > 1)   the reference's own shape beside the process-per-GPU headline: rank 0 ALONE drives all N GPUs -- containers
+  one_process (N > 1)   the reference's own shape beside the process-per-GPU headline: ONE process drives all N GPUs -- containers
                         in blocks per device, boundary fields device to device, spd_parallel_step[_begin / _end] once per model
-                        step over all containers -- while the other ranks sit idle on the host.  `--one-process` runs only this,
-                        in one process, and makes it the line's value.
+                        step over all containers.  Measured by a child process of rank 0 (`bench.py --one-process`) after the
+                        ranks have released their models and while they sit idle on the host; a failure there is recorded in
+                        the object and does not cost the line its headline.  `--one-process` alone runs only this and makes it
+                        the line's value.
   drop_in_step (N = 1)  the reference-shaped host loop: spd_parallel_step once per model step (step + range check + codes
                         back), synchronous and in the overlapped begin / end form, over independent containers.
   every_step_stores (N = 1)  the step with every store of the reference restored (all 91 spectral->grid transforms, the
@@ -82,6 +84,12 @@ CFG2_SIZES = (1, 8, 64, 512, 4096, 16384)  # fields per launch of the cfg2_trans
 # the itemised lists).  Transforms: SURVEY 8d's contract figure S + G per field.
 COLUMN_DOUBLES = {"column_sw": 254, "column": 243}  # doubles moved per column (dynamics 50 in / 55 out + physics)
 DIAG_DOUBLES = 39           # of those, stores of diagnostics nothing on the device reads: only on the last step of a call
+# cfg 5 with fp32 storage: values per column that travel as 4 bytes instead of 8 -- the 27 time-level-1 inputs, the
+# persisted radiation state (read on steps without shortwave: tt_rsw 8 + rad_tau2 30 + rad_strat_corr 2; written on shortwave
+# steps: 8 + 32 + 2), 35 of the 39 diagnostics-only stores; and the fields per member the spectral -> grid launch writes as fp32
+COLUMN_FLOATS = {"column_sw": 27 + 42, "column": 27 + 40}
+DIAG_FLOATS = 35
+S2G_FLOAT_FIELDS = 27
 COUPLER_DOUBLES = (55, 29)  # per column: with the climatologies interpolated (first coupling of a day) / re-used
 ALGO_BYTES = {
     "geopotential": 17 * S_BYTES,
@@ -377,14 +385,20 @@ def kernel_table(model, M, inv_per_member, sppt):
     extra = 8 if sppt else 0  # the column kernel also reads the SPPT pattern
     # average over the 36 launches of the pass: the diagnostics-only stores happen on the last step only (unless the model
     # is told to store them every step), the coupler interpolates its climatologies on one step of the day
-    diag = DIAG_DOUBLES * (0.0 if model.config()["diag_every_step"] else 35.0 / 36.0)
+    skipped = 0.0 if model.config()["diag_every_step"] else 35.0 / 36.0  # share of the launches that do not store the diagnostics
+    diag = DIAG_DOUBLES * skipped
+    store32 = model.config()["physics_storage32"]
     coupler = (COUPLER_DOUBLES[0] + 35 * COUPLER_DOUBLES[1]) / 36.0
     rows = []
     for name, (mean_ms, min_ms, n, units) in prof.items():
-        if name == "spec2grid" or name == "grid2spec":
+        if name == "spec2grid":
+            members = units // (inv_per_member + extra)
+            algo = (S_BYTES + G_BYTES) * units - (G_BYTES // 2) * S2G_FLOAT_FIELDS * members * (1 if store32 else 0)
+        elif name == "grid2spec":
             algo = (S_BYTES + G_BYTES) * units
         elif name in COLUMN_DOUBLES:
-            algo = (COLUMN_DOUBLES[name] + extra - diag) * 8 * NG * units
+            floats = (COLUMN_FLOATS[name] + DIAG_FLOATS * (1.0 - skipped)) if store32 else 0.0
+            algo = ((COLUMN_DOUBLES[name] + extra - diag) * 8 - floats * 4) * NG * units
         elif name in ("physics_sw", "physics"):
             algo = (COLUMN_DOUBLES["column_sw" if name == "physics_sw" else "column"] - 105 + 18 + extra) * 8 * NG * units
         elif name == "sppt":  # the AR(1) update of the spectral pattern; its 8 transforms per member ride in spec2grid
@@ -738,6 +752,21 @@ def file_flag(what, set_it=False, wait_seconds=0.0):
     return False
 
 
+def one_process_child(n_gpus, extra):
+    """`bench.py --one-process --gpus N ...` as a child process; its `one_process` object, or {"error": ...}."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                             "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--one-process", "--gpus", str(n_gpus), "--steps", "200", "--no-cpu-baseline"]
+    try:
+        run = subprocess.run(cmd + extra, env=env, capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+        if run.returncode != 0 or len(lines) != 1:
+            return {"error": "exit code %s: %s" % (run.returncode, (run.stderr or run.stdout)[-600:])}
+        return json.loads(lines[0])["one_process"]
+    except (OSError, ValueError, KeyError, subprocess.TimeoutExpired) as exc:
+        return {"error": "%s: %s" % (type(exc).__name__, exc)}
+
+
 def run_one_process(args):
     """`--one-process`: this process alone drives --gpus devices; the line's value is the begin / end loop over all containers."""
     baseline = None if args.no_cpu_baseline else cpu_baseline(args.cpu_seconds)  # (before the GPU is touched)
@@ -877,16 +906,13 @@ def run_rank(args):
             # The reference's own shape beside the process-per-GPU headline: ONE process (rank 0) drives every GPU through
             # spd_parallel_step.  The other ranks have released their models and wait on the host (a file, not a collective: a
             # pending RCCL barrier would keep a kernel spinning on the very GPUs that are being measured).
+            # The measurement runs in a CHILD process of rank 0 (`bench.py --one-process`): it is ONE process by construction,
+            # and whatever its first contact with a second GPU does, the headline of this line survives it.
             barrier()
             if rank == 0:
-                try:
-                    op = one_process_leg(n_gpus, total_members, 200, "the headline's ensemble (%d members, %d per GPU) driven by ONE "
-                                         "process over %d GPUs" % (total_members, M, n_gpus))
-                    if args.scaling == "weak" and args.members is None:
-                        op["cfg4_strong"] = one_process_leg(n_gpus, 64, 200, "BASELINE cfg 4 as worded: 64 members, %d per GPU, ONE "
-                                                            "process over %d GPUs" % (max(1, 64 // n_gpus), n_gpus))
-                except (Exception, SystemExit) as exc:  # first contact with a second GPU must not cost the line its headline
-                    op = {"error": "%s: %s" % (type(exc).__name__, exc)}
+                op = one_process_child(n_gpus, ["--scaling", "strong", "--members", str(total_members)])
+                if "error" not in op and args.scaling == "weak" and args.members is None:
+                    op["cfg4_strong"] = one_process_child(n_gpus, ["--scaling", "strong", "--members", "64"])
                 legs["one_process"] = op
                 file_flag("one_process_done", set_it=True)
             else:
@@ -895,7 +921,9 @@ def run_rank(args):
     if rank == 0:
         ms_step, ms_min = median(region_s) / args.steps * 1e3, min(region_s) / args.steps * 1e3
         value = E.simulated_years_per_day(total_members, ms_step * 1e-3, STEPS_PER_YEAR)
-        achieved = (S_BYTES + G_BYTES) * nfields / (kern_ms * 1e-3) / 1e9
+        # (cfg 5 stores 27 of a member's fields as fp32: those count S + G / 2)
+        s2g_bytes = (S_BYTES + G_BYTES) * nfields - (G_BYTES // 2) * S2G_FLOAT_FIELDS * M * (1 if cfg["physics_storage32"] else 0)
+        achieved = s2g_bytes / (kern_ms * 1e-3) / 1e9
         traffic, traffic_src = load_traffic(nfields)
         physics = "fp64 column physics" if args.config == "cfg4" else "SPPT on, fp32 arithmetic in the column physics (fp64 state)"
         all_cores = (baseline or {}).get("all_cores")
@@ -927,7 +955,8 @@ def run_rank(args):
                 "kernel": "spec2grid_table_kernel (inverse Legendre + inverse FFT-96, with vort2vel / gradient applied while "
                           "staging the wind and pressure-gradient fields of each member), %d fields/launch" % nfields,
                 "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                "algorithmic_bytes_per_field": S_BYTES + G_BYTES, "avg_launch_ms": kern_ms, "launches_timed": launches,
+                "algorithmic_bytes_per_field": S_BYTES + G_BYTES, "algorithmic_bytes_per_launch": s2g_bytes,
+                "avg_launch_ms": kern_ms, "launches_timed": launches,
                 "measured_in": "%d further regions of %d steps issued in the serial plan (one member group on one stream: the "
                                "duration of a kernel that shares the GPU with another group's kernels is not its own); HIP events "
                                "attached to the dispatch of every spec2grid launch of those regions" % (len(serial_s), args.steps),

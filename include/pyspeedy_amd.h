@@ -232,8 +232,10 @@ int spd_model_profile_read_kernels(spd_model_handle m, double *mean_ms, double *
  * and step (77, or the reference's 91 with PYSPEEDY_AMD_PRUNE_DEAD=0), cfg[1] = 1 when every step stores the diagnostics-only
  * physics outputs (PYSPEEDY_AMD_DIAG_EVERY_STEP=1; default 0: only the last step of a multi-step call does), cfg[2] = member
  * groups stepped on separate streams (PYSPEEDY_AMD_CHUNKS / "member_groups"; the configured number), cfg[3] = 1 for separate dynamics / physics launches, cfg[4] = 1
- * when spectral_step_kernel also computes the next step's geopotential, cfg[5] = 1 when it carries the land / sea-ice coupling */
-int spd_model_get_config(spd_model_handle m, int32_t *cfg /* 6 */);
+ * when spectral_step_kernel also computes the next step's geopotential, cfg[5] = 1 when it carries the land / sea-ice coupling,
+ * cfg[6] = 1 for fp32 arithmetic in the column physics, cfg[7] = 1 while the arrays only the column physics reads back are stored
+ * as fp32 (spd_model_set_physics_precision) */
+int spd_model_get_config(spd_model_handle m, int32_t *cfg /* 8 */);
 /* The launch-plan switches that can change on a live model, by name (the environment variables of README.md set the same
  * fields when the model is created; none of them changes the state a step leaves behind):
  *   "diag_every_step"      0 / 1   store the diagnostics-only physics outputs on every step of a multi-step call

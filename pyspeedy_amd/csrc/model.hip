@@ -1242,6 +1242,8 @@ int spd_model_get_config(spd_model_handle m, int32_t *cfg) {
     cfg[3] = m->split_dyn_physics ? 1 : 0;
     cfg[4] = m->fold_geo ? 1 : 0;
     cfg[5] = m->coupler_in_spectral ? 1 : 0;
+    cfg[6] = m->phys_fp32;
+    cfg[7] = m->stored32 ? 1 : 0;
     return SPD_OK;
 }
 

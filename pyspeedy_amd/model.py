@@ -245,10 +245,11 @@ class EnsembleModel:
 
     def config(self):
         """How the step is configured: dict(inv_per_member, diag_every_step, chunks, split_dyn) -- spd_model_get_config."""
-        cfg = (C.c_int32 * 6)()
+        cfg = (C.c_int32 * 8)()
         check(self._lib.spd_model_get_config(self._m, cfg), "spd_model_get_config")
         return dict(inv_per_member=cfg[0], diag_every_step=bool(cfg[1]), chunks=cfg[2], split_dyn=bool(cfg[3]),
-                    fold_geo=bool(cfg[4]), coupler_in_spectral=bool(cfg[5]))
+                    fold_geo=bool(cfg[4]), coupler_in_spectral=bool(cfg[5]), physics_fp32=bool(cfg[6]),
+                    physics_storage32=bool(cfg[7]))
 
     def set_option(self, name, value):
         """A launch-plan switch of the live model by name (spd_model_set_option: diag_every_step, coupler_in_spectral,
