@@ -7,11 +7,14 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pyspeedy_amd.h"
@@ -693,10 +696,11 @@ std::map<int64_t, PendingStep> g_pending;
 // Host-side order of the device work of the multi-group paths, for tests: (kind, group) pairs, kind 1 = step + check
 // enqueued, 2 = waiting for the check of that group started, 3 = finished.  Off unless spd_driver_trace(1) was called.
 std::atomic<bool> g_trace_on{false};
+std::mutex g_trace_mutex;  // (its own lock: issue threads record while the calling thread holds the library's)
 std::vector<int32_t> g_trace;
 static void trace(int kind, int group) {
     if (!g_trace_on.load(std::memory_order_relaxed)) return;
-    std::lock_guard<std::recursive_mutex> lock(g_mutex);
+    std::lock_guard<std::mutex> lock(g_trace_mutex);
     g_trace.push_back(kind);
     g_trace.push_back(group);
 }
@@ -854,6 +858,90 @@ static void issue_group(const GroupPlan &g, GroupRun &r) {
     }
 }
 
+// One host thread per GPU for the enqueue of a step.  A model step is six launches per device model; a host that drives N GPUs
+// from one process -- the reference's own shape -- would issue 12 N launches per step from one thread, and from about four GPUs
+// on the GPUs would wait for it (one launch costs the host 3-4 us, a 64-member step of one GPU lasts 270).  The calling thread
+// issues the groups of the first device itself and hands the groups of every other device to that device's worker; it holds
+// the library's lock all the while and waits for the workers before it goes on, so nothing else changes: a worker touches
+// nothing but the device models it was handed.  Workers are created on first use and live for the life of the process
+// (detached, asleep between calls).  PYSPEEDY_AMD_ISSUE_THREADS=0: everything from the calling thread; =2: a worker per device
+// MODEL even on one device (how the path is rehearsed on a one-GPU box).
+struct IssueWorker {
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool busy = false;
+    void loop() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return static_cast<bool>(job); });
+            std::function<void()> j = std::move(job);
+            job = nullptr;
+            lk.unlock();
+            j();
+            lk.lock();
+            busy = false;
+            cv.notify_all();
+        }
+    }
+    void submit(std::function<void()> j) {
+        std::lock_guard<std::mutex> lk(m);
+        job = std::move(j);
+        busy = true;
+        cv.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return !busy; });
+    }
+};
+std::map<int, IssueWorker *> g_issue_workers;  // by worker key (device, or device model in the rehearsal mode); under g_mutex
+
+static IssueWorker *issue_worker(int key) {
+    auto it = g_issue_workers.find(key);
+    if (it != g_issue_workers.end()) return it->second;
+    IssueWorker *w = new IssueWorker();  // (never destroyed: its thread may outlive every static of this library)
+    std::thread([w] { w->loop(); }).detach();
+    g_issue_workers[key] = w;
+    return w;
+}
+
+// Enqueue the step and check of every group; after_issue(i) runs on the CALLING thread for every group, in order.  (lock held)
+static void issue_all(const std::vector<GroupPlan> &groups, std::vector<GroupRun> &run) {
+    static const int mode = [] {
+        const char *e = getenv("PYSPEEDY_AMD_ISSUE_THREADS");
+        return e ? atoi(e) : 1;
+    }();
+    std::map<int, std::vector<size_t>> by_key;  // worker key -> groups, in argument order
+    for (size_t i = 0; i < groups.size(); ++i) by_key[mode == 2 ? static_cast<int>(i) : groups[i].batch->device].push_back(i);
+    if (mode == 0 || by_key.size() < 2) {
+        for (size_t i = 0; i < groups.size(); ++i) {
+            issue_group(groups[i], run[i]);
+            trace(1, static_cast<int>(i));
+        }
+        return;
+    }
+    std::vector<IssueWorker *> busy;
+    const int mine = by_key.begin()->first;
+    for (auto &kv : by_key) {
+        if (kv.first == mine) continue;
+        IssueWorker *w = issue_worker(kv.first);
+        const std::vector<size_t> *list = &kv.second;
+        w->submit([list, &groups, &run] {
+            for (size_t i : *list) {
+                issue_group(groups[i], run[i]);
+                trace(1, static_cast<int>(i));
+            }
+        });
+        busy.push_back(w);
+    }
+    for (size_t i : by_key[mine]) {
+        issue_group(groups[i], run[i]);
+        trace(1, static_cast<int>(i));
+    }
+    for (IssueWorker *w : busy) w->wait();
+}
+
 // Wait for the check of one group.  (lock NOT held: other host threads may work on other containers meanwhile)
 static void collect_group(const GroupPlan &g, GroupRun &r, std::vector<int32_t> &codes) {
     Batch &b = *g.batch;
@@ -909,10 +997,7 @@ int spd_parallel_step(const int64_t *state_cnts, const int64_t *control_cnts, in
     // any of them, so the devices (and the models that share one) work side by side; a model that fails does not keep the
     // others from being stepped; and the lock is given up while the host waits, so that other host threads can step THEIR
     // containers meanwhile (the reference's parallel_step is `!f2py threadsafe`).
-    for (size_t i = 0; i < groups.size(); ++i) {
-        issue_group(groups[i], run[i]);
-        trace(1, static_cast<int>(i));
-    }
+    issue_all(groups, run);
     lock.unlock();
     std::vector<std::vector<int32_t>> codes(groups.size());
     for (size_t i = 0; i < groups.size(); ++i) {
@@ -931,11 +1016,10 @@ int spd_parallel_step_begin(const int64_t *state_cnts, const int64_t *control_cn
     LOCK;
     PendingStep p;
     if (int rc = plan_step(state_cnts, control_cnts, n, p.plan, p.run, "spd_parallel_step_begin")) return rc;
+    issue_all(p.plan->groups, p.run);  // (a group that cannot be issued reports at _end; the others go ahead)
     for (size_t i = 0; i < p.run.size(); ++i) {
         const GroupPlan &g = p.plan->groups[i];
         GroupRun &r = p.run[i];
-        issue_group(g, r);  // (a group that cannot be issued reports at _end; the others go ahead)
-        trace(1, static_cast<int>(i));
         if (r.slot < 0) continue;
         for (int64_t id : g.control_ids) {  // the dates run ahead of the check; _end puts a failed member's date back
             auto ci = g_controls.find(id);
@@ -1036,14 +1120,14 @@ int spd_broadcast_boundary_stats(int32_t *peer_copies, int32_t *local_copies) {
 }
 
 int spd_driver_trace(int32_t on) {
-    LOCK;
+    std::lock_guard<std::mutex> lock(g_trace_mutex);
     g_trace_on = on != 0;
     g_trace.clear();
     return SPD_OK;
 }
 
 int spd_driver_trace_read(int32_t *pairs, int32_t capacity) {
-    LOCK;
+    std::lock_guard<std::mutex> lock(g_trace_mutex);
     const int n = static_cast<int>(g_trace.size() / 2);
     if (pairs)
         for (int i = 0; i < n && i < capacity; ++i) {

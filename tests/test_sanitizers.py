@@ -57,7 +57,10 @@ def test_driver_logic_under_asan_ubsan(tmp_path):
 def test_driver_logic_under_tsan(tmp_path):
     run(["g++", "-std=c++17", "-pthread", "-Wall", "-Werror", "-fsanitize=thread", "-g", "-O1", *DRIVER_SOURCES, "-o", "driver_tsan"],
         tmp_path)
-    p = subprocess.run([str(tmp_path / "driver_tsan"), "all"], cwd=tmp_path, capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1"))
-    assert p.returncode == 0 and "driver sanitize ok" in p.stdout and "ThreadSanitizer" not in p.stderr, \
-        p.stdout[-3000:] + p.stderr[-8000:]
+    # the enqueue of a step goes out on one host thread per device (driver.cpp: issue_all): the default (the two pretend devices
+    # of the stub: the calling thread and one worker), a worker per device model, and everything from the calling thread
+    for mode in ("1", "2", "0"):
+        p = subprocess.run([str(tmp_path / "driver_tsan"), "all"], cwd=tmp_path, capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1", PYSPEEDY_AMD_ISSUE_THREADS=mode))
+        assert p.returncode == 0 and "driver sanitize ok" in p.stdout and "ThreadSanitizer" not in p.stderr, \
+            "PYSPEEDY_AMD_ISSUE_THREADS=" + mode + "\n" + p.stdout[-3000:] + p.stderr[-8000:]
