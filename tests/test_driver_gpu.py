@@ -261,7 +261,10 @@ def test_several_device_models_in_one_parallel_step_are_enqueued_before_any_wait
     drv.ok(drv.L.spd_driver_trace(1))
     assert drv.parallel_step(together, ctl_t) == [0, 0, 0, 0]
     assert [drv.stats(s)[1] for s in together] == [2, 2, 2, 2] and drv.stats(0)[0] == alive0 + 2 + 4
-    assert _trace(drv) == [(1, 0), (1, 1), (2, 0), (3, 0), (2, 1), (3, 1)]  # both models enqueued, then the waits
+    # both models enqueued, then the waits (with a host thread per device model -- PYSPEEDY_AMD_ISSUE_THREADS=2, the rehearsal of
+    # the one-thread-per-GPU enqueue -- the two enqueues may be recorded in either order)
+    tr = _trace(drv)
+    assert sorted(tr[:2]) == [(1, 0), (1, 1)] and tr[2:] == [(2, 0), (3, 0), (2, 1), (3, 1)]
     for _ in range(38):
         assert drv.parallel_step(together, ctl_t) == [0, 0, 0, 0]
     # ... and in the overlapped form
@@ -269,7 +272,7 @@ def test_several_device_models_in_one_parallel_step_are_enqueued_before_any_wait
     n = 4
     token, codes = C.c_int64(), (C.c_int32 * n)()
     drv.ok(drv.L.spd_parallel_step_begin((C.c_int64 * n)(*together), (C.c_int64 * n)(*ctl_t), n, C.byref(token)))
-    assert _trace(drv) == [(1, 0), (1, 1)]
+    assert sorted(_trace(drv)) == [(1, 0), (1, 1)]
     drv.ok(drv.L.spd_parallel_step_end(token, codes))
     assert list(codes) == [0, 0, 0, 0] and _trace(drv)[2:] == [(2, 0), (3, 0), (2, 1), (3, 1)]
     drv.ok(drv.L.spd_driver_trace(0))
