@@ -261,8 +261,9 @@ int spd_model_set_option(spd_model_handle m, const char *name, int32_t value);
  * it uses it and computes each one it stores in fp32: nothing is lost, 13 % of the column kernel's and 11 % of the
  * spectral -> grid launch's bytes are).  spd_model_get / _set (and the driver's spd_get / spd_set) keep speaking fp64 and
  * convert; spd_model_device_ptr hands out the array as stored: ask spd_model_var_storage (8 or 4 bytes per element).
- * Switching converts the arrays in place (synchronises the device); spd_model_set_control with another physics_fp32 and
- * spd_model_copy_member from a model with another setting switch the receiving model first. */
+ * Switching converts the arrays in place (synchronises the device); spd_model_set_control with another physics_fp32 switches
+ * the model first, and spd_model_copy_member makes the receiving model take over the source's physics precision (its members
+ * then all run with it: members of one model share their control block). */
 int spd_model_set_physics_precision(spd_model_handle m, int fp32);
 int spd_model_var_storage(spd_model_handle m, const char *name);
 /* registry scalars land_coupling_flag, sst_anomaly_coupling_flag, increase_co2 (model_state_def.py:305-418) */

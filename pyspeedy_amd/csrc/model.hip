@@ -1413,7 +1413,10 @@ int spd_model_copy_member(spd_model_handle dst, int di, spd_model_handle src, in
     hipStream_t s = static_cast<hipStream_t>(stream);
     M_HIP(hipSetDevice(dst->ctx->device));
     M_HIP(hipDeviceSynchronize());  // the two models may have been driven on different streams
-    // whole allocations are copied as they are: both models must store them the same way
+    // whole allocations are copied as they are: both models must store them the same way, and the storage belongs to the
+    // precision of the column physics (fp32 storage is only ever read by the fp32 kernel): the receiving model takes both over
+    dst->phys_fp32 = src->phys_fp32;
+    dst->phys_store32 = src->phys_store32;
     if (int rc = apply_storage(dst, src->stored32)) return rc;
     dst->surf_cache_valid = dst->phi_ahead = false;
     for (const auto &kv : src->reg) {

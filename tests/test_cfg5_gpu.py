@@ -219,3 +219,42 @@ def test_fp32_storage_of_the_physics_only_arrays_loses_nothing(spectral):
         assert np.array_equal(a.get(name, 0), b.get(name, 0)), name
     a.close()
     b.close()
+
+
+def test_cfg5_survives_the_drivers_regrouping(spectral):
+    """The fp32 storage travels with the physics precision wherever the driver moves a member: set BEFORE the members are
+    initialised (each is initialised through a scratch one-member model and copied back), and across a split of the batch in
+    mid-run (one member stepped on its own, then everybody again, which gathers them anew).  Every member stays, bit for bit, on
+    the trajectory of the same member of one batched model that was never regrouped."""
+    from datetime import datetime
+    import pyspeedy_amd
+    from pyspeedy_amd import speedy_driver as drv
+    from pyspeedy_amd.model import EnsembleModel
+    from pyspeedy_amd.speedy import SpeedyEns
+    M = 5
+    ens = SpeedyEns(M, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 2))
+    ens.set_physics_precision(True)  # no SPPT here: an SPPT member keeps its own model and is never gathered again
+    for member in ens:
+        member.set_bc()
+    states, controls = [m._state_cnt for m in ens], [m._control_cnt for m in ens]
+    for _ in range(4):
+        assert (drv.parallel_step(states, controls) == 0).all()
+    assert drv.step(states[2], controls[2]) == 0                      # takes the batch apart
+    assert drv.driver_stats(states[0])[1] == 1
+    others = [i for i in range(M) if i != 2]
+    assert (drv.parallel_step([states[i] for i in others], [controls[i] for i in others]) == 0).all()   # the others catch up
+    for _ in range(3):
+        assert (drv.parallel_step(states, controls) == 0).all()      # ... and all five are one model again
+    assert drv.driver_stats(states[0])[1] == M
+    model, _ = drv.device_model(states[0])
+    assert model.config()["physics_fp32"] and model.config()["physics_storage32"]
+    one = EnsembleModel(spectral, M)
+    one.init_sst_anom(1)
+    with np.load(pyspeedy_amd.example_bc_file()) as z:
+        one.set_bc({k: z[k] for k in z.files})
+    one.set_physics_precision(True)
+    one.run(8)
+    for i in range(M):
+        for name in ("t", "vor", "tr", "ps", "rad_tau2", "tt_rsw"):
+            assert np.array_equal(ens.members[i][name], one.get(name, i)), (i, name)
+    one.close()
