@@ -250,9 +250,9 @@ def test_cfg5_survives_the_drivers_regrouping(spectral):
     assert model.config()["physics_fp32"] and model.config()["physics_storage32"]
     one = EnsembleModel(spectral, M)
     one.init_sst_anom(1)
+    one.set_physics_precision(True)  # (before the initialisation, as above: first_step already runs the fp32 physics)
     with np.load(pyspeedy_amd.example_bc_file()) as z:
         one.set_bc({k: z[k] for k in z.files})
-    one.set_physics_precision(True)
     one.run(8)
     for i in range(M):
         for name in ("t", "vor", "tr", "ps", "rad_tau2", "tt_rsw"):
