@@ -658,7 +658,7 @@ def one_process_leg(n_devices, members_total, steps, what):
         root[state_name] = np.asarray(bc[file_name], dtype=np.float64)
     cnts = [m._state_cnt for m in ens.members]
     drv.broadcast_boundary(cnts, 0)
-    peer, local = drv.broadcast_boundary_stats()
+    peer, local, collective = drv.broadcast_boundary_stats()
     probe = ens.members[-1]["sst12"]  # what arrived in the last container (on the last device) is what the root holds
     arrived = bool(np.array_equal(probe, np.asarray(bc["sst"], dtype=np.float64)))
     for i, member in enumerate(ens.members):
@@ -677,7 +677,9 @@ def one_process_leg(n_devices, members_total, steps, what):
     ms = timing["begin_end_ms_per_step"]
     out = {"workload": what, "processes": 1, "devices_asked": n_devices, "devices_used": len(devices), "containers": members_total,
            "members_per_device": [sum(1 for c in cnts if drv.modelstate_device(c) == d) for d in devices],
-           "device_models": models, "boundary_broadcast": {"peer_copies": peer, "local_copies": local, "arrived_intact": arrived},
+           "device_models": models, "boundary_broadcast": {"collective_devices": collective, "peer_copies": peer, "local_copies": local,
+                                                         "transport": "rccl" if collective else ("peer copies" if peer else "local copies only"),
+                                                         "arrived_intact": arrived},
            "setup_seconds": t_setup, "ms_per_step": ms,
            "value": members_total * 86400.0 / (ms * 1e-3 * STEPS_PER_YEAR), "unit": "simulated-years/day",
            "current_device_preserved": torch.cuda.current_device() == before}

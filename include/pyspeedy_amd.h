@@ -292,6 +292,13 @@ int spd_model_copy_vars(spd_model_handle dst, int dst_member, spd_model_handle s
  * `stream` is a stream of the DESTINATION device, which is the current device when the call returns */
 int spd_model_copy_vars_enqueue(spd_model_handle dst, int dst_member, spd_model_handle src, int src_member,
                                 const char *const *names, int n_names, void *stream);
+/* ONE collective broadcast of the named (fp64) variables between device models that live on different GPUs of this process:
+ * member members[root] of models[root] into member members[i] of every other models[i] -- RCCL (ncclBroadcast in one group call,
+ * single-process communicators) over xGMI, on each device's null stream; the caller synchronises the devices before and
+ * after.  RCCL (librccl.so.1) is loaded when this is first called; SPD_E_DEVICE with the reason when it cannot be.  n = 1 is a
+ * broadcast to nobody (it still initialises the communicator). */
+int spd_model_broadcast_vars(const spd_model_handle *models, const int *members, int n, int root, const char *const *names,
+                             int n_names);
 
 #ifdef __cplusplus
 }

@@ -307,9 +307,10 @@ module pyspeedy_amd_c
             integer(c_int64_t), intent(in) :: state_cnts(*)
             integer(c_int32_t), value :: n, root     ! root: 0-based index into state_cnts
         end function
-        integer(c_int) function spd_broadcast_boundary_stats(peer_copies, local_copies) bind(C, name="spd_broadcast_boundary_stats")
+        integer(c_int) function spd_broadcast_boundary_stats(peer_copies, local_copies, collective_devices) &
+                bind(C, name="spd_broadcast_boundary_stats")
             import :: c_int, c_int32_t
-            integer(c_int32_t), intent(out) :: peer_copies, local_copies
+            integer(c_int32_t), intent(out) :: peer_copies, local_copies, collective_devices
         end function
     end interface
 end module pyspeedy_amd_c

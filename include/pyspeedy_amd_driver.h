@@ -72,15 +72,19 @@ int spd_modelstate_close(int64_t state_cnt);
  *      spd_parallel_step over containers of several devices gathers and steps them per device and enqueues every device's
  *      step and range check before it waits for any, so the GPUs work side by side.  spd_broadcast_boundary copies the shared
  *      boundary fields (orog, fmask_orig, alb0, veg_high, veg_low, stl12, snowd12, soil_wc_l1..3, sst12, sea_ice_frac12 and,
- *      when the lengths agree, sst_anom) of container `root` into all the others, device to device over xGMI. ---- */
+ *      when the lengths agree, sst_anom) of container `root` into all the others, device to device: ONE RCCL broadcast over
+ *      xGMI to the other GPUs, local copies on each of them. ---- */
 int spd_device_count(int32_t *n_devices);
 int spd_set_device_placement(int32_t n_devices);
 int spd_modelstate_init_on(int64_t *state_cnt, int32_t device);
 int spd_modelstate_device(int64_t state_cnt, int32_t *device);
 int spd_broadcast_boundary(const int64_t *state_cnts, int32_t n, int32_t root);
-/* what the last spd_broadcast_boundary did: copies that crossed to another device (one per device that holds a destination:
- * the first container there receives from the root, the others from that container) and copies that stayed on a device */
-int spd_broadcast_boundary_stats(int32_t *peer_copies, int32_t *local_copies);
+/* what the last spd_broadcast_boundary did: how many other GPUs received the fields through the ONE collective broadcast (RCCL
+ * over xGMI: the first container of the list on each of them; 0 when the transport was point-to-point), copies that crossed to
+ * another device one by one (hipMemcpyPeerAsync: the transport without RCCL, PYSPEEDY_AMD_BROADCAST=peer; and single fields a
+ * collective could not carry for everybody) and copies that stayed on a device (the other containers of a GPU take the fields from
+ * its first one) */
+int spd_broadcast_boundary_stats(int32_t *peer_copies, int32_t *local_copies, int32_t *collective_devices);
 
 /* ---- Datetime interface (:163-210) ---- */
 int spd_create_datetime(int32_t year, int32_t month, int32_t day, int32_t hour, int32_t minute, int64_t *datetime_cnt);

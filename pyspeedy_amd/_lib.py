@@ -125,8 +125,9 @@ _SIGNATURES = {
     "spd_driver_trace_read": (C.c_int, [C.POINTER(C.c_int32), C.c_int32]),
     "spd_model_copy_vars": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_void_p]),
     "spd_model_copy_vars_enqueue": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_void_p]),
+    "spd_model_broadcast_vars": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_char_p), C.c_int]),
     "spd_modelstate_init_ensemble_on": (C.c_int, [C.POINTER(C.c_int64), C.c_int32, C.c_int32]),
-    "spd_broadcast_boundary_stats": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "spd_broadcast_boundary_stats": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "spd_modelstate_close": (C.c_int, [C.c_int64]),
     "spd_create_datetime": (C.c_int, [C.c_int32] * 5 + [C.POINTER(C.c_int64)]),
     "spd_get_datetime": (C.c_int, [C.c_int64] + [C.POINTER(C.c_int32)] * 5),

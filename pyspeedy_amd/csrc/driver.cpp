@@ -163,8 +163,8 @@ std::map<int, spd_handle> g_contexts;  // one context per device, alive for the 
 // plan of its last argument list and re-uses it while this has not moved (plan_step).
 uint64_t g_epoch = 1;
 struct BroadcastStats {
-    int peer_copies, local_copies;
-} g_broadcast_stats{0, 0};  // of the last spd_broadcast_boundary
+    int peer_copies, local_copies, collective_devices;
+} g_broadcast_stats{0, 0, 0};  // of the last spd_broadcast_boundary
 
 // The plan of an argument list: which of its containers are (all) the members of which device model.  Made by plan_step,
 // never changed afterwards, shared by the calls that use it.
@@ -1063,10 +1063,12 @@ int spd_parallel_step_end(int64_t token, int32_t *error_codes) {
 // The shared boundary fields (orography, masks, albedo, vegetation, the monthly climatologies and -- when both have
 // the same length -- the SST anomalies) of container `root` into every other container of the list, device to device: the
 // one exchange of a sharded ensemble, for a host that keeps all members in one process.  (One process per GPU: the same
-// broadcast is ensemble.broadcast_boundary_conditions over RCCL.)  The fields cross to another GPU ONCE: into the first
-// container of the list that lives there (hipMemcpyPeerAsync, xGMI); the other containers of that GPU take them from it with
-// local copies queued behind it on the same stream.  Devices are synchronised once before (the copies run on the null stream
-// of the destination device, which must not overtake what the models' own streams still hold) and once after the call.
+// broadcast is ensemble.broadcast_boundary_conditions over RCCL through torch.distributed.)  The fields cross to another GPU
+// ONCE: into the first container of the list that lives there -- all GPUs at once with one RCCL broadcast over xGMI
+// (spd_model_broadcast_vars; PYSPEEDY_AMD_BROADCAST=peer, or an RCCL that cannot be loaded: one hipMemcpyPeerAsync per GPU
+// instead, and spd_broadcast_boundary_stats says which it was) --; the other containers of that GPU take them from it with local
+// copies queued behind on the same stream.  Devices are synchronised once before (the copies run on the null stream of the
+// destination device, which must not overtake what the models' own streams still hold) and once after the call.
 int spd_broadcast_boundary(const int64_t *state_cnts, int32_t n, int32_t root) {
     if (n < 1 || !state_cnts || root < 0 || root >= n) return fail(SPD_E_ARG, "spd_broadcast_boundary: bad argument");
     static const char *const kBoundary[] = {"orog", "fmask_orig", "alb0", "veg_high", "veg_low", "stl12", "snowd12", "soil_wc_l1",
@@ -1088,20 +1090,49 @@ int spd_broadcast_boundary(const int64_t *state_cnts, int32_t n, int32_t root) {
     if (!sync_device(src_device)) return fail(SPD_E_DEVICE, "spd_broadcast_boundary: device error");
     for (auto &kv : on_device)
         if (kv.first != src_device && !sync_device(kv.first)) return fail(SPD_E_DEVICE, "spd_broadcast_boundary: device error");
-    g_broadcast_stats = {0, 0};
+    g_broadcast_stats = {0, 0, 0};
+    auto with_anomalies = [&](int i) {
+        const Batch &d = *dst[i]->batch, &s = *src->batch;
+        return d.sst_anom_allocated == s.sst_anom_allocated && d.n_months == s.n_months;
+    };
+    // ---- across GPUs: the first container of every other device receives from the root, all of them in one collective
+    std::vector<char> filled(n, 0);  // 1: has the 12 fixed fields; 2: and the anomalies
+    const char *transport = getenv("PYSPEEDY_AMD_BROADCAST");
+    std::vector<int> receivers;
+    for (auto &kv : on_device)
+        if (kv.first != src_device) receivers.push_back(kv.second.front());
+    if (!receivers.empty() && !(transport && std::strcmp(transport, "peer") == 0)) {
+        bool all_anom = true;
+        for (int i : receivers) all_anom = all_anom && with_anomalies(i);
+        std::vector<spd_model_handle> models{src->batch->model};
+        std::vector<int> members{src->member};
+        for (int i : receivers) {
+            models.push_back(dst[i]->batch->model);
+            members.push_back(dst[i]->member);
+        }
+        if (spd_model_broadcast_vars(models.data(), members.data(), static_cast<int>(models.size()), 0, kBoundary, all_anom ? 13 : 12) ==
+            SPD_OK) {
+            for (int i : receivers) filled[i] = all_anom ? 2 : 1;
+            g_broadcast_stats.collective_devices = static_cast<int>(receivers.size());
+        }  // (otherwise: point-to-point below; the stats show that no device was reached collectively)
+    }
     int rc = SPD_OK;
     for (auto &kv : on_device) {
         // the source of this device's copies: the root itself on its own device, elsewhere the first container that has
         // received everything (a container whose anomaly length differs from the root's receives 12 fields and cannot pass 13 on)
         std::shared_ptr<State> local = kv.first == src_device ? src : nullptr;
         for (int i : kv.second) {
-            const Batch &d = *dst[i]->batch, &s = *src->batch;
-            const bool anom = d.sst_anom_allocated == s.sst_anom_allocated && d.n_months == s.n_months;
-            const std::shared_ptr<State> &from = local ? local : src;
-            const bool crosses = from->batch->device != d.device;
-            rc = spd_model_copy_vars_enqueue(d.model, dst[i]->member, from->batch->model, from->member, kBoundary, anom ? 13 : 12, nullptr);
-            if (rc != SPD_OK) break;
-            ++(crosses ? g_broadcast_stats.peer_copies : g_broadcast_stats.local_copies);
+            const Batch &d = *dst[i]->batch;
+            const bool anom = with_anomalies(i);
+            if (filled[i] == 0 || (filled[i] == 1 && anom)) {
+                const std::shared_ptr<State> &from = local ? local : src;
+                const bool crosses = from->batch->device != d.device;
+                const char *const *names = filled[i] == 1 ? kBoundary + 12 : kBoundary;  // (only the anomalies are missing)
+                const int count = filled[i] == 1 ? 1 : (anom ? 13 : 12);
+                rc = spd_model_copy_vars_enqueue(d.model, dst[i]->member, from->batch->model, from->member, names, count, nullptr);
+                if (rc != SPD_OK) break;
+                ++(crosses ? g_broadcast_stats.peer_copies : g_broadcast_stats.local_copies);
+            }
             if (!local && anom) local = dst[i];
         }
         if (rc != SPD_OK) break;
@@ -1109,13 +1140,15 @@ int spd_broadcast_boundary(const int64_t *state_cnts, int32_t n, int32_t root) {
     // (the call is synchronous, like every call of this interface)
     for (auto &kv : on_device)
         if (!sync_device(kv.first) && rc == SPD_OK) rc = fail(SPD_E_DEVICE, "spd_broadcast_boundary: device error");
+    if (!receivers.empty() && !sync_device(src_device) && rc == SPD_OK) rc = fail(SPD_E_DEVICE, "spd_broadcast_boundary: device error");
     return rc;
 }
 
-int spd_broadcast_boundary_stats(int32_t *peer_copies, int32_t *local_copies) {
+int spd_broadcast_boundary_stats(int32_t *peer_copies, int32_t *local_copies, int32_t *collective_devices) {
     LOCK;
     if (peer_copies) *peer_copies = g_broadcast_stats.peer_copies;
     if (local_copies) *local_copies = g_broadcast_stats.local_copies;
+    if (collective_devices) *collective_devices = g_broadcast_stats.collective_devices;
     return SPD_OK;
 }
 

@@ -1,6 +1,7 @@
 // Ensemble model object: device-resident state of M members + the step driver (time_stepping.f90:38-147 `step`,
 // tendencies.f90:11-39 `get_tendencies`) built from the hot-path kernels and the dynamics kernels.
 // C ABI: the spd_model_* functions of include/pyspeedy_amd.h.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -8,6 +9,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -1469,6 +1471,112 @@ int spd_model_copy_vars_enqueue(spd_model_handle dst, int di, spd_model_handle s
         if (sdev == ddev) M_HIP(hipMemcpyAsync(to, from, n, hipMemcpyDeviceToDevice, s));
         else M_HIP(hipMemcpyPeerAsync(to, ddev, from, sdev, n, s));
     }
+    return SPD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One collective broadcast of the named variables between device models that live on DIFFERENT GPUs of this process: member
+// members[root] of models[root] into member members[i] of every other models[i].  RCCL (ncclBroadcast inside one group call,
+// one communicator per device created with ncclCommInitAll -- the single-process form) over xGMI: the start-up hand-over of
+// the shared boundary fields of a one-process ensemble, what torch.distributed does for the process-per-GPU layout.
+// RCCL is loaded when this is first called (librccl.so.1: the copy PyTorch has already brought into the process, else ROCm's):
+// a host that keeps its ensemble on one GPU never touches it, and the library carries no link-time dependency on it.
+// Runs on each device's null stream; the caller synchronises (spd_broadcast_boundary does, once per device).
+// ---------------------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    std::string why;  // why it could not be loaded
+    int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Broadcast)(const void *send, void *recv, size_t count, int datatype, int root, void *comm, hipStream_t stream) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::map<std::vector<int>, std::vector<void *>> comms;  // by device list; kept for the life of the process
+    std::mutex mutex;
+};
+Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        r.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!r.lib) r.lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!r.lib) {
+            const char *e = dlerror();
+            r.why = e ? e : "librccl.so.1 not found";
+            return;
+        }
+        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(r.lib, "ncclCommInitAll"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.lib, "ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.lib, "ncclGroupEnd"));
+        r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(dlsym(r.lib, "ncclBroadcast"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+        if (!r.CommInitAll || !r.GroupStart || !r.GroupEnd || !r.Broadcast || !r.GetErrorString) {
+            r.why = "librccl.so.1 lacks an entry point of the collective API";
+            r.lib = nullptr;
+        }
+    });
+    return r;
+}
+constexpr int kNcclFloat64 = 8;  // ncclDataType_t (rccl.h)
+}  // namespace
+
+extern "C" {
+
+int spd_model_broadcast_vars(const spd_model_handle *models, const int *members, int n, int root, const char *const *names,
+                             int nnames) {
+    if (!models || !members || n < 1 || root < 0 || root >= n || (nnames > 0 && !names))
+        return m_fail(SPD_E_ARG, "spd_model_broadcast_vars: bad argument");
+    std::vector<int> devices(n);
+    for (int i = 0; i < n; ++i) {
+        if (!models[i] || members[i] < 0 || members[i] >= models[i]->M) return m_fail(SPD_E_ARG, "spd_model_broadcast_vars: bad model / member");
+        devices[i] = models[i]->ctx->device;
+        for (int j = 0; j < i; ++j)
+            if (devices[j] == devices[i]) return m_fail(SPD_E_ARG, "spd_model_broadcast_vars: one model per GPU (same-device copies are spd_model_copy_vars)");
+    }
+    Rccl &R = rccl();
+    if (!R.lib) return m_fail(SPD_E_DEVICE, "spd_model_broadcast_vars: RCCL is not available: " + R.why);
+    std::lock_guard<std::mutex> lock(R.mutex);
+    auto fail_nccl = [&](const char *what, int rc) {
+        return m_fail(SPD_E_DEVICE, std::string("spd_model_broadcast_vars: ") + what + ": " + R.GetErrorString(rc));
+    };
+    auto it = R.comms.find(devices);
+    if (it == R.comms.end()) {
+        std::vector<void *> comms(n, nullptr);
+        if (int rc = R.CommInitAll(comms.data(), n, devices.data())) return fail_nccl("ncclCommInitAll", rc);
+        it = R.comms.emplace(devices, comms).first;
+    }
+    const std::vector<void *> &comms = it->second;
+    int rc = R.GroupStart();
+    if (rc) return fail_nccl("ncclGroupStart", rc);
+    int first_error = 0;
+    const char *bad = nullptr;
+    for (int v = 0; v < nnames && !bad; ++v) {
+        for (int i = 0; i < n && !bad; ++i) {
+            auto e = models[i]->reg.find(names[v]);
+            auto r0 = models[root]->reg.find(names[v]);
+            if (e == models[i]->reg.end() || r0 == models[root]->reg.end() || e->second.bytes_member != r0->second.bytes_member ||
+                e->second.f32) {
+                bad = names[v];
+                break;
+            }
+            char *mine = static_cast<char *>(e->second.ptr) + e->second.bytes_member * members[i];
+            if (hipSetDevice(devices[i]) != hipSuccess) {
+                bad = "hipSetDevice";
+                break;
+            }
+            const int r = R.Broadcast(mine, mine, e->second.bytes_member / sizeof(double), kNcclFloat64, root, comms[i], nullptr);
+            if (r && !first_error) first_error = r;
+        }
+    }
+    rc = R.GroupEnd();  // (always closed, also after an error inside the group)
+    if (bad) return m_fail(SPD_E_ARG, std::string("spd_model_broadcast_vars: variable '") + bad + "' cannot be broadcast between these models");
+    if (first_error) return fail_nccl("ncclBroadcast", first_error);
+    if (rc) return fail_nccl("ncclGroupEnd", rc);
+    for (int i = 0; i < n; ++i)
+        if (i != root) models[i]->surf_cache_valid = models[i]->phi_ahead = false;
     return SPD_OK;
 }
 

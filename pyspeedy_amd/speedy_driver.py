@@ -113,10 +113,11 @@ def broadcast_boundary(state_cnts, root=0):
 
 
 def broadcast_boundary_stats():
-    """(copies of the last broadcast_boundary that crossed to another device, copies that stayed on one)"""
-    peer, local = C.c_int32(), C.c_int32()
-    _ok(_L().spd_broadcast_boundary_stats(C.byref(peer), C.byref(local)), "broadcast_boundary_stats")
-    return peer.value, local.value
+    """What the last broadcast_boundary did: (copies that crossed to another device one by one, copies that stayed on a device,
+    other GPUs reached by the one collective RCCL broadcast -- 0 when the transport was point-to-point)"""
+    peer, local, coll = C.c_int32(), C.c_int32(), C.c_int32()
+    _ok(_L().spd_broadcast_boundary_stats(C.byref(peer), C.byref(local), C.byref(coll)), "broadcast_boundary_stats")
+    return peer.value, local.value, coll.value
 
 
 def driver_trace(on=True):

@@ -140,16 +140,31 @@ void single_thread() {
         EXPECT(stub_current_device() == 1);
     }
     EXPECT(spd_set_device_placement(0) == 0);
-    // ---- boundary broadcast: the fields cross to the other device once
+    // ---- boundary broadcast: the fields cross to the other device once -- point to point where there is no collective
+    // library (or PYSPEEDY_AMD_BROADCAST=peer), with ONE collective broadcast otherwise
     set_seed(m[0], 1234.5);
     std::vector<int64_t> all;
     for (auto &x : m) all.push_back(x.state);
-    const long peer0 = stub_peer_copies(), local0 = stub_local_copies(), sync0 = stub_device_syncs();
+    long peer0 = stub_peer_copies(), local0 = stub_local_copies(), sync0 = stub_device_syncs(), coll0 = stub_collectives();
+    stub_set_collective_available(0);
     EXPECT(spd_broadcast_boundary(all.data(), 6, 0) == 0);
-    EXPECT(stub_peer_copies() - peer0 == 1 && stub_local_copies() - local0 == 4);
-    EXPECT(stub_device_syncs() - sync0 == 4);  // each of the two devices once before and once after
-    int32_t peer = -1, local = -1;
-    EXPECT(spd_broadcast_boundary_stats(&peer, &local) == 0 && peer == 1 && local == 4);
+    EXPECT(stub_peer_copies() - peer0 == 1 && stub_local_copies() - local0 == 4 && stub_collectives() == coll0);
+    EXPECT(stub_device_syncs() - sync0 == 5);  // each of the two devices once before and once after, the root's once more
+    int32_t peer = -1, local = -1, coll = -1;
+    EXPECT(spd_broadcast_boundary_stats(&peer, &local, &coll) == 0 && peer == 1 && local == 4 && coll == 0);
+    stub_set_collective_available(1);
+    set_seed(m[0], 4321.0);
+    peer0 = stub_peer_copies(), local0 = stub_local_copies();
+    EXPECT(spd_broadcast_boundary(all.data(), 6, 0) == 0);
+    // m[1] (device 1) received collectively; m[5] shares the device but not the anomaly length: no container can hand it 13 fields
+    EXPECT(stub_collectives() - coll0 == 1 && stub_peer_copies() == peer0 && stub_local_copies() - local0 == 4);
+    EXPECT(spd_broadcast_boundary_stats(&peer, &local, &coll) == 0 && peer == 0 && local == 4 && coll == 1);
+    for (auto &x : m) {
+        std::vector<double> orog(NG);
+        EXPECT(spd_get(x.state, "orog", orog.data(), NG * sizeof(double)) == 0 && orog[0] == 4321.0);
+    }
+    set_seed(m[0], 1234.5);
+    EXPECT(spd_broadcast_boundary(all.data(), 6, 0) == 0);
     EXPECT(stub_current_device() == 1);
     for (auto &x : m) {
         std::vector<double> orog(NG);

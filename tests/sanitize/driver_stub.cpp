@@ -28,7 +28,8 @@ namespace {
 std::atomic<int> g_devices{2};
 std::atomic<int> g_check_delay_us{0};
 std::atomic<int> g_fail_next_check_begin{0};
-std::atomic<long> g_device_syncs{0}, g_peer_copies{0}, g_local_copies{0};
+std::atomic<long> g_device_syncs{0}, g_peer_copies{0}, g_local_copies{0}, g_collectives{0};
+std::atomic<int> g_collective_available{1};
 thread_local int t_device = 0;
 thread_local std::string t_error;
 }  // namespace
@@ -39,6 +40,8 @@ void stub_fail_next_check_begin(int count) { g_fail_next_check_begin = count; }
 long stub_device_syncs() { return g_device_syncs.load(); }
 long stub_peer_copies() { return g_peer_copies.load(); }
 long stub_local_copies() { return g_local_copies.load(); }
+long stub_collectives() { return g_collectives.load(); }
+void stub_set_collective_available(int yes) { g_collective_available = yes; }
 int stub_current_device() { return t_device; }
 void stub_set_current_device(int d) { t_device = d; }
 
@@ -205,6 +208,23 @@ int spd_model_copy_vars_enqueue(spd_model_handle dst, int di, spd_model_handle s
         dst->vars[di][names[k]] = it->second;
     }
     ++(dst->device != src->device ? g_peer_copies : g_local_copies);
+    return SPD_OK;
+}
+
+int spd_model_broadcast_vars(const spd_model_handle *models, const int *members, int n, int root, const char *const *names, int nn) {
+    if (!g_collective_available.load()) return spd_set_error(SPD_E_DEVICE, "spd_model_broadcast_vars: RCCL is not available (stub)");
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j)
+            if (models[i]->device == models[j]->device) return spd_set_error(SPD_E_ARG, "spd_model_broadcast_vars: one model per GPU");
+    for (int i = 0; i < n; ++i) {
+        if (i == root) continue;
+        Inside guard(models[i]);
+        for (int k = 0; k < nn; ++k) {
+            auto it = models[root]->vars[members[root]].find(names[k]);
+            if (it != models[root]->vars[members[root]].end()) models[i]->vars[members[i]][names[k]] = it->second;
+        }
+    }
+    ++g_collectives;
     return SPD_OK;
 }
 

@@ -10,6 +10,8 @@ void stub_fail_next_check_begin(int count);   // the next `count` range checks c
 long stub_device_syncs();
 long stub_peer_copies();
 long stub_local_copies();
+long stub_collectives();                      // collective broadcasts between device models
+void stub_set_collective_available(int yes);  // 0: spd_model_broadcast_vars fails as it does when RCCL cannot be loaded
 int stub_current_device();
 void stub_set_current_device(int d);
 

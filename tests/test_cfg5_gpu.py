@@ -224,7 +224,7 @@ def test_fp32_storage_of_the_physics_only_arrays_loses_nothing(spectral):
 def test_cfg5_survives_the_drivers_regrouping(spectral):
     """The fp32 storage travels with the physics precision wherever the driver moves a member: set BEFORE the members are
     initialised (each is initialised through a scratch one-member model and copied back), and across a split of the batch in
-    mid-run (one member stepped on its own, then everybody again, which gathers them anew).  Every member stays, bit for bit, on
+    mid-run (one member stepped on its own, then the others, which are gathered anew, then everybody).  Every member stays, bit for bit, on
     the trajectory of the same member of one batched model that was never regrouped."""
     from datetime import datetime
     import pyspeedy_amd
@@ -243,9 +243,10 @@ def test_cfg5_survives_the_drivers_regrouping(spectral):
     assert drv.driver_stats(states[0])[1] == 1
     others = [i for i in range(M) if i != 2]
     assert (drv.parallel_step([states[i] for i in others], [controls[i] for i in others]) == 0).all()   # the others catch up
+    assert drv.driver_stats(states[0])[1] == 4                       # (the four were gathered into a model of their own)
     for _ in range(3):
-        assert (drv.parallel_step(states, controls) == 0).all()      # ... and all five are one model again
-    assert drv.driver_stats(states[0])[1] == M
+        assert (drv.parallel_step(states, controls) == 0).all()      # two device models from here on: {0, 1, 3, 4} and {2}
+    assert drv.driver_stats(states[0])[1] == 4 and drv.driver_stats(states[2])[1] == 1
     model, _ = drv.device_model(states[0])
     assert model.config()["physics_fp32"] and model.config()["physics_storage32"]
     one = EnsembleModel(spectral, M)

@@ -346,10 +346,11 @@ def test_device_placement_and_boundary_broadcast(drv, bc):
     cnts = [root, other, named.value] + list(ens)
     drv.set_bc(root, bc, 0.2 * np.ones((96, 48, 12)))
     drv.ok(drv.L.spd_broadcast_boundary((C.c_int64 * len(cnts))(*cnts), len(cnts), 0))
-    peer, local = C.c_int32(-1), C.c_int32(-1)
-    drv.ok(drv.L.spd_broadcast_boundary_stats(C.byref(peer), C.byref(local)))
-    # the fields cross to another GPU once per GPU, whatever the number of containers there (here: one GPU, nothing crosses)
-    assert peer.value == (0 if ndev.value == 1 else ndev.value - 1) and peer.value + local.value == len(cnts) - 1
+    peer, local, coll = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)
+    drv.ok(drv.L.spd_broadcast_boundary_stats(C.byref(peer), C.byref(local), C.byref(coll)))
+    # the fields cross to another GPU once per GPU, whatever the number of containers there, all GPUs in ONE RCCL broadcast
+    # (here: one GPU, nothing crosses)
+    assert coll.value + peer.value == ndev.value - 1 and coll.value + peer.value + local.value == len(cnts) - 1
     by_hand = drv.state()
     drv.set_bc(by_hand, bc, 0.2 * np.ones((96, 48, 12)))
     for name in ("orog", "sst12", "soil_wc_l3", "sea_ice_frac12", "alb0"):
@@ -514,3 +515,29 @@ def test_ensemble_placement_by_argument_leaves_the_process_placement_alone(drv):
     finally:
         drv.ok(drv.L.spd_set_device_placement(0))
     assert torch.cuda.current_device() == before
+
+
+def test_collective_broadcast_between_device_models_reaches_rccl(spectral, bc):
+    """spd_model_broadcast_vars is ONE RCCL broadcast (ncclCommInitAll + ncclBroadcast in a group call, single-process
+    communicators) of the boundary fields between device models on different GPUs -- what spd_broadcast_boundary uses across
+    devices.  This box has one GPU: the one-rank form (a broadcast to nobody) still loads RCCL, creates the communicator and runs
+    the collective on the device; two models on the same GPU are refused (same-device copies are spd_model_copy_vars)."""
+    import pyspeedy_amd
+    from pyspeedy_amd.model import EnsembleModel
+    L = pyspeedy_amd.lib()
+    a, b = EnsembleModel(spectral, 2), EnsembleModel(spectral, 1)
+    a.set("sst12", np.asarray(bc["sst"], dtype=np.float64), 1)
+    names = (C.c_char_p * 3)(b"orog", b"sst12", b"stl12")
+    before = a.get("sst12", 1)
+    rc = L.spd_model_broadcast_vars((C.c_void_p * 1)(a._m), (C.c_int * 1)(1), 1, 0, names, 3)
+    assert rc == 0, L.spd_last_error()
+    import torch
+    torch.cuda.synchronize()
+    assert np.array_equal(a.get("sst12", 1), before)
+    rc = L.spd_model_broadcast_vars((C.c_void_p * 2)(a._m, b._m), (C.c_int * 2)(1, 0), 2, 0, names, 3)
+    assert rc < 0 and b"one model per GPU" in L.spd_last_error()
+    assert L.spd_model_broadcast_vars((C.c_void_p * 1)(a._m), (C.c_int * 1)(5), 1, 0, names, 3) < 0
+    bad = (C.c_char_p * 1)(b"rad_tau2")  # (an array whose storage follows the physics precision does not travel this way)
+    assert L.spd_model_broadcast_vars((C.c_void_p * 1)(a._m), (C.c_int * 1)(0), 1, 0, bad, 1) < 0
+    a.close()
+    b.close()
