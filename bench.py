@@ -754,13 +754,13 @@ def file_flag(what, set_it=False, wait_seconds=0.0):
     return False
 
 
-def one_process_child(n_gpus, extra):
+def one_process_child(n_gpus, extra, timeout=420):
     """`bench.py --one-process --gpus N ...` as a child process; its `one_process` object, or {"error": ...}."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
                                                              "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
     cmd = [sys.executable, os.path.abspath(__file__), "--one-process", "--gpus", str(n_gpus), "--steps", "200", "--no-cpu-baseline"]
     try:
-        run = subprocess.run(cmd + extra, env=env, capture_output=True, text=True, timeout=900)
+        run = subprocess.run(cmd + extra, env=env, capture_output=True, text=True, timeout=timeout)
         lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
         if run.returncode != 0 or len(lines) != 1:
             return {"error": "exit code %s: %s" % (run.returncode, (run.stderr or run.stdout)[-600:])}
@@ -914,11 +914,11 @@ def run_rank(args):
             if rank == 0:
                 op = one_process_child(n_gpus, ["--scaling", "strong", "--members", str(total_members)])
                 if "error" not in op and args.scaling == "weak" and args.members is None:
-                    op["cfg4_strong"] = one_process_child(n_gpus, ["--scaling", "strong", "--members", "64"])
+                    op["cfg4_strong"] = one_process_child(n_gpus, ["--scaling", "strong", "--members", "64"], timeout=240)
                 legs["one_process"] = op
                 file_flag("one_process_done", set_it=True)
             else:
-                file_flag("one_process_done", wait_seconds=900.0)
+                file_flag("one_process_done", wait_seconds=700.0)
 
     if rank == 0:
         ms_step, ms_min = median(region_s) / args.steps * 1e3, min(region_s) / args.steps * 1e3
