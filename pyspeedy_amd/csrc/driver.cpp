@@ -179,14 +179,16 @@ struct Plan {
     std::vector<GroupPlan> groups;
     uint64_t epoch = 0;
 };
-// A host with the reference's loop hands parallel_step the same two lists at every model step: the plan of the last call is
-// kept and used again while nothing has happened that could change it (g_epoch) -- the per-step host work of the call is then
-// one comparison of the lists and one control-container look-up per device model, whatever the number of containers.
-std::shared_ptr<const Plan> g_last_plan;
+// A host with the reference's loop hands parallel_step the same two lists at every model step: the plans of the last few
+// argument lists are kept (several host threads may each step a list of their own) and used again while nothing has happened
+// that could change them (g_epoch) -- the per-step host work of the call is then a comparison of the lists and one
+// control-container look-up per device model, whatever the number of containers.
+constexpr size_t kKeptPlans = 8;
+std::vector<std::shared_ptr<const Plan>> g_plans;  // most recently used first
 
 void regrouped() {  // (lock held) something happened after which an argument list may group differently
     ++g_epoch;
-    g_last_plan.reset();   // (the plan holds references to device models: they must be free to die with their containers)
+    g_plans.clear();  // (a plan holds references to device models: they must be free to die with their containers)
 }
 
 
@@ -795,13 +797,21 @@ static int make_plan(const int64_t *state_cnts, const int64_t *control_cnts, int
 static int plan_step(const int64_t *state_cnts, const int64_t *control_cnts, int n, std::shared_ptr<const Plan> &plan,
                      std::vector<GroupRun> &run, const char *who) {
     const size_t bytes = static_cast<size_t>(n) * sizeof(int64_t);
-    if (g_last_plan && g_last_plan->epoch == g_epoch && static_cast<int>(g_last_plan->states.size()) == n &&
-        (n == 0 || (std::memcmp(g_last_plan->states.data(), state_cnts, bytes) == 0 &&
-                    std::memcmp(g_last_plan->controls.data(), control_cnts, bytes) == 0))) {
-        plan = g_last_plan;
-    } else {
+    plan.reset();
+    for (size_t k = 0; k < g_plans.size(); ++k) {
+        const Plan &p = *g_plans[k];
+        if (p.epoch == g_epoch && static_cast<int>(p.states.size()) == n &&
+            (n == 0 || (std::memcmp(p.states.data(), state_cnts, bytes) == 0 && std::memcmp(p.controls.data(), control_cnts, bytes) == 0))) {
+            plan = g_plans[k];
+            if (k > 0) std::rotate(g_plans.begin(), g_plans.begin() + k, g_plans.begin() + k + 1);  // most recently used first
+            break;
+        }
+    }
+    if (!plan) {
         if (int rc = make_plan(state_cnts, control_cnts, n, plan, who)) return rc;
-        g_last_plan = plan;
+        // (making the plan may have regrouped containers and emptied the list)
+        if (g_plans.size() >= kKeptPlans) g_plans.pop_back();
+        g_plans.insert(g_plans.begin(), plan);
     }
     run.assign(plan->groups.size(), GroupRun{});
     for (size_t i = 0; i < run.size(); ++i) {
