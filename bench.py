@@ -705,7 +705,7 @@ def plan_name(cfg, M):
 def load_traffic(nfields):
     """HBM bytes per spec2grid launch from the committed PMC measurement of this very kernel inside this bench (rocprofv3
     cannot run inside bench.py): FETCH_SIZE doubled as the gfx950 guide prescribes, scaled per field."""
-    for name in ("r03_pmc_model_step.json", "r02_pmc_model_step.json", "r01_pmc_model_step.json"):
+    for name in ("r04_pmc_model_step.json", "r03_pmc_model_step.json", "r02_pmc_model_step.json", "r01_pmc_model_step.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 tj = json.load(fh)["kernels"]["spd::spec2grid_table_kernel"]
