@@ -351,10 +351,12 @@ def collective_record(dist, backend, device, coll_device, rank, checksum, nbytes
     the GPU box -- and its GPU's identity to one all_gather_object.  A line that holds this object proves that N ranks met, which
     device each one computed on, and that the broadcast delivered the same bytes everywhere."""
     import torch
-    props = torch.cuda.get_device_properties(device)
-    ident = {"rank": rank, "pid": os.getpid(), "device": device.index, "name": props.name,
-             "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None)}
-    mine = torch.tensor([rank, device.index, checksum], dtype=torch.int64, device=coll_device)
+    index = device.index if device.type == "cuda" else -1  # (a CPU "device": the gloo rehearsal of the CPU test tier)
+    ident = {"rank": rank, "pid": os.getpid(), "device": index}
+    if device.type == "cuda":
+        props = torch.cuda.get_device_properties(device)
+        ident.update(name=props.name, uuid=str(getattr(props, "uuid", "")), pci_bus_id=getattr(props, "pci_bus_id", None))
+    mine = torch.tensor([rank, index, checksum], dtype=torch.int64, device=coll_device)
     if dist is None:
         rows, idents, world = [mine.tolist()], [ident], 1
     else:

@@ -65,6 +65,19 @@ WORKER = textwrap.dedent("""
     mean, spread = E.ensemble_mean_spread(mine, dist)
     assert np.allclose(mean.numpy(), allv.mean(axis=0), rtol=0, atol=1e-15)
     assert np.allclose(spread.numpy(), allv.std(axis=0, ddof=1), rtol=1e-14, atol=0)
+    # ... and what bench.py's N-rank line records about the collective layer, gathered through it: both ranks seen, the
+    # checksum of what each rank received in the broadcast, equal -- and unequal when a rank's fields were tampered with
+    import bench
+    cpu = torch.device("cpu")
+    checksum, nbytes = bench.boundary_checksum(got)
+    rec = bench.collective_record(dist, "gloo", cpu, cpu, rank, checksum, nbytes)
+    assert rec["backend"] == "gloo" and rec["world_size"] == 2 and rec["ranks_seen"] == 2 and rec["device_of_rank"] == [-1, -1]
+    assert rec["boundary_checksum_equal"] is True and len(set(rec["boundary_checksum_of_rank"])) == 1
+    assert rec["boundary_bytes"] == nbytes == 8 * (96 * 48 * 14) and [g["rank"] for g in rec["gpu_of_rank"]] == [0, 1]
+    if rank == 1:
+        got["orog"][3, 4] += 1e-12
+    bad = bench.collective_record(dist, "gloo", cpu, cpu, rank, bench.boundary_checksum(got)[0], nbytes)
+    assert bad["boundary_checksum_equal"] is False and bad["ranks_seen"] == 2
     if rank == 0:
         print("RESULT", first, count, E.simulated_years_per_day(total, slowest))
     dist.barrier()
