@@ -33,7 +33,10 @@ namespace spd {
 namespace {
 
 constexpr int NG = IX * IL;  // columns per member
-constexpr int kPhysThreads = 64;
+#ifndef SPD_PHYS_THREADS
+#define SPD_PHYS_THREADS 64  // one wavefront per workgroup (128 / 256 measured in round 4: profiles/r04_column_workgroup_size.txt)
+#endif
+constexpr int kPhysThreads = SPD_PHYS_THREADS;
 
 // Arithmetic type of the column physics: R = double reproduces the reference (fp64 everywhere); R = float is BASELINE cfg 5's
 // mixed precision -- state, dynamics tendencies and every array in memory stay fp64, the column arithmetic runs in fp32 and
@@ -883,7 +886,7 @@ static int physics_waves32(int nmembers) {
         return e ? atoi(e) : 0;
     }();
     if (forced) return forced;
-    return nmembers * (NG / kPhysThreads) <= 2 * 1024 ? 2 : 3;  // wavefronts of the launch against two per SIMD of the GPU
+    return nmembers * (NG / 64) <= 2 * 1024 ? 2 : 3;  // wavefronts of the launch against two per SIMD of the GPU
 }
 
 template <int W, bool FUSED, bool KEEP, typename R, bool S32 = false>

@@ -259,3 +259,31 @@ def test_cfg5_survives_the_drivers_regrouping(spectral):
         for name in ("t", "vor", "tr", "ps", "rad_tau2", "tt_rsw"):
             assert np.array_equal(ens.members[i][name], one.get(name, i)), (i, name)
     one.close()
+
+
+def test_fp32_physics_thirty_days_same_climate_of_the_ensemble(spectral):
+    """cfg 5 over a month: 32 members, SPPT on, 1080 steps with fp32 and with fp64 column physics from the same perturbed states
+    and the same noise.  After two weeks the members of the two runs have decorrelated (the model is chaotic: a rounding
+    difference grows like any other perturbation), so what is compared is the ENSEMBLE: every member of both runs passes the
+    range check throughout, the ensemble means agree within the sampling error of 32 members, the spreads within 15 %.
+    Observed on MI355X: rms dmean / rms spread 0.21-0.27 (two independent draws of 32 would give sqrt(2/32) = 0.25), spread
+    ratio 0.97-1.04."""
+    fields = {}
+    for fp32 in (False, True):
+        m = make_ensemble(spectral, 32, fp32, True)
+        for _ in range(30):
+            m.run(36)
+            assert (m.check(2) == 0).all()
+        m.spectral2grid()
+        fields[fp32] = {v: m.device_view(v).clone() for v in ("t_grid", "u_grid", "q_grid", "ps_grid")}
+        m.close()
+    rms = lambda x: x.pow(2).mean().sqrt().item()
+    for v in fields[False]:
+        a, b = fields[False][v], fields[True][v]
+        r_mean = rms(a.mean(0) - b.mean(0)) / rms(a.std(0))
+        r_spread = rms(b.std(0)) / rms(a.std(0))
+        r_member = rms(a - b) / rms(a.std(0))
+        print("30 days %-7s rms dmean / rms spread %.3f  spread32/spread64 %.3f  member-wise rms difference / spread %.2f"
+              % (v, r_mean, r_spread, r_member))
+        assert r_mean <= 0.45, (v, r_mean)
+        assert abs(r_spread - 1.0) <= 0.15, (v, r_spread)
