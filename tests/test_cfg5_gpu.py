@@ -263,11 +263,11 @@ def test_cfg5_survives_the_drivers_regrouping(spectral):
 
 def test_fp32_physics_thirty_days_same_climate_of_the_ensemble(spectral):
     """cfg 5 over a month: 32 members, SPPT on, 1080 steps with fp32 and with fp64 column physics from the same perturbed states
-    and the same noise.  After two weeks the members of the two runs have decorrelated (the model is chaotic: a rounding
-    difference grows like any other perturbation), so what is compared is the ENSEMBLE: every member of both runs passes the
-    range check throughout, the ensemble means agree within the sampling error of 32 members, the spreads within 15 %.
-    Observed on MI355X: rms dmean / rms spread 0.21-0.27 (two independent draws of 32 would give sqrt(2/32) = 0.25), spread
-    ratio 0.97-1.04."""
+    and the same noise.  The model is chaotic: a rounding difference grows like any other perturbation, and after a month a
+    member of the fp32 run stands 0.46 ensemble spreads (rms) from the same member of the fp64 run.  What is compared is
+    therefore the ENSEMBLE: every member of both runs passes the range check on every day, the ensemble means agree far inside
+    the sampling error of 32 members, the spreads within a few per cent.  Observed on MI355X: rms dmean / rms spread 0.065-0.074
+    (two independent draws of 32 would give sqrt(2 / 32) = 0.25), spread ratio 0.994-1.020."""
     fields = {}
     for fp32 in (False, True):
         m = make_ensemble(spectral, 32, fp32, True)
@@ -285,5 +285,6 @@ def test_fp32_physics_thirty_days_same_climate_of_the_ensemble(spectral):
         r_member = rms(a - b) / rms(a.std(0))
         print("30 days %-7s rms dmean / rms spread %.3f  spread32/spread64 %.3f  member-wise rms difference / spread %.2f"
               % (v, r_mean, r_spread, r_member))
-        assert r_mean <= 0.45, (v, r_mean)
-        assert abs(r_spread - 1.0) <= 0.15, (v, r_spread)
+        assert r_mean <= 0.2, (v, r_mean)
+        assert abs(r_spread - 1.0) <= 0.08, (v, r_spread)
+        assert 0.05 <= r_member <= 1.2, (v, r_member)  # (the runs did diverge member by member, and not beyond the ensemble)
