@@ -26,7 +26,8 @@ What the ONE JSON line of rank 0 holds:
   roofline              the dominant transform kernel (spec2grid) timed by HIP events on its launch stream in further
                         regions of K steps issued in the SERIAL plan (one member group: with overlapping groups a
                         kernel's duration is not its own); `serial_plan_ms_per_step` beside it; `kernels[]` = every
-                        kernel of the step from a bracketed one-day pass.
+                        kernel of the step from a bracketed one-day pass; `dominant` = the kernel with the largest share of
+                        the step, the fused column kernel, priced the same way (its PMC traffic beside it).
   cpu_baseline          the reference Fortran itself (oracle/_ref; the C port when it did not travel) on one host core
                         and on all host cores, measured BEFORE any process touches the GPU -- by the launcher (N > 1 through
                         this script), or by rank 0 while the other ranks wait (N > 1 under torch.distributed.run).
@@ -718,6 +719,32 @@ def load_traffic(nfields):
     return None, None
 
 
+def dominant_kernel(kernels, M, config):
+    """The kernel that takes the largest share of the step -- the fused column kernel (grid-point dynamics + physics) -- priced
+    like `roofline`: the launches of one simulated day (shortwave and other steps together), algorithmic bytes of its argument
+    list / its dispatch-attached HIP-event time, and the committed PMC traffic of the same kernel per member."""
+    rows = [k for k in kernels or [] if k["kernel"] in ("column", "column_sw")]
+    if not rows:
+        return None
+    t_us = sum(k["avg_launch_us"] * k["launches_timed"] for k in rows)
+    nbytes = sum(k["algorithmic_bytes_per_launch"] * k["launches_timed"] for k in rows)
+    n = sum(k["launches_timed"] for k in rows)
+    all_us = sum(k["avg_launch_us"] * k["launches_timed"] for k in kernels)
+    out = {"kernel": "physics_kernel, fused (grid-point dynamics + column physics), %d members per launch" % M,
+           "share_of_kernel_time": t_us / all_us, "launches_timed": n, "avg_launch_us": t_us / n,
+           "algorithmic_bytes_per_launch": int(round(nbytes / n)), "bound": "hbm", "achieved": nbytes / (t_us * 1e-6) / 1e9,
+           "peak": 8000.0, "unit": "GB/s", "frac": nbytes / (t_us * 1e-6) / 1e9 / 8000.0, "traffic": None}
+    name, key, members = (("r04_pmc_model_step.json", "spd::physics_kernel<2, true, false, double, false>", 64) if config == "cfg4" else
+                          ("r04_pmc_cfg5_storage32_1.json", "spd::physics_kernel<3, true, true, float, true>", 32))
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
+            out["traffic"] = json.load(fh)["kernels"][key]["hbm_bytes_per_launch"] / float(members) * M
+        out["traffic_source"] = "profiles/%s (%d members per launch there; scaled per member)" % (name, members)
+    except (OSError, KeyError, ValueError):
+        pass
+    return out
+
+
 def wait_for_ranks(rank, world, what):
     """A file barrier under /tmp keyed by the rendezvous port: used ONCE, before any process group exists, so that rank 0
     measures the host baseline while the other ranks have finished importing torch and sit idle."""
@@ -965,7 +992,8 @@ def run_rank(args):
                                "duration of a kernel that shares the GPU with another group's kernels is not its own); HIP events "
                                "attached to the dispatch of every spec2grid launch of those regions" % (len(serial_s), args.steps),
                 "serial_plan_ms_per_step": median(serial_s) / args.steps * 1e3,
-                "traffic": traffic, "traffic_source": traffic_src, "kernels": kernels,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "dominant": dominant_kernel(kernels, M, args.config), "kernels": kernels,
                 "kernels_note": "one simulated day (36 steps, serial plan) with events attached to every kernel's dispatch (the "
                                 "kernels' own begin / end time stamps, as in rocprofv3's kernel trace); the rows sum to less than "
                                 "serial_plan_ms_per_step by the gaps between dependent launches",

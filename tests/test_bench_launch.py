@@ -123,6 +123,9 @@ def test_the_one_gpu_line_carries_the_drop_in_and_every_store_legs():
     assert d["containers"] == 8 and 0 < d["begin_end_ms_per_step"] and 0 < d["sync_ms_per_step"]
     e = res["every_step_stores"]
     assert e["spec2grid_per_member"] == 91 and e["ms_per_step"] > 0
+    dom = res["roofline"]["dominant"]  # the fused column kernel: the largest share of the step, priced like the line's kernel
+    assert dom["share_of_kernel_time"] > 0.25 and 0 < dom["frac"] < 1 and dom["traffic"] > 0
+    assert abs(dom["achieved"] - dom["algorithmic_bytes_per_launch"] / (dom["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * dom["achieved"]
     assert res["cpu_baseline"]["all_cores"]["cores"] >= 1 and res["vs_baseline"] > 0
     # every BASELINE config on the same clock (SURVEY 8d "Configs as concrete inputs")
     for key, members in (("cfg3", 1), ("cfg4_shard8", 8), ("cfg5", 32)):
