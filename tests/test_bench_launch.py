@@ -145,9 +145,12 @@ def test_the_one_gpu_line_carries_the_drop_in_and_every_store_legs():
     t = res["cfg2_transforms"]
     assert t["algorithmic_bytes_per_field"] == 52736
     assert sorted({r["fields"] for r in t["rows"]}) == [1, 8, 64, 512, 4096, 16384]
-    assert {r["kernel"] for r in t["rows"]} == {"spec2grid", "grid2spec"} and len(t["rows"]) == 12
+    assert {r["kernel"] for r in t["rows"]} == {"spec2grid", "grid2spec", "legendre_inv", "legendre"} and len(t["rows"]) == 16
+    assert sorted(r["fields"] for r in t["rows"] if r["kernel"] == "legendre") == [4096, 16384]  # the Legendre stage on its own
     for r in t["rows"]:
-        assert r["ns_per_field"] > 0 and abs(r["frac"] - 52736 / r["ns_per_field"] / 8000.0) < 1e-6
+        want = 39680 if r["kernel"].startswith("legendre") else 52736
+        assert r["algorithmic_bytes_per_field"] == want
+        assert r["ns_per_field"] > 0 and abs(r["frac"] - want / r["ns_per_field"] / 8000.0) < 1e-6
 
 
 @pytest.mark.gpu

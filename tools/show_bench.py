@@ -47,7 +47,7 @@ for f in sys.argv[1:]:
                     key, o["members"], o["ms_per_step"], o["us_per_member_step"], o["step_roofline"]["frac"], o["plan"]))
                 print("                kernels us: %s" % "  ".join("%s %.1f" % kv for kv in o["kernel_us"].items()))
         if "cfg2_transforms" in d:
-            for name in ("spec2grid", "grid2spec"):
+            for name in ("spec2grid", "grid2spec", "legendre_inv", "legendre"):
                 print("   cfg2 %-9s ns/field (frac): %s" % (name, "  ".join("B=%d %.1f (%.3f)" % (r["fields"], r["ns_per_field"], r["frac"])
                                                                               for r in d["cfg2_transforms"]["rows"] if r["kernel"] == name)))
         if "cfg4_strong" in d:
