@@ -581,7 +581,10 @@ def transforms_leg(args, device):
             "algorithmic_bytes_per_field": S_BYTES + G_BYTES, "algorithmic_bytes_per_field_legendre_stage": S_BYTES + F_BYTES,
             "peak": 8000.0, "unit": "GB/s", "timed_seconds": total, "rows": rows,
             "note": "back-to-back launches on one stream between two HIP events; at B = 1 and 8 a launch is one dependent chain of "
-                    "one workgroup (load, Legendre, FFT, store) and the figure is that latency, not a bandwidth"}
+                    "one workgroup (load, Legendre, FFT, store) and the figure is that latency, not a bandwidth; the in- and outputs "
+                    "of a batch of up to 4096 fields (216 MB fused, 162 MB Legendre stage) largely stay in the 256 MB Infinity "
+                    "Cache between launches, so the 16 384-field rows (864 / 650 MB) are the HBM figures; legendre_inv / legendre = "
+                    "the Legendre stage on its own (39 680 algorithmic bytes per field: north_star's >= 40 % target)"}
 
 
 def _time_container_loop(ens, steps):
