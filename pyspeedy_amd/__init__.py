@@ -7,8 +7,8 @@ driver function set (speedy_driver) and the user-facing Speedy / SpeedyEns class
 """
 from ._lib import (IL, IX, IY, KX, MX, NX, TRUNC, SpeedyHipError, build, lib)  # noqa: F401
 
-__all__ = ["ModSpectral", "ColumnPhysics", "Speedy", "SpeedyEns", "example_bc_file", "DEFAULT_OUTPUT_VARS", "SpeedyHipError",
-           "build", "lib"]
+__all__ = ["ModSpectral", "ColumnPhysics", "Speedy", "SpeedyEns", "example_bc_file", "example_sst_anomaly_file",
+           "MODEL_STATE_DEF", "DEFAULT_OUTPUT_VARS", "SpeedyHipError", "build", "lib"]
 
 
 def __getattr__(name):
@@ -19,7 +19,7 @@ def __getattr__(name):
     if name == "ColumnPhysics":
         from .physics import ColumnPhysics
         return ColumnPhysics
-    if name in ("Speedy", "SpeedyEns", "example_bc_file"):
+    if name in ("Speedy", "SpeedyEns", "example_bc_file", "example_sst_anomaly_file", "MODEL_STATE_DEF"):
         from . import speedy
         return getattr(speedy, name)
     if name == "DEFAULT_OUTPUT_VARS":

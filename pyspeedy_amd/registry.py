@@ -89,3 +89,27 @@ def shape_of(name, n_months=1):
 
 def is_array(name):
     return REGISTRY[name].shape is not None
+
+
+_FORTRAN_TYPE = {np.dtype(np.complex128): "complex(8)", np.dtype(np.float64): "real(8)", np.dtype(np.float32): "real",
+                 np.dtype(np.int32): "integer", np.dtype(np.bool_): "logical"}
+_DIM_NAME = {IX: "ix", IL: "il", KX: "kx", MX: "mx", NX: "nx"}
+
+
+def model_state_def():
+    """The registry in the layout of the reference's `pyspeedy/data/model_state.json` (what `pyspeedy.speedy.MODEL_STATE_DEF`
+    holds: name -> dtype, dims, desc, time_dim, units, nc_dims, alt_name, std_name), generated from the table above: host code
+    that looks variables up there (`MODEL_STATE_DEF[var]["alt_name"]`, `["nc_dims"]`, `["time_dim"]`) keeps working.  `dims` is
+    the Fortran shape with the reference's dimension names where a size has one; `desc` is the long name used in the export."""
+    out = {}
+    for name, v in REGISTRY.items():
+        timed = v.shape is not None and N_MONTHS in v.shape
+        dims = None
+        if v.shape is not None:
+            dims = "(" + ", ".join("0:n_months+1" if s == N_MONTHS else _DIM_NAME.get(s, str(s)) for s in v.shape) + ")"
+        nc_dims = None if v.nc_dims is None else ["0:n_months+1" if (timed and i == len(v.shape) - 1) else d
+                                                  for i, d in enumerate(v.nc_dims)]
+        out[name] = {"dtype": _FORTRAN_TYPE[np.dtype(v.dtype)], "dims": dims, "desc": v.long_name,
+                     "time_dim": "n_months" if timed else None, "units": v.units, "nc_dims": nc_dims, "alt_name": v.alt_name,
+                     "std_name": name}
+    return out

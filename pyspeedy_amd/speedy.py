@@ -19,7 +19,7 @@ import numpy as np
 
 from . import speedy_driver as _speedy
 from .dataset import Dataset, Variable, open_dataset
-from .registry import DEFAULT_OUTPUT_VARS, REGISTRY
+from .registry import DEFAULT_OUTPUT_VARS, REGISTRY, model_state_def
 from .speedy_driver import ERROR_CODES
 
 PACKAGE_DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
@@ -30,11 +30,19 @@ _BC_FIELDS = (("orog", "orog"), ("fmask_orig", "lsm"), ("alb0", "alb"), ("veg_hi
               ("sst12", "sst"), ("sea_ice_frac12", "icec"))
 
 _DT_STEP = timedelta(seconds=3600 * 24 / 36)
+MODEL_STATE_DEF = model_state_def()  # pyspeedy/speedy.py:36-37 loads the same table from model_state.json
 
 
 def example_bc_file():
     """Path of the packaged example boundary conditions (ERA-interim 1979-2008 climatology of the original SPEEDY)."""
     return os.path.join(PACKAGE_DATA_DIR, "example_bc.npz")
+
+
+def example_sst_anomaly_file():
+    """Path where the reference keeps its example SST anomalies (pyspeedy/__init__.py:33).  The file is not distributed with the
+    reference (its repository lists it under .MISSING_LARGE_BLOBS) and is not packaged here either: `set_bc(sst_anomaly=None)`
+    means zero anomalies; pass this path (or any file / mapping with `ssta` and `time`) once you have the data."""
+    return os.path.join(PACKAGE_DATA_DIR, "sst_anomaly.nc")
 
 
 def _add_months(date, months):

@@ -25,6 +25,41 @@ def test_registry_covers_the_reference_state():
     assert [R.REGISTRY[v].alt_name for v in R.DEFAULT_OUTPUT_VARS] == ["u", "v", "t", "q", "phi", "ps"]
 
 
+def test_model_state_def_has_the_layout_of_the_references_json():
+    """`pyspeedy.speedy.MODEL_STATE_DEF` is the reference's data/model_state.json; here the same mapping is generated from the
+    registry.  Where the reference is at hand (build container) every entry is compared with it: Fortran type, dimension string,
+    run-length dimension, export name and export dimensions, and the units of the default output variables."""
+    import json
+    import pyspeedy_amd
+    from pyspeedy_amd import registry as R
+    from pyspeedy_amd.error_codes import ERROR_CODES
+    mine = pyspeedy_amd.MODEL_STATE_DEF
+    assert set(mine) == set(R.REGISTRY) and mine["u_grid"]["alt_name"] == "u" and mine["sst_anom"]["time_dim"] == "n_months"
+    assert set(mine["vor"]) == {"dtype", "dims", "desc", "time_dim", "units", "nc_dims", "alt_name", "std_name"}
+    assert ERROR_CODES[0] == "Run successful." and "range" in ERROR_CODES[-2] and "Unexpected" in ERROR_CODES[-77]
+    assert pyspeedy_amd.example_sst_anomaly_file().endswith("sst_anomaly.nc")
+    path = "/root/reference/pyspeedy/data/model_state.json"
+    if not os.path.isfile(path):
+        pytest.skip("the reference is not on this machine")
+    with open(path) as fh:
+        ref = json.load(fh)
+    squash = lambda s: None if s is None else s.replace(" ", "")
+    for name, r in ref.items():
+        if name in ("mod_geometry", "mod_spectral", "mod_implicit"):
+            continue  # (polymorphic module instances: no getters in the reference either)
+        m = mine[name]
+        assert m["dtype"] == r["dtype"].replace("real(p)", "real(8)"), name
+        want = squash(r["dims"])
+        if want is not None:
+            for sym, val in (("aux_dim", "3"), ("t_levs", "2"), ("ntr", "1"), ("100:400", "301")):
+                want = want.replace(sym, val)
+            want = want.replace(",1)", ")") if name == "tr" else want  # (tr: the single tracer's axis is dropped here)
+        assert squash(m["dims"]) == want, (name, m["dims"], r["dims"])
+        assert m["time_dim"] == r["time_dim"] and m["alt_name"] == r["alt_name"] and m["std_name"] == r["std_name"], name
+        if name in R.DEFAULT_OUTPUT_VARS:
+            assert m["nc_dims"] == r["nc_dims"] and m["units"] == r["units"], name
+
+
 def test_driver_function_names():
     from pyspeedy_amd import registry as R
     from pyspeedy_amd import speedy_driver as drv
