@@ -193,7 +193,13 @@ def test_fp32_storage_of_the_physics_only_arrays_loses_nothing(spectral):
     a = make_ensemble(spectral, 4, False, True)   # fp64 physics first: the switch below converts what IT left in memory
     b = make_ensemble(spectral, 4, False, True)
     b.set_option("physics_storage32", 0)
-    for m in (a, b):
+    os.environ["PYSPEEDY_AMD_PRUNE_DEAD"] = "0"   # ... and with all 91 transforms issued (the 14 dead ones as fp32 fields too)
+    try:
+        c = make_ensemble(spectral, 4, False, True)
+    finally:
+        del os.environ["PYSPEEDY_AMD_PRUNE_DEAD"]
+    assert c.config()["inv_per_member"] == 91
+    for m in (a, b, c):
         m.run(4)
         m.set_physics_precision(True)
         m.run(1)
@@ -204,6 +210,8 @@ def test_fp32_storage_of_the_physics_only_arrays_loses_nothing(spectral):
     for name in a.variables():
         x, y = a.get(name, 2), b.get(name, 2)
         assert x.dtype == y.dtype and np.array_equal(x, y), name
+        assert np.array_equal(x, c.get(name, 2)), name
+    c.close()
     # the boundary converts: what get() returns is the float32 array on the device, widened
     tau = a.device_view("rad_tau2")[2].cpu().numpy().astype(np.float64)      # [4][8][48][96]
     assert np.array_equal(tau.transpose(3, 2, 1, 0), a.get("rad_tau2", 2))
