@@ -575,8 +575,40 @@ def transforms_leg(args, device):
             rows.append({"kernel": name, "fields": B, "launches_timed": n, "us_per_launch": per_launch * 1e6,
                          "ns_per_field": per_launch / B * 1e9, "algorithmic_bytes_per_field": field_bytes, "achieved": gbs,
                          "frac": gbs / 8000.0})
+    # BASELINE cfg 2 as worded keeps the physics -- and with it the state -- on the HOST: every batch of transforms then crosses
+    # PCIe both ways.  The same two kernels with their in- and outputs in pinned host memory (copy in, transform, copy out, one
+    # stream): what the operator-level boundary costs a host-resident model.  Never `value`.
+    Bh = min(4096, bmax)
+    spec_h, grid_h = spec_d[:Bh].cpu().pin_memory(), grid_d[:Bh].cpu().pin_memory()
+    back_grid, back_spec = torch.empty_like(grid_h).pin_memory(), torch.empty_like(spec_h).pin_memory()
+    pcie = {}
+    for name in ("spec2grid", "grid2spec"):
+        def once():
+            if name == "spec2grid":
+                spec_d[:Bh].copy_(spec_h, non_blocking=True)
+                rc = L.spd_spec2grid(h, p(spec_d), p(out_grid), 1, Bh, st)
+                back_grid.copy_(out_grid[:Bh], non_blocking=True)
+            else:
+                grid_d[:Bh].copy_(grid_h, non_blocking=True)
+                rc = L.spd_grid2spec(h, p(grid_d), p(out_spec), Bh, st)
+                back_spec.copy_(out_spec[:Bh], non_blocking=True)
+            if rc != 0:
+                raise SystemExit("bench.py: cfg2 leg: " + L.spd_last_error().decode())
+        once()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(5):
+            once()
+        b.record()
+        b.synchronize()
+        per = a.elapsed_time(b) * 1e-3 / 5
+        total += 5 * per
+        pcie[name] = {"fields": Bh, "ns_per_field": per / Bh * 1e9, "achieved": (S_BYTES + G_BYTES) * Bh / per / 1e9, "unit": "GB/s"}
     sp.close()
-    return {"workload": "BASELINE cfg 2: the fused transform kernels alone, contiguous batches of B fields (spd_spec2grid / "
+    return {"pcie_inclusive": dict(pcie, note="in- and outputs in pinned HOST memory (copy in, transform, copy out on one stream): "
+                                               "BASELINE cfg 2 as worded, physics and state on the host; bound by PCIe, not by the GPU"),
+            "workload": "BASELINE cfg 2: the fused transform kernels alone, contiguous batches of B fields (spd_spec2grid / "
                         "spd_grid2spec), SURVEY 8d inputs (seed 1234, band-limited grids)",
             "algorithmic_bytes_per_field": S_BYTES + G_BYTES, "algorithmic_bytes_per_field_legendre_stage": S_BYTES + F_BYTES,
             "peak": 8000.0, "unit": "GB/s", "timed_seconds": total, "rows": rows,

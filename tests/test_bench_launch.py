@@ -147,6 +147,9 @@ def test_the_one_gpu_line_carries_the_drop_in_and_every_store_legs():
     assert sorted({r["fields"] for r in t["rows"]}) == [1, 8, 64, 512, 4096, 16384]
     assert {r["kernel"] for r in t["rows"]} == {"spec2grid", "grid2spec", "legendre_inv", "legendre"} and len(t["rows"]) == 16
     assert sorted(r["fields"] for r in t["rows"] if r["kernel"] == "legendre") == [4096, 16384]  # the Legendre stage on its own
+    on_device = {r["kernel"]: r["ns_per_field"] for r in t["rows"] if r["fields"] == 4096}
+    for k in ("spec2grid", "grid2spec"):  # cfg 2 as worded (state on the host): the same kernels through PCIe, far slower
+        assert t["pcie_inclusive"][k]["fields"] == 4096 and t["pcie_inclusive"][k]["ns_per_field"] > 5 * on_device[k]
     for r in t["rows"]:
         want = 39680 if r["kernel"].startswith("legendre") else 52736
         assert r["algorithmic_bytes_per_field"] == want
