@@ -702,23 +702,13 @@ def one_process_leg(n_devices, members_total, steps, what):
     used = max(1, min(n_devices, drv.device_count()))
     t0 = time.perf_counter()
     ens = S.SpeedyEns(members_total, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 3, 1), devices=used)
-    root = ens.members[0]
-    for member in ens:
-        member._set_sst_anomalies(None)  # (zero anomalies of the run's length in every container: they travel with the rest)
-    bc = load_bc()
-    for state_name, file_name in S._BC_FIELDS:
-        root[state_name] = np.asarray(bc[file_name], dtype=np.float64)
     cnts = [m._state_cnt for m in ens.members]
-    drv.broadcast_boundary(cnts, 0)
+    ens.set_bc()  # member 0 reads the packaged boundary file; every other member receives the fields device to device
     peer, local, collective = drv.broadcast_boundary_stats()
-    probe = ens.members[-1]["sst12"]  # what arrived in the last container (on the last device) is what the root holds
-    arrived = bool(np.array_equal(probe, np.asarray(bc["sst"], dtype=np.float64)))
+    bc = load_bc()
+    probe = ens.members[-1]["orog"]  # what arrived in the last container (on the last device) is what the file holds
+    arrived = bool(np.array_equal(probe, np.asarray(bc["orog"], dtype=np.float64)))
     for i, member in enumerate(ens.members):
-        code = drv.init(member._state_cnt, member._control_cnt)
-        if code < 0:
-            raise SystemExit("bench.py: one-process leg: init of member %d returned %d" % (i, code))
-        member._initialized_bc = True
-        member.spectral2grid()
         noise = np.random.default_rng(i).normal(0.0, 0.01, (96, 48, 8))
         member["t_grid"] = member["t_grid"] + noise
         member.grid2spectral()

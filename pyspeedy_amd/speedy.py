@@ -166,10 +166,19 @@ class Speedy:
         first day of each month) covering one month before the start to one month after the end of the run."""
         if self._initialized_bc:
             raise RuntimeError("The model was already initialized. Create a new instance if you need different boundary conditions.")
+        self._load_bc(bc_file, sst_anomaly)
+        self._init_from_loaded_bc()
+
+    def _load_bc(self, bc_file, sst_anomaly):
+        """the boundary fields and SST anomalies into the state container (no initialisation yet)"""
         self._set_sst_anomalies(sst_anomaly)
         fields = _load_fields(example_bc_file() if bc_file is None else bc_file)
         for state_name, file_name in _BC_FIELDS:
             self[state_name] = np.asarray(fields[file_name], dtype=np.float64)
+
+    def _init_from_loaded_bc(self):
+        """the reference's `init` on boundary fields that are in the container already (set here, or handed over device to
+        device by SpeedyEns.set_bc)"""
         code = _speedy.init(self._state_cnt, self._control_cnt)
         if code < 0:
             raise RuntimeError(ERROR_CODES[code])
@@ -331,6 +340,22 @@ class SpeedyEns:
         for member in self:
             member.set_params(start_date=start_date, end_date=end_date)
         self.current_date = start_date
+
+    def set_bc(self, bc_file=None, sst_anomaly=None):
+        """Extension (the reference initialises an ensemble with `for member in ens: member.set_bc()`, which still works): load
+        the boundary conditions ONCE, into member 0, hand them to every other member device to device -- across the GPUs of a
+        `devices=k` ensemble with one RCCL broadcast over xGMI, on a GPU with local copies (speedy_driver.broadcast_boundary) --
+        and initialise every member.  The file is read and its 3.4 MB cross PCIe once instead of once per member; the members
+        are bitwise what `member.set_bc(bc_file, sst_anomaly)` gives each of them."""
+        for member in self:
+            if member._initialized_bc:
+                raise RuntimeError("The model was already initialized. Create a new instance if you need different boundary conditions.")
+        self.members[0]._load_bc(bc_file, sst_anomaly)
+        for member in self.members[1:]:
+            member._set_sst_anomalies(None)  # (allocates the same number of months: the anomalies travel with the other fields)
+        _speedy.broadcast_boundary([m._state_cnt for m in self], 0)
+        for member in self:
+            member._init_from_loaded_bc()
 
     def to_dataframe(self, variables=None):
         """All members along the `ens` dimension: one batched spectral -> grid conversion and one device-to-host copy per

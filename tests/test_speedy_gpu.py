@@ -313,3 +313,28 @@ def test_ens_speedy_across_two_device_models(gold):
     for m in (0, 16, 17, 32):
         assert_matches(ens_ds.sel(ens=m), exp)
     assert ens.get_current_step() == 36 and ens.members[32].get_current_step() == 36
+
+
+def test_ensemble_set_bc_loads_once_and_hands_the_fields_on():
+    """SpeedyEns.set_bc (extension): the boundary file goes into member 0 only, every other member receives the fields device to
+    device, all members are initialised -- bitwise what the reference's `for member in ens: member.set_bc()` gives, also with SST
+    anomalies and across the two device models of a 34-member ensemble."""
+    from pyspeedy_amd import speedy_driver as drv
+    from pyspeedy_amd.speedy import SpeedyEns
+    start, end = datetime(1982, 1, 1), datetime(1982, 1, 1, 4, 0)
+    months = np.array(["1981-12-01", "1982-01-01", "1982-02-01"], dtype="datetime64[s]")
+    ssta = {"time": months, "ssta": 0.3 * np.random.default_rng(4).standard_normal((96, 48, 3))}
+    for n, anomalies in ((3, None), (34, ssta)):
+        once, each = SpeedyEns(n, start_date=start, end_date=end), SpeedyEns(n, start_date=start, end_date=end)
+        once.set_bc(sst_anomaly=anomalies)
+        assert drv.broadcast_boundary_stats() == (0, n - 1, 0)  # one GPU: n - 1 local copies, nothing crosses
+        for member in each:
+            member.set_bc(sst_anomaly=anomalies)
+        with pytest.raises(RuntimeError):
+            once.set_bc()
+        once.run()
+        each.run()
+        for i in (0, 1, n - 1):
+            for name in ("t", "vor", "ps", "sst12", "sst_anom", "land_temp", "stl12"):
+                assert np.array_equal(once.members[i][name], each.members[i][name]), (n, i, name)
+        assert np.abs(once.members[1]["sst_anom"]).max() > 0 if anomalies else True
