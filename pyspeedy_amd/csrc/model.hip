@@ -1415,7 +1415,7 @@ int spd_model_copy_member(spd_model_handle dst, int di, spd_model_handle src, in
     hipStream_t s = static_cast<hipStream_t>(stream);
     M_HIP(hipSetDevice(dst->ctx->device));
     M_HIP(hipDeviceSynchronize());  // the two models may have been driven on different streams
-    // whole allocations are copied as they are: both models must store them the same way, and the storage belongs to the
+    // a member's arrays are copied as they are stored: both models must store them the same way, and the storage belongs to the
     // precision of the column physics (fp32 storage is only ever read by the fp32 kernel): the receiving model takes both over
     dst->phys_fp32 = src->phys_fp32;
     dst->phys_store32 = src->phys_store32;
@@ -1425,7 +1425,8 @@ int spd_model_copy_member(spd_model_handle dst, int di, spd_model_handle src, in
         auto it = dst->reg.find(kv.first);
         if (it == dst->reg.end() || it->second.bytes_member != kv.second.bytes_member)
             return m_fail(SPD_E_SIZE, "spd_model_copy_member: variable '" + kv.first + "' differs between the models");
-        const size_t b = kv.second.bytes_member;
+        // (an array kept as fp32 is compact in fp32: member i starts half as far into the allocation and is half as long)
+        const size_t b = (kv.second.f32 && src->stored32) ? kv.second.bytes_member / 2 : kv.second.bytes_member;
         M_HIP(hipMemcpyAsync(static_cast<char *>(it->second.ptr) + b * di, static_cast<const char *>(kv.second.ptr) + b * si, b,
                              hipMemcpyDeviceToDevice, s));
     }

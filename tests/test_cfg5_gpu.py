@@ -242,8 +242,12 @@ def test_cfg5_survives_the_drivers_regrouping(spectral):
     M = 5
     ens = SpeedyEns(M, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 2))
     ens.set_physics_precision(True)  # no SPPT here: an SPPT member keeps its own model and is never gathered again
-    for member in ens:
+    rng = np.random.default_rng(8)
+    noise = [rng.normal(0.0, 0.5, (96, 48, 8)) for _ in range(M)]  # (members that differ: a copy from the wrong slot must show)
+    for member, dt in zip(ens, noise):
         member.set_bc()
+        member["t_grid"] = member["t_grid"] + dt
+        member.grid2spectral()
     states, controls = [m._state_cnt for m in ens], [m._control_cnt for m in ens]
     for _ in range(4):
         assert (drv.parallel_step(states, controls) == 0).all()
@@ -262,10 +266,15 @@ def test_cfg5_survives_the_drivers_regrouping(spectral):
     one.set_physics_precision(True)  # (before the initialisation, as above: first_step already runs the fp32 physics)
     with np.load(pyspeedy_amd.example_bc_file()) as z:
         one.set_bc({k: z[k] for k in z.files})
+    one.spectral2grid()
+    for i, dt in enumerate(noise):
+        one.set("t_grid", one.get("t_grid", i) + dt, i)
+    one.grid2spectral()
     one.run(8)
     for i in range(M):
-        for name in ("t", "vor", "tr", "ps", "rad_tau2", "tt_rsw"):
+        for name in ("t", "vor", "tr", "ps", "rad_tau2", "tt_rsw", "olr", "precnv"):
             assert np.array_equal(ens.members[i][name], one.get(name, i)), (i, name)
+    assert not np.array_equal(one.get("rad_tau2", 0), one.get("rad_tau2", 3))
     one.close()
 
 
