@@ -1465,7 +1465,9 @@ int spd_model_copy_vars_enqueue(spd_model_handle dst, int di, spd_model_handle s
             return m_fail(SPD_E_ARG, std::string("spd_model_copy_vars: unknown variable '") + names[i] + "'");
         if (a->second.bytes_member != b->second.bytes_member)
             return m_fail(SPD_E_SIZE, std::string("spd_model_copy_vars: variable '") + names[i] + "' differs between the models");
-        const size_t n = a->second.bytes_member;
+        if (a->second.f32 && src->stored32 != dst->stored32)
+            return m_fail(SPD_E_ARG, std::string("spd_model_copy_vars: variable '") + names[i] + "' is stored as fp32 in one model and as fp64 in the other");
+        const size_t n = (a->second.f32 && src->stored32) ? a->second.bytes_member / 2 : a->second.bytes_member;  // (as stored)
         char *to = static_cast<char *>(b->second.ptr) + n * di;
         const char *from = static_cast<const char *>(a->second.ptr) + n * si;
         if (to == from) continue;
