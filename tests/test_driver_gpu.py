@@ -399,11 +399,13 @@ def test_init_of_a_batched_member_never_resets_the_other_members(drv, bc):
     drv.close(*states, *ens2)
 
 
-def test_random_groupings_keep_every_container_on_the_trajectory_of_a_lone_container(drv, bc):
+@pytest.mark.parametrize("fp32", [False, True])
+def test_random_groupings_keep_every_container_on_the_trajectory_of_a_lone_container(drv, bc, fp32):
     """A randomised sequence (fixed seed) of parallel_step / begin-end over changing subsets of six containers, state writes and
     a scalar change -- gathers, partial gathers, splits and two-model calls in whatever order they come -- against six twin
     containers that are only ever stepped alone with step(): every container ends bitwise on its twin's trajectory, with its
-    twin's date and step counter."""
+    twin's date and step counter.  fp32: the same with BASELINE cfg 5's fp32 column physics in every container, whose fp32-stored
+    arrays have to travel with their members through every gather and split."""
     rng = np.random.default_rng(20260410)
     n = 6
     world = [drv.state() for _ in range(n)]
@@ -413,6 +415,10 @@ def test_random_groupings_keep_every_container_on_the_trajectory_of_a_lone_conta
     for i in range(n):
         for s, c in ((world[i], cw[i]), (twins[i], ct[i])):
             drv.set_bc(s, bc, 0.05 * i * np.ones((96, 48, 12)))
+            if fp32:
+                model = C.c_void_p()
+                drv.ok(drv.L.spd_driver_model(s, C.byref(model), None, None))
+                drv.ok(drv.L.spd_model_set_physics_precision(model, 1))
             assert drv.init(s, c) == 0
     steps, largest = [0] * n, 0
     for op in range(60):
@@ -460,8 +466,12 @@ def test_random_groupings_keep_every_container_on_the_trajectory_of_a_lone_conta
         assert drv.get(world[i], "current_step", np.int32) == drv.get(twins[i], "current_step", np.int32)
         for name, dt in (("vor", np.complex128), ("t", np.complex128), ("ps", np.complex128), ("tr", np.complex128)):
             assert np.array_equal(drv.get(world[i], name, dt), drv.get(twins[i], name, dt)), (i, name)
-        for name in ("olr", "land_temp", "sst_am", "rad_tau2", "hfluxn"):
+        for name in ("olr", "land_temp", "sst_am", "rad_tau2", "hfluxn", "tt_rsw", "precnv", "ustr"):
             assert np.array_equal(drv.get(world[i], name), drv.get(twins[i], name)), (i, name)
+    if fp32:
+        model = C.c_void_p()
+        drv.ok(drv.L.spd_driver_model(world[0], C.byref(model), None, None))
+        assert drv.L.spd_model_var_storage(model, b"rad_tau2") == 4 and drv.L.spd_model_var_storage(model, b"t") == 8
     drv.close(*world, *twins)
 
 
