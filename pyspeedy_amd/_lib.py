@@ -136,6 +136,7 @@ _SIGNATURES = {
     "spd_controlparams_close": (C.c_int, [C.c_int64]),
     "spd_controlparams_get_model_datetime": (C.c_int, [C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "spd_init": (C.c_int, [C.c_int64, C.c_int64, C.POINTER(C.c_int32)]),
+    "spd_init_ensemble": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int32]),
     "spd_step": (C.c_int, [C.c_int64, C.c_int64, C.POINTER(C.c_int32)]),
     "spd_parallel_step": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int32]),
     "spd_parallel_step_begin": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_int64)]),

@@ -354,8 +354,12 @@ class SpeedyEns:
         for member in self.members[1:]:
             member._set_sst_anomalies(None)  # (allocates the same number of months: the anomalies travel with the other fields)
         _speedy.broadcast_boundary([m._state_cnt for m in self], 0)
+        codes = _speedy.init_ensemble([m._state_cnt for m in self], [m._control_cnt for m in self])  # one pass per device model
+        if (codes < 0).any():
+            raise RuntimeError("".join("Member%d: %s\n" % (n, ERROR_CODES[int(c)]) for n, c in enumerate(codes)))
         for member in self:
-            member._init_from_loaded_bc()
+            member.spectral2grid()
+            member._initialized_bc = True
 
     def to_dataframe(self, variables=None):
         """All members along the `ens` dimension: one batched spectral -> grid conversion and one device-to-host copy per

@@ -183,6 +183,18 @@ def init(state_cnt, control_cnt):
     return code.value
 
 
+def init_ensemble(state_cnts, control_cnts):
+    """Extension: `init` for every container; the members of a device model that nobody has initialised yet are initialised
+    together (spd_init_ensemble).  Returns the int32 codes."""
+    s, n = _cnts(state_cnts)
+    c, nc = _cnts(control_cnts)
+    if n != nc:
+        raise ValueError("init_ensemble: one control container per state container")
+    codes = np.zeros(n, dtype=np.int32)
+    _ok(_L().spd_init_ensemble(s, c, codes.ctypes.data_as(C.POINTER(C.c_int32)), n), "init_ensemble")
+    return codes
+
+
 def step(state_cnt, control_cnt):
     """do_single_step (speedy.f90:20-74) followed by the range check of diagnostics.f90."""
     code = C.c_int32(0)

@@ -355,8 +355,15 @@ void single_thread() {
             e[i].state = ids[i];
             make_controls(e[i]);
             set_seed(e[i], 1000.0 + i);
-            init(e[i]);
+            if (i < 35) init(e[i]);  // (the two device models of device 0 member by member, ...)
             ep.push_back(&e[i]);
+        }
+        {   // ... the two of device 1 in one pass each
+            std::vector<Member *> rest(ep.begin() + 35, ep.end());
+            Lists l(rest);
+            EXPECT(spd_init_ensemble(l.s.data(), l.c.data(), l.codes.data(), 35) == 0);
+            for (int i = 0; i < 35; ++i) EXPECT(l.codes[i] == 0);
+            EXPECT(spd_init_ensemble(l.s.data(), l.c.data(), l.codes.data(), -1) < 0);
         }
         EXPECT(models_alive() == 4);
         for (int k = 0; k < 5; ++k) step_all(ep);
