@@ -133,3 +133,13 @@ def test_sharded_ensemble_forecast_is_independent_of_the_sharding(tmp_path):
     for v in ("t_mean", "t_spread"):
         np.testing.assert_allclose(a[v].values, b[v].values, rtol=1e-6, atol=1e-7)
     assert float(a["t_spread"].values.max()) > 1e-3
+    # ... and the reference's own shape, ONE process over the GPUs it can see (examples/ensemble_one_process.py: SpeedyEns with
+    # devices=k, ens.set_bc(), one parallel_step per model step), gives the same forecast
+    out3 = str(tmp_path / "one_process")
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "ensemble_one_process.py"), "--members", "5", "--days", "1",
+                          "--out", out3], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "5 members on device(s) [0]" in run.stdout and "36 steps" in run.stdout
+    c = open_dataset(os.path.join(out3, "tstat_1982-01-02_0000.nc"))
+    for v in ("t_mean", "t_spread"):
+        np.testing.assert_allclose(a[v].values, c[v].values, rtol=1e-6, atol=1e-7)
