@@ -41,6 +41,19 @@ def test_launcher_reports_a_failing_rank():
     assert "rank" in run.stderr
 
 
+def test_a_failing_one_process_child_costs_the_line_an_object_not_its_headline():
+    """The one-process measurement of an N-rank line runs in a child process of rank 0; whatever happens to it (here: no GPU at
+    all) comes back as {"error": ...} for the `one_process` object."""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("needs a machine without a GPU")
+    sys.path.insert(0, ROOT)
+    import bench
+    op = bench.one_process_child(2, ["--scaling", "strong", "--members", "4"], timeout=300)
+    assert set(op) == {"error"} and "exit code" in op["error"]
+    assert bench.file_flag("test_flag_%d" % os.getpid(), wait_seconds=0.1) is False
+    assert bench.file_flag("test_flag_%d" % os.getpid(), set_it=True) and bench.file_flag("test_flag_%d" % os.getpid(), wait_seconds=1.0)
+
+
 def _result(run):
     assert run.returncode == 0, run.stdout + run.stderr
     lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
