@@ -115,6 +115,42 @@ def test_members_of_a_large_batch_equal_single_member_runs(spectral, bc):
     assert not np.array_equal(ens.get("t", 1), ens.get("t", 2))
 
 
+def test_initialisation_preprocesses_distinct_boundary_sets_only(spectral, bc):
+    """spd_model_init compares every member's boundary fields with member 0's on the device: the members that share them take
+    member 0's preprocessed fields (land / sea masks, cleaned climatologies, heat capacities) with device-to-device copies, a
+    member with fields of its own goes through the host itself.  Six members, two of them with their own SST and soil
+    climatologies (one with missing values inside the sea mask, which the preprocessing has to fill): every member is bitwise
+    the one-member model initialised from the same fields, after the initialisation and after 7 steps."""
+    from pyspeedy_amd.model import BC_MAP, EnsembleModel
+    M = 6
+    fields = {i: {k: np.asarray(bc[k], dtype=np.float64).copy() for k in bc.files} for i in range(M)}
+    fields[2]["sst"] += 0.7
+    fields[2]["sst"][40:44, 20:22, :] = 9.97e36   # missing values over the open ocean
+    fields[5]["swl1"] *= 0.9
+    fields[5]["stl"] += 0.25
+    ens = EnsembleModel(spectral, M)
+    for state_name, bc_name in BC_MAP:
+        ens.set(state_name, fields[0][bc_name], -1)
+        for i in (2, 5):
+            ens.set(state_name, fields[i][bc_name], i)
+    ens.init((1982, 1, 1, 0, 0))
+    names = SPEC + ("sst12", "stl12", "soilw12", "fmask_land", "fmask_sea", "rhcapl", "cdsea", "land_temp", "sst_am", "phis0")
+    singles = {}
+    for i in (0, 2, 3, 5):
+        singles[i] = EnsembleModel(spectral, 1)
+        singles[i].set_bc(fields[i])
+        for n in names:
+            assert np.array_equal(ens.get(n, i), singles[i].get(n, 0)), (i, n, "after init")
+    assert not np.array_equal(ens.get("sst12", 2), ens.get("sst12", 0)) and np.isfinite(ens.get("sst12", 2)).all()
+    ens.run(7)
+    for i, single in singles.items():
+        single.run(7)
+        for n in names + ("olr", "rad_tau2"):
+            assert np.array_equal(ens.get(n, i), single.get(n, 0)), (i, n, "after 7 steps")
+        single.close()
+    ens.close()
+
+
 def _through_a_file(snapshot):
     with tempfile.TemporaryDirectory() as tmp:  # as a checkpoint would travel
         np.savez(os.path.join(tmp, "ckpt.npz"), **snapshot)
