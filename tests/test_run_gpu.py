@@ -125,7 +125,7 @@ def test_initialisation_preprocesses_distinct_boundary_sets_only(spectral, bc):
     M = 6
     fields = {i: {k: np.asarray(bc[k], dtype=np.float64).copy() for k in bc.files} for i in range(M)}
     fields[2]["sst"] += 0.7
-    fields[2]["sst"][40:44, 20:22, :] = 9.97e36   # missing values over the open ocean
+    fields[2]["sst"][40:44, 20:22, :] = -999.0    # missing values (anything below 0, boundaries.f90:40-114) over the open ocean
     fields[5]["swl1"] *= 0.9
     fields[5]["stl"] += 0.25
     ens = EnsembleModel(spectral, M)
