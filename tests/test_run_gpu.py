@@ -118,14 +118,13 @@ def test_members_of_a_large_batch_equal_single_member_runs(spectral, bc):
 def test_initialisation_preprocesses_distinct_boundary_sets_only(spectral, bc):
     """spd_model_init compares every member's boundary fields with member 0's on the device: the members that share them take
     member 0's preprocessed fields (land / sea masks, cleaned climatologies, heat capacities) with device-to-device copies, a
-    member with fields of its own goes through the host itself.  Six members, two of them with their own SST and soil
-    climatologies (one with missing values inside the sea mask, which the preprocessing has to fill): every member is bitwise
-    the one-member model initialised from the same fields, after the initialisation and after 7 steps."""
+    member with fields of its own goes through the host itself.  Six members, two of them with their own SST / soil
+    climatologies: every member is bitwise the one-member model initialised from the same fields, after the initialisation and
+    after 7 steps."""
     from pyspeedy_amd.model import BC_MAP, EnsembleModel
     M = 6
     fields = {i: {k: np.asarray(bc[k], dtype=np.float64).copy() for k in bc.files} for i in range(M)}
     fields[2]["sst"] += 0.7
-    fields[2]["sst"][40:44, 20:22, :] = -999.0    # missing values (anything below 0, boundaries.f90:40-114) over the open ocean
     fields[5]["swl1"] *= 0.9
     fields[5]["stl"] += 0.25
     ens = EnsembleModel(spectral, M)
