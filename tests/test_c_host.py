@@ -17,17 +17,18 @@ NAMES = ("orog", "lsm", "alb", "vegh", "vegl", "stl", "snowd", "swl1", "swl2", "
 needs_gcc = pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not available")
 
 
-def build(tmp_path):
+def build(tmp_path, name="c_host"):
     libdir = os.path.join(ROOT, "pyspeedy_amd")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
-                    os.path.join(ROOT, "examples", "c_host.c"), "-L" + libdir, "-lpyspeedy_amd", "-lpthread",
-                    "-Wl,-rpath," + libdir, "-o", "c_host"], cwd=tmp_path, check=True, capture_output=True, text=True)
-    return str(tmp_path / "c_host")
+                    os.path.join(ROOT, "examples", name + ".c"), "-L" + libdir, "-lpyspeedy_amd", "-lpthread",
+                    "-Wl,-rpath," + libdir, "-o", name], cwd=tmp_path, check=True, capture_output=True, text=True)
+    return str(tmp_path / name)
 
 
 @needs_gcc
 def test_the_headers_are_plain_c_and_the_host_fails_loudly_without_a_device(tmp_path, hip_lib):
     exe = build(tmp_path)
+    build(tmp_path, "c_ensemble_host")  # (the host of the library's extensions: plain C too)
     if os.path.exists("/dev/kfd"):
         pytest.skip("the rest needs a machine without a GPU")
     run = subprocess.run([exe, os.devnull, "out.bin", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
@@ -55,3 +56,11 @@ def test_c_host_steps_four_containers_from_one_and_from_two_threads(tmp_path, hi
     assert np.abs(t0 - ref).max() <= 1e-10 * np.abs(ref).max()
     assert np.abs(outs[0][3] - outs[0][0]).max() > 1e-3  # member 3: SST + 0.75 K
     assert np.array_equal(outs[0], outs[1])  # the same trajectories whether one thread steps all four or two threads two each
+    # ... and through the library's extensions (examples/c_ensemble_host.c): containers batched from the start, the boundary file
+    # into container 0 only and handed on device to device, one initialisation per device model, the overlapped time loop
+    ens = build(tmp_path, "c_ensemble_host")
+    run = subprocess.run([ens, "bc.bin", "out_ens.bin", "36", "4"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "model date 1982-01-02 00:00 members in the first device model 4" in run.stdout, run.stdout
+    assert "0 peer copies, 3 local copies" in run.stdout or "GPUs reached collectively" in run.stdout, run.stdout
+    assert np.array_equal(np.fromfile(tmp_path / "out_ens.bin", dtype=np.float64).reshape((4, 96 * 48 * 8)), outs[0])
