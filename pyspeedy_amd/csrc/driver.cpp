@@ -291,6 +291,7 @@ int split_batch(const std::shared_ptr<Batch> &b) {
     if (b->members == 1) return SPD_OK;
     spd_model_control mc;
     if (int rc = spd_model_get_control(b->model, &mc)) return rc;
+    regrouped();  // (first: a copy that fails below leaves some containers moved already, and no kept plan may outlive that)
     for (auto &st : members_of(b)) {
         std::shared_ptr<Batch> single;
         if (int rc = new_batch(1, b->device, &single)) return rc;
@@ -317,7 +318,6 @@ int split_batch(const std::shared_ptr<Batch> &b) {
         st->batch = single;
         st->member = 0;
     }
-    regrouped();
     if (!drvdev::device_synchronize()) return fail(SPD_E_DEVICE, "speedy driver: device error while splitting a batch");
     return SPD_OK;  // (`b` dies with the caller's reference)
 }
