@@ -276,6 +276,27 @@ def physics(inputs, compute_shortwave, air_absortivity_co2):
 # ---------------------------------------------------------------------------------------------------
 # dynamics / time stepping (callers of the hot path)
 # ---------------------------------------------------------------------------------------------------
+
+def land_sea_init(fields, fmean=0.0):
+    """land_model_init + sea_model_init (orc_surface.c) on a dict of registry inputs (oracle/init_cases.py); returns the dict of
+    the 16 outputs and the running mean fill_missing_values is left with."""
+    f = {k: np.array(v, dtype=np.float64, order="F") for k, v in fields.items()}
+    n_planes = f["sst_anom"].shape[2] if "sst_anom" in f else 0
+    anom = f.get("sst_anom", np.zeros((96, 48, 0), order="F"))
+    out = {k: np.zeros((96, 48), order="F") for k in ("fmask_land", "bmask_land", "fmask_sea", "bmask_sea", "rhcapl", "cdland",
+                                                      "rhcaps", "rhcapi", "cdsea", "cdice")}
+    out["soilw12"] = np.zeros((96, 48, 12), order="F")
+    carry = np.array([fmean], dtype=np.float64)
+    _call("land_sea_init", n_planes, f["fmask_orig"], f["alb0"], f["veg_high"], f["veg_low"], f["soil_wc_l1"], f["soil_wc_l2"],
+          f["stl12"], f["snowd12"], f["sst12"], f["sea_ice_frac12"], anom, out["soilw12"], out["fmask_land"], out["bmask_land"],
+          out["fmask_sea"], out["bmask_sea"], out["rhcapl"], out["cdland"], out["rhcaps"], out["rhcapi"], out["cdsea"],
+          out["cdice"], carry)
+    for k in ("stl12", "snowd12", "sst12", "sea_ice_frac12"):
+        out[k] = f[k]
+    out["sst_anom"] = anom
+    return out, float(carry[0])
+
+
 class DynTables(C.Structure):
     _fields_ = [(n, C.c_double * 992) for n in ("dmp", "dmpd", "dmps", "dmp1", "dmp1d", "dmp1s")] + [
         ("tcorv", C.c_double * 8), ("qcorv", C.c_double * 8), ("tref", C.c_double * 8), ("tref2", C.c_double * 8),

@@ -148,6 +148,16 @@ void orc_get_tendencies(const orc_tables *t, const orc_dyn_tables *d, orc_state 
 void orc_step(const orc_tables *t, const orc_dyn_tables *d, orc_state *s, int j1, int j2, double dt);
 int orc_check_diagnostics(const orc_tables *t, const orc_state *s, int time_lev, double *diag);
 
+/* ---- boundary-field preprocessing of the initialisation (orc_surface.c): land_model_init + sea_model_init.
+ * Monthly fields (ix, il, 12) and sst_anom (ix, il, n_anom_planes) are cleaned in place; *fmean is the SAVEd running mean
+ * of fill_missing_values (boundaries.f90:77), 0 in a fresh process. */
+void orc_land_sea_init(const orc_tables *t, int n_anom_planes, const double *fmask_orig, const double *alb0,
+                       const double *veg_high, const double *veg_low, const double *soil_wc_l1, const double *soil_wc_l2,
+                       double *stl12, double *snowd12, double *sst12, double *sea_ice_frac12, double *sst_anom,
+                       double *soilw12, double *fmask_land, double *bmask_land, double *fmask_sea, double *bmask_sea,
+                       double *rhcapl, double *cdland, double *rhcaps, double *rhcapi, double *cdsea, double *cdice,
+                       double *fmean);
+
 #ifdef __cplusplus
 }
 #endif

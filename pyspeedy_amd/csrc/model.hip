@@ -42,7 +42,7 @@ hipError_t run_forcing(const SurfacePtrs &S, int first, int count, const ZonalDe
 hipError_t run_rest_state(const RestPtrs &R, int M, const RestConsts &c, hipStream_t s);
 hipError_t run_scale_orog(const double *orog, double *phi0, long n, hipStream_t s);
 hipError_t run_change_storage(double *array, long n, bool to_float, void *scratch, hipStream_t s);
-hipError_t run_differs_from_first(const double *v, long n, int M, int *flags, hipStream_t s);
+hipError_t run_land_sea_init(const LandSeaPtrs &P, const LandSeaConsts &K, int M, hipStream_t s);
 hipError_t run_copy_from_first(double *v, long n, int M, const int *flags, hipStream_t s);
 hipError_t run_rest_surface(const double *phis0, double *forog, double *surf_ps, double *surf_q, const RestConsts &c, long n,
                             hipStream_t s);
@@ -928,57 +928,22 @@ int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, i
     const int M = m->M;
     const DeviceTables &T = m->ctx->dev;
     M_HIP(hipSetDevice(m->ctx->device));
-    M_HIP(hipDeviceSynchronize());  // (blocking host <-> device copies follow; see xfer)
+    M_HIP(hipDeviceSynchronize());  // (the boundary fields came through the null stream, see xfer; `stream` may be any)
     m->cal.set(year, month, day, hour, minute);
     m->current_step = 0;
     m->surf_cache_valid = m->phi_ahead = false;
-    // ---- land_model_init / sea_model_init on the host (runs once): 11 fields down, 16 up, per DISTINCT set of boundary fields.
-    // The members of an ensemble normally share one set: the device compares every member's inputs with member 0's (bit for
-    // bit), member 0 is preprocessed on the host, and the members that hold the same inputs take its results with device-to-device
-    // copies; only a member whose fields differ goes through the host itself.  (A 256-member model with shared boundary fields:
-    // 27 blocking copies and 27 small launches instead of 6912 blocking copies.)
-    const size_t G12 = static_cast<size_t>(12) * NG, GA = static_cast<size_t>(m->anom_planes) * NG;
-    struct Var {
-        double *dev;
-        size_t n;
-        std::vector<double> SurfaceFields::*field;
-    };
-    const Var in[] = {{m->fmask_orig, NG, &SurfaceFields::fmask_orig}, {const_cast<double *>(m->S.alb0), NG, &SurfaceFields::alb0},
-                      {m->veg_high, NG, &SurfaceFields::veg_high}, {m->veg_low, NG, &SurfaceFields::veg_low},
-                      {m->S.stl12, G12, &SurfaceFields::stl12}, {m->S.snowd12, G12, &SurfaceFields::snowd12},
-                      {m->soil_wc_l1, G12, &SurfaceFields::soil_wc_l1}, {m->soil_wc_l2, G12, &SurfaceFields::soil_wc_l2},
-                      {m->S.sst12, G12, &SurfaceFields::sst12}, {m->S.sea_ice_frac12, G12, &SurfaceFields::sea_ice_frac12},
-                      {m->S.sst_anom, GA, &SurfaceFields::sst_anom}};
-    const Var out[] = {{const_cast<double *>(m->pa.fmask_land), NG, &SurfaceFields::fmask_land},
-                       {m->bmask_land, NG, &SurfaceFields::bmask_land}, {m->S.fmask_sea, NG, &SurfaceFields::fmask_sea},
-                       {m->bmask_sea, NG, &SurfaceFields::bmask_sea}, {m->S.stl12, G12, &SurfaceFields::stl12},
-                       {m->S.snowd12, G12, &SurfaceFields::snowd12}, {m->S.soilw12, G12, &SurfaceFields::soilw12},
-                       {m->S.sst12, G12, &SurfaceFields::sst12}, {m->S.sea_ice_frac12, G12, &SurfaceFields::sea_ice_frac12},
-                       {m->S.sst_anom, GA, &SurfaceFields::sst_anom}, {m->S.rhcapl, NG, &SurfaceFields::rhcapl},
-                       {m->S.cdland, NG, &SurfaceFields::cdland}, {m->S.rhcaps, NG, &SurfaceFields::rhcaps},
-                       {m->S.rhcapi, NG, &SurfaceFields::rhcapi}, {m->S.cdsea, NG, &SurfaceFields::cdsea},
-                       {m->S.cdice, NG, &SurfaceFields::cdice}};
-    std::vector<int> differs(M, 0);
-    if (M > 1) {  // (before member 0's inputs are cleaned in place below)
-        M_HIP(hipMemsetAsync(m->d_err, 0, sizeof(int) * M, s));
-        for (const Var &v : in) M_HIP(run_differs_from_first(v.dev, static_cast<long>(v.n), M, m->d_err, s));
-        M_HIP(hipMemcpyAsync(differs.data(), m->d_err, sizeof(int) * M, hipMemcpyDeviceToHost, s));
-        M_HIP(hipStreamSynchronize(s));
-    }
-    for (int i = 0; i < M; ++i) {
-        if (i > 0 && !differs[i]) continue;
-        SurfaceFields sf;
-        for (const Var &v : in) {
-            (sf.*(v.field)).resize(v.n);
-            M_HIP(hipMemcpy((sf.*(v.field)).data(), v.dev + v.n * i, v.n * sizeof(double), hipMemcpyDeviceToHost));
-        }
-        land_sea_init(m->ctx->host, sf);
-        for (const Var &v : out)
-            M_HIP(hipMemcpy(v.dev + v.n * i, (sf.*(v.field)).data(), v.n * sizeof(double), hipMemcpyHostToDevice));
-    }
-    if (M > 1) {
-        M_HIP(hipMemcpy(m->d_err, differs.data(), sizeof(int) * M, hipMemcpyHostToDevice));
-        for (const Var &v : out) M_HIP(run_copy_from_first(v.dev, static_cast<long>(v.n), M, m->d_err, s));
+    // ---- land_model_init / sea_model_init: every member's boundary fields preprocessed where they lie, one workgroup per member
+    {
+        LandSeaPtrs L{};
+        L.fmask_orig = m->fmask_orig; L.alb0 = m->S.alb0; L.veg_high = m->veg_high; L.veg_low = m->veg_low;
+        L.soil_wc_l1 = m->soil_wc_l1; L.soil_wc_l2 = m->soil_wc_l2;
+        L.stl12 = m->S.stl12; L.snowd12 = m->S.snowd12; L.sst12 = m->S.sst12; L.sea_ice_frac12 = m->S.sea_ice_frac12;
+        L.sst_anom = m->S.sst_anom;
+        L.soilw12 = m->S.soilw12; L.fmask_land = const_cast<double *>(m->pa.fmask_land); L.bmask_land = m->bmask_land;
+        L.fmask_sea = m->S.fmask_sea; L.bmask_sea = m->bmask_sea; L.rhcapl = m->S.rhcapl; L.cdland = m->S.cdland;
+        L.rhcaps = m->S.rhcaps; L.rhcapi = m->S.rhcapi; L.cdsea = m->S.cdsea; L.cdice = m->S.cdice;
+        L.anom_planes = m->anom_planes;
+        M_HIP(run_land_sea_init(L, land_sea_consts(m->ctx->host), M, s));
     }
     // ---- initialize_boundaries (boundaries.f90:22-37): phi0 = g * orog, phis0 = spectrally truncated phi0
     double *phis0 = const_cast<double *>(m->pa.phis0);

@@ -22,6 +22,15 @@ struct SurfacePtrs {
     const double *alb0, *fmask_land, *phis0;
 };
 
+// land_sea_init_kernel: the boundary fields of every member as the host stored them, and what land_model_init / sea_model_init
+// make of them.  [M][48][96], monthly fields [M][12][48][96], sst_anom [M][anom_planes][48][96].
+struct LandSeaPtrs {
+    const double *fmask_orig, *alb0, *veg_high, *veg_low, *soil_wc_l1, *soil_wc_l2;  // read
+    double *stl12, *snowd12, *sst12, *sea_ice_frac12, *sst_anom;                      // cleaned in place
+    double *soilw12, *fmask_land, *bmask_land, *fmask_sea, *bmask_sea, *rhcapl, *cdland, *rhcaps, *rhcapi, *cdsea, *cdice;  // written
+    int anom_planes;
+};
+
 struct ZonalDevice {
     double v[5][48];  // flux_solar_in, flux_ozone_upper, flux_ozone_lower, zenit_correction, stratospheric_correction
 };

@@ -6,7 +6,6 @@
 
 namespace spd {
 namespace {
-constexpr int NG = IX * IL;
 const int kDaysInMonth[12] = {31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31};  // ncal365, model_control.f90:60
 inline int days_before(int month /*1-based*/) {
     int s = 0;
@@ -132,125 +131,47 @@ ZonalForcing zonal_average_fields(const HostTables &t, double tyear) {
     return z;
 }
 
-// ------------------------------------------------------------------------------------------- boundaries.f90:40-114
-namespace {
-// fill_missing_values keeps its running mean in a SAVEd variable (boundaries.f90:77): one instance per process in the
-// reference; per call sequence here, which is equivalent because every caller starts from a complete first row.
-struct MissingFiller {
-    double fmean = 0.0;
-    void operator()(double *sf /*(ix,il)*/, double fmis) {
-        double sf2[IX + 2];
-        int j1 = 0;
-        for (int hemisphere = 1; hemisphere <= 2; ++hemisphere) {
-            int j2, j3;
-            if (hemisphere == 1) { j1 = IL / 2; j2 = 1; j3 = -1; } else { j1 = j1 + 1; j2 = IL; j3 = 1; }
-            for (int j = j1; j3 > 0 ? j <= j2 : j >= j2; j += j3) {
-                double *row = sf + IX * (j - 1);
-                int nmis = 0;
-                for (int i = 1; i <= IX; ++i) {
-                    sf2[i] = row[i - 1];
-                    if (row[i - 1] < fmis) { ++nmis; sf2[i] = 0.0; }
-                }
-                if (nmis < IX) {
-                    double s = 0.0;
-                    for (int i = 1; i <= IX; ++i) s += sf2[i];
-                    fmean = s / static_cast<double>(static_cast<float>(IX - nmis));
-                }
-                for (int i = 1; i <= IX; ++i)
-                    if (row[i - 1] < fmis) sf2[i] = fmean;
-                sf2[0] = sf2[IX];
-                sf2[IX + 1] = sf2[1];
-                for (int i = 1; i <= IX; ++i)
-                    if (row[i - 1] < fmis) row[i - 1] = 0.5f * (sf2[i - 1] + sf2[i + 1]);
-            }
-        }
-    }
-};
-
-void check_surface_fields(const std::vector<double> &mask, int nf, double fset, std::vector<double> &field) {
-    for (int f = 0; f < nf; ++f)
-        for (int p = 0; p < NG; ++p)
-            if (!(mask[p] > 0.0)) field[static_cast<size_t>(f) * NG + p] = fset;
-}
-}  // namespace
-
-void land_sea_init(const HostTables &t, SurfaceFields &s) {
-    const double thrsh = 0.1f;
-    MissingFiller fill;
-    // ---------------- land_model_init, land_model.f90:50-148
-    s.fmask_land = s.fmask_orig;
-    s.bmask_land.assign(NG, 0.0);
-    for (int p = 0; p < NG; ++p) {
-        if (s.fmask_land[p] >= thrsh) {
-            s.bmask_land[p] = 1.0;
-            if (s.fmask_orig[p] > (1.0f - thrsh)) s.fmask_land[p] = 1.0;
-        } else {
-            s.bmask_land[p] = 0.0;
-            s.fmask_land[p] = 0.0;
-        }
-    }
-    for (int m = 0; m < 12; ++m) fill(s.stl12.data() + static_cast<size_t>(m) * NG, 0.0);
-    check_surface_fields(s.bmask_land, 12, 273.0, s.stl12);
-    check_surface_fields(s.bmask_land, 12, 0.0, s.snowd12);
+// ------------------------------------------------------------------------------------------- land / sea model constants
+LandSeaConsts land_sea_consts(const HostTables &t) {
+    LandSeaConsts k{};
+    const double thrsh = 0.1f;  // land_model.f90:38, sea_model.f90:75
+    k.thrsh = thrsh;
+    k.one_minus_thrsh = 1.0f - thrsh;
+    k.one = 1.0f;
+    k.alb_thr = 0.4f;
+    k.veg_low_weight = 0.8f;
+    // soil moisture, land_model.f90:27-31, 89-94
     const double swcap = 0.30f, swwil = 0.17f;
     const int idep2 = 3;
-    const double swwil2 = idep2 * swwil;
-    const double rsw = 1.0f / (swcap + idep2 * (swcap - swwil));
-    s.soilw12.assign(static_cast<size_t>(12) * NG, 0.0);
-    for (int m = 0; m < 12; ++m)
-        for (int p = 0; p < NG; ++p) {
-            const double veg = std::max(0.0, s.veg_high[p] + 0.8f * s.veg_low[p]);
-            const double swroot = idep2 * s.soil_wc_l2[static_cast<size_t>(m) * NG + p];
-            s.soilw12[static_cast<size_t>(m) * NG + p] =
-                std::min(1.0, rsw * (s.soil_wc_l1[static_cast<size_t>(m) * NG + p] + veg * std::max(0.0, swroot - swwil2)));
-        }
-    check_surface_fields(s.bmask_land, 12, 0.0, s.soilw12);
-    const double delt = 86400.0f / 36, tdland = 40.f, flandmin = static_cast<double>(1.f / 3.f);
+    k.idep2 = idep2;
+    k.swwil2 = idep2 * swwil;
+    k.rsw = 1.0f / (swcap + idep2 * (swcap - swwil));
+    // heat capacities and dissipation times, land_model.f90:119-146
+    const double delt = 86400.0f / 36, tdland = 40.f;
     const double hcapl = 1.0f * 2.50e+6f, hcapli = 5.0f * 1.93e+6f;
-    s.rhcapl.assign(NG, 0.0);
-    s.cdland.assign(NG, 0.0);
-    for (int p = 0; p < NG; ++p) {
-        const double dmask = (s.fmask_land[p] < flandmin) ? 0.0 : 1.0;
-        s.rhcapl[p] = (s.alb0[p] < 0.4f) ? delt / hcapl : delt / hcapli;
-        s.cdland[p] = dmask * tdland / (1.f + dmask * tdland);
-    }
-    // ---------------- sea_model_init, sea_model.f90:90-192
-    s.fmask_sea.assign(NG, 0.0);
-    s.bmask_sea.assign(NG, 0.0);
-    for (int p = 0; p < NG; ++p) {
-        s.fmask_sea[p] = 1.0f - s.fmask_orig[p];
-        if (s.fmask_sea[p] >= thrsh) {
-            s.bmask_sea[p] = 1.0;
-            if (s.fmask_sea[p] > (1.0f - thrsh)) s.fmask_sea[p] = 1.0;
-        } else {
-            s.bmask_sea[p] = 0.0;
-            s.fmask_sea[p] = 0.0;
-        }
-    }
+    k.flandmin = static_cast<double>(1.f / 3.f);
+    k.rhcapl[0] = delt / hcapl;
+    k.rhcapl[1] = delt / hcapli;
+    // sea_model.f90:57-72, 146-187 (global domain: the smoothed domain mask is 1 wherever there is enough sea)
     const float pih = std::asin(1.0f);
-    for (int j = 0; j < IL; ++j) s.deglat_s[j] = t.radang[j] * 90.0f / pih;
-    for (int m = 0; m < 12; ++m) fill(s.sst12.data() + static_cast<size_t>(m) * NG, 0.0);
-    check_surface_fields(s.bmask_sea, 12, 273.0, s.sst12);
-    for (auto &v : s.sea_ice_frac12) v = std::max(v, 0.0);
-    check_surface_fields(s.bmask_sea, 12, 0.0, s.sea_ice_frac12);
-    if (s.sst_anom.size() >= static_cast<size_t>(3) * NG) check_surface_fields(s.bmask_sea, 3, 0.0, s.sst_anom);
     const double crad = static_cast<double>(pih / 90.f);
     const double depth_ml = 60.f, dept0_ml = 40.f, depth_ice = 2.5f, dept0_ice = 1.5f, tdsst = 90.f, tdice = 30.0f;
-    const double fseamin = static_cast<double>(1.f / 3.f);
-    s.rhcaps.assign(NG, 0.0); s.rhcapi.assign(NG, 0.0); s.cdsea.assign(NG, 0.0); s.cdice.assign(NG, 0.0);
+    k.fseamin = static_cast<double>(1.f / 3.f);
+    for (int d = 0; d < 2; ++d) {
+        const double dmask = d;
+        k.cdland[d] = dmask * tdland / (1.f + dmask * tdland);
+        k.cdsea[d] = dmask * tdsst / (1.f + dmask * tdsst);
+        k.cdice[d] = dmask * tdice / (1.f + dmask * tdice);
+    }
     for (int j = 0; j < IL; ++j) {
-        const double coslat = std::cos(crad * s.deglat_s[j]);
+        const double deglat_s = t.radang[j] * 90.0f / pih;  // sea_model.f90:108
+        const double coslat = std::cos(crad * deglat_s);
         const double hcaps = 4.18e+6f * (depth_ml + (dept0_ml - depth_ml) * ((coslat * coslat) * coslat));
         const double hcapi = 1.93e+6f * (depth_ice + (dept0_ice - depth_ice) * (coslat * coslat));
-        for (int i = 0; i < IX; ++i) {
-            const int p = i + IX * j;
-            const double dmask = (s.fmask_sea[p] < fseamin) ? 0.0 : 1.0;  // global domain: smoothed mask is 1 everywhere
-            s.rhcaps[p] = delt / hcaps;
-            s.rhcapi[p] = delt / hcapi;
-            s.cdsea[p] = dmask * tdsst / (1.f + dmask * tdsst);
-            s.cdice[p] = dmask * tdice / (1.f + dmask * tdice);
-        }
+        k.rhcaps_row[j] = delt / hcaps;
+        k.rhcapi_row[j] = delt / hcapi;
     }
+    return k;
 }
 
 void orog_land_sfc_drag(const std::vector<double> &phis0, std::vector<double> &forog) {

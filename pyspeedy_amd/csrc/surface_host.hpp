@@ -1,6 +1,6 @@
 // Host-side pieces of the model that run once per day or once per run: calendar (model_control.f90), time interpolation
-// weights (interpolation.f90), zonally averaged radiative forcing (shortwave_radiation.f90:218-322) and the land / sea
-// boundary-condition preprocessing of land_model_init / sea_model_init (land_model.f90:23-149, sea_model.f90:33-192).
+// weights (interpolation.f90), zonally averaged radiative forcing (shortwave_radiation.f90:218-322) and the member-independent
+// constants of land_model_init / sea_model_init (land_model.f90:23-149, sea_model.f90:33-192).
 // Compiled with floating-point contraction off; fp32 sub-expressions of the reference are evaluated in float.
 #pragma once
 #include <array>
@@ -36,16 +36,20 @@ struct ZonalForcing {  // one value per latitude, shortwave_radiation.f90:218-32
 };
 ZonalForcing zonal_average_fields(const HostTables &t, double tyear);
 
-// land_model_init + sea_model_init for one member.  All arrays (ix, il[, 12]) column-major, modified in place.
-struct SurfaceFields {
-    std::vector<double> fmask_orig, alb0, veg_high, veg_low;                       // inputs (ix,il)
-    std::vector<double> stl12, snowd12, soil_wc_l1, soil_wc_l2, sst12, sea_ice_frac12;  // inputs (ix,il,12), cleaned in place
-    std::vector<double> sst_anom;                                                  // (ix,il,n_months+2), cleaned in place
-    std::vector<double> fmask_land, bmask_land, fmask_sea, bmask_sea, soilw12;     // outputs
-    std::vector<double> rhcapl, cdland, rhcaps, rhcapi, cdsea, cdice;              // outputs (ix,il)
-    std::array<double, 48> deglat_s{};
+// land_model_init + sea_model_init (land_model.f90:23-148, sea_model.f90:33-192) run on the device, one workgroup per member
+// (land_sea_init_kernel, surface.hip).  What does not depend on the member's fields is evaluated here, once, with the host's
+// arithmetic -- the reference's default-real literals in float, no contraction, the host's cos() for the latitude-dependent
+// heat capacities -- and handed to the kernel by value, so that the device only compares, selects, adds and multiplies.
+struct LandSeaConsts {
+    double thrsh, one_minus_thrsh, one;         // mask threshold 0.1 (default real), 1.0 - thrsh, 1.0
+    double alb_thr, veg_low_weight, idep2;      // 0.4, 0.8 (default real), 3
+    double swwil2, rsw;                         // land_model.f90:93-94
+    double flandmin, fseamin;                   // 1./3. (default real)
+    double rhcapl[2];                           // delt / hcapl (alb0 < 0.4), delt / hcapli
+    double cdland[2], cdsea[2], cdice[2];       // d td / (1 + d td) for the domain mask d = 0, 1
+    double rhcaps_row[48], rhcapi_row[48];      // delt / hcaps(j), delt / hcapi(j)
 };
-void land_sea_init(const HostTables &t, SurfaceFields &s);
+LandSeaConsts land_sea_consts(const HostTables &t);
 
 // set_orog_land_sfc_drag, surface_fluxes.f90:324-334
 void orog_land_sfc_drag(const std::vector<double> &phis0, std::vector<double> &forog);

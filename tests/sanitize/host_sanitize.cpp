@@ -39,21 +39,10 @@ int main() {
         }
     }
     const int NG = 96 * 48;
-    SurfaceFields sf;
-    auto fill = [&](std::vector<double> &v, int planes, double lo, double hi) {
-        v.resize(static_cast<size_t>(NG) * planes);
-        for (size_t i = 0; i < v.size(); ++i) v[i] = lo + (hi - lo) * (0.5 + 0.5 * std::sin(0.37 * i));
-    };
-    fill(sf.fmask_orig, 1, 0.0, 1.0); fill(sf.alb0, 1, 0.05, 0.6); fill(sf.veg_high, 1, 0.0, 1.0); fill(sf.veg_low, 1, 0.0, 1.0);
-    fill(sf.stl12, 12, 230.0, 310.0); fill(sf.snowd12, 12, 0.0, 400.0); fill(sf.soil_wc_l1, 12, 0.0, 0.5);
-    fill(sf.soil_wc_l2, 12, 0.0, 0.5); fill(sf.sst12, 12, 270.0, 303.0); fill(sf.sea_ice_frac12, 12, 0.0, 1.0);
-    fill(sf.sst_anom, 5, -1.0, 1.0);
-    for (size_t i = 0; i < sf.stl12.size(); i += 7) sf.stl12[i] = 9.97e36;  // missing values, as in the boundary files
-    for (size_t i = 3; i < sf.sst12.size(); i += 11) sf.sst12[i] = 9.97e36;
-    land_sea_init(t, sf);
-    for (double v : sf.fmask_land) acc += v;
-    for (double v : sf.rhcapl) acc += v;
-    for (double v : sf.cdsea) acc += v;
+    const LandSeaConsts k = land_sea_consts(t);
+    for (int j = 0; j < 48; ++j) acc += k.rhcaps_row[j] + k.rhcapi_row[j];
+    acc += k.rsw + k.swwil2 + k.cdland[1] + k.cdsea[1] + k.cdice[1] + k.rhcapl[0] + k.rhcapl[1];
+    if (k.cdland[0] != 0.0 || !(k.one_minus_thrsh < 1.0)) return 4;
     std::vector<double> phis0(NG, 1500.0), forog;
     orog_land_sfc_drag(phis0, forog);
     acc += forog[17];

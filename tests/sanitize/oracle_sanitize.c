@@ -85,6 +85,18 @@ int main(void) {
     orc_dyn_tables_init(t, d);
     orc_dyn_set_time_step(t, d, 2400.0);
     acc += d->xj[5] + d->elz[991];
+    /* boundary-field preprocessing of init: holes, rows without a valid point, five anomaly planes */
+    {
+        double *in2[4], *in12[6], *out2[10], *soilw = calloc(12 * NG, 8), *anom = arr(5 * NG, -1.0, 1.0, 77u), fmean = 0.0;
+        for (int k = 0; k < 4; ++k) in2[k] = arr(NG, -0.2, 1.0, 31u + k);
+        for (int k = 0; k < 6; ++k) in12[k] = arr(12 * NG, k < 2 ? -0.2 : -80.0, k < 2 ? 0.8 : 310.0, 41u + k);
+        for (int k = 0; k < 10; ++k) out2[k] = calloc(NG, 8);
+        for (int i = 0; i < 96; ++i) in12[2][i + 96 * 23] = in12[4][i + 96 * 47 + 5 * NG] = -1.0;
+        orc_land_sea_init(t, 5, in2[0], in2[1], in2[2], in2[3], in12[0], in12[1], in12[2], in12[3], in12[4], in12[5], anom, soilw,
+                          out2[0], out2[1], out2[2], out2[3], out2[4], out2[5], out2[6], out2[7], out2[8], out2[9], &fmean);
+        for (int p = 0; p < NG; ++p) acc += in12[2][p] + in12[4][p + 11 * NG] + soilw[p] + out2[0][p] + out2[9][p] + anom[p + 4 * NG];
+        acc += fmean;
+    }
     printf("oracle sanitize ok %.6e\n", acc);
     return isfinite(acc) ? 0 : 1;
 }

@@ -115,12 +115,10 @@ def test_members_of_a_large_batch_equal_single_member_runs(spectral, bc):
     assert not np.array_equal(ens.get("t", 1), ens.get("t", 2))
 
 
-def test_initialisation_preprocesses_distinct_boundary_sets_only(spectral, bc):
-    """spd_model_init compares every member's boundary fields with member 0's on the device: the members that share them take
-    member 0's preprocessed fields (land / sea masks, cleaned climatologies, heat capacities) with device-to-device copies, a
-    member with fields of its own goes through the host itself.  Six members, two of them with their own SST / soil
-    climatologies: every member is bitwise the one-member model initialised from the same fields, after the initialisation and
-    after 7 steps."""
+def test_initialisation_with_distinct_boundary_sets(spectral, bc):
+    """spd_model_init preprocesses every member's boundary fields on the device, one workgroup per member.  Six members, two of
+    them with their own SST / soil climatologies: every member is bitwise the one-member model initialised from the same fields,
+    after the initialisation and after 7 steps."""
     from pyspeedy_amd.model import BC_MAP, EnsembleModel
     M = 6
     fields = {i: {k: np.asarray(bc[k], dtype=np.float64).copy() for k in bc.files} for i in range(M)}

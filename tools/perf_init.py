@@ -20,6 +20,9 @@ for M in [int(a) for a in sys.argv[1:]] or [32, 256]:
         model.init_sst_anom(2)
         for state_name, bc_name in pyspeedy_amd.model.BC_MAP:
             model.set(state_name, np.asarray(bc[bc_name], dtype=np.float64), -1)
+        if os.environ.get("PERF_INIT_DISTINCT"):  # every member with an SST climatology of its own
+            for i in range(1, M):
+                model.set("sst12", np.asarray(bc["sst"], dtype=np.float64) + 0.01 * i, i)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         model.init((1982, 1, 1, 0, 0))
