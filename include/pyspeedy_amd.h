@@ -134,6 +134,8 @@ typedef struct spd_model *spd_model_handle;
 int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out);
 int spd_model_destroy(spd_model_handle m);
 int spd_model_members(spd_model_handle m);
+/* device memory of the model, all members: bytes reserved (a few large blocks the arrays are carved from) and bytes in use */
+int spd_model_memory(spd_model_handle m, size_t *bytes_reserved, size_t *bytes_used);
 /* bytes of one member's copy of `name`, or a negative error */
 long spd_model_var_bytes(spd_model_handle m, const char *name);
 /* host <-> device copy of one member's array (get_<v>/set_<v> of speedy_driver.f90.j2:250-334); member = -1 in

@@ -84,6 +84,7 @@ _SIGNATURES = {
     "spd_model_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "spd_model_destroy": (C.c_int, [C.c_void_p]),
     "spd_model_members": (C.c_int, [C.c_void_p]),
+    "spd_model_memory": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "spd_model_var_bytes": (C.c_long, [C.c_void_p, C.c_char_p]),
     "spd_model_var_storage": (C.c_int, [C.c_void_p, C.c_char_p]),
     "spd_model_set": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]),
@@ -153,6 +154,7 @@ _SIGNATURES = {
     "spd_registry_entry": (C.c_int, [C.c_int32, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                      C.POINTER(C.c_int32)]),
     "spd_driver_stats": (C.c_int, [C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "spd_driver_trim": (C.c_int, []),
     "spd_model_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "spd_model_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "spd_model_profile_read_kernels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

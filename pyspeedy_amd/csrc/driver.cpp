@@ -115,6 +115,23 @@ size_t elem_bytes(int dtype) { return dtype == SPD_T_COMPLEX128 ? 16 : (dtype ==
 // ---------------------------------------------------------------------------------------------------------------------
 std::atomic<int> g_models_alive{0};
 
+// idle streams by device (its own lock: a device model may die on any thread, with or without the library's lock held)
+std::mutex g_stream_pool_mutex;
+std::map<int, std::vector<void *>> g_stream_pool;
+constexpr size_t kPooledStreams = 16;  // per device; more than that are destroyed when they come back
+void release_stream(int device, void *stream) {
+    if (!stream) return;
+    {
+        std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
+        std::vector<void *> &idle = g_stream_pool[device];
+        if (idle.size() < kPooledStreams) {
+            idle.push_back(stream);
+            return;
+        }
+    }
+    drvdev::stream_destroy(stream);  // (the caller has made the stream's device current)
+}
+
 struct Batch {  // one device model shared by the containers of its members
     Batch() { ++g_models_alive; }
     Batch(const Batch &) = delete;
@@ -125,7 +142,10 @@ struct Batch {  // one device model shared by the containers of its members
     std::vector<char> initialized;
     // The steps and range checks of this model are issued on a stream of its own, so that the models of one parallel_step --
     // on different devices, or several on one device -- run side by side.  A blocking stream: everything else the driver does
-    // (initialisation, copies, transforms) stays on the null stream, which orders itself against it.
+    // (initialisation, copies, transforms) stays on the null stream, which orders itself against it.  Taken from the device's
+    // pool when the model is first stepped (stream_for) and handed back when it dies: creating and destroying a stream costs a
+    // millisecond each, and the one-member models of a host with the reference's call sequence are gathered into batched
+    // models before any of them is stepped on its own.
     void *stream = nullptr;
     // A step was enqueued and its range check (or anything else that had to follow it) could not be: the device state has
     // moved on while date and codes say it has not.  Nothing steps such a model again until it is initialised anew.
@@ -134,8 +154,8 @@ struct Batch {  // one device model shared by the containers of its members
         --g_models_alive;
         drvdev::DeviceGuard guard;  // (may run from any entry point that drops the last reference, or from a host's garbage collector)
         (void)drvdev::set_device(device);
-        if (model) (void)spd_model_destroy(model);
-        drvdev::stream_destroy(stream);
+        if (model) (void)spd_model_destroy(model);  // (waits for whatever the stream still holds)
+        release_stream(device, stream);
     }
 };
 struct State {
@@ -239,11 +259,25 @@ int new_batch(int members, int device, std::shared_ptr<Batch> *out) {
     if (!drvdev::set_device(device)) return fail(SPD_E_DEVICE, "speedy driver: hipSetDevice(" + std::to_string(device) + ") failed");
     if (int rc = context_for_device(device, &b->ctx)) return rc;
     if (int rc = spd_model_create(b->ctx, members, &b->model)) return rc;
-    if (!drvdev::stream_create(&b->stream)) return fail(SPD_E_DEVICE, "speedy driver: hipStreamCreate failed");
     b->members = members;
     b->initialized.assign(members, 0);
     *out = b;
     return SPD_OK;
+}
+
+// the stream a device model is stepped on (its device is current)
+bool stream_for(Batch &b) {
+    if (b.stream) return true;
+    {
+        std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
+        std::vector<void *> &idle = g_stream_pool[b.device];
+        if (!idle.empty()) {
+            b.stream = idle.back();
+            idle.pop_back();
+            return true;
+        }
+    }
+    return drvdev::stream_create(&b.stream);
 }
 
 std::shared_ptr<State> state_of(int64_t cnt) {
@@ -895,6 +929,7 @@ static void issue_group(const GroupPlan &g, GroupRun &r) {
     if (b.advanced_without_check)
         rc = fail(SPD_E_ARG, "speedy driver: an earlier step of this device model was enqueued but could not be checked; initialise its members again");
     if (rc == SPD_OK && !drvdev::set_device(b.device)) rc = fail(SPD_E_DEVICE, "speedy driver: hipSetDevice failed");
+    if (rc == SPD_OK && !stream_for(b)) rc = fail(SPD_E_DEVICE, "speedy driver: hipStreamCreate failed");
     if (rc == SPD_OK && spd_model_checks_in_flight(b.model) >= 2)  // (a step without its check is no step)
         rc = fail(SPD_E_ARG, "speedy driver: two steps of this device model are in flight already; end one with spd_parallel_step_end first");
     if (rc == SPD_OK) rc = push_date(b, r.before);
@@ -1390,6 +1425,20 @@ int spd_driver_model(int64_t state_cnt, void **model, int32_t *member, int32_t *
     *model = st->batch->model;
     if (member) *member = st->member;
     if (members_in_model) *members_in_model = st->batch->members;
+    return SPD_OK;
+}
+
+int spd_driver_trim(void) {
+    drvdev::DeviceGuard guard;
+    std::map<int, std::vector<void *>> idle;
+    {
+        std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
+        idle.swap(g_stream_pool);
+    }
+    for (auto &kv : idle) {
+        if (!drvdev::set_device(kv.first)) continue;
+        for (void *s : kv.second) drvdev::stream_destroy(s);
+    }
     return SPD_OK;
 }
 

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -42,7 +43,8 @@ hipError_t run_forcing(const SurfacePtrs &S, int first, int count, const ZonalDe
 hipError_t run_rest_state(const RestPtrs &R, int M, const RestConsts &c, hipStream_t s);
 hipError_t run_scale_orog(const double *orog, double *phi0, long n, hipStream_t s);
 hipError_t run_change_storage(double *array, long n, bool to_float, void *scratch, hipStream_t s);
-hipError_t run_land_sea_init(const LandSeaPtrs &P, const LandSeaConsts &K, int M, hipStream_t s);
+hipError_t run_land_sea_init(const LandSeaPtrs &P, const LandSeaConsts &K, int first, int count, double *rows, hipStream_t s);
+hipError_t run_multi_copy(const CopyList &L, hipStream_t s);
 hipError_t run_copy_from_first(double *v, long n, int M, const int *flags, hipStream_t s);
 hipError_t run_rest_surface(const double *phis0, double *forog, double *surf_ps, double *surf_q, const RestConsts &c, long n,
                             hipStream_t s);
@@ -80,10 +82,18 @@ struct spd_model {
     spd_context *ctx = nullptr;
     int M = 0;
     ModelPtrs P{};
-    DynHostTables *dynh = nullptr;
+    const spd_dyn_tables *dyn = nullptr;            // the context's tables of the current time step (nullptr: none set yet)
+    std::unique_ptr<spd_dyn_tables> dyn_private;    // only when the context already holds kMaxDynSteps other time steps
     DynDeviceTables D{};
     spd_physics_args pa{};
-    std::vector<void *> allocs;
+    // Device memory of the model: a few large zero-filled blocks the arrays are carved from (arena_alloc).  A model has some 170
+    // arrays and tables; one hipMalloc + hipMemset + hipFree each made creating and closing a state container the most
+    // expensive calls of a host that follows the reference's sequence (1.3 ms and 1.8 ms per one-member model).
+    struct Block {
+        char *base;
+        size_t size, used;
+    };
+    std::vector<Block> blocks;
     std::map<std::string, RegEntry> reg;
     FieldDesc *inv_table[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [dynamics time level j2 (0-based)][phi buffer]
     FieldDesc *inv_table_sppt[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // the same + 8 SPPT pattern transforms per member
@@ -161,8 +171,6 @@ struct spd_model {
     // grid-space copies of the prognostic variables in output units (prognostics.f90:125-219) and their transform tables
     double *u_grid = nullptr, *v_grid = nullptr, *t_grid = nullptr, *q_grid = nullptr, *phi_grid = nullptr, *ps_grid = nullptr;
     FieldDesc *exp_inv_table[2] = {nullptr, nullptr}, *exp_fwd_table[2] = {nullptr, nullptr};  // 41 / 40 per member; [phi buffer]
-    double *d_dmp1 = nullptr, *d_dmp1d = nullptr, *d_dmp1s = nullptr, *d_elz = nullptr, *d_xj = nullptr, *d_xc = nullptr,
-           *d_xd = nullptr;
 };
 
 namespace spd {
@@ -181,11 +189,30 @@ static int apply_storage(spd_model *m, bool want32);  // (with spd_model_set_phy
         if (e_ != hipSuccess) return m_fail(SPD_E_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// `bytes` of zero-filled device memory that lives as long as the model.  Every array starts on a 256-byte boundary.  The first
+// block is sized for everything spd_model_create asks for (18.5 MB per member); whatever comes later -- SST anomalies of a
+// longer period, the tables of another configuration -- opens further blocks.
+static int arena_alloc(spd_model *m, size_t bytes, void **out) {
+    constexpr size_t kAlign = 256;
+    bytes = (bytes + kAlign - 1) / kAlign * kAlign;
+    if (m->blocks.empty() || m->blocks.back().used + bytes > m->blocks.back().size) {
+        const size_t M = static_cast<size_t>(m->M);
+        const size_t want = m->blocks.empty() ? M * (19u << 20) + (1u << 20) : M * (2u << 20) + (1u << 20);
+        const size_t size = bytes > want ? bytes : want;
+        void *p = nullptr;
+        M_HIP(hipMalloc(&p, size));
+        m->blocks.push_back({static_cast<char *>(p), size, 0});
+        M_HIP(hipMemset(p, 0, size));
+    }
+    spd_model::Block &b = m->blocks.back();
+    *out = b.base + b.used;
+    b.used += bytes;
+    return SPD_OK;
+}
+
 static int dalloc(spd_model *m, size_t doubles, double **out, const char *name = nullptr, size_t bytes_member = 0) {
     void *p = nullptr;
-    M_HIP(hipMalloc(&p, doubles * sizeof(double)));
-    M_HIP(hipMemset(p, 0, doubles * sizeof(double)));
-    m->allocs.push_back(p);
+    if (int rc = arena_alloc(m, doubles * sizeof(double), &p)) return rc;
     *out = static_cast<double *>(p);
     if (name) m->reg[name] = RegEntry{p, bytes_member};
     return SPD_OK;
@@ -199,10 +226,40 @@ static int upload_const(spd_model *m, const double *src, size_t n, const double 
     return SPD_OK;
 }
 
+// Descriptor tables built on the host and uploaded TOGETHER: one allocation, one host-to-device copy for all the tables of a
+// build (creating a model builds nine; one blocking copy each was a quarter of what creating a one-member model cost).
+struct TableBatch {
+    std::vector<std::vector<FieldDesc>> tables;
+    std::vector<FieldDesc **> outs;
+    void add(std::vector<FieldDesc> &&t, FieldDesc **out) {
+        tables.push_back(std::move(t));
+        outs.push_back(out);
+    }
+    int upload(spd_model *m) {
+        constexpr size_t kAlign = 256;
+        std::vector<size_t> at(tables.size());
+        size_t total = 0;
+        for (size_t i = 0; i < tables.size(); ++i) {
+            at[i] = total;
+            total += (tables[i].size() * sizeof(FieldDesc) + kAlign - 1) / kAlign * kAlign;
+        }
+        if (total == 0) return SPD_OK;
+        void *d = nullptr;
+        if (int rc = arena_alloc(m, total, &d)) return rc;
+        std::vector<char> packed(total, 0);
+        for (size_t i = 0; i < tables.size(); ++i) std::memcpy(packed.data() + at[i], tables[i].data(), tables[i].size() * sizeof(FieldDesc));
+        M_HIP(hipMemcpy(d, packed.data(), total, hipMemcpyHostToDevice));
+        for (size_t i = 0; i < tables.size(); ++i) *outs[i] = reinterpret_cast<FieldDesc *>(static_cast<char *>(d) + at[i]);
+        tables.clear();
+        outs.clear();
+        return SPD_OK;
+    }
+};
+
 // The four spectral -> grid descriptor tables ([dynamics time level][phi buffer]) of the step.  with_sppt: every member's
 // entries are followed by the 8 transforms of its SPPT pattern (spectral AR(1) state -> grid, kcos = 1), so that they ride
 // in the same launch instead of being a launch of their own.
-static int build_inverse_tables(spd_model *m, bool with_sppt, bool phys_as_float, FieldDesc *(&out)[2][2]) {
+static void build_inverse_tables(spd_model *m, bool with_sppt, bool phys_as_float, FieldDesc *(&out)[2][2], TableBatch &batch) {
     const int M = m->M;
     const ModelPtrs &P = m->P;
     const spd_physics_args &pa = m->pa;
@@ -250,22 +307,16 @@ static int build_inverse_tables(spd_model *m, bool with_sppt, bool phys_as_float
             if (with_sppt)
                 for (int k = 0; k < 8; ++k) t.push_back({spec(m->sppt_spec, w + k), grid(m->sppt_grid, w + k), 1, 0});
         }
-        void *d = nullptr;
-        M_HIP(hipMalloc(&d, t.size() * sizeof(FieldDesc)));
-        m->allocs.push_back(d);
-        M_HIP(hipMemcpy(d, t.data(), t.size() * sizeof(FieldDesc), hipMemcpyHostToDevice));
-        out[j2 & 1][par] = static_cast<FieldDesc *>(d);
+        batch.add(std::move(t), &out[j2 & 1][par]);
     }
-    return SPD_OK;
 }
 
 // the descriptor tables of the cfg 5 step (physics-only outputs as fp32), built when they are first needed
 static int ensure_tables32(spd_model *m) {
-    if (!m->inv_table32[0][0])
-        if (int rc = build_inverse_tables(m, false, true, m->inv_table32)) return rc;
-    if (m->sppt_spec && !m->inv_table_sppt32[0][0])
-        if (int rc = build_inverse_tables(m, true, true, m->inv_table_sppt32)) return rc;
-    return SPD_OK;
+    TableBatch batch;
+    if (!m->inv_table32[0][0]) build_inverse_tables(m, false, true, m->inv_table32, batch);
+    if (m->sppt_spec && !m->inv_table_sppt32[0][0]) build_inverse_tables(m, true, true, m->inv_table_sppt32, batch);
+    return batch.upload(m);
 }
 
 static int build_tables(spd_model *m) {
@@ -273,7 +324,8 @@ static int build_tables(spd_model *m) {
     const ModelPtrs &P = m->P;
     auto spec = [](double *base, size_t field) { return base + field * NSPEC * C; };
     auto grid = [](double *base, size_t field) { return base + field * NG; };
-    if (int rc = build_inverse_tables(m, false, false, m->inv_table)) return rc;
+    TableBatch batch;
+    build_inverse_tables(m, false, false, m->inv_table, batch);
     std::vector<FieldDesc> t;
     t.reserve(static_cast<size_t>(M) * 73);
     const size_t pair = static_cast<size_t>(M) * 8;
@@ -293,11 +345,7 @@ static int build_tables(spd_model *m) {
         }
         t.push_back({grid(P.psdtg, i), spec(P.spec_ps, i), 0, 0});
     }
-    void *d = nullptr;
-    M_HIP(hipMalloc(&d, t.size() * sizeof(FieldDesc)));
-    m->allocs.push_back(d);
-    M_HIP(hipMemcpy(d, t.data(), t.size() * sizeof(FieldDesc), hipMemcpyHostToDevice));
-    m->fwd_table = static_cast<FieldDesc *>(d);
+    batch.add(std::move(t), &m->fwd_table);
     // export tables (prognostics.f90:125-219), time level 1.  sv holds ucos | vcos in the [M][2][8] layout of vor / div.
     for (int par = 0; par < 2; ++par) {
         std::vector<FieldDesc> ti, tf;
@@ -318,19 +366,96 @@ static int build_tables(spd_model *m) {
             }
             ti.push_back({spec(P.ps, static_cast<size_t>(i) * 2), grid(m->ps_grid, i), 1, 0});
         }
-        for (int pass = 0; pass < 2; ++pass) {
-            const std::vector<FieldDesc> &t = pass ? tf : ti;
-            void *dd = nullptr;
-            M_HIP(hipMalloc(&dd, t.size() * sizeof(FieldDesc)));
-            m->allocs.push_back(dd);
-            M_HIP(hipMemcpy(dd, t.data(), t.size() * sizeof(FieldDesc), hipMemcpyHostToDevice));
-            (pass ? m->exp_fwd_table : m->exp_inv_table)[par] = static_cast<FieldDesc *>(dd);
-        }
+        batch.add(std::move(ti), &m->exp_inv_table[par]);
+        batch.add(std::move(tf), &m->exp_fwd_table[par]);
     }
-    return SPD_OK;
+    return batch.upload(m);
 }
 
 extern "C" {
+
+// The context's dynamics tables for time step `dt` (0: the dt-independent ones only), made on first demand.  `owner`: the model
+// that asks -- when the context is full (a host that keeps inventing time steps) it gets a set of its own instead, rebuilt and
+// uploaded in place at every change as every model's was before the tables moved to the context.
+constexpr size_t kMaxDynSteps = 64;
+static int dyn_upload(spd_context *ctx, spd_dyn_tables &set, const spd_dyn_tables *base, double *slab) {
+    const DynHostTables &dh = set.host;
+    DynDeviceTables &D = set.dev;
+    std::vector<double> packed;
+    auto put = [&](const std::vector<double> &v) {
+        const double *at = slab + packed.size();
+        packed.insert(packed.end(), v.begin(), v.end());
+        return at;
+    };
+    if (!base) {  // dt-independent: horizontal diffusion coefficients and the Coriolis parameter
+        D.dmp = put(dh.dmp); D.dmpd = put(dh.dmpd); D.dmps = put(dh.dmps);
+        D.coriol = put(std::vector<double>(ctx->host.coriol.begin(), ctx->host.coriol.end()));
+        for (int k = 0; k < 8; ++k) {
+            D.tcorv[k] = dh.tcorv[k]; D.qcorv[k] = dh.qcorv[k]; D.tref[k] = dh.tref[k]; D.tref2[k] = dh.tref2[k];
+            D.tref3[k] = dh.tref3[k]; D.xgeop1[k] = dh.xgeop1[k]; D.xgeop2[k] = dh.xgeop2[k]; D.geo_corf[k] = dh.geo_corf[k];
+            D.dhs[k] = ctx->host.dhs[k]; D.dhsr[k] = ctx->host.dhsr[k]; D.fsgr[k] = ctx->host.fsgr[k];
+        }
+    } else {
+        D = base->dev;
+        D.dmp1 = put(dh.dmp1); D.dmp1d = put(dh.dmp1d); D.dmp1s = put(dh.dmp1s); D.elz = put(dh.elz); D.xj = put(dh.xj);
+        D.xc = put(std::vector<double>(dh.xc.begin(), dh.xc.end()));
+        D.xd = put(std::vector<double>(dh.xd.begin(), dh.xd.end()));
+        for (int k = 0; k < 8; ++k) D.dhsx[k] = dh.dhsx[k];
+    }
+    M_HIP(hipMemcpy(slab, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice));
+    return SPD_OK;
+}
+constexpr size_t kDynSlabDoubles = 4 * NSPEC + 8 * 8 * (MX + NX + 1) + 128;  // the larger of the two sets
+
+static int dyn_tables(spd_context *ctx, double dt, spd_model *owner, const spd_dyn_tables **out) {
+    std::lock_guard<std::mutex> lock(ctx->dyn_mutex);
+    M_HIP(hipSetDevice(ctx->device));
+    auto slab = [&](double **p) -> int {
+        void *d = nullptr;
+        M_HIP(hipMalloc(&d, kDynSlabDoubles * sizeof(double)));
+        ctx->allocations.push_back(d);
+        *p = static_cast<double *>(d);
+        return SPD_OK;
+    };
+    if (!ctx->dyn_base) {
+        auto base = std::make_unique<spd_dyn_tables>(DynHostTables(ctx->host));
+        double *d = nullptr;
+        if (int rc = slab(&d)) return rc;
+        if (int rc = dyn_upload(ctx, *base, nullptr, d)) return rc;
+        ctx->dyn_base = std::move(base);
+    }
+    if (dt == 0.0) {
+        *out = ctx->dyn_base.get();
+        return SPD_OK;
+    }
+    auto it = ctx->dyn_by_step.find(dt);
+    if (it != ctx->dyn_by_step.end()) {
+        *out = it->second.get();
+        return SPD_OK;
+    }
+    auto set = std::make_unique<spd_dyn_tables>(ctx->dyn_base->host);
+    set->host.set_time_step(ctx->host, dt);
+    if (ctx->dyn_by_step.size() < kMaxDynSteps) {
+        double *d = nullptr;
+        if (int rc = slab(&d)) return rc;
+        if (int rc = dyn_upload(ctx, *set, ctx->dyn_base.get(), d)) return rc;
+        *out = set.get();
+        ctx->dyn_by_step.emplace(dt, std::move(set));
+        return SPD_OK;
+    }
+    if (!owner) return m_fail(SPD_E_ARG, "dyn_tables: the context holds its maximum of time steps");
+    double *d = owner->dyn_private ? const_cast<double *>(owner->dyn_private->dev.dmp1) : nullptr;
+    if (!d) {
+        void *p = nullptr;
+        if (int rc = arena_alloc(owner, kDynSlabDoubles * sizeof(double), &p)) return rc;
+        d = static_cast<double *>(p);
+    }
+    M_HIP(hipDeviceSynchronize());  // kernels in flight may still read the set this one replaces
+    if (int rc = dyn_upload(ctx, *set, ctx->dyn_base.get(), d)) return rc;
+    owner->dyn_private = std::move(set);
+    *out = owner->dyn_private.get();
+    return SPD_OK;
+}
 
 int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
     if (!h || !out) return m_fail(SPD_E_ARG, "spd_model_create: null argument");
@@ -450,33 +575,18 @@ int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
                              "tt_rsw", "rad_tau2", "rad_strat_corr",                                                 // persisted
                              "rad_st4a", "rad_flux", "precnv", "precls", "cbmf", "slrd", "slr", "olr", "slru", "ustr", "vstr"})
         m->reg[name].f32 = true;
-    // dynamics tables
-    m->dynh = new DynHostTables(h->host);
-    const DynHostTables &dh = *m->dynh;
-    DynDeviceTables &D = m->D;
-    auto up = [&](const double *src, size_t n, const double **dst) {
-        if (rc == SPD_OK) rc = upload_const(m, src, n, dst);
-    };
-    up(dh.dmp.data(), NSPEC, &D.dmp); up(dh.dmpd.data(), NSPEC, &D.dmpd); up(dh.dmps.data(), NSPEC, &D.dmps);
-    up(dh.dmp1.data(), NSPEC, &D.dmp1); up(dh.dmp1d.data(), NSPEC, &D.dmp1d); up(dh.dmp1s.data(), NSPEC, &D.dmp1s);
-    up(dh.elz.data(), NSPEC, &D.elz); up(dh.xj.data(), dh.xj.size(), &D.xj);
-    up(dh.xc.data(), 64, &D.xc); up(dh.xd.data(), 64, &D.xd);
-    up(h->host.coriol.data(), 48, &D.coriol);
+    // dynamics tables: the context's (dyn_tables); the time-step dependent ones arrive with spd_model_set_time_step
     if (rc == SPD_OK) {
-        m->d_dmp1 = const_cast<double *>(D.dmp1); m->d_dmp1d = const_cast<double *>(D.dmp1d);
-        m->d_dmp1s = const_cast<double *>(D.dmp1s); m->d_elz = const_cast<double *>(D.elz);
-        m->d_xj = const_cast<double *>(D.xj); m->d_xc = const_cast<double *>(D.xc); m->d_xd = const_cast<double *>(D.xd);
-        for (int k = 0; k < 8; ++k) {
-            D.tcorv[k] = dh.tcorv[k]; D.qcorv[k] = dh.qcorv[k]; D.tref[k] = dh.tref[k]; D.tref2[k] = dh.tref2[k];
-            D.tref3[k] = dh.tref3[k]; D.dhsx[k] = dh.dhsx[k]; D.xgeop1[k] = dh.xgeop1[k]; D.xgeop2[k] = dh.xgeop2[k];
-            D.geo_corf[k] = dh.geo_corf[k]; D.dhs[k] = h->host.dhs[k]; D.dhsr[k] = h->host.dhsr[k]; D.fsgr[k] = h->host.fsgr[k];
-        }
+        const spd_dyn_tables *base = nullptr;
+        rc = dyn_tables(h, 0.0, nullptr, &base);
+        if (rc == SPD_OK) m->D = base->dev;
+    }
+    if (rc == SPD_OK) {
         void *p = nullptr;
-        hipError_t e = hipMalloc(&p, sizeof(int) * M);
-        if (e == hipSuccess) { m->allocs.push_back(p); m->d_err = static_cast<int *>(p); e = hipMemset(p, 0, sizeof(int) * M); }
-        if (e == hipSuccess) e = hipMalloc(&p, sizeof(double) * M * 24);
-        if (e == hipSuccess) { m->allocs.push_back(p); m->d_diag = static_cast<double *>(p); }
-        if (e != hipSuccess) rc = m_fail(SPD_E_DEVICE, std::string("spd_model_create: ") + hipGetErrorString(e));
+        rc = arena_alloc(m, sizeof(int) * M, &p);
+        m->d_err = static_cast<int *>(p);
+        if (rc == SPD_OK) rc = arena_alloc(m, sizeof(double) * M * 24, &p);
+        m->d_diag = static_cast<double *>(p);
     }
     if (rc == SPD_OK) rc = build_tables(m);
     if (rc != SPD_OK) {
@@ -490,7 +600,7 @@ int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
 int spd_model_destroy(spd_model_handle m) {
     if (!m) return SPD_OK;
     (void)hipSetDevice(m->ctx->device);
-    for (void *p : m->allocs) (void)hipFree(p);
+    for (const spd_model::Block &b : m->blocks) (void)hipFree(b.base);
     for (int i = 0; i < 4; ++i) {
         if (m->cstream[i]) (void)hipStreamDestroy(m->cstream[i]);
         if (m->cev[i]) (void)hipEventDestroy(m->cev[i]);
@@ -506,12 +616,23 @@ int spd_model_destroy(spd_model_handle m) {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
     }
-    delete m->dynh;
     delete m;
     return SPD_OK;
 }
 
 int spd_model_members(spd_model_handle m) { return m ? m->M : SPD_E_ARG; }
+
+int spd_model_memory(spd_model_handle m, size_t *bytes_reserved, size_t *bytes_used) {
+    if (!m) return m_fail(SPD_E_ARG, "spd_model_memory: null model");
+    size_t reserved = 0, used = 0;
+    for (const spd_model::Block &b : m->blocks) {
+        reserved += b.size;
+        used += b.used;
+    }
+    if (bytes_reserved) *bytes_reserved = reserved;
+    if (bytes_used) *bytes_used = used;
+    return SPD_OK;
+}
 
 long spd_model_var_bytes(spd_model_handle m, const char *name) {
     if (!m || !name) return m_fail(SPD_E_ARG, "spd_model_var_bytes: null argument");
@@ -619,18 +740,11 @@ double spd_model_co2(spd_model_handle m) { return m ? m->air_absortivity_co2 : 0
 
 int spd_model_set_time_step(spd_model_handle m, double dt) {
     if (!m) return m_fail(SPD_E_ARG, "spd_model_set_time_step: null model");
-    M_HIP(hipSetDevice(m->ctx->device));
-    m->dynh->set_time_step(m->ctx->host, dt);
-    const DynHostTables &dh = *m->dynh;
-    M_HIP(hipDeviceSynchronize());  // kernels in flight may still read the old tables
-    M_HIP(hipMemcpy(m->d_dmp1, dh.dmp1.data(), NSPEC * sizeof(double), hipMemcpyHostToDevice));
-    M_HIP(hipMemcpy(m->d_dmp1d, dh.dmp1d.data(), NSPEC * sizeof(double), hipMemcpyHostToDevice));
-    M_HIP(hipMemcpy(m->d_dmp1s, dh.dmp1s.data(), NSPEC * sizeof(double), hipMemcpyHostToDevice));
-    M_HIP(hipMemcpy(m->d_elz, dh.elz.data(), NSPEC * sizeof(double), hipMemcpyHostToDevice));
-    M_HIP(hipMemcpy(m->d_xj, dh.xj.data(), dh.xj.size() * sizeof(double), hipMemcpyHostToDevice));
-    M_HIP(hipMemcpy(m->d_xc, dh.xc.data(), 64 * sizeof(double), hipMemcpyHostToDevice));
-    M_HIP(hipMemcpy(m->d_xd, dh.xd.data(), 64 * sizeof(double), hipMemcpyHostToDevice));
-    for (int k = 0; k < 8; ++k) m->D.dhsx[k] = dh.dhsx[k];
+    if (!(dt > 0.0)) return m_fail(SPD_E_ARG, "spd_model_set_time_step: the time step must be positive");
+    const spd_dyn_tables *set = nullptr;
+    if (int rc = dyn_tables(m->ctx, dt, m, &set)) return rc;
+    m->dyn = set;
+    m->D = set->dev;
     return SPD_OK;
 }
 
@@ -758,7 +872,7 @@ static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int comput
 int spd_model_step_dynamics(spd_model_handle m, int j1, int j2, double dt, int compute_shortwave, void *stream) {
     if (!m) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: null model");
     if (j1 < 1 || j1 > 2 || j2 < 1 || j2 > 2) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: time levels are 1 or 2");
-    if (m->dynh->dt == 0.0) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: call spd_model_set_time_step first");
+    if (!m->dyn) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: call spd_model_set_time_step first");
     const bool run_geo = begin_step_geopotential(m);
     const hipError_t e = step_range(m, j1, j2, dt, compute_shortwave, 0, m->M, 1, run_geo, nullptr, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_step_dynamics: ") + hipGetErrorString(e));
@@ -932,7 +1046,7 @@ int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, i
     m->cal.set(year, month, day, hour, minute);
     m->current_step = 0;
     m->surf_cache_valid = m->phi_ahead = false;
-    // ---- land_model_init / sea_model_init: every member's boundary fields preprocessed where they lie, one workgroup per member
+    // ---- land_model_init / sea_model_init: every member's boundary fields preprocessed where they lie (surface.hip)
     {
         LandSeaPtrs L{};
         L.fmask_orig = m->fmask_orig; L.alb0 = m->S.alb0; L.veg_high = m->veg_high; L.veg_low = m->veg_low;
@@ -943,7 +1057,9 @@ int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, i
         L.fmask_sea = m->S.fmask_sea; L.bmask_sea = m->bmask_sea; L.rhcapl = m->S.rhcapl; L.cdland = m->S.cdland;
         L.rhcaps = m->S.rhcaps; L.rhcapi = m->S.rhcapi; L.cdsea = m->S.cdsea; L.cdice = m->S.cdice;
         L.anom_planes = m->anom_planes;
-        M_HIP(run_land_sea_init(L, land_sea_consts(m->ctx->host), M, s));
+        // (row statistics of the 24 planes: 2304 doubles per member in the spectral scratch, which holds 3968 per member)
+        static_assert(2 * 24 * IL <= 2 * NSPEC * C, "scratch_spec holds the row statistics of land_sea_init");
+        M_HIP(run_land_sea_init(L, land_sea_consts(m->ctx->host), 0, M, m->scratch_spec, s));
     }
     // ---- initialize_boundaries (boundaries.f90:22-37): phi0 = g * orog, phis0 = spectrally truncated phi0
     double *phis0 = const_cast<double *>(m->pa.phis0);
@@ -953,7 +1069,6 @@ int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, i
     if (e == hipSuccess) e = run_spec2grid(T, 0, m->scratch_spec, phis0, 1, M, s);
     // ---- initialize_from_rest_state (prognostics.f90:29-120)
     RestConsts rc{};
-    const DynHostTables &dh = *m->dynh;
     rc.gam1 = static_cast<double>(6.0f) / (1000.0f * static_cast<double>(9.81f));
     rc.tref = 288.0f;
     rc.ttop = 216.0f;
@@ -965,7 +1080,6 @@ int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, i
             rc.fsg_qexp[k] = std::pow(m->ctx->host.fsg[k], qexp);
         }
     }
-    (void)dh;
     if (e == hipSuccess) e = run_grid2spec(T, 0, phis0, m->P.phis, 0, M, s);
     if (e == hipSuccess)
         e = run_rest_surface(phis0, const_cast<double *>(m->pa.forog), m->corh_t, m->corh_q, rc, static_cast<long>(M) * NG, s);
@@ -1001,6 +1115,7 @@ int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, i
 int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
     if (!m) return m_fail(SPD_E_ARG, "spd_model_step: null model");
     if (!m->initialized) return m_fail(SPD_E_ARG, "spd_model_step: model state not initialized (error code -1 of the reference)");
+    if (!m->dyn) return m_fail(SPD_E_ARG, "spd_model_step: call spd_model_set_time_step first");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double delt = 86400.0 / 36;
     // Members never exchange data, so the step is issued group by group on separate streams: every group runs the same
@@ -1355,7 +1470,9 @@ int spd_model_set_sppt(spd_model_handle m, int on, uint64_t seed, int64_t first_
         const size_t M = m->M;
         if (int rc = dalloc(m, M * 8 * NSPEC * C, &m->sppt_spec, "sppt_spec", 8 * NSPEC * C * sizeof(double))) return rc;
         if (int rc = dalloc(m, M * 8 * NG, &m->sppt_grid, "sppt_pattern", static_cast<size_t>(8) * NG * sizeof(double))) return rc;
-        if (int rc = build_inverse_tables(m, true, false, m->inv_table_sppt)) return rc;
+        TableBatch batch;
+        build_inverse_tables(m, true, false, m->inv_table_sppt, batch);
+        if (int rc = batch.upload(m)) return rc;
         if (m->stored32)
             if (int rc = ensure_tables32(m)) return rc;
     }
@@ -1395,15 +1512,29 @@ int spd_model_copy_member(spd_model_handle dst, int di, spd_model_handle src, in
     dst->phys_store32 = src->phys_store32;
     if (int rc = apply_storage(dst, src->stored32)) return rc;
     dst->surf_cache_valid = dst->phi_ahead = false;
+    CopyList list{};
     for (const auto &kv : src->reg) {
         auto it = dst->reg.find(kv.first);
         if (it == dst->reg.end() || it->second.bytes_member != kv.second.bytes_member)
             return m_fail(SPD_E_SIZE, "spd_model_copy_member: variable '" + kv.first + "' differs between the models");
         // (an array kept as fp32 is compact in fp32: member i starts half as far into the allocation and is half as long)
         const size_t b = (kv.second.f32 && src->stored32) ? kv.second.bytes_member / 2 : kv.second.bytes_member;
-        M_HIP(hipMemcpyAsync(static_cast<char *>(it->second.ptr) + b * di, static_cast<const char *>(kv.second.ptr) + b * si, b,
-                             hipMemcpyDeviceToDevice, s));
+        char *to = static_cast<char *>(it->second.ptr) + b * di;
+        const char *from = static_cast<const char *>(kv.second.ptr) + b * si;
+        if (b % 16 != 0 || b > 0xffffffffu || reinterpret_cast<uintptr_t>(to) % 16 != 0 || reinterpret_cast<uintptr_t>(from) % 16 != 0) {
+            M_HIP(hipMemcpyAsync(to, from, b, hipMemcpyDeviceToDevice, s));
+            continue;
+        }
+        // all the arrays of the member in one launch (one more whenever the list is full)
+        list.src[list.n] = from;
+        list.dst[list.n] = to;
+        list.bytes[list.n] = static_cast<unsigned>(b);
+        if (++list.n == kCopyListMax) {
+            M_HIP(run_multi_copy(list, s));
+            list.n = 0;
+        }
     }
+    M_HIP(run_multi_copy(list, s));
     return SPD_OK;
 }
 

@@ -5,7 +5,7 @@
 //   forcing_kernel   set_forcing (forcing.f90:15-102): snow cover, albedos, zonal radiation fields and the two grid
 //                    fields whose spectral transforms are the orographic diffusion corrections tcorh / qcorh.
 //   rest-state helpers for initialize_from_rest_state (prognostics.f90:29-120).
-//   land_sea_init_kernel   land_model_init + sea_model_init (boundary-field preprocessing of init), one workgroup per member.
+//   land_sea_rows_kernel, land_sea_init_kernel   land_model_init + sea_model_init (boundary-field preprocessing of init).
 #include <hip/hip_runtime.h>
 
 #include "coupler_point.hpp"
@@ -134,119 +134,162 @@ __global__ __launch_bounds__(kT) void rest_surface_kernel(const double *phis0, d
 }
 
 // land_model_init + sea_model_init (land_model.f90:23-148, sea_model.f90:33-192) with fill_missing_values and
-// check_surface_fields (boundaries.f90:41-113): one workgroup per member.
+// check_surface_fields (boundaries.f90:41-113), two launches over (plane, member) workgroups.
 //  * Point by point: the fractional / binary masks, heat capacities and dissipation times (selections among the constants of
 //    LandSeaConsts), soil water availability, snow depth, sea-ice fraction and SST anomalies blanked outside their mask.
-//  * fill_missing_values on the 12 + 12 planes of stl12 and sst12, in the reference's order: a negative value is replaced by the
-//    mean of its two zonal neighbours, missing neighbours counting as the mean of the valid points of their row.  The row mean is
-//    a sequential sum (the reference's bits); a row without a valid point takes the mean of the row visited before it -- rows
-//    24 .. 1, then 25 .. 48, the previous month's last row at row 24, and the land sequence's last mean at the first sea row
-//    (a SAVEd variable of the reference, boundaries.f90:77, which starts at 0 in a fresh process; every call starts there here).
-//    One plane at a time in LDS: 48 lanes sum their rows, lane 0 walks the 48 means in visiting order, all lanes patch.
+//  * fill_missing_values on the 12 + 12 planes of stl12 and sst12: a negative value is replaced by the mean of its two zonal
+//    neighbours, missing neighbours counting as the mean of the valid points of their row.  The row mean is a sequential sum
+//    (the reference's bits); a row without a valid point takes the mean of the row visited before it -- rows 24 .. 1, then
+//    25 .. 48, the previous month's last row at row 24, and the land sequence's last mean at the first sea row (a SAVEd
+//    variable of the reference, boundaries.f90:77, which starts at 0 in a fresh process; every call starts there here).
+//    land_sea_rows_kernel leaves (valid points, mean) of every row of every plane; land_sea_init_kernel walks its plane's 48
+//    means in visiting order -- and, only when its first row has no valid point, the rows of the planes before it backwards
+//    until it meets one that has -- and patches the plane from a copy in LDS.  The planes of a member are independent but for
+//    that look-back, so they run side by side (one workgroup that did the 24 planes in turn took 0.68 ms per member).
 // No contraction: every product and sum below is rounded on its own, as on the reference's host.
-__global__ __launch_bounds__(kT) void land_sea_init_kernel(LandSeaPtrs P, LandSeaConsts K) {
+__device__ inline int visit_row(int k) { return k < IL / 2 ? IL / 2 - 1 - k : k; }  // the k-th row fill_missing_values visits
+
+__global__ __launch_bounds__(kT) void land_sea_rows_kernel(LandSeaPtrs P, int first, double *rows /*[count][24][48][2]*/) {
 #pragma clang fp contract(off)
     __shared__ double plane[NG];
-    __shared__ double row_mean[IL];
-    __shared__ int row_nmis[IL];
-    __shared__ double carry;
-    const int mem = blockIdx.x, t = threadIdx.x;
+    const int f = blockIdx.x, mem = first + blockIdx.y, t = threadIdx.x;
+    const double *field = (f < 12 ? P.stl12 : P.sst12) + (static_cast<size_t>(mem) * 12 + f % 12) * NG;
+    for (int p = t; p < NG; p += kT) plane[p] = field[p];
+    __syncthreads();
+    if (t < IL) {
+        int nmis = 0;
+        double s = 0.0;
+        for (int i = 0; i < IX; ++i) {
+            const double v = plane[t * IX + i];
+            const bool missing = v < 0.0;
+            nmis += missing ? 1 : 0;
+            s = s + (missing ? 0.0 : v);
+        }
+        double *out = rows + ((static_cast<size_t>(blockIdx.y) * 24 + f) * IL + t) * 2;
+        out[0] = IX - nmis;
+        out[1] = nmis < IX ? s / static_cast<double>(static_cast<float>(IX - nmis)) : 0.0;
+    }
+}
+
+// blockIdx.x < 24: plane x of the fill (stl12 months 0 .. 11, sst12 months 0 .. 11) and that month's share of the point-by-point
+// work; blockIdx.x == 24: the fields without a month and the SST anomalies
+__global__ __launch_bounds__(kT) void land_sea_init_kernel(LandSeaPtrs P, LandSeaConsts K, int first, const double *rows) {
+#pragma clang fp contract(off)
+    __shared__ double plane[NG];
+    __shared__ double row_fill[IL];
+    const int f = blockIdx.x, mem = first + blockIdx.y, t = threadIdx.x;
     const size_t o2 = static_cast<size_t>(mem) * NG, o12 = o2 * 12;
-    if (t == 0) carry = 0.0;
+    if (f == 24) {
+        for (int p = t; p < NG; p += kT) {
+            const double fo = P.fmask_orig[o2 + p];
+            double fl = fo, bl, fs = K.one - fo, bs;
+            if (fl >= K.thrsh) {
+                bl = 1.0;
+                if (fo > K.one_minus_thrsh) fl = 1.0;
+            } else {
+                bl = 0.0;
+                fl = 0.0;
+            }
+            if (fs >= K.thrsh) {
+                bs = 1.0;
+                if (fs > K.one_minus_thrsh) fs = 1.0;
+            } else {
+                bs = 0.0;
+                fs = 0.0;
+            }
+            P.fmask_land[o2 + p] = fl;
+            P.bmask_land[o2 + p] = bl;
+            P.fmask_sea[o2 + p] = fs;
+            P.bmask_sea[o2 + p] = bs;
+            const int j = p / IX;
+            P.rhcapl[o2 + p] = P.alb0[o2 + p] < K.alb_thr ? K.rhcapl[0] : K.rhcapl[1];
+            P.cdland[o2 + p] = K.cdland[fl < K.flandmin ? 0 : 1];
+            P.rhcaps[o2 + p] = K.rhcaps_row[j];
+            P.rhcapi[o2 + p] = K.rhcapi_row[j];
+            P.cdsea[o2 + p] = K.cdsea[fs < K.fseamin ? 0 : 1];
+            P.cdice[o2 + p] = K.cdice[fs < K.fseamin ? 0 : 1];
+            if (P.anom_planes >= 3 && !(bs > 0.0))
+                for (int k = 0; k < 3; ++k) P.sst_anom[(static_cast<size_t>(mem) * P.anom_planes + k) * NG + p] = 0.0;
+        }
+        return;
+    }
+    const int month = f % 12;
+    double *field = (f < 12 ? P.stl12 : P.sst12) + o12 + static_cast<size_t>(month) * NG;
+    for (int p = t; p < NG; p += kT) plane[p] = field[p];
+    if (t == 0) {
+        const double *mine = rows + (static_cast<size_t>(blockIdx.y) * 24 + f) * IL * 2;
+        double c = 0.0;
+        if (mine[visit_row(0) * 2] == 0.0) {  // the first row has no valid point: the mean the rows before this plane leave behind
+            bool found = false;
+            for (int g = f - 1; g >= 0 && !found; --g)
+                for (int k = IL - 1; k >= 0 && !found; --k) {
+                    const double *row = rows + ((static_cast<size_t>(blockIdx.y) * 24 + g) * IL + visit_row(k)) * 2;
+                    if (row[0] > 0.0) {
+                        c = row[1];
+                        found = true;
+                    }
+                }
+        }
+        for (int k = 0; k < IL; ++k) {
+            const int r = visit_row(k);
+            if (mine[r * 2] > 0.0) c = mine[r * 2 + 1];
+            row_fill[r] = c;  // what a missing point of this row counts as
+        }
+    }
+    __syncthreads();
     for (int p = t; p < NG; p += kT) {
+        const int j = p / IX, i = p - j * IX;
         const double fo = P.fmask_orig[o2 + p];
-        double fl = fo, bl, fs = K.one - fo, bs;
-        if (fl >= K.thrsh) {
-            bl = 1.0;
-            if (fo > K.one_minus_thrsh) fl = 1.0;
-        } else {
-            bl = 0.0;
-            fl = 0.0;
+        const bool land = fo >= K.thrsh, sea = (K.one - fo) >= K.thrsh;  // bmask_land, bmask_sea
+        double v = plane[p];
+        if (v < 0.0) {
+            const double fm = row_fill[j];
+            double a = plane[j * IX + (i == 0 ? IX - 1 : i - 1)], b = plane[j * IX + (i == IX - 1 ? 0 : i + 1)];
+            a = a < 0.0 ? fm : a;
+            b = b < 0.0 ? fm : b;
+            const double both = a + b;
+            v = 0.5 * both;
         }
-        if (fs >= K.thrsh) {
-            bs = 1.0;
-            if (fs > K.one_minus_thrsh) fs = 1.0;
-        } else {
-            bs = 0.0;
-            fs = 0.0;
-        }
-        P.fmask_land[o2 + p] = fl;
-        P.bmask_land[o2 + p] = bl;
-        P.fmask_sea[o2 + p] = fs;
-        P.bmask_sea[o2 + p] = bs;
-        const int j = p / IX;
-        P.rhcapl[o2 + p] = P.alb0[o2 + p] < K.alb_thr ? K.rhcapl[0] : K.rhcapl[1];
-        P.cdland[o2 + p] = K.cdland[fl < K.flandmin ? 0 : 1];
-        P.rhcaps[o2 + p] = K.rhcaps_row[j];
-        P.rhcapi[o2 + p] = K.rhcapi_row[j];
-        P.cdsea[o2 + p] = K.cdsea[fs < K.fseamin ? 0 : 1];
-        P.cdice[o2 + p] = K.cdice[fs < K.fseamin ? 0 : 1];
+        field[p] = (f < 12 ? land : sea) ? v : 273.0;
         // (MAX / MIN as the reference's compiler evaluates them: one ordered comparison and a select)
-        const double weighted = K.veg_low_weight * P.veg_low[o2 + p];
-        const double vsum = P.veg_high[o2 + p] + weighted;
-        const double veg = 0.0 > vsum ? 0.0 : vsum;
-        for (int month = 0; month < 12; ++month) {
-            const size_t q = o12 + static_cast<size_t>(month) * NG + p;
+        const size_t q = o12 + static_cast<size_t>(month) * NG + p;
+        if (f < 12) {
+            const double weighted = K.veg_low_weight * P.veg_low[o2 + p];
+            const double vsum = P.veg_high[o2 + p] + weighted;
+            const double veg = 0.0 > vsum ? 0.0 : vsum;
             const double swroot = K.idep2 * P.soil_wc_l2[q];
             const double excess = swroot - K.swwil2;
             const double rooted = veg * (0.0 > excess ? 0.0 : excess);
             const double water = P.soil_wc_l1[q] + rooted;
             const double avail = K.rsw * water;
-            P.soilw12[q] = bl > 0.0 ? (1.0 < avail ? 1.0 : avail) : 0.0;
-            if (!(bl > 0.0)) P.snowd12[q] = 0.0;
+            P.soilw12[q] = land ? (1.0 < avail ? 1.0 : avail) : 0.0;
+            if (!land) P.snowd12[q] = 0.0;
+        } else {
             const double ice = P.sea_ice_frac12[q];
-            P.sea_ice_frac12[q] = bs > 0.0 ? (ice > 0.0 ? ice : 0.0) : 0.0;
-        }
-        if (P.anom_planes >= 3 && !(bs > 0.0))
-            for (int k = 0; k < 3; ++k) P.sst_anom[(static_cast<size_t>(mem) * P.anom_planes + k) * NG + p] = 0.0;
-    }
-    for (int f = 0; f < 24; ++f) {
-        double *field = (f < 12 ? P.stl12 : P.sst12) + o12 + static_cast<size_t>(f % 12) * NG;
-        __syncthreads();  // (the lanes that still read the previous plane; `carry` of the first round)
-        for (int p = t; p < NG; p += kT) plane[p] = field[p];
-        __syncthreads();
-        if (t < IL) {
-            int nmis = 0;
-            double s = 0.0;
-            for (int i = 0; i < IX; ++i) {
-                const double v = plane[t * IX + i];
-                const bool missing = v < 0.0;
-                nmis += missing ? 1 : 0;
-                s = s + (missing ? 0.0 : v);
-            }
-            row_nmis[t] = nmis;
-            row_mean[t] = nmis < IX ? s / static_cast<double>(static_cast<float>(IX - nmis)) : 0.0;
-        }
-        __syncthreads();
-        if (t == 0) {
-            double c = carry;
-            for (int k = 0; k < IL; ++k) {
-                const int r = k < IL / 2 ? IL / 2 - 1 - k : k;
-                if (row_nmis[r] < IX) c = row_mean[r];
-                row_mean[r] = c;  // what a missing point of this row counts as
-            }
-            carry = c;
-        }
-        __syncthreads();
-        for (int p = t; p < NG; p += kT) {
-            const int j = p / IX, i = p - j * IX;
-            double v = plane[p];
-            if (v < 0.0) {
-                const double fm = row_mean[j];
-                double a = plane[j * IX + (i == 0 ? IX - 1 : i - 1)], b = plane[j * IX + (i == IX - 1 ? 0 : i + 1)];
-                a = a < 0.0 ? fm : a;
-                b = b < 0.0 ? fm : b;
-                const double both = a + b;
-                v = 0.5 * both;
-            }
-            const double fo = P.fmask_orig[o2 + p];
-            const bool inside = f < 12 ? fo >= K.thrsh : (K.one - fo) >= K.thrsh;  // bmask_land / bmask_sea
-            field[p] = inside ? v : 273.0;
+            P.sea_ice_frac12[q] = sea ? (ice > 0.0 ? ice : 0.0) : 0.0;
         }
     }
 }
-hipError_t run_land_sea_init(const LandSeaPtrs &P, const LandSeaConsts &K, int M, hipStream_t s) {
-    hipLaunchKernelGGL(land_sea_init_kernel, dim3(M), dim3(kT), 0, s, P, K);
+// members [first, first + count); `rows`: 2 * 24 * 48 doubles of scratch per member of the range
+hipError_t run_land_sea_init(const LandSeaPtrs &P, const LandSeaConsts &K, int first, int count, double *rows, hipStream_t s) {
+    hipLaunchKernelGGL(land_sea_rows_kernel, dim3(24, count), dim3(kT), 0, s, P, first, rows);
+    hipLaunchKernelGGL(land_sea_init_kernel, dim3(25, count), dim3(kT), 0, s, P, K, first, rows);
+    return hipGetLastError();
+}
+
+// A member's arrays from one model into another (spd_model_copy_member: the driver's gather / split of batched models): the
+// ~150 registry arrays of a member lie in 150 places, and one hipMemcpyAsync each made a gather of 64 members cost 60 ms of host
+// time.  One launch: block (x, y) copies every gridDim.y-th 4 KiB piece of array x.
+__global__ __launch_bounds__(kT) void multi_copy_kernel(CopyList L) {
+    const int a = blockIdx.x;
+    const uint4 *src = reinterpret_cast<const uint4 *>(L.src[a]);
+    uint4 *dst = reinterpret_cast<uint4 *>(L.dst[a]);
+    const unsigned n = L.bytes[a] / 16;
+    for (unsigned i = blockIdx.y * kT + threadIdx.x; i < n; i += gridDim.y * kT) dst[i] = src[i];
+}
+hipError_t run_multi_copy(const CopyList &L, hipStream_t s) {
+    if (L.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(multi_copy_kernel, dim3(L.n, 16), dim3(kT), 0, s, L);
     return hipGetLastError();
 }
 

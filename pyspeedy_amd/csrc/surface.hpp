@@ -31,6 +31,15 @@ struct LandSeaPtrs {
     int anom_planes;
 };
 
+// multi_copy_kernel: up to kCopyListMax device-to-device copies in one launch (the arrays of one member, model to model)
+constexpr int kCopyListMax = 160;
+struct CopyList {
+    const char *src[kCopyListMax];
+    char *dst[kCopyListMax];
+    unsigned bytes[kCopyListMax];  // multiples of 16; both pointers 16-byte aligned
+    int n;
+};
+
 struct ZonalDevice {
     double v[5][48];  // flux_solar_in, flux_ozone_upper, flux_ozone_lower, zenit_correction, stratospheric_correction
 };

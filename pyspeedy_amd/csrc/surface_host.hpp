@@ -36,8 +36,8 @@ struct ZonalForcing {  // one value per latitude, shortwave_radiation.f90:218-32
 };
 ZonalForcing zonal_average_fields(const HostTables &t, double tyear);
 
-// land_model_init + sea_model_init (land_model.f90:23-148, sea_model.f90:33-192) run on the device, one workgroup per member
-// (land_sea_init_kernel, surface.hip).  What does not depend on the member's fields is evaluated here, once, with the host's
+// land_model_init + sea_model_init (land_model.f90:23-148, sea_model.f90:33-192) run on the device, one workgroup per monthly plane
+// and member (land_sea_init_kernel, surface.hip).  What does not depend on the member's fields is evaluated here, once, with the host's
 // arithmetic -- the reference's default-real literals in float, no contraction, the host's cos() for the latitude-dependent
 // heat capacities -- and handed to the kernel by value, so that the device only compares, selects, adds and multiplies.
 struct LandSeaConsts {

@@ -243,6 +243,12 @@ class EnsembleModel:
         arrays in place."""
         check(self._lib.spd_model_set_physics_precision(self._m, int(bool(fp32))), "spd_model_set_physics_precision")
 
+    def memory(self):
+        """Device memory of the model in bytes: (reserved, in use) -- spd_model_memory."""
+        reserved, used = C.c_size_t(0), C.c_size_t(0)
+        check(self._lib.spd_model_memory(self._m, C.byref(reserved), C.byref(used)), "spd_model_memory")
+        return reserved.value, used.value
+
     def config(self):
         """How the step is configured: dict(inv_per_member, diag_every_step, chunks, split_dyn) -- spd_model_get_config."""
         cfg = (C.c_int32 * 8)()

@@ -1,5 +1,5 @@
 """GPU tier: the boundary-field preprocessing of init (land_model_init + sea_model_init with fill_missing_values and
-check_surface_fields) runs on the device, one workgroup per member (land_sea_init_kernel, surface.hip).  Bit for bit:
+check_surface_fields) runs on the device, one workgroup per monthly plane and member (land_sea_init_kernel, surface.hip).  Bit for bit:
   * against what the REFERENCE's init made of the same boundary-field sets (tests/golden/init.npz; oracle/init_cases.py has
     the sets: the example file, and the example with missing-value patterns the example itself never contains);
   * against the oracle (pinned on the same golden, tests/test_oracle_init.py) on random sets: random masks and fractions

@@ -116,7 +116,7 @@ def test_members_of_a_large_batch_equal_single_member_runs(spectral, bc):
 
 
 def test_initialisation_with_distinct_boundary_sets(spectral, bc):
-    """spd_model_init preprocesses every member's boundary fields on the device, one workgroup per member.  Six members, two of
+    """spd_model_init preprocesses every member's boundary fields on the device.  Six members, two of
     them with their own SST / soil climatologies: every member is bitwise the one-member model initialised from the same fields,
     after the initialisation and after 7 steps."""
     from pyspeedy_amd.model import BC_MAP, EnsembleModel
