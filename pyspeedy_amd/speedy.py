@@ -50,15 +50,31 @@ def _add_months(date, months):
     return date.replace(year=y, month=m + 1)
 
 
+_last_file = [None, None]  # (path, mtime, size) and the fields of the file read last
+
+
 def _load_fields(source):
-    """Mapping name -> array from an .npz file, a NetCDF-3 file, a Dataset or a plain mapping."""
+    """Mapping name -> array from an .npz file, a NetCDF-3 file, a Dataset or a plain mapping.  The file read last is kept
+    (read-only arrays): the reference's `for member in ens: member.set_bc()` reads the same file once per member, and
+    decompressing it costs more than everything else a member's set_bc does."""
     if isinstance(source, (str, os.PathLike)):
         if not os.path.isfile(source):
             raise RuntimeError("The boundary conditions file does not exist.\nFile: %s" % source)
+        st = os.stat(source)
+        key = (os.path.realpath(source), st.st_mtime_ns, st.st_size)
+        if _last_file[0] == key:
+            return dict(_last_file[1])
         if str(source).endswith(".npz"):
             with np.load(source) as z:
-                return {k: z[k] for k in z.files}
-        source = open_dataset(source)
+                fields = {k: z[k] for k in z.files}
+        else:
+            fields = {k: np.asarray(v.values) for k, v in open_dataset(source).variables.items()}
+        # (as the state containers take them: float64, Fortran order -- converting costs as much as a member's 12 transfers)
+        fields = {k: np.asfortranarray(v, dtype=np.float64) if v.dtype.kind == "f" else v for k, v in fields.items()}
+        for v in fields.values():
+            v.setflags(write=False)
+        _last_file[0], _last_file[1] = key, fields
+        return dict(fields)
     if isinstance(source, Dataset):
         return {k: v.values for k, v in source.variables.items()}
     return dict(source)
