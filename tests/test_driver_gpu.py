@@ -499,6 +499,50 @@ def test_a_synchronous_step_beside_a_pending_one_takes_the_free_check_slot(drv, 
     drv.close(a, twin)
 
 
+def test_containers_come_and_go_cheaply_and_leave_nothing_behind(drv, bc, spectral):
+    """A device model carves its arrays from one zero-filled block and takes its stream from the device's pool only when it
+    is first stepped: a host with the reference's call sequence creates, initialises, gathers and closes one-member models by the
+    hundred.  Fresh containers read back zeros whatever lived in that memory before; the trajectory of a container does not
+    depend on how many came and went before it; spd_model_memory reports what a member costs."""
+    import ctypes
+    from pyspeedy_amd.model import EnsembleModel
+    start, end = (1982, 1, 1, 0, 0), (1982, 1, 3, 0, 0)
+    alive0 = C.c_int32()
+    drv.ok(drv.L.spd_driver_stats(0, C.byref(alive0), None))
+
+    def one_run(perturb):
+        s, c = drv.state(), drv.control(start, end)
+        assert not drv.get(s, "t", np.complex128).any() and not drv.get(s, "sst12").any() and not drv.get(s, "rad_tau2").any()  # zero-filled
+        drv.set_bc(s, bc, perturb)
+        assert drv.init(s, c) == 0
+        for _ in range(5):
+            assert drv.step(s, c) == 0
+        t = drv.get(s, "t", np.complex128)
+        drv.ok(drv.L.spd_modelstate_close(s))
+        drv.ok(drv.L.spd_controlparams_close(c))
+        return t
+
+    first = one_run(0.5)
+    for k in range(40):  # (never stepped: these never take a stream; their blocks dirty the memory the next ones get)
+        s = drv.state()
+        drv.set_bc(s, bc, 1.0 + k)
+        drv.ok(drv.L.spd_modelstate_close(s))
+    assert np.array_equal(one_run(0.5), first)
+    drv.ok(drv.L.spd_driver_trim())
+    assert np.array_equal(one_run(0.5), first)  # (with a stream created anew)
+    alive = C.c_int32()
+    drv.ok(drv.L.spd_driver_stats(0, C.byref(alive), None))
+    assert alive.value == alive0.value
+    for members in (1, 8):
+        m = EnsembleModel(spectral, members)
+        reserved, used = m.memory()
+        assert 18.0e6 * members < used <= reserved < 21.5e6 * members + 2e6, (members, reserved, used)
+        m.init_sst_anom(14)  # (16 planes per member instead of 3: a second block)
+        assert m.memory()[1] >= used + members * 16 * 96 * 48 * 8
+        m.close()
+    assert ctypes.sizeof(ctypes.c_size_t) == 8
+
+
 def test_ensemble_placement_by_argument_leaves_the_process_placement_alone(drv):
     """spd_modelstate_init_ensemble_on(cnts, n, k) takes the number of devices as an argument: the process-wide placement
     (spd_set_device_placement / PYSPEEDY_AMD_DEVICES) is neither read nor reset by it -- SpeedyEns(devices=k) used to switch it to
