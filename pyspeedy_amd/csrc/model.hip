@@ -200,6 +200,7 @@ static int arena_alloc(spd_model *m, size_t bytes, void **out) {
         const size_t want = m->blocks.empty() ? M * (19u << 20) + (1u << 20) : M * (2u << 20) + (1u << 20);
         const size_t size = bytes > want ? bytes : want;
         void *p = nullptr;
+        M_HIP(hipSetDevice(m->ctx->device));
         M_HIP(hipMalloc(&p, size));
         m->blocks.push_back({static_cast<char *>(p), size, 0});
         M_HIP(hipMemset(p, 0, size));
