@@ -148,6 +148,34 @@ def test_initialisation_with_distinct_boundary_sets(spectral, bc):
     ens.close()
 
 
+def test_time_step_tables_are_shared_per_context_and_survive_a_host_that_keeps_changing_the_step(spectral, bc):
+    """The dynamics tables of a time step exist once per context (a model that changes its step switches pointers).  A context
+    keeps 64 of them; a model that asks for a 65th gets a private set, rebuilt in place at every change.  Either way the run is
+    the same, bit for bit."""
+    import pyspeedy_amd
+    from pyspeedy_amd.model import DELT, EnsembleModel
+    ref = EnsembleModel(spectral, 2)
+    ref.set_bc(bc)
+    ref.run(7)
+    crowded = pyspeedy_amd.ModSpectral(0)  # (a context of its own: the session's keeps its three steps)
+    other = EnsembleModel(crowded, 1)
+    for k in range(64):
+        other.set_time_step(100.0 + k)  # fills the context
+    m = EnsembleModel(crowded, 2)
+    m.set_bc(bc)                        # delt / 2, delt, 2 delt: three private rebuilds
+    m.set_time_step(123.0)              # ... a fourth, and back
+    m.set_time_step(2 * DELT)
+    other.set_time_step(2 * DELT)       # (two models with private sets of the same step do not share them)
+    m.run(7)
+    for n in SPEC + ("phi", "olr", "land_temp", "rad_tau2"):
+        assert np.array_equal(m.get(n, 1), ref.get(n, 1)), n
+    with pytest.raises(Exception):
+        m.set_time_step(0.0)
+    for model in (m, other, ref):
+        model.close()
+    crowded.close()
+
+
 def _through_a_file(snapshot):
     with tempfile.TemporaryDirectory() as tmp:  # as a checkpoint would travel
         np.savez(os.path.join(tmp, "ckpt.npz"), **snapshot)
