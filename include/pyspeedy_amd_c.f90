@@ -283,9 +283,6 @@ module pyspeedy_amd_c
             integer(c_int64_t), value :: state_cnt
             integer(c_int32_t), intent(out) :: models_alive, members_in_model
         end function
-        integer(c_int) function spd_driver_trim() bind(C, name="spd_driver_trim")
-            import :: c_int
-        end function
         ! ---- one process, several GPUs (extension; the reference's ensemble is one process, speedy_driver.f90.j2:58-79) ----
         integer(c_int) function spd_device_count(n_devices) bind(C, name="spd_device_count")
             import :: c_int, c_int32_t

@@ -141,9 +141,6 @@ int spd_registry_entry(int32_t index, char *name /* 32 bytes */, int32_t *dtype,
 int spd_driver_model(int64_t state_cnt, void **model, int32_t *member, int32_t *members_in_model);
 /* how many device models are alive and how many members the container's model holds (tests / diagnostics of batching) */
 int spd_driver_stats(int64_t state_cnt, int32_t *models_alive, int32_t *members_in_model);
-/* hands back what the driver keeps for re-use between device models (the idle streams of every device; a device model takes
- * its stream from there when it is first stepped and returns it when it dies).  Never needed for correctness. */
-int spd_driver_trim(void);
 /* Host-side order in which parallel_step (begin / end) handled its device models when there were several: spd_driver_trace(1)
  * starts recording, _read copies up to `capacity` (kind, group) pairs and returns how many there are; kind 1 = step + check
  * of the group enqueued, 2 = the host starts waiting for the group, 3 = its codes are back. */

@@ -115,23 +115,6 @@ size_t elem_bytes(int dtype) { return dtype == SPD_T_COMPLEX128 ? 16 : (dtype ==
 // ---------------------------------------------------------------------------------------------------------------------
 std::atomic<int> g_models_alive{0};
 
-// idle streams by device (its own lock: a device model may die on any thread, with or without the library's lock held)
-std::mutex g_stream_pool_mutex;
-std::map<int, std::vector<void *>> g_stream_pool;
-constexpr size_t kPooledStreams = 16;  // per device; more than that are destroyed when they come back
-void release_stream(int device, void *stream) {
-    if (!stream) return;
-    {
-        std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
-        std::vector<void *> &idle = g_stream_pool[device];
-        if (idle.size() < kPooledStreams) {
-            idle.push_back(stream);
-            return;
-        }
-    }
-    drvdev::stream_destroy(stream);  // (the caller has made the stream's device current)
-}
-
 struct Batch {  // one device model shared by the containers of its members
     Batch() { ++g_models_alive; }
     Batch(const Batch &) = delete;
@@ -142,10 +125,12 @@ struct Batch {  // one device model shared by the containers of its members
     std::vector<char> initialized;
     // The steps and range checks of this model are issued on a stream of its own, so that the models of one parallel_step --
     // on different devices, or several on one device -- run side by side.  A blocking stream: everything else the driver does
-    // (initialisation, copies, transforms) stays on the null stream, which orders itself against it.  Taken from the device's
-    // pool when the model is first stepped (stream_for) and handed back when it dies: creating and destroying a stream costs a
-    // millisecond each, and the one-member models of a host with the reference's call sequence are gathered into batched
-    // models before any of them is stepped on its own.
+    // (initialisation, copies, transforms) stays on the null stream, which orders itself against it.  Created when the model is
+    // first stepped (stream_for): creating and destroying a stream costs a millisecond each, and the one-member models of a host
+    // with the reference's call sequence are gathered into batched models before any of them is stepped on its own.  Destroyed
+    // with the model, not kept for the next one: an idle stream still holds its place among the device's few hardware queues,
+    // and streams created after it double up on the others (measured: two idle streams of this kind made a model that steps
+    // three member groups on streams of its own 33 % slower, tools/experiments/r04_idle_streams.py).
     void *stream = nullptr;
     // A step was enqueued and its range check (or anything else that had to follow it) could not be: the device state has
     // moved on while date and codes say it has not.  Nothing steps such a model again until it is initialised anew.
@@ -154,8 +139,8 @@ struct Batch {  // one device model shared by the containers of its members
         --g_models_alive;
         drvdev::DeviceGuard guard;  // (may run from any entry point that drops the last reference, or from a host's garbage collector)
         (void)drvdev::set_device(device);
-        if (model) (void)spd_model_destroy(model);  // (waits for whatever the stream still holds)
-        release_stream(device, stream);
+        if (model) (void)spd_model_destroy(model);
+        if (stream) drvdev::stream_destroy(stream);
     }
 };
 struct State {
@@ -212,6 +197,20 @@ void regrouped() {  // (lock held) something happened after which an argument li
 }
 
 
+// The stream a device model is stepped on, created when it is first needed (lock held, calling thread; the model's device is
+// current) -- on a hardware queue of its own among the models of its device: the device models of one parallel_step are there to
+// run side by side, and two streams that HIP has put on one hardware queue do not (stream_apart.hpp).
+bool stream_for(Batch &b) {
+    if (b.stream) return true;
+    std::vector<void *> others;
+    for (auto &kv : g_states) {
+        const Batch &o = *kv.second->batch;
+        if (&o != &b && o.device == b.device && o.stream && std::find(others.begin(), others.end(), o.stream) == others.end())
+            others.push_back(o.stream);
+    }
+    return drvdev::stream_create_apart(&b.stream, others.data(), static_cast<int>(others.size()));
+}
+
 int fail(int code, const std::string &msg) { return spd_set_error(code, msg); }
 
 int context_for_device(int dev, spd_handle *out) {
@@ -265,20 +264,6 @@ int new_batch(int members, int device, std::shared_ptr<Batch> *out) {
     return SPD_OK;
 }
 
-// the stream a device model is stepped on (its device is current)
-bool stream_for(Batch &b) {
-    if (b.stream) return true;
-    {
-        std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
-        std::vector<void *> &idle = g_stream_pool[b.device];
-        if (!idle.empty()) {
-            b.stream = idle.back();
-            idle.pop_back();
-            return true;
-        }
-    }
-    return drvdev::stream_create(&b.stream);
-}
 
 std::shared_ptr<State> state_of(int64_t cnt) {
     auto it = g_states.find(cnt);
@@ -929,7 +914,7 @@ static void issue_group(const GroupPlan &g, GroupRun &r) {
     if (b.advanced_without_check)
         rc = fail(SPD_E_ARG, "speedy driver: an earlier step of this device model was enqueued but could not be checked; initialise its members again");
     if (rc == SPD_OK && !drvdev::set_device(b.device)) rc = fail(SPD_E_DEVICE, "speedy driver: hipSetDevice failed");
-    if (rc == SPD_OK && !stream_for(b)) rc = fail(SPD_E_DEVICE, "speedy driver: hipStreamCreate failed");
+    if (rc == SPD_OK && !b.stream) rc = fail(SPD_E_DEVICE, "speedy driver: hipStreamCreate failed");  // (issue_all made it)
     if (rc == SPD_OK && spd_model_checks_in_flight(b.model) >= 2)  // (a step without its check is no step)
         rc = fail(SPD_E_ARG, "speedy driver: two steps of this device model are in flight already; end one with spd_parallel_step_end first");
     if (rc == SPD_OK) rc = push_date(b, r.before);
@@ -1008,6 +993,10 @@ static void issue_all(const std::vector<GroupPlan> &groups, std::vector<GroupRun
         const char *e = getenv("PYSPEEDY_AMD_ISSUE_THREADS");
         return e ? atoi(e) : 1;
     }();
+    for (const GroupPlan &g : groups) {  // (streams are made here, by the calling thread, not by the device's issue thread)
+        Batch &b = *g.batch;
+        if (!b.stream && all_initialized(b) && !b.advanced_without_check && drvdev::set_device(b.device)) (void)stream_for(b);
+    }
     std::map<int, std::vector<size_t>> by_key;  // worker key -> groups, in argument order
     for (size_t i = 0; i < groups.size(); ++i) by_key[mode == 2 ? static_cast<int>(i) : groups[i].batch->device].push_back(i);
     if (mode == 0 || by_key.size() < 2) {
@@ -1425,20 +1414,6 @@ int spd_driver_model(int64_t state_cnt, void **model, int32_t *member, int32_t *
     *model = st->batch->model;
     if (member) *member = st->member;
     if (members_in_model) *members_in_model = st->batch->members;
-    return SPD_OK;
-}
-
-int spd_driver_trim(void) {
-    drvdev::DeviceGuard guard;
-    std::map<int, std::vector<void *>> idle;
-    {
-        std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
-        idle.swap(g_stream_pool);
-    }
-    for (auto &kv : idle) {
-        if (!drvdev::set_device(kv.first)) continue;
-        for (void *s : kv.second) drvdev::stream_destroy(s);
-    }
     return SPD_OK;
 }
 

@@ -10,7 +10,9 @@ namespace drvdev {
 int device_count();
 bool get_device(int *device);
 bool set_device(int device);
-bool stream_create(void **stream);  // a blocking stream on the current device
+// a blocking stream on the current device that runs side by side with each of `others` (streams of the same device, idle now):
+// not on a hardware queue one of them is on (stream_apart.hpp)
+bool stream_create_apart(void **stream, void *const *others, int n_others);
 void stream_destroy(void *stream);
 bool device_synchronize();          // the current device
 bool null_stream_synchronize();

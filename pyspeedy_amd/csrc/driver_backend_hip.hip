@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include "driver_backend.hpp"
+#include "stream_apart.hpp"
 
 namespace drvdev {
 int device_count() {
@@ -10,9 +11,9 @@ int device_count() {
 }
 bool get_device(int *device) { return hipGetDevice(device) == hipSuccess; }
 bool set_device(int device) { return hipSetDevice(device) == hipSuccess; }
-bool stream_create(void **stream) {
+bool stream_create_apart(void **stream, void *const *others, int n_others) {
     hipStream_t s = nullptr;
-    if (hipStreamCreate(&s) != hipSuccess) return false;
+    if (spd::create_stream_apart(&s, reinterpret_cast<const hipStream_t *>(others), n_others, hipStreamDefault) != hipSuccess) return false;
     *stream = s;
     return true;
 }

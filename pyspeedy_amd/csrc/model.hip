@@ -21,6 +21,7 @@
 #include "coupler_point.hpp"
 #include "launch_events.hpp"
 #include "sppt_point.hpp"
+#include "stream_apart.hpp"
 #include "surface.hpp"
 
 namespace spd {
@@ -1132,7 +1133,8 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
         M_HIP(hipEventRecord(m->ev_start, s));
         for (int g = 0; g < G; ++g) {
             if (!m->cstream[g]) {
-                M_HIP(hipStreamCreateWithFlags(&m->cstream[g], hipStreamNonBlocking));
+                // on a hardware queue none of the groups before it is on (stream_apart.hpp: measured, not assumed)
+                M_HIP(create_stream_apart(&m->cstream[g], m->cstream, g, hipStreamNonBlocking));
                 M_HIP(hipEventCreateWithFlags(&m->cev[g], hipEventDisableTiming));
             }
             gs[g] = m->cstream[g];

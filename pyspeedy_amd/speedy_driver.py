@@ -317,11 +317,6 @@ def driver_stats(state_cnt=0):
     return alive.value, members.value
 
 
-def driver_trim():
-    """Hand back what the driver keeps for re-use between device models (the idle streams of every device)."""
-    _ok(_lib.lib().spd_driver_trim(), "driver_trim")
-
-
 # --------------------------------------------------------------------------------------------------------------------
 # registry access: get_<v>, set_<v>, get_<v>_shape, is_array_<v> (generated per variable in the reference)
 # --------------------------------------------------------------------------------------------------------------------

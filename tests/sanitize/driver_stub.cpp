@@ -57,7 +57,9 @@ bool set_device(int device) {
     t_device = device;
     return true;
 }
-bool stream_create(void **stream) {
+bool stream_create_apart(void **stream, void *const *others, int n_others) {
+    for (int i = 0; i < n_others; ++i)
+        if (others[i] && *static_cast<int *>(others[i]) != t_device) std::abort();  // (only streams of the current device are compared)
     *stream = new int(t_device);
     return true;
 }

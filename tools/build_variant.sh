@@ -16,7 +16,7 @@ while [ $# -gt 0 ]; do
 done
 BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=on"
 pids=()
-for f in capi transforms specops physics dynamics model surface sppt driver_backend_hip; do
+for f in capi transforms specops physics dynamics model surface sppt stream_apart driver_backend_hip; do
   extra="${FLAGS[*]}"
   if [ ${#ONLY[@]} -gt 0 ]; then
     extra=""
