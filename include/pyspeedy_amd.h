@@ -179,7 +179,11 @@ int spd_model_checks_in_flight(spd_model_handle m); /* 0, 1 or 2: checks begun a
 int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, int minute, void *stream);
 /* do_single_step (speedy.f90:20-74) `nsteps` times for all members: daily forcing, shortwave every third step, leapfrog
  * step, date advance, land/sea coupling.  Stream-ordered, no synchronisation; returns SPD_E_ARG when the state was not
- * initialised (the reference's error code -1).  spd_model_check runs the reference's per-step range check on demand. */
+ * initialised (the reference's error code -1).  spd_model_check runs the reference's per-step range check on demand.
+ * A call of several steps on a model of 20 members or more issues the members in 2 or 3 groups on streams of the model's own
+ * (forked from and joined to `stream` around the call).  The FIRST such call creates them and spends a few milliseconds making
+ * sure they sit on different hardware queues (it measures: HIP's hand-out depends on every stream the process created before,
+ * and two group streams on one queue run one after the other); that first call blocks the host for that long. */
 int spd_model_step(spd_model_handle m, int nsteps, void *stream);
 int spd_model_current_step(spd_model_handle m);
 int spd_model_get_date(spd_model_handle m, int *ymdhm /* 5 ints */);
