@@ -132,6 +132,8 @@ int spd_physics(spd_handle h, const spd_physics_args *args, int nmembers, void *
 typedef struct spd_model *spd_model_handle;
 
 int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out);
+/* (waits for the device; the model's memory block is kept by its context for the next model of the same size, up to 1 GiB per
+ * context, and returned to the device with the context) */
 int spd_model_destroy(spd_model_handle m);
 int spd_model_members(spd_model_handle m);
 /* device memory of the model, all members: bytes reserved (a few large blocks the arrays are carved from) and bytes in use */

@@ -196,6 +196,7 @@ int spd_destroy(spd_handle h) {
     if (!h) return SPD_OK;
     (void)hipSetDevice(h->device);
     for (void *p : h->allocations) (void)hipFree(p);
+    for (const spd_context::IdleBlock &b : h->idle_blocks) (void)hipFree(b.base);
     if (h->scratch) (void)hipFree(h->scratch);
     delete h;
     return SPD_OK;

@@ -28,6 +28,15 @@ struct spd_context {
     double *scratch = nullptr;
     size_t scratch_bytes = 0;
     std::mutex scratch_mutex;
+    // Memory blocks of models that have died, kept for the next model of the same size (model.hip: arena_alloc / spd_model_destroy):
+    // a host with the reference's call sequence creates and closes one-member models by the hundred, and hipFree costs 0.22 ms.
+    struct IdleBlock {
+        void *base;
+        size_t size;
+    };
+    std::vector<IdleBlock> idle_blocks;
+    size_t idle_bytes = 0;
+    std::mutex idle_mutex;
     std::mutex dyn_mutex;
     std::unique_ptr<spd_dyn_tables> dyn_base;                       // time step 0: the dt-independent tables only
     std::map<double, std::unique_ptr<spd_dyn_tables>> dyn_by_step;  // never shrinks while the context lives (kMaxDynSteps)

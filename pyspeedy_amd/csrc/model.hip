@@ -202,7 +202,17 @@ static int arena_alloc(spd_model *m, size_t bytes, void **out) {
         const size_t size = bytes > want ? bytes : want;
         void *p = nullptr;
         M_HIP(hipSetDevice(m->ctx->device));
-        M_HIP(hipMalloc(&p, size));
+        {  // a block of this size that a dead model of this context left behind?
+            std::lock_guard<std::mutex> lock(m->ctx->idle_mutex);
+            auto &idle = m->ctx->idle_blocks;
+            for (size_t i = 0; i < idle.size() && !p; ++i)
+                if (idle[i].size == size) {
+                    p = idle[i].base;
+                    m->ctx->idle_bytes -= size;
+                    idle.erase(idle.begin() + static_cast<long>(i));
+                }
+        }
+        if (!p) M_HIP(hipMalloc(&p, size));
         m->blocks.push_back({static_cast<char *>(p), size, 0});
         M_HIP(hipMemset(p, 0, size));
     }
@@ -602,7 +612,19 @@ int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
 int spd_model_destroy(spd_model_handle m) {
     if (!m) return SPD_OK;
     (void)hipSetDevice(m->ctx->device);
-    for (const spd_model::Block &b : m->blocks) (void)hipFree(b.base);
+    // The first block (everything spd_model_create allocated) is kept for the next model of this size, up to kIdleBytes per
+    // context; what hipFree would have waited for is waited for here.
+    constexpr size_t kIdleBytes = static_cast<size_t>(1) << 30;
+    bool keep_first = false;
+    if (!m->blocks.empty() && hipDeviceSynchronize() == hipSuccess) {
+        std::lock_guard<std::mutex> lock(m->ctx->idle_mutex);
+        if (m->ctx->idle_bytes + m->blocks[0].size <= kIdleBytes) {
+            m->ctx->idle_blocks.push_back({m->blocks[0].base, m->blocks[0].size});
+            m->ctx->idle_bytes += m->blocks[0].size;
+            keep_first = true;
+        }
+    }
+    for (size_t i = keep_first ? 1 : 0; i < m->blocks.size(); ++i) (void)hipFree(m->blocks[i].base);
     for (int i = 0; i < 4; ++i) {
         if (m->cstream[i]) (void)hipStreamDestroy(m->cstream[i]);
         if (m->cev[i]) (void)hipEventDestroy(m->cev[i]);
