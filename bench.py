@@ -483,6 +483,7 @@ def config_leg(args, config, members, what, device, dist, rank, coll_device, bar
     cfg = model.config()
     model.run(leg.warmup)
     secs = timed_regions(model, leg, barrier, dist, coll_device, MAX_STEPS - leg.warmup - 72, args.leg_seconds, 500)
+    cfg = model.config()
     model.profile(2)  # a first bracketed day that is not read: it creates the events and takes the one-off costs of the
     model.run(36)     # profiling path (the headline's table comes behind its serial-plan regions, which do the same for it)
     model.sync()
@@ -739,9 +740,14 @@ def pyspeedy_amd_lib():
 
 
 def plan_name(cfg, M):
+    """cfg: model.config(), read AFTER the run for the last clause (the group streams exist from the first multi-step call on)"""
     g = cfg["chunks"]
-    return ("%d member groups of %d / %d members on %d HIP streams" % (g, (M + g - 1) // g, M // g, g)) if g > 1 else \
-        "serial: one member group on one stream"
+    if g <= 1:
+        return "serial: one member group on one stream"
+    plan = "%d member groups of %d / %d members on %d HIP streams" % (g, (M + g - 1) // g, M // g, g)
+    if cfg.get("group_streams", 0) > 1:  # (csrc/stream_apart.hpp: measured when the streams were created)
+        plan += " (measured: side by side)" if cfg["group_streams_apart"] else " (MEASURED: NOT ALL SIDE BY SIDE -- two share a hardware queue)"
+    return plan
 
 
 def load_traffic(nfields):
@@ -927,6 +933,13 @@ def run_rank(args):
     # ---- headline: the library's default plan
     region_s = timed_regions(model, args, barrier, dist, coll_device, budget * 3 // 4, args.min_seconds)
     budget -= len(region_s) * args.steps
+    plan = plan_name(model.config(), M)
+    # (every rank's group streams, not only rank 0's: one all_gather_object; a rank whose streams share a hardware queue is the
+    # slowest rank, and the line's time is the slowest rank's)
+    apart_by_rank = [bool(model.config()["group_streams_apart"])]
+    if dist is not None:
+        apart_by_rank = [None] * n_gpus
+        dist.all_gather_object(apart_by_rank, bool(model.config()["group_streams_apart"]))
     # ---- roofline: the dominant transform kernel by HIP events on its launch stream, serial plan (profiling implies it)
     model.profile(1)
     saved_regions, args.regions = args.regions, (min(args.regions, 10) if args.regions else 0)
@@ -1016,6 +1029,7 @@ def run_rank(args):
                             "grid2spec + spectral tendencies/semi-implicit/diffusion/RAW filter + coupler + daily "
                             "forcing), all on the GPU" % (args.config, args.scaling, M, total_members, physics, nfields // M),
                 "members_per_gpu": M, "members_total": total_members, "plan": plan,
+                "group_streams_side_by_side_by_rank": apart_by_rank,
                 "ms_per_member_step": ms_step * n_gpus / total_members, "simulated_days_per_region": args.steps / 36.0,
                 "parallelism": "ensemble members sharded per GPU, no collective in the step",
                 "backend": backend if dist is not None else "none (single process)",

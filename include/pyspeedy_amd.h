@@ -244,6 +244,10 @@ int spd_model_profile_read_kernels(spd_model_handle m, double *mean_ms, double *
  * cfg[6] = 1 for fp32 arithmetic in the column physics, cfg[7] = 1 while the arrays only the column physics reads back are stored
  * as fp32 (spd_model_set_physics_precision) */
 int spd_model_get_config(spd_model_handle m, int32_t *cfg /* 8 */);
+/* the streams the member groups of multi-step calls are issued on: how many the model has created so far, and whether each was
+ * measured to run side by side with the others when it was created (0: after several replacements two of them still shared a
+ * hardware queue -- their groups then run one after the other; PYSPEEDY_AMD_STREAMS_APART=2 reports the measurements) */
+int spd_model_group_streams(spd_model_handle m, int32_t *created, int32_t *apart);
 /* The launch-plan switches that can change on a live model, by name (the environment variables of README.md set the same
  * fields when the model is created; none of them changes the state a step leaves behind):
  *   "diag_every_step"      0 / 1   store the diagnostics-only physics outputs on every step of a multi-step call

@@ -159,6 +159,7 @@ _SIGNATURES = {
     "spd_model_profile_read_kernels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spd_model_set_physics_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "spd_model_get_config": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "spd_model_group_streams": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "spd_model_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
 }
 

@@ -111,6 +111,7 @@ struct spd_model {
     // chains and one launch less is worth 1-3 %; at 64 members the longer spectral_step_kernel costs 2 % more than the
     // geopotential launch it saves (A/B in one session, profiles/).  PYSPEEDY_AMD_FOLD_GEO=0 / 1 overrides.
     bool phi_ahead = false, fold_geo = true;
+    bool groups_apart = true;  // every group stream created so far was measured to run side by side with the others
     int *d_err = nullptr;
     double *d_diag = nullptr;
     // asynchronous range check (spd_model_check_begin / _end): two pinned result slots with their events
@@ -1156,7 +1157,9 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
         for (int g = 0; g < G; ++g) {
             if (!m->cstream[g]) {
                 // on a hardware queue none of the groups before it is on (stream_apart.hpp: measured, not assumed)
-                M_HIP(create_stream_apart(&m->cstream[g], m->cstream, g, hipStreamNonBlocking));
+                bool apart = true;
+                M_HIP(create_stream_apart(&m->cstream[g], m->cstream, g, hipStreamNonBlocking, &apart));
+                m->groups_apart = m->groups_apart && apart;
                 M_HIP(hipEventCreateWithFlags(&m->cev[g], hipEventDisableTiming));
             }
             gs[g] = m->cstream[g];
@@ -1347,6 +1350,15 @@ int spd_model_set_control(spd_model_handle m, const spd_model_control *in) {
 int spd_model_get_date(spd_model_handle m, int *ymdhm) {
     if (!m || !ymdhm) return m_fail(SPD_E_ARG, "spd_model_get_date: null argument");
     ymdhm[0] = m->cal.year; ymdhm[1] = m->cal.month; ymdhm[2] = m->cal.day; ymdhm[3] = m->cal.hour; ymdhm[4] = m->cal.minute;
+    return SPD_OK;
+}
+
+int spd_model_group_streams(spd_model_handle m, int32_t *created, int32_t *apart) {
+    if (!m) return m_fail(SPD_E_ARG, "spd_model_group_streams: null model");
+    int n = 0;
+    for (int g = 0; g < 4; ++g) n += m->cstream[g] ? 1 : 0;
+    if (created) *created = n;
+    if (apart) *apart = m->groups_apart ? 1 : 0;
     return SPD_OK;
 }
 

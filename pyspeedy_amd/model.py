@@ -253,9 +253,11 @@ class EnsembleModel:
         """How the step is configured: dict(inv_per_member, diag_every_step, chunks, split_dyn) -- spd_model_get_config."""
         cfg = (C.c_int32 * 8)()
         check(self._lib.spd_model_get_config(self._m, cfg), "spd_model_get_config")
+        created, apart = C.c_int32(0), C.c_int32(1)
+        check(self._lib.spd_model_group_streams(self._m, C.byref(created), C.byref(apart)), "spd_model_group_streams")
         return dict(inv_per_member=cfg[0], diag_every_step=bool(cfg[1]), chunks=cfg[2], split_dyn=bool(cfg[3]),
                     fold_geo=bool(cfg[4]), coupler_in_spectral=bool(cfg[5]), physics_fp32=bool(cfg[6]),
-                    physics_storage32=bool(cfg[7]))
+                    physics_storage32=bool(cfg[7]), group_streams=created.value, group_streams_apart=bool(apart.value))
 
     def set_option(self, name, value):
         """A launch-plan switch of the live model by name (spd_model_set_option: diag_every_step, coupler_in_spectral,
