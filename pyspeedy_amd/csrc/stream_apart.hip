@@ -48,6 +48,10 @@ hipError_t create_stream_apart(hipStream_t *out, const hipStream_t *others, int 
             ok = true;
             for (int i = 0; i < n_others && ok && e == hipSuccess; ++i) {
                 if (!others[i] || others[i] == cand) continue;
+                if (hipStreamQuery(others[i]) != hipSuccess) {  // busy: it cannot be measured now (and is not made to wait)
+                    (void)hipGetLastError();
+                    continue;
+                }
                 double both = 0.0;
                 e = sleep_time(cand, others[i], &both);
                 ok = both < 1.5 * alone;

@@ -15,6 +15,6 @@
 namespace spd {
 constexpr int kApartTries = 4;
 // flags: hipStreamDefault or hipStreamNonBlocking.  *apart (may be null): whether the stream overlapped with all of `others` in
-// the end.  The current device must be the streams' device; `others` must be idle or the measurement waits for them.
+// the end.  The current device must be the streams' device; a stream of `others` that is busy is not measured against.
 hipError_t create_stream_apart(hipStream_t *out, const hipStream_t *others, int n_others, unsigned flags, bool *apart = nullptr);
 }  // namespace spd
