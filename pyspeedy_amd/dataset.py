@@ -34,6 +34,23 @@ class Dataset:
         self.coords = {k: as_var(v) for k, v in (coords or {}).items()}
         self.attrs = dict(attrs or {})
 
+    def __repr__(self):
+        """Dimensions, coordinates and data variables with their dimensions, types and value ranges (what a notebook shows)."""
+        def line(name, v):
+            vals = np.asarray(v.values)
+            rng = ""
+            if vals.size and vals.dtype.kind in "fiu":
+                rng = "  %.6g .. %.6g" % (np.nanmin(vals), np.nanmax(vals))
+            elif vals.size and vals.dtype.kind == "M":
+                rng = "  %s .. %s" % (vals.min(), vals.max())
+            return "    %-12s (%s) %s%s" % (name, ", ".join(v.dims), vals.dtype, rng)
+        out = ["<pyspeedy_amd.Dataset>", "Dimensions:  (" + ", ".join("%s: %d" % kv for kv in self.dims.items()) + ")", "Coordinates:"]
+        out += [line(k, v) for k, v in self.coords.items()]
+        out += ["Data variables:"] + [line(k, v) for k, v in self.data_vars.items()]
+        if self.attrs:
+            out.append("Attributes: " + ", ".join(sorted(self.attrs)))
+        return "\n".join(out)
+
     # ---- mapping-style access (what the reference's tests use of xarray) ----
     def keys(self):
         return self.data_vars.keys()

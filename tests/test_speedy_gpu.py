@@ -338,3 +338,4 @@ def test_ensemble_set_bc_loads_once_and_hands_the_fields_on():
             for name in ("t", "vor", "ps", "sst12", "sst_anom", "land_temp", "stl12"):
                 assert np.array_equal(once.members[i][name], each.members[i][name]), (n, i, name)
         assert np.abs(once.members[1]["sst_anom"]).max() > 0 if anomalies else True
+

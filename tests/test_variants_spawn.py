@@ -86,3 +86,23 @@ def test_group_streams_end_up_on_hardware_queues_of_their_own(idle_streams):
     assert all(v for g in groups for k, v in g.items() if k != "attempt"), model_part
     models = final_verdicts(driver_part)
     assert len(models) == 1 and all(v for k, v in models[0].items() if k != "attempt"), driver_part
+
+
+@pytest.mark.gpu
+def test_the_references_first_example_runs_with_the_import_changed(tmp_path):
+    """examples/my_first_forecast.py is the model cell of the reference's My_first_forecast.ipynb with `pyspeedy` replaced by
+    `pyspeedy_amd` in the two import lines: Speedy, set_bc, XarrayExporter + ModelCheckpoint with a spin-up date, run, state
+    access by name.  A shorter period here (5 days, 2 of them spin-up); in a process of its own (it is a script)."""
+    out = tmp_path / "data"
+    run = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "examples", "my_first_forecast.py"), "--end", "1980-01-06", "--spinup", "1980-01-03",
+                          "--out", str(out)], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
+    files = sorted(f for f in os.listdir(out) if f.endswith(".nc"))
+    assert files == ["1980-01-0%d_0000.nc" % d for d in (3, 4, 5, 6)], files  # (from the end of the spin-up on, daily)
+    assert "model date 1980-01-06 00:00:00, 4 files" in run.stdout
+    assert "96 longitudes 0.00 .. 356.25, 48 latitudes -87." in run.stdout
+    from pyspeedy_amd.dataset import open_dataset
+    last = open_dataset(str(out / files[-1]))
+    assert set(("u", "v", "t", "q", "phi", "ps")) <= set(last.variables) and last.variables["t"].values.shape == (1, 8, 48, 96)
+    t_low = last.variables["t"].values[0, 0]  # (lev is written bottom-up reversed: index 0 = sigma 0.95)
+    assert 200.0 < t_low.min() < t_low.max() < 330.0
