@@ -154,3 +154,14 @@ def test_example_bc_is_packaged():
     with np.load(pyspeedy_amd.example_bc_file()) as z:
         assert z["orog"].shape == (96, 48) and z["sst"].shape == (96, 48, 12)
         assert {"orog", "lsm", "alb", "vegh", "vegl", "stl", "snowd", "swl1", "swl2", "swl3", "sst", "icec"} <= set(z.files)
+
+
+def test_dataset_prints_what_it_holds():
+    import numpy as np
+    from pyspeedy_amd.dataset import Dataset
+    d = Dataset({"t": (("time", "lev", "lat", "lon"), np.full((2, 8, 48, 96), 280.0, np.float32))},
+                {"lon": (("lon",), np.arange(96.0) * 3.75), "time": (("time",), np.array(["1980-01-01", "1980-01-02"], dtype="datetime64[s]"))},
+                {"title": "x"})
+    text = repr(d)
+    assert "Dimensions:" in text and "time: 2" in text and "lon: 96" in text
+    assert "t            (time, lev, lat, lon) float32  280 .. 280" in text and "1980-01-02T00:00:00" in text and "Attributes: title" in text
