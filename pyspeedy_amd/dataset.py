@@ -94,6 +94,38 @@ class Dataset:
             idx[d] = int(hits[0])
         return self.isel(**idx)
 
+    # ---- reductions (the ones the reference's ensemble notebook applies to the checkpoint dataframe; xarray's defaults:
+    # missing values skipped, population variance, attributes of the variables dropped) ----
+    def _reduce(self, func, dim):
+        dims = (dim,) if isinstance(dim, str) else tuple(dim) if dim is not None else None
+
+        def red(v):
+            hit = tuple(i for i, d in enumerate(v.dims) if dims is None or d in dims)
+            if not hit or np.asarray(v.values).dtype.kind not in "fiu":
+                return Variable(v.dims, v.values, v.attrs)
+            return Variable(tuple(d for i, d in enumerate(v.dims) if i not in hit), func(np.asarray(v.values, dtype=np.float64), axis=hit))
+        gone = set(self.dims) if dims is None else set(dims)
+        return Dataset({k: red(v) for k, v in self.data_vars.items()},
+                       {k: v for k, v in self.coords.items() if not gone.intersection(v.dims)}, self.attrs)
+
+    def mean(self, dim=None):
+        return self._reduce(np.nanmean, dim)
+
+    def var(self, dim=None):
+        return self._reduce(np.nanvar, dim)
+
+    def std(self, dim=None):
+        return self._reduce(np.nanstd, dim)
+
+    def apply(self, func):
+        """`func` on the values of every data variable (xarray's Dataset.apply / map)."""
+        return Dataset({k: Variable(v.dims, func(v.values), v.attrs) for k, v in self.data_vars.items()}, self.coords, self.attrs)
+
+    map = apply
+
+    def __iter__(self):
+        return iter(self.data_vars)
+
     def to_xarray(self):
         """The same data as an `xarray.Dataset` -- what the reference's `to_dataframe()` returns (pyspeedy/speedy.py:415-477) --
         for hosts that have xarray installed (it is not a dependency of this package; ImportError otherwise)."""

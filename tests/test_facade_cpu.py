@@ -165,3 +165,26 @@ def test_dataset_prints_what_it_holds():
     text = repr(d)
     assert "Dimensions:" in text and "time: 2" in text and "lon: 96" in text
     assert "t            (time, lev, lat, lon) float32  280 .. 280" in text and "1980-01-02T00:00:00" in text and "Attributes: title" in text
+
+
+def test_dataset_reductions_of_the_references_ensemble_notebook():
+    """Ensemble_forecast.ipynb post-processes the checkpoint dataframe with `var(dim="ens").mean(dim=[...]).apply(np.sqrt)` and
+    `std(dim="ens").apply(np.sqrt).isel(lev=0)` and copies attributes variable by variable."""
+    import numpy as np
+    from pyspeedy_amd.dataset import Dataset
+    rng = np.random.default_rng(3)
+    t = rng.normal(280.0, 5.0, (3, 4, 8, 6, 12)).astype(np.float32)
+    ps = rng.normal(1e5, 500.0, (3, 4, 6, 12)).astype(np.float32)
+    ds = Dataset({"t": (("time", "ens", "lev", "lat", "lon"), t, {"units": "K"}), "ps": (("time", "ens", "lat", "lon"), ps, {"units": "Pa"})},
+                 {"time": (("time",), np.arange(3)), "ens": (("ens",), np.arange(4)), "lev": (("lev",), np.linspace(0.95, 0.025, 8)),
+                  "lat": (("lat",), np.arange(6.0)), "lon": (("lon",), np.arange(12.0))})
+    spr = ds.var(dim="ens").mean(dim=["lev", "lat", "lon"]).apply(np.sqrt)
+    assert list(spr) == ["t", "ps"] and spr["t"].dims == ("time",) and set(spr.coords) == {"time"}
+    assert np.allclose(spr["t"].values, np.sqrt(t.astype(np.float64).var(axis=1).mean(axis=(1, 2, 3))))
+    assert np.allclose(spr["ps"].values, np.sqrt(ps.astype(np.float64).var(axis=1).mean(axis=(1, 2))))
+    for var in spr:
+        spr[var].attrs.update(**ds[var].attrs)
+    assert spr["t"].attrs["units"] == "K"
+    low = ds.std(dim="ens").apply(np.sqrt).isel(lev=0)
+    assert low["t"].dims == ("time", "lat", "lon") and np.allclose(low["t"].values, np.sqrt(t.astype(np.float64).std(axis=1))[:, 0])
+    assert low["ps"].dims == ("time", "lat", "lon")

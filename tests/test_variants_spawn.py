@@ -106,3 +106,19 @@ def test_the_references_first_example_runs_with_the_import_changed(tmp_path):
     assert set(("u", "v", "t", "q", "phi", "ps")) <= set(last.variables) and last.variables["t"].values.shape == (1, 8, 48, 96)
     t_low = last.variables["t"].values[0, 0]  # (lev is written bottom-up reversed: index 0 = sigma 0.95)
     assert 200.0 < t_low.min() < t_low.max() < 330.0
+
+
+@pytest.mark.gpu
+def test_the_references_ensemble_example_runs_with_the_import_changed():
+    """examples/ensemble_forecast.py: the model and post-processing cells of Ensemble_forecast.ipynb, import changed: members set
+    up one by one (set_bc, `member["t_grid"] += ...`, grid2spectral), ModelCheckpoint + DiagnosticCheck, the spread statistics on
+    the checkpoint dataframe.  4 members and 6 days here; the spread of the perturbed members grows from day to day."""
+    run = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "examples", "ensemble_forecast.py"), "--members", "4",
+                          "--end", "1980-01-07", "--spinup", "1980-01-02"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
+    assert "ens: 4" in run.stdout and "time: 6" in run.stdout, run.stdout[-2000:]
+    tail = run.stdout.split("Domain-averaged ensemble spread by day:")[1]
+    line = [ln for ln in tail.splitlines() if ln.strip().startswith("t ")][0]
+    spread = [float(v) for v in line.split()[1:]]
+    assert len(spread) == 6 and all(v > 0 for v in spread) and spread[-1] > spread[0], spread
+
