@@ -172,6 +172,15 @@ int spd_model_check(spd_model_handle m, int time_level, int32_t *error_codes_hos
  * step k, launch step k + 1, then end the check of step k. */
 int spd_model_check_begin(spd_model_handle m, int time_level, void *stream);
 int spd_model_check_end(spd_model_handle m, int slot, int32_t *error_codes_host);
+/* spd_model_check_begin without a launch of its own: the check is put off and rides in the first launch of the NEXT
+ * spd_model_step on this stream (`members` more workgroups of its spectral -> grid launch), on the state exactly as it is now --
+ * for hosts that collect the check of step k after they have enqueued step k + 1 (spd_parallel_step_begin / _end: the range check
+ * then costs the step's stream nothing, 5 % of the step at 64 members, 11 % at one).  Anything else that would read or change the
+ * state first -- spd_model_set, the export transforms, member copies, a call of several steps in member groups, spd_model_check_end
+ * itself -- makes it a launch of its own there and then.  Returns the slot for spd_model_check_end. */
+int spd_model_check_defer(spd_model_handle m, int time_level, void *stream);
+/* how many of the model's begun / deferred range checks went out as launches of their own and how many rode in a step's launch */
+int spd_model_check_counts(spd_model_handle m, int32_t *alone, int32_t *rode);
 int spd_model_checks_in_flight(spd_model_handle m); /* 0, 1 or 2: checks begun and not yet ended */
 
 /* initialize_state (initialization.f90:13-91) for every member from the boundary fields stored beforehand with

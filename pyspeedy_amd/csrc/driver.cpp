@@ -906,7 +906,7 @@ constexpr int32_t kStepFailed = -3;
 // Everything that can refuse is asked BEFORE the step is enqueued (a free check slot, the control block); what fails from the
 // step on is a device error, and it leaves the model marked: its state has moved while its date and codes say it has not, and
 // it is not stepped again until its members are initialised anew.
-static void issue_group(const GroupPlan &g, GroupRun &r) {
+static void issue_group(const GroupPlan &g, GroupRun &r, bool defer_check) {
     Batch &b = *g.batch;
     if (!all_initialized(b)) return;  // slot stays -1: E_STATE_NOT_INITIALIZED
     int rc = SPD_OK;
@@ -923,7 +923,8 @@ static void issue_group(const GroupPlan &g, GroupRun &r) {
         rc = spd_model_step(b.model, 1, b.stream);
     }
     if (rc == SPD_OK) {
-        r.slot = spd_model_check_begin(b.model, 2, b.stream);
+        // (the overlapped form collects the check after the NEXT step has been enqueued: that step's first launch carries it)
+        r.slot = defer_check ? spd_model_check_defer(b.model, 2, b.stream) : spd_model_check_begin(b.model, 2, b.stream);
         if (r.slot < 0) rc = r.slot;
     }
     if (rc == SPD_OK) rc = pull_date(b, r.advanced);
@@ -988,7 +989,7 @@ static IssueWorker *issue_worker(int key) {
 }
 
 // Enqueue the step and check of every group; after_issue(i) runs on the CALLING thread for every group, in order.  (lock held)
-static void issue_all(const std::vector<GroupPlan> &groups, std::vector<GroupRun> &run) {
+static void issue_all(const std::vector<GroupPlan> &groups, std::vector<GroupRun> &run, bool defer_check) {
     static const int mode = [] {
         const char *e = getenv("PYSPEEDY_AMD_ISSUE_THREADS");
         return e ? atoi(e) : 1;
@@ -1001,7 +1002,7 @@ static void issue_all(const std::vector<GroupPlan> &groups, std::vector<GroupRun
     for (size_t i = 0; i < groups.size(); ++i) by_key[mode == 2 ? static_cast<int>(i) : groups[i].batch->device].push_back(i);
     if (mode == 0 || by_key.size() < 2) {
         for (size_t i = 0; i < groups.size(); ++i) {
-            issue_group(groups[i], run[i]);
+            issue_group(groups[i], run[i], defer_check);
             trace(1, static_cast<int>(i));
         }
         return;
@@ -1012,16 +1013,16 @@ static void issue_all(const std::vector<GroupPlan> &groups, std::vector<GroupRun
         if (kv.first == mine) continue;
         IssueWorker *w = issue_worker(kv.first);
         const std::vector<size_t> *list = &kv.second;
-        w->submit([list, &groups, &run] {
+        w->submit([list, &groups, &run, defer_check] {
             for (size_t i : *list) {
-                issue_group(groups[i], run[i]);
+                issue_group(groups[i], run[i], defer_check);
                 trace(1, static_cast<int>(i));
             }
         });
         busy.push_back(w);
     }
     for (size_t i : by_key[mine]) {
-        issue_group(groups[i], run[i]);
+        issue_group(groups[i], run[i], defer_check);
         trace(1, static_cast<int>(i));
     }
     for (IssueWorker *w : busy) w->wait();
@@ -1082,7 +1083,7 @@ int spd_parallel_step(const int64_t *state_cnts, const int64_t *control_cnts, in
     // any of them, so the devices (and the models that share one) work side by side; a model that fails does not keep the
     // others from being stepped; and the lock is given up while the host waits, so that other host threads can step THEIR
     // containers meanwhile (the reference's parallel_step is `!f2py threadsafe`).
-    issue_all(groups, run);
+    issue_all(groups, run, false);
     lock.unlock();
     std::vector<std::vector<int32_t>> codes(groups.size());
     for (size_t i = 0; i < groups.size(); ++i) {
@@ -1101,7 +1102,10 @@ int spd_parallel_step_begin(const int64_t *state_cnts, const int64_t *control_cn
     LOCK;
     PendingStep p;
     if (int rc = plan_step(state_cnts, control_cnts, n, p.plan, p.run, "spd_parallel_step_begin")) return rc;
-    issue_all(p.plan->groups, p.run);  // (a group that cannot be issued reports at _end; the others go ahead)
+    // (the range check of this step is put off: the next _begin's first launch carries it.  PYSPEEDY_AMD_DEFER_CHECK=0: a launch of
+    // its own behind the step, as in the synchronous form)
+    static const bool defer = !(getenv("PYSPEEDY_AMD_DEFER_CHECK") && atoi(getenv("PYSPEEDY_AMD_DEFER_CHECK")) == 0);
+    issue_all(p.plan->groups, p.run, defer);  // (a group that cannot be issued reports at _end; the others go ahead)
     for (size_t i = 0; i < p.run.size(); ++i) {
         const GroupPlan &g = p.plan->groups[i];
         GroupRun &r = p.run[i];

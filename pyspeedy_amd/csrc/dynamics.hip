@@ -19,6 +19,7 @@
 
 #include "coupler_point.hpp"
 #include "device_tables.hpp"
+#include "diagnostics_block.hpp"
 #include "dyn_column.hpp"
 #include "launch_events.hpp"
 #include "model.hpp"
@@ -420,59 +421,8 @@ __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTa
 // launch travels with every code, so the host can tell a fresh code from what an earlier launch left there by looking at the
 // memory alone, the moment the store lands (model.hip: wait_codes), instead of waiting for a completion event behind the kernel.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * KX) void diagnostics_kernel(ModelPtrs P, DeviceTables T, int M, int tl, int *err, double *diag,
-                                                              int ticket) {
-    __shared__ int bad[KX];
-    const int mem = blockIdx.x, l = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const size_t so = ((static_cast<size_t>(mem) * 2 + tl) * 8 + l) * NSPEC;
-    const d2 *vor = reinterpret_cast<const d2 *>(P.vor) + so, *div = reinterpret_cast<const d2 *>(P.div) + so;
-    double d1 = 0.0, d2s = 0.0;
-    // (the 16 rounds of a lane are requested in two batches of 8 before anything is summed: the kernel is one dependent chain per
-    // wavefront, launched once per model step by hosts with the reference's loop; the order of the sum is unchanged)
-    constexpr int kRounds = (NSPEC + 63) / 64, kBatch = 8;
-    static_assert(kRounds % kBatch == 0, "two full batches");
-#pragma unroll
-    for (int r0 = 0; r0 < kRounds; r0 += kBatch) {
-        d2 a[kBatch], b[kBatch];
-        double e[kBatch];
-#pragma unroll
-        for (int r = 0; r < kBatch; ++r) {
-            const int k = lane + 64 * (r0 + r), kc = k < NSPEC ? k : NSPEC - 1;
-            e[r] = T.elm2[kc];
-            a[r] = vor[kc];
-            b[r] = div[kc];
-        }
-#pragma unroll
-        for (int r = 0; r < kBatch; ++r) {
-            const int k = lane + 64 * (r0 + r);
-            if (k >= NSPEC || k % MX == 0) continue;  // m = 1 (zonal mean) is excluded: only the eddies count
-            // temp = -x * elm2 ; diag -= real(temp * conjg(x))
-            d1 = d1 - ((-a[r].x * e[r]) * a[r].x + (-a[r].y * e[r]) * a[r].y);
-            d2s = d2s - ((-b[r].x * e[r]) * b[r].x + (-b[r].y * e[r]) * b[r].y);
-        }
-    }
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) {
-        d1 += __shfl_down(d1, s, 64);
-        d2s += __shfl_down(d2s, s, 64);
-    }
-    if (lane == 0) {
-        const double tmean = 0.707106769084930420 /* sqrt(0.5) in fp32 */ * P.t[2 * so];
-        if (diag) {
-            double *dg = diag + static_cast<size_t>(mem) * KX * 3;
-            dg[l] = d1;
-            dg[l + KX] = d2s;
-            dg[l + 2 * KX] = tmean;
-        }
-        bad[l] = (d1 > 500.0f || d2s > 500.0f || tmean < 180.0f || tmean > 320.0f) ? 1 : 0;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int any = 0;
-#pragma unroll
-        for (int k = 0; k < KX; ++k) any |= bad[k];
-        __hip_atomic_store(err + mem, 4 * ticket + (any ? 1 : 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+__global__ __launch_bounds__(64 * KX) void diagnostics_kernel(CheckArgs c, DeviceTables T) {
+    diagnostics_block(c, T, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -526,7 +476,7 @@ hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const Dy
 }
 hipError_t run_diagnostics(const ModelPtrs &P, const DeviceTables &T, int M, int tl, int *err, double *diag, int ticket,
                            hipStream_t s) {
-    hipLaunchKernelGGL(diagnostics_kernel, dim3(M), dim3(64 * KX), 0, s, P, T, M, tl, err, diag, ticket);
+    hipLaunchKernelGGL(diagnostics_kernel, dim3(M), dim3(64 * KX), 0, s, CheckArgs{P.vor, P.div, P.t, tl, err, diag, ticket}, T);
     return hipGetLastError();
 }
 

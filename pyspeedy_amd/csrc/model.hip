@@ -19,6 +19,7 @@
 #include "context.hpp"
 #include "model.hpp"
 #include "coupler_point.hpp"
+#include "diagnostics_block.hpp"
 #include "launch_events.hpp"
 #include "sppt_point.hpp"
 #include "stream_apart.hpp"
@@ -46,6 +47,8 @@ hipError_t run_scale_orog(const double *orog, double *phi0, long n, hipStream_t 
 hipError_t run_change_storage(double *array, long n, bool to_float, void *scratch, hipStream_t s);
 hipError_t run_land_sea_init(const LandSeaPtrs &P, const LandSeaConsts &K, int first, int count, double *rows, hipStream_t s);
 hipError_t run_multi_copy(const CopyList &L, hipStream_t s);
+hipError_t run_spec2grid_table_check(const DeviceTables &T, const FieldDesc *table, int nfields, const CheckArgs &check, int members,
+                                     hipStream_t st);
 hipError_t run_copy_from_first(double *v, long n, int M, const int *flags, hipStream_t s);
 hipError_t run_rest_surface(const double *phis0, double *forog, double *surf_ps, double *surf_q, const RestConsts &c, long n,
                             hipStream_t s);
@@ -120,6 +123,16 @@ struct spd_model {
     int next_slot = 0;
     bool slot_busy[2] = {false, false};  // begun and not yet ended
     int check_ticket = 0, slot_ticket[2] = {0, 0};  // every range-check launch publishes its codes under a ticket of its own
+    // A check whose launch is put off until the next step (spd_model_check_defer): it then rides in that step's spectral -> grid
+    // launch.  Launched on its own as soon as anything else would look at or change the state first (settle_deferred_check).
+    struct DeferredCheck {
+        bool active = false;
+        int slot = -1, time_level = 2;
+        hipStream_t stream = nullptr;
+    } deferred;
+    hipStream_t slot_stream[2] = {nullptr, nullptr};  // the stream a slot's launch went out on
+    bool slot_rode[2] = {false, false};               // ... inside a step's launch (no completion event of its own)
+    int checks_alone = 0, checks_rode = 0;            // range checks launched on their own / carried by a step's launch
     double air_absortivity_co2 = 6.0;  // model_state_def.py:320 default
     // device copies of the dt-dependent tables (re-uploaded by set_time_step)
     // surface / coupler state, calendar and run control (do_single_step, speedy.f90:20-74)
@@ -184,6 +197,7 @@ LaunchEvents &pending_launch_events() {
 
 static int m_fail(int code, const std::string &msg) { return spd_set_error(code, msg); }
 static int apply_storage(spd_model *m, bool want32);  // (with spd_model_set_physics_precision)
+static int settle_deferred_check(spd_model *m);        // (with spd_model_check_defer)
 
 #define M_HIP(call)                                                                   \
     do {                                                                              \
@@ -685,6 +699,8 @@ static int xfer(spd_model_handle m, const char *name, int member, void *host, si
     if (member < -1 || member >= m->M) return m_fail(SPD_E_ARG, "spd_model_get/set: member index out of range");
     if (member == -1 && !to_device) return m_fail(SPD_E_ARG, "spd_model_get: member = -1 (broadcast) is only valid for set");
     M_HIP(hipSetDevice(m->ctx->device));
+    if (to_device)  // (a range check that was put off looks at the state as it is NOW)
+        if (int rc = settle_deferred_check(m)) return rc;
     // the copies below are blocking copies on the null stream, which does not order against the (non-blocking) streams the
     // model's kernels were issued on: wait for everything in flight on the device first
     M_HIP(hipDeviceSynchronize());
@@ -744,6 +760,7 @@ void *spd_model_device_ptr(spd_model_handle m, const char *name) {
     if (!m || !name) return nullptr;
     auto it = m->reg.find(name);
     if (it == m->reg.end()) return nullptr;
+    if (settle_deferred_check(m) != SPD_OK) return nullptr;
     m->surf_cache_valid = m->phi_ahead = false;  // the caller may write through the pointer
     if (it->first == "phi") m->fold_geo = false;
     return it->second.ptr;
@@ -751,6 +768,7 @@ void *spd_model_device_ptr(spd_model_handle m, const char *name) {
 
 int spd_model_invalidate(spd_model_handle m) {
     if (!m) return m_fail(SPD_E_ARG, "spd_model_invalidate: null model");
+    if (int rc = settle_deferred_check(m)) return rc;
     m->surf_cache_valid = m->phi_ahead = false;
     return SPD_OK;
 }
@@ -862,7 +880,18 @@ static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int comput
         FieldDesc *table = (m->stored32 ? (m->sppt_on ? m->inv_table_sppt32 : m->inv_table32)
                                          : (m->sppt_on ? m->inv_table_sppt : m->inv_table))[j2 - 1][m->phi_cur];
         ProfScope ps(m, SPD_K_SPEC2GRID, per * count, s);
-        e = run_spec2grid_table(T, table + static_cast<size_t>(first) * per, per * count, s);
+        if (m->deferred.active && first == 0 && count == M && s == m->deferred.stream) {
+            // the range check a host put off at the previous step (spd_model_check_defer): `M` more workgroups of this launch,
+            // on the state as that step left it -- nothing of this step has written to it yet
+            const int slot = m->deferred.slot;
+            const CheckArgs chk{m->P.vor, m->P.div, m->P.t, m->deferred.time_level - 1, m->h_err[slot], m->d_diag, m->slot_ticket[slot]};
+            e = run_spec2grid_table_check(T, table, per * count, chk, M, s);
+            m->deferred.active = false;
+            m->slot_rode[slot] = true;
+            ++m->checks_rode;
+        } else {
+            e = run_spec2grid_table(T, table + static_cast<size_t>(first) * per, per * count, s);
+        }
     }
     if (e == hipSuccess) {
         if (m->split_dyn_physics && !m->phys_fp32) {  // whole model, fp64 only; the default is the fused launch (with SPPT: KEEP)
@@ -898,6 +927,7 @@ int spd_model_step_dynamics(spd_model_handle m, int j1, int j2, double dt, int c
     if (!m) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: null model");
     if (j1 < 1 || j1 > 2 || j2 < 1 || j2 > 2) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: time levels are 1 or 2");
     if (!m->dyn) return m_fail(SPD_E_ARG, "spd_model_step_dynamics: call spd_model_set_time_step first");
+    if (int rc = settle_deferred_check(m)) return rc;
     const bool run_geo = begin_step_geopotential(m);
     const hipError_t e = step_range(m, j1, j2, dt, compute_shortwave, 0, m->M, 1, run_geo, nullptr, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_step_dynamics: ") + hipGetErrorString(e));
@@ -972,29 +1002,81 @@ int spd_model_check(spd_model_handle m, int time_level, int32_t *error_codes_hos
 // asynchronous copy of the codes into pinned memory and returns a slot (0 or 1; at most two checks may be in flight);
 // _end waits for that slot only and hands out the codes.  A host loop that begins the check of step k, launches step k + 1
 // and only then ends the check of step k keeps the GPU busy while still seeing every code (one step late).
-int spd_model_check_begin(spd_model_handle m, int time_level, void *stream) {
-    if (!m) return m_fail(SPD_E_ARG, "spd_model_check_begin: null model");
-    if (time_level < 1 || time_level > 2) return m_fail(SPD_E_ARG, "spd_model_check_begin: time level is 1 or 2");
-    hipStream_t s = static_cast<hipStream_t>(stream);
+// a free slot with its pinned memory and event, a ticket for it; -> slot or a negative error
+static int reserve_check_slot(spd_model *m, const char *who) {
     // any free slot (alternating while both are free): the condition for refusing is exactly "two in flight", which is what
     // spd_model_checks_in_flight lets a caller ask BEFORE it enqueues the step this check belongs to
     const int slot = m->slot_busy[m->next_slot] ? 1 - m->next_slot : m->next_slot;
     if (m->slot_busy[slot])
-        return m_fail(SPD_E_ARG, "spd_model_check_begin: two checks are in flight already; end one with spd_model_check_end first");
+        return m_fail(SPD_E_ARG, std::string(who) + ": two checks are in flight already; end one with spd_model_check_end first");
     if (!m->h_err[slot]) {  // (pinned, coherent: the kernel stores the codes there itself, see spd_model_check)
         void *p = nullptr;
         M_HIP(hipHostMalloc(&p, sizeof(int) * m->M, hipHostMallocCoherent));
         m->h_err[slot] = static_cast<int *>(p);
         M_HIP(hipEventCreateWithFlags(&m->err_event[slot], hipEventDisableTiming));
     }
-    const int ticket = next_ticket(m);
-    hipError_t e = run_diagnostics(m->P, m->ctx->dev, m->M, time_level - 1, m->h_err[slot], m->d_diag, ticket, s);
-    if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_check_begin: ") + hipGetErrorString(e));
-    M_HIP(hipEventRecord(m->err_event[slot], s));
-    m->slot_ticket[slot] = ticket;
+    m->slot_ticket[slot] = next_ticket(m);
     m->slot_busy[slot] = true;
+    m->slot_rode[slot] = false;
     m->next_slot = 1 - slot;
     return slot;
+}
+
+static int launch_check(spd_model *m, int slot, int time_level, hipStream_t s, const char *who) {
+    hipError_t e = run_diagnostics(m->P, m->ctx->dev, m->M, time_level - 1, m->h_err[slot], m->d_diag, m->slot_ticket[slot], s);
+    if (e == hipSuccess) e = hipEventRecord(m->err_event[slot], s);
+    if (e != hipSuccess) {
+        m->slot_busy[slot] = false;
+        return m_fail(SPD_E_DEVICE, std::string(who) + ": " + hipGetErrorString(e));
+    }
+    m->slot_stream[slot] = s;
+    ++m->checks_alone;
+    return SPD_OK;
+}
+
+// A deferred check that has not found a step to ride in is launched on its own, now, on the stream it was deferred on.  Called
+// by everything that is about to read or change what the check looks at in another way than the next step of that stream does.
+static int settle_deferred_check(spd_model *m) {
+    if (!m->deferred.active) return SPD_OK;
+    m->deferred.active = false;
+    M_HIP(hipSetDevice(m->ctx->device));
+    return launch_check(m, m->deferred.slot, m->deferred.time_level, m->deferred.stream, "deferred range check");
+}
+
+int spd_model_check_begin(spd_model_handle m, int time_level, void *stream) {
+    if (!m) return m_fail(SPD_E_ARG, "spd_model_check_begin: null model");
+    if (time_level < 1 || time_level > 2) return m_fail(SPD_E_ARG, "spd_model_check_begin: time level is 1 or 2");
+    if (int rc = settle_deferred_check(m)) return rc;
+    const int slot = reserve_check_slot(m, "spd_model_check_begin");
+    if (slot < 0) return slot;
+    if (int rc = launch_check(m, slot, time_level, static_cast<hipStream_t>(stream), "spd_model_check_begin")) return rc;
+    return slot;
+}
+
+// The same, except that nothing is launched now: the check is carried by the spectral -> grid launch of the NEXT spd_model_step
+// call of ONE step on this stream (its first launch, `members` more workgroups: no launch of its own, no time on the step's
+// stream), on the state exactly as it is now -- anything else that would read or write the state first (spd_model_set, the
+// export transforms, member copies, a multi-step call, spd_model_check_end itself) launches it on its own before it goes on.
+// For hosts that collect the check of step k after they have enqueued step k + 1 (spd_parallel_step_begin / _end).
+int spd_model_check_defer(spd_model_handle m, int time_level, void *stream) {
+    if (!m) return m_fail(SPD_E_ARG, "spd_model_check_defer: null model");
+    if (time_level < 1 || time_level > 2) return m_fail(SPD_E_ARG, "spd_model_check_defer: time level is 1 or 2");
+    if (int rc = settle_deferred_check(m)) return rc;
+    const int slot = reserve_check_slot(m, "spd_model_check_defer");
+    if (slot < 0) return slot;
+    m->deferred.active = true;
+    m->deferred.slot = slot;
+    m->deferred.time_level = time_level;
+    m->deferred.stream = static_cast<hipStream_t>(stream);
+    m->slot_stream[slot] = m->deferred.stream;
+    return slot;
+}
+
+int spd_model_check_counts(spd_model_handle m, int32_t *alone, int32_t *rode) {
+    if (!m) return m_fail(SPD_E_ARG, "spd_model_check_counts: null model");
+    if (alone) *alone = m->checks_alone;
+    if (rode) *rode = m->checks_rode;
+    return SPD_OK;
 }
 
 int spd_model_checks_in_flight(spd_model_handle m) {
@@ -1005,8 +1087,12 @@ int spd_model_checks_in_flight(spd_model_handle m) {
 int spd_model_check_end(spd_model_handle m, int slot, int32_t *error_codes_host) {
     if (!m || !error_codes_host) return m_fail(SPD_E_ARG, "spd_model_check_end: null argument");
     if (slot < 0 || slot > 1 || !m->slot_busy[slot]) return m_fail(SPD_E_ARG, "spd_model_check_end: no check was begun in this slot");
+    if (m->deferred.active && m->deferred.slot == slot)  // no step came to carry it
+        if (int rc = settle_deferred_check(m)) return rc;
     m->slot_busy[slot] = false;
-    return wait_codes(m, m->h_err[slot], m->slot_ticket[slot], m->err_event[slot], nullptr, error_codes_host, "spd_model_check_end");
+    // (a check that rode in a step's launch has no completion event of its own: its stream is asked instead)
+    return wait_codes(m, m->h_err[slot], m->slot_ticket[slot], m->slot_rode[slot] ? nullptr : m->err_event[slot], m->slot_stream[slot],
+                      error_codes_host, "spd_model_check_end");
 }
 
 
@@ -1067,6 +1153,7 @@ int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, i
     const int M = m->M;
     const DeviceTables &T = m->ctx->dev;
     M_HIP(hipSetDevice(m->ctx->device));
+    if (int rc = settle_deferred_check(m)) return rc;
     M_HIP(hipDeviceSynchronize());  // (the boundary fields came through the null stream, see xfer; `stream` may be any)
     m->cal.set(year, month, day, hour, minute);
     m->current_step = 0;
@@ -1149,6 +1236,10 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
     // (a call of ONE step forks and joins the group streams around that step -- two dependent cross-stream hand-overs per
     // step cost more than the overlap gains: measured +12 % at 64 members through spd_parallel_step -- so it is issued serially)
     const int G = (m->split_dyn_physics || m->profile > 0 || nsteps == 1) ? 1 : m->nchunks;
+    // a range check that was put off rides in the first spectral -> grid launch of this call -- when that is ONE launch over all
+    // members on the stream the check was put off on; otherwise it goes out on its own first
+    if (m->deferred.active && (G > 1 || s != m->deferred.stream))
+        if (int rc = settle_deferred_check(m)) return rc;
     hipStream_t gs[4] = {s, nullptr, nullptr, nullptr};
     if (G > 1) {
         M_HIP(hipSetDevice(m->ctx->device));
@@ -1470,6 +1561,7 @@ int spd_model_grid2spectral(spd_model_handle m, int first, int count, void *stre
     hipStream_t s = static_cast<hipStream_t>(stream);
     const DeviceTables &T = m->ctx->dev;
     const size_t S = NSPEC * C, half = static_cast<size_t>(m->M) * 16;
+    if (int rc = settle_deferred_check(m)) return rc;
     m->phi_ahead = false;  // the temperature changes under the look-ahead geopotential
     hipError_t e = run_grid2spec_table(T, m->exp_fwd_table[m->phi_cur] + static_cast<size_t>(first) * 40, count * 40, s);
     for (int i = first; i < first + count && e == hipSuccess; ++i) {
@@ -1542,6 +1634,8 @@ int spd_model_copy_member(spd_model_handle dst, int di, spd_model_handle src, in
     if (dst->ctx->device != src->ctx->device) return m_fail(SPD_E_ARG, "spd_model_copy_member: models live on different devices");
     hipStream_t s = static_cast<hipStream_t>(stream);
     M_HIP(hipSetDevice(dst->ctx->device));
+    if (int rc = settle_deferred_check(dst)) return rc;
+    if (int rc = settle_deferred_check(src)) return rc;  // (the source usually dies next: its check must be out before)
     M_HIP(hipDeviceSynchronize());  // the two models may have been driven on different streams
     // a member's arrays are copied as they are stored: both models must store them the same way, and the storage belongs to the
     // precision of the column physics (fp32 storage is only ever read by the fp32 kernel): the receiving model takes both over
@@ -1599,6 +1693,8 @@ int spd_model_copy_vars_enqueue(spd_model_handle dst, int di, spd_model_handle s
     if (di < 0 || di >= dst->M || si < 0 || si >= src->M) return m_fail(SPD_E_ARG, "spd_model_copy_vars: member index out of range");
     const int ddev = dst->ctx->device, sdev = src->ctx->device;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    M_HIP(hipSetDevice(ddev));
+    if (int rc = settle_deferred_check(dst)) return rc;
     M_HIP(hipSetDevice(ddev));
     dst->surf_cache_valid = dst->phi_ahead = false;
     for (int i = 0; i < nnames; ++i) {
@@ -1681,6 +1777,9 @@ int spd_model_broadcast_vars(const spd_model_handle *models, const int *members,
         for (int j = 0; j < i; ++j)
             if (devices[j] == devices[i]) return m_fail(SPD_E_ARG, "spd_model_broadcast_vars: one model per GPU (same-device copies are spd_model_copy_vars)");
     }
+    for (int i = 0; i < n; ++i)
+        if (i != root)
+            if (int rc = settle_deferred_check(models[i])) return rc;
     Rccl &R = rccl();
     if (!R.lib) return m_fail(SPD_E_DEVICE, "spd_model_broadcast_vars: RCCL is not available: " + R.why);
     std::lock_guard<std::mutex> lock(R.mutex);

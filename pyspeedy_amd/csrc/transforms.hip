@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_tables.hpp"
+#include "diagnostics_block.hpp"
 #include "launch_events.hpp"
 #include "fft96.hpp"
 
@@ -511,6 +512,23 @@ __global__ __launch_bounds__(kThreads) void spec2grid_table_kernel(const FieldDe
     spec2grid_body<Stage::Fused>(e.src, e.dst, T, e.flag, e.mode, e.src2);
 }
 
+// The same launch with the range check of every member in front of the fields: workgroup i < members checks member i on the
+// spectral state the step is about to read -- the check of the PREVIOUS step, for hosts that collect it one step late
+// (spd_model_check_defer, diagnostics_block.hpp).  In front, so that the 8 us chain of a check runs beside the bulk of the launch
+// instead of behind it; padded to a multiple of 8 workgroups, so that the field blocks keep their XCDs (blockIdx mod 8).
+// Held to the transform's 64 registers and 8 wavefronts per SIMD (the check takes its loads two rounds at a time here).
+static_assert(kThreads == 64 * KX, "a check block is a workgroup of the transform launch");
+__global__ __launch_bounds__(kThreads, 8) void spec2grid_table_check_kernel(const FieldDesc *__restrict__ table, DeviceTables T,
+                                                                            int members, CheckArgs check) {
+    const int front = (members + 7) & ~7;
+    if (static_cast<int>(blockIdx.x) < front) {
+        if (static_cast<int>(blockIdx.x) < members) diagnostics_block<2>(check, T, static_cast<int>(blockIdx.x));
+        return;
+    }
+    const FieldDesc e = table[blockIdx.x - front];
+    spec2grid_body<Stage::Fused>(e.src, e.dst, T, e.flag, e.mode, e.src2);
+}
+
 __global__ __launch_bounds__(kThreads) void grid2spec_table_kernel(const FieldDesc *__restrict__ table, DeviceTables T) {
     const FieldDesc e = table[blockIdx.x];
     grid2spec_body<Stage::Fused>(e.src, e.dst, T, e.flag);
@@ -556,6 +574,14 @@ hipError_t run_spec2grid_table(const DeviceTables &T, const FieldDesc *table, in
     const hipError_t cfg = SPD_CONFIGURE(&spec2grid_table_kernel);
     if (cfg != hipSuccess) return cfg;
     launch(spec2grid_table_kernel, dim3(nfields), dim3(kThreads), kLdsBytes, st, table, T);
+    return hipGetLastError();
+}
+
+hipError_t run_spec2grid_table_check(const DeviceTables &T, const FieldDesc *table, int nfields, const CheckArgs &check, int members,
+                                     hipStream_t st) {
+    const hipError_t cfg = SPD_CONFIGURE(&spec2grid_table_check_kernel);
+    if (cfg != hipSuccess) return cfg;
+    launch(spec2grid_table_check_kernel, dim3(((members + 7) & ~7) + nfields), dim3(kThreads), kLdsBytes, st, table, T, members, check);
     return hipGetLastError();
 }
 

@@ -308,6 +308,20 @@ class EnsembleModel:
             check(slot, "spd_model_check_begin")
         return slot
 
+    def check_defer(self, time_level=2):
+        """check_begin without a launch of its own: the check rides in the next single-step run() on this stream, or goes out when
+        anything else would touch the state first (spd_model_check_defer).  Returns the token for check_end."""
+        slot = self._lib.spd_model_check_defer(self._m, int(time_level), self._stream())
+        if slot < 0:
+            check(slot, "spd_model_check_defer")
+        return slot
+
+    def check_counts(self):
+        """(range checks launched on their own, range checks carried by a step's launch)"""
+        alone, rode = C.c_int32(0), C.c_int32(0)
+        check(self._lib.spd_model_check_counts(self._m, C.byref(alone), C.byref(rode)), "spd_model_check_counts")
+        return alone.value, rode.value
+
     def check_end(self, token):
         codes = np.zeros(self.nmembers, dtype=np.int32)
         check(self._lib.spd_model_check_end(self._m, int(token), codes.ctypes.data_as(C.c_void_p)), "spd_model_check_end")

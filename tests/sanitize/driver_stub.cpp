@@ -324,6 +324,10 @@ int spd_model_check_begin(spd_model_handle m, int, void *) {
     return slot;
 }
 
+// (the stub has no launches to save: the check is evaluated where it is put off, on the state as it is then -- which is what the
+// real one guarantees to look at)
+int spd_model_check_defer(spd_model_handle m, int time_level, void *stream) { return spd_model_check_begin(m, time_level, stream); }
+
 int spd_model_check_end(spd_model_handle m, int slot, int32_t *codes) {
     if (!m || !codes || slot < 0 || slot > 1 || !m->slot_busy[slot]) return spd_set_error(SPD_E_ARG, "spd_model_check_end: no check in this slot");
     Inside guard(m);

@@ -540,6 +540,65 @@ def test_containers_come_and_go_cheaply_and_leave_nothing_behind(drv, bc, spectr
     assert ctypes.sizeof(ctypes.c_size_t) == 8
 
 
+def test_the_overlapped_form_carries_its_range_checks_in_the_next_step(drv, bc):
+    """spd_parallel_step_begin puts the range check of its step off (spd_model_check_defer): the next _begin's first launch
+    carries it, the last one goes out when it is collected.  A member that leaves the accepted range in the middle of a pipelined
+    loop is reported at the step it happened, and the codes and states are those of the synchronous loop."""
+    import ctypes
+    n, steps = 3, 6
+
+    def setup():
+        states = [drv.state() for _ in range(n)]
+        controls = [drv.control(START, END) for _ in range(n)]
+        for k, (s, c) in enumerate(zip(states, controls)):
+            drv.set_bc(s, bc, 0.1 * k)
+            assert drv.init(s, c) == 0
+        return states, controls
+
+    def spoil(states):
+        t = drv.get(states[1], "t", np.complex128)
+        t[0, 0, :, :] = 500.0 * np.sqrt(2.0)
+        drv.set(states[1], "t", t)
+
+    sync_states, sync_controls = setup()
+    sync_codes = []
+    for k in range(steps):
+        if k == 3:
+            spoil(sync_states)
+        sync_codes.append(drv.parallel_step(sync_states, sync_controls))
+    states, controls = setup()
+    arr_s, arr_c = (C.c_int64 * n)(*states), (C.c_int64 * n)(*controls)
+    codes, pending = [], None
+    for k in range(steps):
+        if k == 3:  # (a host write between two steps of the pipeline: collect what is in flight first, as a callback would)
+            out = (C.c_int32 * n)()
+            drv.ok(drv.L.spd_parallel_step_end(pending, out))
+            codes.append(list(out))
+            pending = None
+            model, member, members = ctypes.c_void_p(), C.c_int32(), C.c_int32()
+            drv.ok(drv.L.spd_driver_model(states[0], C.byref(model), C.byref(member), C.byref(members)))
+            alone, rode = C.c_int32(), C.c_int32()
+            drv.ok(drv.L.spd_model_check_counts(model, C.byref(alone), C.byref(rode)))
+            # (the gathered model of the three containers: the checks of steps 1 and 2 rode in steps 2 and 3, that of step 3 went out
+            # when it was collected just now)
+            assert members.value == n and (alone.value, rode.value) == (1, 2), (members.value, alone.value, rode.value)
+            spoil(states)
+        token = C.c_int64()
+        drv.ok(drv.L.spd_parallel_step_begin(arr_s, arr_c, n, C.byref(token)))
+        if pending is not None:
+            out = (C.c_int32 * n)()
+            drv.ok(drv.L.spd_parallel_step_end(pending, out))
+            codes.append(list(out))
+        pending = token
+    out = (C.c_int32 * n)()
+    drv.ok(drv.L.spd_parallel_step_end(pending, out))
+    codes.append(list(out))
+    assert codes == sync_codes and codes[2] == [0, 0, 0] and codes[3] == [0, -2, 0], (codes, sync_codes)
+    for k in (0, 2):
+        assert np.array_equal(drv.get(states[k], "t", np.complex128), drv.get(sync_states[k], "t", np.complex128))
+    drv.close(*states, *sync_states)
+
+
 def test_ensemble_placement_by_argument_leaves_the_process_placement_alone(drv):
     """spd_modelstate_init_ensemble_on(cnts, n, k) takes the number of devices as an argument: the process-wide placement
     (spd_set_device_placement / PYSPEEDY_AMD_DEVICES) is neither read nor reset by it -- SpeedyEns(devices=k) used to switch it to

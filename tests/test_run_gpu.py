@@ -176,6 +176,46 @@ def test_time_step_tables_are_shared_per_context_and_survive_a_host_that_keeps_c
     crowded.close()
 
 
+def test_a_deferred_range_check_rides_in_the_next_step_and_sees_the_state_it_was_deferred_on(spectral, bc):
+    """spd_model_check_defer: the check of step k has no launch of its own -- it rides in the spectral -> grid launch of step k + 1
+    -- and looks at the state as step k left it, whatever happens next: another step (it rides), a host write (it goes out on
+    its own first), nothing at all (it goes out when it is collected).  Same codes as check_begin in every case, same state."""
+    from pyspeedy_amd.model import EnsembleModel
+    a, b = EnsembleModel(spectral, 3), EnsembleModel(spectral, 3)
+    for m in (a, b):
+        m.set_bc(bc)
+        m.run(2)
+    hot = a.get("t", 1).copy()
+    hot[0, 0, :, :] = 500.0 * np.sqrt(2.0)  # a global-mean temperature of 500 K: outside diagnostics.f90's 180 ... 320 K
+
+    def drive(m, defer):
+        begin = m.check_defer if defer else m.check_begin
+        codes = []
+        m.run(1)
+        t0 = begin()              # check of step 3 ...
+        m.run(1)                  # ... rides in step 4 (deferred) / is a launch behind step 3 (begun)
+        t1 = begin()
+        codes.append(m.check_end(t0))
+        m.set("t", hot, 1)        # a host write: the put-off check of step 4 goes out first and still sees a healthy member 1
+        codes.append(m.check_end(t1))
+        m.run(1)                  # step 5 starts from the hot state
+        t2 = begin()
+        codes.append(m.check_end(t2))  # nothing came to carry it: it goes out here
+        m.run(1)
+        t3 = begin()
+        m.run(2)                  # a call of several steps: the put-off check rides in its first step (one member group here)
+        codes.append(m.check_end(t3))
+        return [c.tolist() for c in codes]
+
+    begun, deferred = drive(a, False), drive(b, True)
+    assert begun == deferred == [[0, 0, 0], [0, 0, 0], [0, -2, 0], [0, -2, 0]], (begun, deferred)
+    assert a.check_counts() == (4, 0) and b.check_counts() == (2, 2), (a.check_counts(), b.check_counts())
+    for n in SPEC + ("phi", "olr"):
+        assert np.array_equal(a.get(n, 0), b.get(n, 0)) and np.array_equal(a.get(n, 2), b.get(n, 2)), n
+    for m in (a, b):
+        m.close()
+
+
 def _through_a_file(snapshot):
     with tempfile.TemporaryDirectory() as tmp:  # as a checkpoint would travel
         np.savez(os.path.join(tmp, "ckpt.npz"), **snapshot)
