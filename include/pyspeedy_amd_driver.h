@@ -109,7 +109,9 @@ int spd_parallel_step(const int64_t *state_cnts, const int64_t *control_cnts, in
  * returns a token; _end waits for that check only and hands out the codes.  A host loop that begins step k + 1 before ending
  * step k never leaves the GPU waiting for the host; the price is that the code of step k is seen after step k + 1 has been
  * enqueued.  The model dates in the control containers advance at _begin and are put back at _end for a member whose check
- * failed.  At most two steps may be in flight per device model. */
+ * failed.  At most two steps may be in flight per device model.  The check of a step has no launch of its own in this form:
+ * the first launch of the NEXT step of the same containers carries it (it looks at the state as its own step left it; whatever
+ * else touches the state first -- spd_set, a regrouping, the _end that collects it -- sends it out there and then). */
 int spd_parallel_step_begin(const int64_t *state_cnts, const int64_t *control_cnts, int32_t n_members, int64_t *token);
 int spd_parallel_step_end(int64_t token, int32_t *error_codes /* n_members of the matching _begin */);
 int spd_check(int64_t state_cnt, int32_t *error_code); /* diagnostics on time level 1 */
