@@ -682,8 +682,20 @@ def drop_in_leg(M, steps):
     del ens
     out["note"] = ("spd_parallel_step(state_cnts, control_cnts, error_codes, n) once per model step over independent containers "
                    "(one device model up to 31 containers, two from 32 up, both enqueued before either is waited for): every "
-                   "step stores all diagnostics and runs the range check as a launch of its own; sync = the call returns the codes, "
-                   "begin_end = the check of step k is collected after step k + 1 has been enqueued; medians of per-step wall times")
+                   "step stores all diagnostics and runs the range check; sync = the call returns the codes (the check is a launch "
+                   "behind the step), begin_end = the check of step k is collected after step k + 1 has been enqueued (and rides in "
+                   "that step's first launch); medians of per-step wall times")
+    return out
+
+
+def small_drop_in_legs(steps):
+    """The same host loop for the small cases of BASELINE.json: one container (cfg 3 through the reference's `step()` contract --
+    what Speedy.run() pays per step) and 8 (cfg 4's share of one GPU)."""
+    out = {}
+    for containers in (1, 8):
+        leg = drop_in_leg(containers, steps)
+        out["containers_%d" % containers] = {k: leg[k] for k in ("containers", "device_models", "steps_timed", "sync_ms_per_step",
+                                                                 "begin_end_ms_per_step")}
     return out
 
 
@@ -958,6 +970,7 @@ def run_rank(args):
         if n_gpus == 1 and args.config == "cfg4":
             legs["every_step_stores"] = fidelity_leg(args, M, first_id, device, dist, rank, coll_device, barrier)
             legs["drop_in_step"] = drop_in_leg(M, 360)
+            legs["drop_in_step"].update(small_drop_in_legs(360))
             # the other BASELINE configs on the same clock (SURVEY 8d "Configs as concrete inputs")
             legs["cfg2_transforms"] = transforms_leg(args, device)
             legs["cfg3"] = config_leg(args, "cfg4", 1, "BASELINE cfg 3: one member, fp64, the full step on the GPU", device, dist, rank,

@@ -134,6 +134,8 @@ def test_the_one_gpu_line_carries_the_drop_in_and_every_store_legs():
     assert res["n_gpus"] == 1 and res["config"]["members_total"] == 8
     d = res["drop_in_step"]
     assert d["containers"] == 8 and 0 < d["begin_end_ms_per_step"] and 0 < d["sync_ms_per_step"]
+    assert d["containers_1"]["containers"] == 1 and 0 < d["containers_1"]["begin_end_ms_per_step"] < d["containers_1"]["sync_ms_per_step"]
+    assert d["containers_8"]["containers"] == 8 and d["containers_8"]["device_models"] == 1
     e = res["every_step_stores"]
     assert e["spec2grid_per_member"] == 91 and e["ms_per_step"] > 0
     dom = res["roofline"]["dominant"]  # the fused column kernel: the largest share of the step, priced like the line's kernel

@@ -38,6 +38,10 @@ for f in sys.argv[1:]:
             o = d["drop_in_step"]
             print("   drop-in spd_parallel_step per model step (%d containers, %d device models): sync %.4f ms, begin/end %.4f ms" % (
                 o["containers"], o.get("device_models", 0), o["sync_ms_per_step"], o["begin_end_ms_per_step"]))
+            for key in ("containers_1", "containers_8"):
+                if key in o:
+                    print("      %d container(s): sync %.4f ms, begin/end %.4f ms" % (o[key]["containers"], o[key]["sync_ms_per_step"],
+                                                                                      o[key]["begin_end_ms_per_step"]))
         if "every_step_stores" in d:
             print("   every store of the reference restored: %.4f ms/step" % d["every_step_stores"]["ms_per_step"])
         for key in ("cfg3", "cfg4_shard8", "cfg5"):
