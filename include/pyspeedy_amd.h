@@ -61,6 +61,20 @@ const char *spd_version(void);
  * h may be NULL: the tables are then built on the host without touching any device. */
 long spd_get_table_host(spd_handle h, const char *name, double *buf_host, size_t buf_elems);
 
+/* Host-only (no device is touched): the model calendar, model_control.f90:79-185 -- initialize_control at the given start date,
+ * then `nsteps` times advance_date (one 40-minute step each: February has 29 days when mod(year, 4) == 0, :135-142; the month
+ * counter month_idx keeps counting across the year end, :153-157) with update_forcing_params (:162-185: imont1, tmonth, tyear in
+ * the reference's default-real arithmetic).  Row 0 of every output is the state after initialize_control, row s the state
+ * after s steps; ymdhm is [nsteps + 1][5] (year, month, day, hour, minute).  Any output pointer may be NULL.  This is the
+ * calendar spd_model_step advances on the host beside the device state. */
+int spd_calendar_walk(int year, int month, int day, int hour, int minute, int nsteps, int32_t *ymdhm, int32_t *month_idx,
+                      int32_t *imont1, double *tmonth, double *tyear);
+/* Host-only: the zonally uniform daily forcing of set_forcing / get_zonal_average_fields (forcing.f90:84-101,
+ * shortwave_radiation.f90:218-322) for a fraction of the year `tyear`: out[5][48] = flux_solar_in, flux_ozone_upper,
+ * flux_ozone_lower, zenit_correction, stratospheric_correction by latitude (south to north), as the model uploads them once
+ * per simulated day. */
+int spd_daily_forcing_host(double tyear, double *out);
+
 /* ---- spectral transforms (spectral.f90:251-273, legendre.f90:130-221, fourier.f90:63-123) ---- */
 /* spec2grid: kcos == 1 -> no scaling, otherwise multiply row j by cosgr(j) (fourier.f90:87-91). */
 int spd_spec2grid(spd_handle h, const double *spec, double *grid, int kcos, int nfields, void *stream);

@@ -1,0 +1,167 @@
+"""Generate tests/golden/calendar.npz from the flang-compiled REFERENCE: the calendar's own edge cases and the two
+runtime coupling flags, none of which the January 1982 goldens reach.  TEST INFRASTRUCTURE.
+
+Cases (all with the example boundary conditions; every case records the calendar after EVERY step and the model after
+every simulated day):
+
+  leap      1980-02-26 00:00 -> 1980-03-02 00:00 (180 steps).  The period of the reference's two notebooks ends on
+            1980-02-29: `advance_date` keeps February at 29 days when mod(year, 4) == 0 (model_control.f90:135-142) while
+            `update_forcing_params` still divides by ndaycal(2, 1) = 28 (:182-183), so tmonth exceeds 1 on Feb 29.
+            Non-zero SST anomaly (planes Jan..Apr 1980).
+  newyear   1982-12-29 00:00 -> 1983-01-03 00:00 (180 steps).  month 12 -> 1 with the year carried (:153-157); month_idx
+            goes on counting (2) and indexes the anomaly planes Nov 1982 .. Feb 1983, while imont1 wraps for the
+            climatologies (interpolation.f90); tyear falls back from 0.998 to 0.001.  Non-zero SST anomaly, CO2 trend on
+            (its exponent uses year + tyear, forcing.f90:60-64).
+  land_off  1982-01-01 -> 1982-01-03 with land_coupling_flag = .false. (land_model.f90:179-186): land_temp is the
+            interpolated climatology, the slab model is not run.
+  ssta_off  1982-01-01 -> 1982-01-03 with sst_anomaly_coupling_flag = .false. (sea_model.f90:218-222, 279) and a NON-ZERO
+            anomaly in the state: it must not reach sstan_am / sst_am.
+
+The anomaly is analytic so that the tests can rebuild it (same form as gen_golden_anomaly.py):
+    ssta(i, j, t) = 1.5 sin(2 pi i / 96 + 0.7 t) cos(lat_j) + 0.3 t - 0.4        [K], t = plane index 0..n_months+1
+
+Stored per case `<c>`:
+  <c>_cal_ymdhm [n+1, 5] int32, <c>_cal_month_idx / _imont1 [n+1] int32, <c>_cal_tmonth / _tyear [n+1] float64 -- the
+      ControlParams_t after init (row 0) and after each of the n steps (oracle/ref_shim.f90: shim_control_params);
+  <c>_d<k>_<var>  -- after day k = 1..: vor, t, ps at time level 1, the slab / coupler fields of DAILY, the daily forcing
+      that depends on tyear and on the month (zonal profiles as [48]), air_absortivity_co2; after the LAST day also div, tr,
+      phi and the whole SLAB list.
+  forcing_tyear [365], forcing_fields [365, 5, 48] -- get_zonal_average_fields (shortwave_radiation.f90:218-275) for the tyear of
+      every day of the model's 365-day year, rows = flux_solar_in, flux_ozone_upper, flux_ozone_lower, zenit_correction,
+      stratospheric_correction.  (The compiled reference evaluates sin and cos of one argument with one `sincos` call -- flang
+      and gfortran both merge them --, and glibc's sincos is not always its sin: 1 ulp on Jan 2.  Every day is here so that a
+      host restatement is pinned to the bit on all of them.)
+Run in the build container:  python oracle/gen_golden_calendar.py
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import refmodel as R  # noqa: E402
+
+SLAB = ("sst_am", "sstan_am", "sice_am", "tice_am", "land_temp", "stl_lm", "snow_depth", "soil_avail_water", "sst_om",
+        "sice_om", "tice_om", "ssti_om", "sstcl_ob", "sicecl_ob", "ticecl_ob", "sstan_ob", "stlcl_obs", "snowdcl_obs",
+        "soilwcl_obs", "alb_land", "alb_sea", "alb_surface", "snowc", "olr", "precnv", "hfseacl")
+DAILY = ("sst_am", "sstan_am", "sice_am", "tice_am", "land_temp", "stl_lm", "sstcl_ob", "sstan_ob", "stlcl_obs", "ssti_om",
+         "snowdcl_obs", "alb_surface")  # every day; the whole SLAB list and all prognostics on the last day
+ZONAL = ("flux_solar_in", "flux_ozone_lower", "flux_ozone_upper", "zenit_correction", "stratospheric_correction")
+
+CASES = {
+    # name: (start, end, anomaly?, {scalar: value})
+    "leap": ((1980, 2, 26, 0, 0), (1980, 3, 2, 0, 0), True, {}),
+    "newyear": ((1982, 12, 29, 0, 0), (1983, 1, 3, 0, 0), True, {"increase_co2": 1}),
+    "land_off": ((1982, 1, 1, 0, 0), (1982, 1, 3, 0, 0), False, {"land_coupling_flag": 0}),
+    "ssta_off": ((1982, 1, 1, 0, 0), (1982, 1, 3, 0, 0), True, {"sst_anomaly_coupling_flag": 0}),
+}
+
+
+def synthetic_ssta(lat_deg, planes):
+    i = np.arange(96)[:, None, None]
+    t = np.arange(planes)[None, None, :]
+    return 1.5 * np.sin(2 * np.pi * i / 96 + 0.7 * t) * np.cos(np.deg2rad(lat_deg))[None, :, None] + 0.3 * t - 0.4
+
+
+def n_steps(start, end):
+    import datetime
+    return int((datetime.datetime(*end) - datetime.datetime(*start)).total_seconds()) // 2400
+
+
+def control(m):
+    ymdhm = (C.c_int * 5)()
+    mi, im = C.c_int(0), C.c_int(0)
+    tm, ty = C.c_double(0), C.c_double(0)
+    R.lib().shim_control_params(m.ctl, ymdhm, C.byref(mi), C.byref(im), C.byref(tm), C.byref(ty))
+    return list(ymdhm), mi.value, im.value, tm.value, ty.value
+
+
+def latitudes(bc):
+    tmp = R.RefModel()
+    tmp.set_bc(bc)
+    lat = np.zeros(48, dtype=np.float32)
+    R._drv("get_lat")(C.byref(tmp.cnt), R._p(lat))
+    return lat
+
+
+def run_case(name, bc, lat, out):
+    start, end, anomaly, scalars = CASES[name]
+    m = R.RefModel(start=start, end=end)
+    planes = m.n_months + 2
+    R._drv("modelstate_init_sst_anom")(C.byref(m.cnt), C.byref(C.c_int(m.n_months)))
+    for state_name, bc_name in R.BC_MAP:
+        m.set(state_name, np.asarray(bc[bc_name], dtype=np.float64))
+    if anomaly:
+        ssta = np.asfortranarray(synthetic_ssta(lat.astype(np.float64), planes))
+        R._drv("set_sst_anom")(C.byref(m.cnt), R._p(ssta), C.byref(C.c_int(m.n_months)))
+    for k, v in scalars.items():
+        m.set(k, v)
+    err = C.c_int(0)
+    R._drv("init")(C.byref(m.cnt), C.byref(m.ctl), C.byref(err))
+    assert err.value == 0
+    n = n_steps(start, end)
+    cal = [control(m)]
+    for s in range(1, n + 1):
+        assert m.step() == 0
+        cal.append(control(m))
+        if s % 36 == 0:
+            p = "%s_d%d_" % (name, s // 36)
+            last = s == n
+            for v in ("vor", "div", "t", "ps") if last else ("vor", "t", "ps"):
+                out[p + v] = m.get(v)[..., 0]
+            if last:
+                out[p + "tr"] = m.get("tr")[..., 0, 0]
+                out[p + "phi"] = m.get("phi")
+            for v in SLAB if last else DAILY:
+                out[p + v] = m.get(v)
+            for v in ZONAL:
+                f = m.get(v)
+                assert np.all(f == f[:1, :])  # zonally uniform: keep one meridian
+                out[p + v] = f[0].copy()
+            out[p + "air_absortivity_co2"] = np.float64(m.get("air_absortivity_co2"))
+            out[p + "current_step"] = np.int32(m.get("current_step"))
+    out[name + "_cal_ymdhm"] = np.array([c[0] for c in cal], dtype=np.int32)
+    out[name + "_cal_month_idx"] = np.array([c[1] for c in cal], dtype=np.int32)
+    out[name + "_cal_imont1"] = np.array([c[2] for c in cal], dtype=np.int32)
+    out[name + "_cal_tmonth"] = np.array([c[3] for c in cal], dtype=np.float64)
+    out[name + "_cal_tyear"] = np.array([c[4] for c in cal], dtype=np.float64)
+    out[name + "_planes"] = np.int32(planes)
+    print(name, "steps", n, "last date", cal[-1][0], "month_idx", cal[-1][1], "tmonth max", max(c[3] for c in cal))
+
+
+def forcing_sweep(bc, out):
+    m = R.RefModel()
+    m.set_bc(bc)
+    ndays = (31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31)
+    tyear = []
+    for month in range(12):
+        for day in range(1, ndays[month] + 1):  # update_forcing_params, model_control.f90:183, in default real
+            tyear.append(float((np.float32(sum(ndays[:month]) + day) - np.float32(0.5)) / np.float32(365)))
+    fields = np.zeros((365, 5, 48))
+    for d, ty in enumerate(tyear):
+        R.lib().shim_zonal_average_fields(m.cnt, C.c_double(ty))
+        for r, v in enumerate(("flux_solar_in", "flux_ozone_upper", "flux_ozone_lower", "zenit_correction",
+                               "stratospheric_correction")):
+            f = m.get(v)
+            assert np.all(f == f[:1, :])
+            fields[d, r] = f[0]
+    out["forcing_tyear"] = np.array(tyear)
+    out["forcing_fields"] = fields
+
+
+def main():
+    bc = np.load(os.path.join(HERE, "..", "pyspeedy_amd", "data", "example_bc.npz"))
+    lat = latitudes(bc)
+    out = {"lat": lat}
+    forcing_sweep(bc, out)
+    for name in CASES:
+        run_case(name, bc, lat, out)
+    dst = os.path.join(HERE, "..", "tests", "golden", "calendar.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, "%.1f MB" % (os.path.getsize(dst) / 1e6))
+
+
+if __name__ == "__main__":
+    main()

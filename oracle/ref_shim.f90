@@ -362,6 +362,36 @@ contains
         elz = s%mod_implicit%elz
     end subroutine
 
+    !> The calendar a ControlParams_t carries (model_control.f90:37-47): the reference's driver has no getter for it.
+    subroutine shim_control_params(ctl, ymdhm, month_idx, imont1, tmonth, tyear) bind(C, name = "shim_control_params")
+        use model_control, only : ControlParams_t, ControlParams_Ptr_t
+        integer(c_int64_t), value :: ctl
+        integer(c_int), intent(out) :: ymdhm(5), month_idx, imont1
+        real(c_double), intent(out) :: tmonth, tyear
+        type(ControlParams_Ptr_t) :: ptr
+        ptr = transfer(ctl, ptr)
+        ymdhm(1) = ptr%p%model_datetime%year
+        ymdhm(2) = ptr%p%model_datetime%month
+        ymdhm(3) = ptr%p%model_datetime%day
+        ymdhm(4) = ptr%p%model_datetime%hour
+        ymdhm(5) = ptr%p%model_datetime%minute
+        month_idx = ptr%p%month_idx
+        imont1 = ptr%p%imont1
+        tmonth = ptr%p%tmonth
+        tyear = ptr%p%tyear
+    end subroutine
+
+    !> The zonally uniform daily forcing for an arbitrary fraction of the year (shortwave_radiation.f90:218-275), as
+    !  set_forcing calls it once per simulated day (forcing.f90:84).
+    subroutine shim_zonal_average_fields(cnt, tyear) bind(C, name = "shim_zonal_average_fields")
+        use shortwave_radiation, only : get_zonal_average_fields
+        integer(c_int64_t), value :: cnt
+        real(c_double), value :: tyear
+        type(ModelState_t), pointer :: s
+        s => state_of(cnt)
+        call get_zonal_average_fields(s, tyear)
+    end subroutine
+
     subroutine shim_set_geopotential(cnt, time_level) bind(C, name = "shim_set_geopotential")
         use geopotential, only : set_geopotential
         integer(c_int64_t), value :: cnt

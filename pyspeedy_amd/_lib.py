@@ -67,6 +67,8 @@ _SIGNATURES = {
     "spd_last_error": (C.c_char_p, []),
     "spd_version": (C.c_char_p, []),
     "spd_get_table_host": (C.c_long, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "spd_calendar_walk": (C.c_int, [C.c_int] * 6 + [C.c_void_p] * 5),
+    "spd_daily_forcing_host": (C.c_int, [C.c_double, C.c_void_p]),
     "spd_spec2grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "spd_grid2spec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "spd_legendre_inv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

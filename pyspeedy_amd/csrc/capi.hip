@@ -11,6 +11,7 @@
 #include "../../include/pyspeedy_amd.h"
 #include "context.hpp"
 #include "device_tables.hpp"
+#include "surface_host.hpp"
 
 namespace spd {
 hipError_t run_spec2grid(const DeviceTables &T, int stage, const double *src, double *dst, int kcos, int nfields,
@@ -236,6 +237,36 @@ long spd_get_table_host(spd_handle h, const char *name, double *buf, size_t buf_
         std::memcpy(buf, src, n * sizeof(double));
     }
     return static_cast<long>(n);
+}
+
+int spd_calendar_walk(int year, int month, int day, int hour, int minute, int nsteps, int32_t *ymdhm, int32_t *month_idx,
+                      int32_t *imont1, double *tmonth, double *tyear) {
+    if (nsteps < 0 || month < 1 || month > 12 || day < 1 || day > 31) return fail(SPD_E_ARG, "spd_calendar_walk: bad start date or step count");
+    Calendar c;
+    c.set(year, month, day, hour, minute);
+    for (int s = 0;; ++s) {
+        if (ymdhm) {
+            int32_t *row = ymdhm + 5 * static_cast<size_t>(s);
+            row[0] = c.year; row[1] = c.month; row[2] = c.day; row[3] = c.hour; row[4] = c.minute;
+        }
+        if (month_idx) month_idx[s] = c.month_idx;
+        if (imont1) imont1[s] = c.imont1;
+        if (tmonth) tmonth[s] = c.tmonth;
+        if (tyear) tyear[s] = c.tyear;
+        if (s == nsteps) break;
+        c.advance();
+    }
+    return SPD_OK;
+}
+
+int spd_daily_forcing_host(double tyear, double *out) {
+    if (!out) return fail(SPD_E_ARG, "spd_daily_forcing_host: null buffer");
+    static const HostTables deviceless;
+    const ZonalForcing z = zonal_average_fields(deviceless, tyear);
+    const std::array<double, 48> *rows[5] = {&z.flux_solar_in, &z.flux_ozone_upper, &z.flux_ozone_lower, &z.zenit_correction,
+                                              &z.stratospheric_correction};
+    for (int r = 0; r < 5; ++r) std::memcpy(out + 48 * r, rows[r]->data(), 48 * sizeof(double));
+    return SPD_OK;
 }
 
 }  // extern "C"

@@ -8,6 +8,7 @@
 #include <atomic>
 #include <cmath>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -135,6 +136,8 @@ struct Batch {  // one device model shared by the containers of its members
     // A step was enqueued and its range check (or anything else that had to follow it) could not be: the device state has
     // moved on while date and codes say it has not.  Nothing steps such a model again until it is initialised anew.
     bool advanced_without_check = false;
+    // step counter of the last range failure each member was told about on stderr (-1: none); see report_out_of_range
+    std::vector<int32_t> failed_step;
     ~Batch() {
         --g_models_alive;
         drvdev::DeviceGuard guard;  // (may run from any entry point that drops the last reference, or from a host's garbage collector)
@@ -288,9 +291,10 @@ int push_date(Batch &b, const Control &c) {
     mc.month_idx = c.month_idx;
     return spd_model_set_control(b.model, &mc);
 }
-int pull_date(Batch &b, Control &c) {
+int pull_date(Batch &b, Control &c, int32_t *current_step = nullptr) {
     spd_model_control mc;
     if (int rc = spd_model_get_control(b.model, &mc)) return rc;
+    if (current_step) *current_step = mc.current_step;
     c.now.ymdhm[0] = mc.year; c.now.ymdhm[1] = mc.month; c.now.ymdhm[2] = mc.day; c.now.ymdhm[3] = mc.hour;
     c.now.ymdhm[4] = mc.minute;
     c.month_idx = mc.month_idx;
@@ -757,6 +761,8 @@ struct GroupRun {
     Control before;    // model date before the step
     Control advanced;  // ... and after it (valid when slot >= 0)
     int slot = -1;     // pending check; -1: the members were not initialised; -2: the step could not be issued
+    int32_t step = 0;  // the model's step counter after the step: what the range check reports on stderr
+    bool behind = false;  // enqueued while the check of the step before it was still out
     int rc = SPD_OK;   // status of this group's device calls
     std::string error; // ... and its message
 };
@@ -917,6 +923,7 @@ static void issue_group(const GroupPlan &g, GroupRun &r, bool defer_check) {
     if (rc == SPD_OK && !b.stream) rc = fail(SPD_E_DEVICE, "speedy driver: hipStreamCreate failed");  // (issue_all made it)
     if (rc == SPD_OK && spd_model_checks_in_flight(b.model) >= 2)  // (a step without its check is no step)
         rc = fail(SPD_E_ARG, "speedy driver: two steps of this device model are in flight already; end one with spd_parallel_step_end first");
+    if (rc == SPD_OK) r.behind = spd_model_checks_in_flight(b.model) >= 1;
     if (rc == SPD_OK) rc = push_date(b, r.before);
     if (rc == SPD_OK) {
         step_enqueued = true;
@@ -927,7 +934,7 @@ static void issue_group(const GroupPlan &g, GroupRun &r, bool defer_check) {
         r.slot = defer_check ? spd_model_check_defer(b.model, 2, b.stream) : spd_model_check_begin(b.model, 2, b.stream);
         if (r.slot < 0) rc = r.slot;
     }
-    if (rc == SPD_OK) rc = pull_date(b, r.advanced);
+    if (rc == SPD_OK) rc = pull_date(b, r.advanced, &r.step);
     if (rc != SPD_OK) {
         r.rc = rc;
         r.error = spd_last_error();
@@ -1043,6 +1050,16 @@ static void collect_group(const GroupPlan &g, GroupRun &r, std::vector<int32_t> 
     }
 }
 
+// What check_diagnostics writes to unit 0 for a state out of range (diagnostics.f90:69-70: `write(0, *) "Model variables out of
+// accepted range"; write(0, *) "step =", state%current_step`), once per failing state.  List-directed output as gfortran -- the
+// reference's compiler -- formats it: a leading blank, a default integer in 12 columns (the flang-built oracle library prints
+// ` step = 36`).  One fwrite per message, so that the lines of concurrent host threads do not interleave inside one.
+static void report_out_of_range(int32_t step) {
+    char text[96];
+    const int n = std::snprintf(text, sizeof(text), " Model variables out of accepted range\n step =%12d\n", static_cast<int>(step));
+    if (n > 0) std::fwrite(text, 1, static_cast<size_t>(n), stderr);
+}
+
 // Hand the codes out and settle the dates: speedy.f90:57-71 advances the date only after a successful check.  (lock held)
 // dates_ran_ahead: the begin / end form moved the dates at _begin already (and a later _begin may have moved them again): only
 // a member whose check failed gets the date from before its step back.
@@ -1053,6 +1070,15 @@ static void settle_group(const GroupPlan &g, const GroupRun &r, const std::vecto
         const int32_t code = codes[g.members[k]];
         error_codes[g.positions[k]] = code;
         any_failed = any_failed || code != 0;
+        if (code == -2) {
+            // The overlapped form enqueues step k + 1 before it has seen the check of step k.  When step k failed, the failure of
+            // step k + 1 is one the reference's loop cannot produce (it stops at the first code, speedy.py:398-405): not reported.
+            std::vector<int32_t> &told = g.batch->failed_step;
+            if (told.size() != static_cast<size_t>(g.batch->members)) told.assign(g.batch->members, -1);
+            const bool consequence = dates_ran_ahead && r.behind && told[g.members[k]] == r.step - 1;
+            if (!consequence) report_out_of_range(r.step);
+            told[g.members[k]] = r.step;
+        }
         auto ci = g_controls.find(g.control_ids[k]);
         if (ci == g_controls.end() || (code == 0 && dates_ran_ahead)) continue;
         const Control &to = code == 0 ? r.advanced : r.before;
@@ -1279,6 +1305,7 @@ int spd_check(int64_t state_cnt, int32_t *error_code) {
     std::vector<int32_t> codes(b.members, 0);
     if (int rc = spd_model_check(b.model, 1, codes.data(), nullptr, nullptr)) return rc;
     *error_code = codes[st->member];
+    if (*error_code == -2) report_out_of_range(spd_model_current_step(b.model));
     return SPD_OK;
 }
 

@@ -87,6 +87,12 @@ TimeInterp time_interp(const Calendar &c) {
 }
 
 // ------------------------------------------------------------------------------------------- daily solar forcing
+// sin and cos of ONE argument: the compiled reference gets both from one `sincos` call (flang and gfortran merge the pair, neither
+// keeps errno semantics), and glibc's sincos does not always return its sin() -- one ulp for the rzen of January 2.  The host code
+// asks for the pair the same way; tests/golden/calendar.npz holds every day of the year (tests/test_calendar_host.py, bitwise).
+namespace {
+inline void sin_cos(double x, double &s, double &c) { ::sincos(x, &s, &c); }
+}  // namespace
 ZonalForcing zonal_average_fields(const HostTables &t, double tyear) {
     ZonalForcing z{};
     const float pih = std::asin(1.0f);  // asin(1.0) in fp32
@@ -103,13 +109,16 @@ ZonalForcing zonal_average_fields(const HostTables &t, double tyear) {
         const double csol = 4.0f * solc;
         const double pigr = static_cast<double>(2.0f * pih);
         const double al = 2.0f * pigr * tyear;
-        const double ca1 = std::cos(al), sa1 = std::sin(al);
+        double ca1, sa1;
+        sin_cos(al, sa1, ca1);
         const double ca2 = ca1 * ca1 - sa1 * sa1, sa2 = 2.f * sa1 * ca1;
         const double ca3 = ca1 * ca2 - sa1 * sa2, sa3 = sa1 * ca2 + sa2 * ca1;
         const double decl = 0.006918f - 0.399912f * ca1 + 0.070257f * sa1 - 0.006758f * ca2 + 0.000907f * sa2 -
                             0.002697f * ca3 + 0.001480f * sa3;
         const double fdis = 1.000110f + 0.034221f * ca1 + 0.001280f * sa1 + 0.000719f * ca2 + 0.000077f * sa2;
-        const double cdecl = std::cos(decl), sdecl = std::sin(decl), tdecl = sdecl / cdecl;
+        double cdecl, sdecl;
+        sin_cos(decl, sdecl, cdecl);
+        const double tdecl = sdecl / cdecl;
         const double csolp = csol / pigr;
         for (int j = 0; j < IL; ++j) {
             const double ch0 = std::min(1.0, std::max(-1.0, -tdecl * t.sia[j] / t.coa[j]));
@@ -117,12 +126,14 @@ ZonalForcing zonal_average_fields(const HostTables &t, double tyear) {
             topsr[j] = csolp * fdis * (h0 * t.sia[j] * sdecl + sh0 * t.coa[j] * cdecl);
         }
     }
+    double cos_rzen, sin_rzen;
+    sin_cos(rzen, sin_rzen, cos_rzen);
     for (int j = 0; j < IL; ++j) {
         const double flat2 = 1.5f * (t.sia[j] * t.sia[j]) - 0.5f;
         z.flux_solar_in[j] = topsr[j];
         double o3u = 0.5f * epssw;
         double o3l = 0.4f * epssw * (1.0f + coz1 * t.sia[j] + coz2 * flat2);
-        const double q = 1.0f - (t.coa[j] * std::cos(rzen) + t.sia[j] * std::sin(rzen));
+        const double q = 1.0f - (t.coa[j] * cos_rzen + t.sia[j] * sin_rzen);
         z.zenit_correction[j] = 1.0f + azen * (q * q);
         z.flux_ozone_upper[j] = z.flux_solar_in[j] * o3u * z.zenit_correction[j];
         z.flux_ozone_lower[j] = z.flux_solar_in[j] * o3l * z.zenit_correction[j];

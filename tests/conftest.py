@@ -19,7 +19,7 @@ def pytest_configure(config):
 # process that has initialised the GPU to exec another program (not even in a forked child), and the test process
 # initialises it as soon as the first device fixture is used.
 _SPAWNING_MODULES = ("test_fortran_host.py", "test_ensemble_dist.py", "test_bench_launch.py", "test_variants_spawn.py",
-                     "test_sanitizers.py", "test_c_host.py")
+                     "test_sanitizers.py", "test_c_host.py", "test_calendar_host.py")
 
 
 def pytest_sessionstart(session):

@@ -346,6 +346,7 @@ int spd_model_check(spd_model_handle m, int, int32_t *codes, double *, void *) {
     return SPD_OK;
 }
 
+int spd_model_current_step(spd_model_handle m) { return m ? m->ctl.current_step : SPD_E_ARG; }
 int spd_model_spectral2grid(spd_model_handle m, int, int, void *) { return m ? SPD_OK : SPD_E_ARG; }
 int spd_model_grid2spectral(spd_model_handle m, int, int, void *) { return m ? SPD_OK : SPD_E_ARG; }
 int spd_model_grid_filter(spd_model_handle m, int, int, void *) { return m ? SPD_OK : SPD_E_ARG; }

@@ -123,7 +123,7 @@ def test_ens_members_are_independent(gold):
     assert 1e-4 < np.abs(d).max() < 5.0
 
 
-def test_exceptions(gold):
+def test_exceptions(gold, capfd):
     from pyspeedy_amd.speedy import Speedy
     model = Speedy(start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 2))
     with pytest.raises(RuntimeError):
@@ -137,8 +137,12 @@ def test_exceptions(gold):
     t[:] = 0
     model["t"] = t
     assert int(gold["chk_zero_t"]) == -2
+    capfd.readouterr()
     with pytest.raises(RuntimeError):
         model.check()
+    # ... and says so on stderr as check_diagnostics does (diagnostics.f90:69-70, list-directed output as gfortran formats it; the
+    # flang-built reference library prints the same two lines with ` step = 36`, tests/test_calendar_oracle.py)
+    assert capfd.readouterr().err == " Model variables out of accepted range\n step =%12d\n" % 36
     # a run that leaves the accepted range fails too: the per-step check is collected one step late, never dropped
     hot = Speedy(start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 1, 2, 0))
     hot.set_bc()
@@ -147,6 +151,7 @@ def test_exceptions(gold):
     hot["t"] = t
     with pytest.raises(RuntimeError):
         hot.run()
+    assert capfd.readouterr().err == " Model variables out of accepted range\n step =%12d\n" % 1  # (the reference: step 1 too)
     with pytest.raises(ValueError):
         model["t"] = np.zeros((3, 3))
     with pytest.raises(AttributeError):
