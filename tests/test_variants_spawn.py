@@ -89,18 +89,18 @@ def test_group_streams_end_up_on_hardware_queues_of_their_own(idle_streams):
 
 
 @pytest.mark.gpu
-def test_the_references_first_example_runs_with_the_import_changed(tmp_path):
-    """examples/my_first_forecast.py is the model cell of the reference's My_first_forecast.ipynb with `pyspeedy` replaced by
-    `pyspeedy_amd` in the two import lines: Speedy, set_bc, XarrayExporter + ModelCheckpoint with a spin-up date, run, state
-    access by name.  A shorter period here (5 days, 2 of them spin-up); in a process of its own (it is a script)."""
+def test_single_forecast_example(tmp_path):
+    """examples/winter_week.py: a caller of the facade written for this repository -- Speedy, set_bc, XarrayExporter +
+    ModelCheckpoint with a spin-up date, run, state access by name -- over the 1982/83 year end (5 days, 2 of them discarded);
+    in a process of its own (it is a script)."""
     out = tmp_path / "data"
-    run = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "examples", "my_first_forecast.py"), "--end", "1980-01-06", "--spinup", "1980-01-03",
-                          "--out", str(out)], capture_output=True, text=True, timeout=600)
+    run = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "examples", "winter_week.py"), "--from", "1982-12-29", "--days", "5",
+                          "--discard", "2", "--dir", str(out)], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
     files = sorted(f for f in os.listdir(out) if f.endswith(".nc"))
-    assert files == ["1980-01-0%d_0000.nc" % d for d in (3, 4, 5, 6)], files  # (from the end of the spin-up on, daily)
-    assert "model date 1980-01-06 00:00:00, 4 files" in run.stdout
-    assert "96 longitudes 0.00 .. 356.25, 48 latitudes -87." in run.stdout
+    assert files == ["1982-12-31_0000.nc", "1983-01-01_0000.nc", "1983-01-02_0000.nc", "1983-01-03_0000.nc"], files
+    assert "forecast ended 1983-01-03 00:00:00 after 180 steps; 4 daily files, 4 days in memory" in run.stdout
+    assert "grid: 96 x 48, first latitude -87." in run.stdout
     from pyspeedy_amd.dataset import open_dataset
     last = open_dataset(str(out / files[-1]))
     assert set(("u", "v", "t", "q", "phi", "ps")) <= set(last.variables) and last.variables["t"].values.shape == (1, 8, 48, 96)
@@ -109,16 +109,16 @@ def test_the_references_first_example_runs_with_the_import_changed(tmp_path):
 
 
 @pytest.mark.gpu
-def test_the_references_ensemble_example_runs_with_the_import_changed():
-    """examples/ensemble_forecast.py: the model and post-processing cells of Ensemble_forecast.ipynb, import changed: members set
-    up one by one (set_bc, `member["t_grid"] += ...`, grid2spectral), ModelCheckpoint + DiagnosticCheck, the spread statistics on
-    the checkpoint dataframe.  4 members and 6 days here; the spread of the perturbed members grows from day to day."""
-    run = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "examples", "ensemble_forecast.py"), "--members", "4",
-                          "--end", "1980-01-07", "--spinup", "1980-01-02"], capture_output=True, text=True, timeout=600)
+def test_ensemble_spread_example():
+    """examples/ensemble_spread.py: members set up one by one (set_bc, `member["t_grid"] += ...`, grid2spectral), ModelCheckpoint +
+    DiagnosticCheck, the spread statistics on the checkpoint dataframe (var / std / mean / apply / isel).  4 members and 7 days
+    here; the spread of the perturbed members grows from day to day."""
+    run = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "examples", "ensemble_spread.py"), "--size", "4",
+                          "--days", "7", "--quiet-days", "1"], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
-    assert "ens: 4" in run.stdout and "time: 6" in run.stdout, run.stdout[-2000:]
-    tail = run.stdout.split("Domain-averaged ensemble spread by day:")[1]
+    assert "ens: 4" in run.stdout and "time: 7" in run.stdout, run.stdout[-2000:]
+    tail = run.stdout.split("domain-mean spread per kept day")[1]
     line = [ln for ln in tail.splitlines() if ln.strip().startswith("t ")][0]
     spread = [float(v) for v in line.split()[1:]]
-    assert len(spread) == 6 and all(v > 0 for v in spread) and spread[-1] > spread[0], spread
-
+    assert len(spread) == 7 and all(v > 0 for v in spread) and spread[-1] > spread[0], spread
+    assert "temperature spread grew by a factor" in run.stdout
