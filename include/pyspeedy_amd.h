@@ -40,6 +40,7 @@ extern "C" {
 #define SPD_E_ARG (-1)    /* bad argument (null pointer, negative count, unknown name) */
 #define SPD_E_DEVICE (-2) /* HIP runtime error (no device, launch failure, ...) */
 #define SPD_E_SIZE (-3)   /* caller buffer too small */
+#define SPD_E_TIMEOUT (-4) /* a collective did not complete inside its bound; work of unknown state is left on the devices it ran on */
 
 typedef struct spd_context *spd_handle;
 
@@ -193,6 +194,10 @@ int spd_model_check_end(spd_model_handle m, int slot, int32_t *error_codes_host)
  * state first -- spd_model_set, the export transforms, member copies, a call of several steps in member groups, spd_model_check_end
  * itself -- makes it a launch of its own there and then.  Returns the slot for spd_model_check_end. */
 int spd_model_check_defer(spd_model_handle m, int time_level, void *stream);
+/* launches a check put off by spd_model_check_defer now, if it is still waiting for a step to carry it: afterwards
+ * spd_model_check_end of its slot is a pure wait (a host may then make that call outside the lock it serialises its other calls
+ * on this model with) */
+int spd_model_check_settle(spd_model_handle m);
 /* how many of the model's begun / deferred range checks went out as launches of their own and how many rode in a step's launch */
 int spd_model_check_counts(spd_model_handle m, int32_t *alone, int32_t *rode);
 int spd_model_checks_in_flight(spd_model_handle m); /* 0, 1 or 2: checks begun and not yet ended */
@@ -331,7 +336,11 @@ int spd_model_copy_vars_enqueue(spd_model_handle dst, int dst_member, spd_model_
  * member members[root] of models[root] into member members[i] of every other models[i] -- RCCL (ncclBroadcast in one group call,
  * single-process communicators) over xGMI, on each device's null stream; the caller synchronises the devices before and
  * after.  RCCL (librccl.so.1) is loaded when this is first called; SPD_E_DEVICE with the reason when it cannot be.  n = 1 is a
- * broadcast to nobody (it still initialises the communicator). */
+ * broadcast to nobody (it still initialises the communicator).  Every (variable, model) pair is validated before RCCL is
+ * touched (SPD_E_ARG / SPD_E_SIZE: nothing was enqueued).  RCCL's initialisation, its group call and the completion of the
+ * broadcasts are each waited for PYSPEEDY_AMD_RCCL_TIMEOUT seconds (default 30) at most: an initialisation that does not come
+ * back gives SPD_E_DEVICE (nothing enqueued: the caller may copy point to point instead, and RCCL is not tried again in this
+ * process), a group call or broadcast that does not come back SPD_E_TIMEOUT (nothing may be queued behind it). */
 int spd_model_broadcast_vars(const spd_model_handle *models, const int *members, int n, int root, const char *const *names,
                              int n_names);
 

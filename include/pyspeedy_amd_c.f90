@@ -312,5 +312,9 @@ module pyspeedy_amd_c
             import :: c_int, c_int32_t
             integer(c_int32_t), intent(out) :: peer_copies, local_copies, collective_devices
         end function
+        function spd_broadcast_boundary_note() bind(C, name="spd_broadcast_boundary_note") result(text)
+            import :: c_ptr
+            type(c_ptr) :: text   ! NUL-terminated, valid until this thread's next call
+        end function
     end interface
 end module pyspeedy_amd_c

@@ -85,6 +85,12 @@ int spd_broadcast_boundary(const int64_t *state_cnts, int32_t n, int32_t root);
  * collective could not carry for everybody) and copies that stayed on a device (the other containers of a GPU take the fields from
  * its first one) */
 int spd_broadcast_boundary_stats(int32_t *peer_copies, int32_t *local_copies, int32_t *collective_devices);
+/* ... and in words (valid until this thread's next call): "one RCCL broadcast to 7 other device(s)", "peer copies
+ * (PYSPEEDY_AMD_BROADCAST=peer)", "peer copies, because: <why the collective was not used>" -- RCCL not loadable, or its
+ * initialisation did not come back within PYSPEEDY_AMD_RCCL_TIMEOUT seconds (default 30; spd_model_broadcast_vars bounds every
+ * wait on RCCL) --, "local copies only (one device)", or "failed: ..." when the collective was enqueued and did not complete
+ * inside its bound (spd_broadcast_boundary then returns SPD_E_TIMEOUT: nothing can be queued behind it) */
+const char *spd_broadcast_boundary_note(void);
 
 /* ---- Datetime interface (:163-210) ---- */
 int spd_create_datetime(int32_t year, int32_t month, int32_t day, int32_t hour, int32_t minute, int64_t *datetime_cnt);

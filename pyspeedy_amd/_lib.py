@@ -102,6 +102,7 @@ _SIGNATURES = {
     "spd_model_check_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "spd_model_check_end": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "spd_model_check_defer": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "spd_model_check_settle": (C.c_int, [C.c_void_p]),
     "spd_model_check_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "spd_model_init": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
     "spd_model_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
@@ -133,6 +134,7 @@ _SIGNATURES = {
     "spd_model_broadcast_vars": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_char_p), C.c_int]),
     "spd_modelstate_init_ensemble_on": (C.c_int, [C.POINTER(C.c_int64), C.c_int32, C.c_int32]),
     "spd_broadcast_boundary_stats": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "spd_broadcast_boundary_note": (C.c_char_p, []),
     "spd_modelstate_close": (C.c_int, [C.c_int64]),
     "spd_create_datetime": (C.c_int, [C.c_int32] * 5 + [C.POINTER(C.c_int64)]),
     "spd_get_datetime": (C.c_int, [C.c_int64] + [C.POINTER(C.c_int32)] * 5),

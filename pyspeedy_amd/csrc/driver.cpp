@@ -173,6 +173,7 @@ uint64_t g_epoch = 1;
 struct BroadcastStats {
     int peer_copies, local_copies, collective_devices;
 } g_broadcast_stats{0, 0, 0};  // of the last spd_broadcast_boundary
+std::string g_broadcast_note;    // ... and its transport in words, with the reason when the collective was not used
 
 // The plan of an argument list: which of its containers are (all) the members of which device model.  Made by plan_step,
 // never changed afterwards, shared by the calls that use it.
@@ -1035,6 +1036,22 @@ static void issue_all(const std::vector<GroupPlan> &groups, std::vector<GroupRun
     for (IssueWorker *w : busy) w->wait();
 }
 
+// A check that was put off (the begin / end form: it rides in the next step's first launch) and has found no step to ride in
+// is launched here, WITH the lock held: spd_model_check_end would otherwise launch it from the unlocked wait below -- a kernel
+// launch and a change of the model's check bookkeeping beside whatever another host thread does to the same model under the
+// lock (spd_set, a regrouping).  After this, collect_group only waits and reads.  (lock held)
+static void settle_deferred(const GroupPlan &g, GroupRun &r) {
+    if (r.slot < 0) return;
+    Batch &b = *g.batch;
+    int rc = SPD_OK;
+    if (!drvdev::set_device(b.device)) rc = fail(SPD_E_DEVICE, "speedy driver: hipSetDevice failed");
+    if (rc == SPD_OK) rc = spd_model_check_settle(b.model);
+    if (rc != SPD_OK) {  // (collect_group still ends the slot; its codes no longer count)
+        r.rc = rc;
+        r.error = spd_last_error();
+    }
+}
+
 // Wait for the check of one group.  (lock NOT held: other host threads may work on other containers meanwhile)
 static void collect_group(const GroupPlan &g, GroupRun &r, std::vector<int32_t> &codes) {
     Batch &b = *g.batch;
@@ -1043,11 +1060,11 @@ static void collect_group(const GroupPlan &g, GroupRun &r, std::vector<int32_t> 
     int rc = SPD_OK;
     if (!drvdev::set_device(b.device)) rc = fail(SPD_E_DEVICE, "speedy driver: hipSetDevice failed");
     if (rc == SPD_OK) rc = spd_model_check_end(b.model, r.slot, codes.data());
-    if (rc != SPD_OK) {
+    if (rc != SPD_OK && r.rc == SPD_OK) {
         r.rc = rc;
         r.error = spd_last_error();
-        codes.assign(b.members, kStepFailed);
     }
+    if (r.rc != SPD_OK) codes.assign(b.members, kStepFailed);
 }
 
 // What check_diagnostics writes to unit 0 for a state out of range (diagnostics.f90:69-70: `write(0, *) "Model variables out of
@@ -1110,6 +1127,7 @@ int spd_parallel_step(const int64_t *state_cnts, const int64_t *control_cnts, in
     // others from being stepped; and the lock is given up while the host waits, so that other host threads can step THEIR
     // containers meanwhile (the reference's parallel_step is `!f2py threadsafe`).
     issue_all(groups, run, false);
+    for (size_t i = 0; i < groups.size(); ++i) settle_deferred(groups[i], run[i]);  // (the synchronous form defers nothing: a no-op)
     lock.unlock();
     std::vector<std::vector<int32_t>> codes(groups.size());
     for (size_t i = 0; i < groups.size(); ++i) {
@@ -1155,6 +1173,7 @@ int spd_parallel_step_end(int64_t token, int32_t *error_codes) {
     if (it == g_pending.end() || !error_codes) return fail(SPD_E_ARG, "spd_parallel_step_end: not a pending step");
     PendingStep p = std::move(it->second);
     g_pending.erase(it);
+    for (size_t i = 0; i < p.plan->groups.size(); ++i) settle_deferred(p.plan->groups[i], p.run[i]);
     lock.unlock();
     const std::vector<GroupPlan> &groups = p.plan->groups;
     std::vector<std::vector<int32_t>> codes(groups.size());
@@ -1206,6 +1225,7 @@ int spd_broadcast_boundary(const int64_t *state_cnts, int32_t n, int32_t root) {
     for (auto &kv : on_device)
         if (kv.first != src_device && !sync_device(kv.first)) return fail(SPD_E_DEVICE, "spd_broadcast_boundary: device error");
     g_broadcast_stats = {0, 0, 0};
+    g_broadcast_note = "local copies only (one device)";
     auto with_anomalies = [&](int i) {
         const Batch &d = *dst[i]->batch, &s = *src->batch;
         return d.sst_anom_allocated == s.sst_anom_allocated && d.n_months == s.n_months;
@@ -1216,6 +1236,7 @@ int spd_broadcast_boundary(const int64_t *state_cnts, int32_t n, int32_t root) {
     std::vector<int> receivers;
     for (auto &kv : on_device)
         if (kv.first != src_device) receivers.push_back(kv.second.front());
+    if (!receivers.empty() && transport && std::strcmp(transport, "peer") == 0) g_broadcast_note = "peer copies (PYSPEEDY_AMD_BROADCAST=peer)";
     if (!receivers.empty() && !(transport && std::strcmp(transport, "peer") == 0)) {
         bool all_anom = true;
         for (int i : receivers) all_anom = all_anom && with_anomalies(i);
@@ -1225,11 +1246,21 @@ int spd_broadcast_boundary(const int64_t *state_cnts, int32_t n, int32_t root) {
             models.push_back(dst[i]->batch->model);
             members.push_back(dst[i]->member);
         }
-        if (spd_model_broadcast_vars(models.data(), members.data(), static_cast<int>(models.size()), 0, kBoundary, all_anom ? 13 : 12) ==
-            SPD_OK) {
+        const int brc = spd_model_broadcast_vars(models.data(), members.data(), static_cast<int>(models.size()), 0, kBoundary, all_anom ? 13 : 12);
+        if (brc == SPD_OK) {
             for (int i : receivers) filled[i] = all_anom ? 2 : 1;
             g_broadcast_stats.collective_devices = static_cast<int>(receivers.size());
-        }  // (otherwise: point-to-point below; the stats show that no device was reached collectively)
+            g_broadcast_note = "one RCCL broadcast to " + std::to_string(receivers.size()) + " other device(s)";
+        } else if (brc == SPD_E_TIMEOUT) {
+            // the collective was enqueued and did not complete inside its bound: whatever would be queued behind it on those
+            // devices' null streams would wait with it.  No fallback; the caller gets the reason.
+            g_broadcast_note = std::string("failed: ") + spd_last_error();
+            return fail(SPD_E_TIMEOUT, g_broadcast_note);
+        } else {
+            // (RCCL cannot be loaded, refused to initialise, or its initialisation did not come back in time: nothing was
+            // enqueued, the fields go point to point below and the stats show that no device was reached collectively)
+            g_broadcast_note = std::string("peer copies, because: ") + spd_last_error();
+        }
     }
     int rc = SPD_OK;
     for (auto &kv : on_device) {
@@ -1265,6 +1296,13 @@ int spd_broadcast_boundary_stats(int32_t *peer_copies, int32_t *local_copies, in
     if (local_copies) *local_copies = g_broadcast_stats.local_copies;
     if (collective_devices) *collective_devices = g_broadcast_stats.collective_devices;
     return SPD_OK;
+}
+
+const char *spd_broadcast_boundary_note(void) {
+    LOCK;
+    static thread_local std::string copy;
+    copy = g_broadcast_note;
+    return copy.c_str();
 }
 
 int spd_driver_trace(int32_t on) {

@@ -6,12 +6,14 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -20,6 +22,7 @@
 #include "model.hpp"
 #include "coupler_point.hpp"
 #include "diagnostics_block.hpp"
+#include "bounded_call.hpp"
 #include "launch_events.hpp"
 #include "sppt_point.hpp"
 #include "stream_apart.hpp"
@@ -1072,6 +1075,14 @@ int spd_model_check_defer(spd_model_handle m, int time_level, void *stream) {
     return slot;
 }
 
+// Launch a check that spd_model_check_defer put off, now, if one is still waiting for a step to ride in.  After this call
+// spd_model_check_end of that slot only waits and reads: it changes nothing another host thread could be looking at, so a host
+// may call it without the lock it serialises its other calls on this model with (csrc/driver.cpp does).
+int spd_model_check_settle(spd_model_handle m) {
+    if (!m) return m_fail(SPD_E_ARG, "spd_model_check_settle: null model");
+    return settle_deferred_check(m);
+}
+
 int spd_model_check_counts(spd_model_handle m, int32_t *alone, int32_t *rode) {
     if (!m) return m_fail(SPD_E_ARG, "spd_model_check_counts: null model");
     if (alone) *alone = m->checks_alone;
@@ -1737,6 +1748,7 @@ struct Rccl {
     const char *(*GetErrorString)(int) = nullptr;
     std::map<std::vector<int>, std::vector<void *>> comms;  // by device list; kept for the life of the process
     std::mutex mutex;
+    std::string wedged;  // a call into RCCL did not come back (spd_model_broadcast_vars): it is not called again in this process
 };
 Rccl &rccl() {
     static Rccl r;
@@ -1777,48 +1789,118 @@ int spd_model_broadcast_vars(const spd_model_handle *models, const int *members,
         for (int j = 0; j < i; ++j)
             if (devices[j] == devices[i]) return m_fail(SPD_E_ARG, "spd_model_broadcast_vars: one model per GPU (same-device copies are spd_model_copy_vars)");
     }
+    // Every (variable, model) pair is checked BEFORE the collective layer is touched: a variable refused inside the group call
+    // would leave the ranks before it with one broadcast more than the rest, and mismatched collectives do not fail, they hang.
+    struct Piece {
+        void *ptr;
+        size_t count;
+    };
+    std::vector<std::vector<Piece>> pieces(nnames, std::vector<Piece>(n));  // [variable][model]
+    for (int v = 0; v < nnames; ++v) {
+        if (!names[v]) return m_fail(SPD_E_ARG, "spd_model_broadcast_vars: null variable name");
+        auto r0 = models[root]->reg.find(names[v]);
+        for (int i = 0; i < n; ++i) {
+            auto e = models[i]->reg.find(names[v]);
+            if (e == models[i]->reg.end() || r0 == models[root]->reg.end())
+                return m_fail(SPD_E_ARG, std::string("spd_model_broadcast_vars: unknown variable '") + names[v] + "'");
+            if (e->second.bytes_member != r0->second.bytes_member)
+                return m_fail(SPD_E_SIZE, std::string("spd_model_broadcast_vars: variable '") + names[v] + "' differs between the models");
+            if (e->second.f32)
+                return m_fail(SPD_E_ARG, std::string("spd_model_broadcast_vars: variable '") + names[v] + "' may be stored as fp32 (spd_model_copy_vars moves those)");
+            pieces[v][i] = {static_cast<char *>(e->second.ptr) + e->second.bytes_member * members[i], e->second.bytes_member / sizeof(double)};
+        }
+    }
     for (int i = 0; i < n; ++i)
         if (i != root)
             if (int rc = settle_deferred_check(models[i])) return rc;
     Rccl &R = rccl();
     if (!R.lib) return m_fail(SPD_E_DEVICE, "spd_model_broadcast_vars: RCCL is not available: " + R.why);
     std::lock_guard<std::mutex> lock(R.mutex);
-    auto fail_nccl = [&](const char *what, int rc) {
-        return m_fail(SPD_E_DEVICE, std::string("spd_model_broadcast_vars: ") + what + ": " + R.GetErrorString(rc));
-    };
+    if (!R.wedged.empty()) return m_fail(SPD_E_DEVICE, "spd_model_broadcast_vars: RCCL is not used again in this process: " + R.wedged);
+    // RCCL's single-process initialisation and its group call talk to every GPU of the list; where a device or a link does not
+    // answer they do not fail, they block.  Both run on a thread of their own with a bound on the wait (bounded_call.hpp;
+    // PYSPEEDY_AMD_RCCL_TIMEOUT seconds, default 30).  An initialisation that does not come back has enqueued nothing: SPD_E_DEVICE,
+    // and the caller may take the point-to-point path (spd_broadcast_boundary does).  A group call or a broadcast that does not
+    // come back leaves work of unknown state on the devices' null streams: SPD_E_TIMEOUT, nothing may be queued behind it.
+    const double bound = [] {
+        const char *e = getenv("PYSPEEDY_AMD_RCCL_TIMEOUT");
+        const double v = e ? atof(e) : 30.0;
+        return v > 0.0 ? v : 30.0;
+    }();
+    auto nccl_text = [&R](int rc) { return std::string(R.GetErrorString(rc)); };
     auto it = R.comms.find(devices);
     if (it == R.comms.end()) {
-        std::vector<void *> comms(n, nullptr);
-        if (int rc = R.CommInitAll(comms.data(), n, devices.data())) return fail_nccl("ncclCommInitAll", rc);
-        it = R.comms.emplace(devices, comms).first;
+        auto comms = std::make_shared<std::vector<void *>>(n, nullptr);
+        auto init = R.CommInitAll;
+        const spd::BoundedResult r = spd::run_bounded([init, comms, devices, n] { return init(comms->data(), n, devices.data()); }, bound);
+        if (!r.finished) {
+            R.wedged = "ncclCommInitAll over " + std::to_string(n) + " devices did not return within " + std::to_string(static_cast<int>(bound)) + " s";
+            return m_fail(SPD_E_DEVICE, "spd_model_broadcast_vars: " + R.wedged);
+        }
+        if (r.rc) return m_fail(SPD_E_DEVICE, "spd_model_broadcast_vars: ncclCommInitAll: " + nccl_text(r.rc));
+        it = R.comms.emplace(devices, *comms).first;
     }
-    const std::vector<void *> &comms = it->second;
-    int rc = R.GroupStart();
-    if (rc) return fail_nccl("ncclGroupStart", rc);
-    int first_error = 0;
-    const char *bad = nullptr;
-    for (int v = 0; v < nnames && !bad; ++v) {
-        for (int i = 0; i < n && !bad; ++i) {
-            auto e = models[i]->reg.find(names[v]);
-            auto r0 = models[root]->reg.find(names[v]);
-            if (e == models[i]->reg.end() || r0 == models[root]->reg.end() || e->second.bytes_member != r0->second.bytes_member ||
-                e->second.f32) {
-                bad = names[v];
-                break;
+    const std::vector<void *> comms = it->second;
+    struct GroupStatus {
+        int start = 0, first_error = 0, end = 0, set_device = 0;
+    };
+    auto status = std::make_shared<GroupStatus>();
+    auto start = R.GroupStart, finish = R.GroupEnd;
+    auto broadcast = R.Broadcast;
+    const spd::BoundedResult g = spd::run_bounded([=] {
+        status->start = start();
+        if (status->start) return 1;
+        for (int v = 0; v < nnames; ++v)
+            for (int i = 0; i < n; ++i) {
+                if (hipSetDevice(devices[i]) != hipSuccess) {
+                    status->set_device = 1;
+                    continue;  // (the group is still closed below; the call fails as a whole)
+                }
+                const Piece &p = pieces[v][i];
+                const int r = broadcast(p.ptr, p.ptr, p.count, kNcclFloat64, root, comms[i], nullptr);
+                if (r && !status->first_error) status->first_error = r;
             }
-            char *mine = static_cast<char *>(e->second.ptr) + e->second.bytes_member * members[i];
-            if (hipSetDevice(devices[i]) != hipSuccess) {
-                bad = "hipSetDevice";
-                break;
+        status->end = finish();  // (always closed, also after an error inside the group)
+        return 0;
+    }, bound);
+    if (!g.finished) {
+        R.wedged = "the group call of " + std::to_string(nnames) + " broadcasts over " + std::to_string(n) + " devices did not return within " +
+                   std::to_string(static_cast<int>(bound)) + " s";
+        return m_fail(SPD_E_TIMEOUT, "spd_model_broadcast_vars: " + R.wedged);
+    }
+    if (status->start) return m_fail(SPD_E_DEVICE, "spd_model_broadcast_vars: ncclGroupStart: " + nccl_text(status->start));
+    if (status->set_device) return m_fail(SPD_E_TIMEOUT, "spd_model_broadcast_vars: hipSetDevice failed inside the group call");
+    if (status->first_error) return m_fail(SPD_E_TIMEOUT, "spd_model_broadcast_vars: ncclBroadcast: " + nccl_text(status->first_error));
+    if (status->end) return m_fail(SPD_E_TIMEOUT, "spd_model_broadcast_vars: ncclGroupEnd: " + nccl_text(status->end));
+    // ... and the broadcasts themselves: an event behind them on every device's null stream, asked until the bound is up
+    {
+        std::vector<hipEvent_t> events(n, nullptr);
+        bool ok = true;
+        for (int i = 0; i < n && ok; ++i)
+            ok = hipSetDevice(devices[i]) == hipSuccess && hipEventCreateWithFlags(&events[i], hipEventDisableTiming) == hipSuccess &&
+                 hipEventRecord(events[i], nullptr) == hipSuccess;
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(bound);
+        int pending = ok ? n : 0;
+        hipError_t bad = hipSuccess;
+        while (pending > 0 && bad == hipSuccess && std::chrono::steady_clock::now() < deadline) {
+            pending = 0;
+            for (int i = 0; i < n; ++i) {
+                const hipError_t q = hipEventQuery(events[i]);
+                if (q == hipErrorNotReady) ++pending;
+                else if (q != hipSuccess) bad = q;
             }
-            const int r = R.Broadcast(mine, mine, e->second.bytes_member / sizeof(double), kNcclFloat64, root, comms[i], nullptr);
-            if (r && !first_error) first_error = r;
+            if (pending) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+        for (int i = 0; i < n; ++i)
+            if (events[i] && (pending == 0 || bad != hipSuccess)) (void)hipEventDestroy(events[i]);  // (a pending event is left alone)
+        if (!ok) return m_fail(SPD_E_TIMEOUT, "spd_model_broadcast_vars: could not record the completion events of the broadcast");
+        if (bad != hipSuccess) return m_fail(SPD_E_TIMEOUT, std::string("spd_model_broadcast_vars: ") + hipGetErrorString(bad));
+        if (pending) {
+            R.wedged = "the broadcast did not complete on " + std::to_string(pending) + " of " + std::to_string(n) + " devices within " +
+                       std::to_string(static_cast<int>(bound)) + " s";
+            return m_fail(SPD_E_TIMEOUT, "spd_model_broadcast_vars: " + R.wedged);
         }
     }
-    rc = R.GroupEnd();  // (always closed, also after an error inside the group)
-    if (bad) return m_fail(SPD_E_ARG, std::string("spd_model_broadcast_vars: variable '") + bad + "' cannot be broadcast between these models");
-    if (first_error) return fail_nccl("ncclBroadcast", first_error);
-    if (rc) return fail_nccl("ncclGroupEnd", rc);
     for (int i = 0; i < n; ++i)
         if (i != root) models[i]->surf_cache_valid = models[i]->phi_ahead = false;
     return SPD_OK;

@@ -120,6 +120,11 @@ def broadcast_boundary_stats():
     return peer.value, local.value, coll.value
 
 
+def broadcast_boundary_note():
+    """... and in words: the transport, with the reason when the collective was not used (spd_broadcast_boundary_note)."""
+    return (_L().spd_broadcast_boundary_note() or b"").decode()
+
+
 def driver_trace(on=True):
     _ok(_L().spd_driver_trace(int(bool(on))), "driver_trace")
 

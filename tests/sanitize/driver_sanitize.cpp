@@ -7,15 +7,20 @@
 // the library's lock is released around every wait -- that none of it races.  Every container's toy state after n steps is
 // predictable (driver_stub.hpp), whatever grouping the driver chose on the way.
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "../../include/pyspeedy_amd.h"
 #include "../../include/pyspeedy_amd_driver.h"
+#include "../../pyspeedy_amd/csrc/bounded_call.hpp"
 #include "driver_stub.hpp"
 
 #define EXPECT(cond)                                                                                      \
@@ -171,6 +176,60 @@ void single_thread() {
         EXPECT(spd_get(x.state, "orog", orog.data(), NG * sizeof(double)) == 0 && orog[0] == 1234.5);
     }
     EXPECT(spd_broadcast_boundary(all.data(), 6, 6) < 0 && spd_broadcast_boundary(all.data(), 0, 0) < 0);
+    EXPECT(std::string(spd_broadcast_boundary_note()).find("one RCCL broadcast to 1 other device") == 0);
+    // ---- a collective library that does not answer.  Its initialisation not coming back inside the bound has enqueued nothing:
+    // the fields go point to point and the note says why.  A broadcast that was enqueued and does not complete cannot be worked
+    // around (whatever is queued behind it waits with it): the call fails with SPD_E_TIMEOUT and the reason.
+    stub_set_collective_available(2);
+    set_seed(m[0], 777.0);
+    peer0 = stub_peer_copies(), coll0 = stub_collectives();
+    EXPECT(spd_broadcast_boundary(all.data(), 6, 0) == 0);
+    EXPECT(stub_peer_copies() - peer0 == 1 && stub_collectives() == coll0);
+    EXPECT(spd_broadcast_boundary_stats(&peer, &local, &coll) == 0 && peer == 1 && local == 4 && coll == 0);
+    {
+        const std::string note = spd_broadcast_boundary_note();
+        EXPECT(note.find("peer copies, because:") == 0 && note.find("did not return within") != std::string::npos);
+    }
+    for (auto &x : m) {
+        std::vector<double> orog(NG);
+        EXPECT(spd_get(x.state, "orog", orog.data(), NG * sizeof(double)) == 0 && orog[0] == 777.0);
+    }
+    stub_set_collective_available(3);
+    peer0 = stub_peer_copies(), local0 = stub_local_copies();
+    EXPECT(spd_broadcast_boundary(all.data(), 6, 0) == SPD_E_TIMEOUT);
+    EXPECT(stub_peer_copies() == peer0 && stub_local_copies() == local0);  // nothing was queued behind the stuck collective
+    EXPECT(std::string(spd_broadcast_boundary_note()).find("failed:") == 0);
+    EXPECT(std::string(spd_last_error()).find("did not complete") != std::string::npos);
+    stub_set_collective_available(1);
+    EXPECT(spd_broadcast_boundary(all.data(), 6, 0) == 0);
+    // ---- the bound itself (csrc/bounded_call.hpp, what spd_model_broadcast_vars wraps RCCL's calls in): a call that returns is
+    // reported with its value; a call that NEVER returns costs the caller the bound and nothing else -- its thread is left
+    // behind with everything it uses kept alive by the state it owns (released here at the end so that the run ends clean)
+    {
+        auto quick = spd::run_bounded([] { return 42; }, 5.0);
+        EXPECT(quick.finished && quick.rc == 42);
+        auto gate = std::make_shared<std::pair<std::mutex, std::condition_variable>>();
+        auto open = std::make_shared<std::atomic<bool>>(false);
+        auto entered = std::make_shared<std::atomic<int>>(0);
+        const auto t0 = std::chrono::steady_clock::now();
+        auto stuck = spd::run_bounded([gate, open, entered] {
+            entered->fetch_add(1);
+            std::unique_lock<std::mutex> lk(gate->first);
+            gate->second.wait(lk, [&] { return open->load(); });
+            entered->fetch_add(1);
+            return 7;
+        }, 0.3);
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        EXPECT(!stuck.finished && waited >= 0.29 && waited < 5.0 && entered->load() == 1);
+        {
+            std::lock_guard<std::mutex> lk(gate->first);
+            open->store(true);
+        }
+        gate->second.notify_all();
+        for (int spin = 0; spin < 2000 && entered->load() < 2; ++spin) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        EXPECT(entered->load() == 2);
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));  // (the thread's last lines run after the counter moved)
+    }
     // ---- uninitialised containers step with code -1 and keep their date
     {
         std::vector<Member *> ms = {&m[0], &m[1]};
@@ -494,6 +553,38 @@ void close_during_wait() {
     EXPECT(spd_controlparams_close(m[3].control) == 0);
 }
 
+// The last pending step of a begin / end loop has no next step for its put-off check to ride in: spd_parallel_step_end has to
+// send it out itself.  It does so under the library's lock, before it lets go of the lock for the wait -- otherwise that launch
+// (work INSIDE the model: the stub aborts on two threads inside one model) would run beside whatever another host thread does to
+// the same model under the lock.  Here a second thread writes a variable of the same container all through the wait.
+void end_beside_set() {
+    stub_set_check_delay_us(20000);
+    Member m;
+    EXPECT(spd_modelstate_init_on(&m.state, 0) == 0);
+    make_controls(m);
+    set_seed(m, 5.0);
+    init(m);
+    for (int round = 0; round < 6; ++round) {
+        int64_t token = 0;
+        int32_t code = 9;
+        EXPECT(spd_parallel_step_begin(&m.state, &m.control, 1, &token) == 0);
+        std::atomic<bool> waiting{false}, done{false};
+        std::thread writer([&] {
+            while (!waiting.load()) std::this_thread::yield();
+            std::vector<double> field(NG, 1.0 + round);
+            while (!done.load()) EXPECT(spd_set(m.state, "alb0", field.data(), NG * sizeof(double)) == 0);
+        });
+        waiting = true;
+        EXPECT(spd_parallel_step_end(token, &code) == 0 && code == 0);
+        done = true;
+        writer.join();
+        m.predict_step();
+    }
+    verify(m);
+    stub_set_check_delay_us(100);
+    close(m);
+}
+
 void threads() {
     stub_set_device_count(2);
     stub_set_check_delay_us(100);
@@ -503,6 +594,7 @@ void threads() {
     for (int t = 0; t < 4; ++t) workers.emplace_back(stepping_thread, t, 12);
     for (auto &w : workers) w.join();
     close_during_wait();
+    end_beside_set();
     g_stop = true;
     tables.join();
     EXPECT(models_alive() == 0);

@@ -88,7 +88,10 @@ struct spd_model {
     spd_model_control ctl{};
     bool initialized = false;
     std::vector<std::map<std::string, std::vector<char>>> vars;  // per member
-    bool slot_busy[2] = {false, false};
+    std::atomic<bool> slot_busy[2] = {{false}, {false}};
+    // a check that was put off and not yet settled: ending it would have to LAUNCH it (the real model does), which is work inside
+    // the model; a settled one is a pure wait
+    std::atomic<bool> unsettled[2] = {{false}, {false}};
     int next_slot = 0;
     std::vector<int32_t> slot_codes[2];
     // a model is driven by one host thread at a time (the contract of the boundary): two threads inside one model are a bug of
@@ -104,6 +107,7 @@ struct Inside {
             std::fprintf(stderr, "driver_stub: two host threads inside one device model\n");
             std::abort();
         }
+        m->unsettled[0] = m->unsettled[1] = false;  // (whatever enters the model sends a check that was put off out first)
     }
     ~Inside() { m->inside.fetch_sub(1); }
 };
@@ -214,7 +218,13 @@ int spd_model_copy_vars_enqueue(spd_model_handle dst, int di, spd_model_handle s
 }
 
 int spd_model_broadcast_vars(const spd_model_handle *models, const int *members, int n, int root, const char *const *names, int nn) {
+    // modes: 0 = no collective library, 1 = works, 2 = its initialisation did not come back inside the bound (nothing enqueued),
+    //        3 = the broadcast was enqueued and did not complete inside the bound
     if (!g_collective_available.load()) return spd_set_error(SPD_E_DEVICE, "spd_model_broadcast_vars: RCCL is not available (stub)");
+    if (g_collective_available.load() == 2)
+        return spd_set_error(SPD_E_DEVICE, "spd_model_broadcast_vars: ncclCommInitAll over 2 devices did not return within 30 s (stub)");
+    if (g_collective_available.load() == 3)
+        return spd_set_error(SPD_E_TIMEOUT, "spd_model_broadcast_vars: the broadcast did not complete on 1 of 2 devices within 30 s (stub)");
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < i; ++j)
             if (models[i]->device == models[j]->device) return spd_set_error(SPD_E_ARG, "spd_model_broadcast_vars: one model per GPU");
@@ -326,14 +336,32 @@ int spd_model_check_begin(spd_model_handle m, int, void *) {
 
 // (the stub has no launches to save: the check is evaluated where it is put off, on the state as it is then -- which is what the
 // real one guarantees to look at)
-int spd_model_check_defer(spd_model_handle m, int time_level, void *stream) { return spd_model_check_begin(m, time_level, stream); }
+int spd_model_check_defer(spd_model_handle m, int time_level, void *stream) {
+    const int slot = spd_model_check_begin(m, time_level, stream);
+    if (slot >= 0) m->unsettled[slot] = true;  // (after the guard of check_begin has gone)
+    return slot;
+}
 
+int spd_model_check_settle(spd_model_handle m) {
+    if (!m) return spd_set_error(SPD_E_ARG, "spd_model_check_settle: null model");
+    Inside guard(m);
+    m->unsettled[0] = m->unsettled[1] = false;
+    return SPD_OK;
+}
+
+// The wait for a check that is out already happens OUTSIDE the model (the driver makes this call without its lock, beside
+// whatever another host thread does to the model under the lock); ending a check that still has to be launched is work inside
+// it, and the Inside guard aborts when the driver lets that happen beside another thread.
 int spd_model_check_end(spd_model_handle m, int slot, int32_t *codes) {
     if (!m || !codes || slot < 0 || slot > 1 || !m->slot_busy[slot]) return spd_set_error(SPD_E_ARG, "spd_model_check_end: no check in this slot");
-    Inside guard(m);
-    if (const int us = g_check_delay_us.load()) std::this_thread::sleep_for(std::chrono::microseconds(us));
-    m->slot_busy[slot] = false;
+    if (m->unsettled[slot].exchange(false)) {
+        Inside guard(m);
+        if (const int us = g_check_delay_us.load()) std::this_thread::sleep_for(std::chrono::microseconds(us));
+    } else if (const int us = g_check_delay_us.load()) {
+        std::this_thread::sleep_for(std::chrono::microseconds(us));
+    }
     std::memcpy(codes, m->slot_codes[slot].data(), sizeof(int32_t) * m->M);
+    m->slot_busy[slot] = false;
     return SPD_OK;
 }
 
