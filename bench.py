@@ -53,6 +53,24 @@ What the ONE JSON line of rank 0 holds:
   cfg2_transforms (N = 1)  BASELINE cfg 2: spec2grid / grid2spec alone over batches of B = 1 ... 16 384 fields: ns per field and
                         fraction of the HBM peak.
 
+  facade_run (N = 1)    the reference's own entry points on the same clock: SpeedyEns(64).run() and Speedy().run()
+                        (pyspeedy/speedy.py:572-586, :398-405) over ten simulated days, without callbacks and with the default daily
+                        XarrayExporter; ms per model step, Python loop, range check and file output included.
+  projected_8gpu_cfg4   (N = 1) BASELINE cfg 4 as worded on 8 GPUs, PROJECTED from this box: 8 members per GPU step in
+                        cfg4_shard8.ms_per_step whatever the other 7 GPUs do (no collective in the step), so the node's
+                        throughput is 64 members / that time; speedup and efficiency against this line's 64-members-on-one-GPU
+                        headline.  A projection, labelled so: the first measured 8-GPU record is to be checked against it.
+  config.step_contract_* / config.facade_* / config.projected_8gpu_cfg4_*   the scalars of drop_in_step, facade_run and
+                        projected_8gpu_cfg4 once more, flat, where a reader that keeps only the contract's objects sees them.
+                        `ms_per_step` is the multi-step device loop spd_model_step(m, K); the reference's step() contract -- one
+                        call per model step with the range check and the codes back -- is config.step_contract_ms_per_step_*.
+
+Wall-clock budget: `--budget SECONDS` (default 300) bounds the WHOLE run.  The headline, the roofline regions and the host
+baseline always run; every secondary object (the legs above, cfg4_strong, one_process and its cfg4_strong) starts only while
+the time that is left covers its allowance, and says `{"skipped": "budget"}` otherwise.  The child processes of the one_process
+object get timeouts that sum to at most 150 s, and the ranks that wait for them wait exactly that long: a secondary leg that
+hangs on the first contact with a second GPU cannot out-wait the driver's own timeout and cost the line its headline.
+
 Launching: with N > 1 and no torchrun environment, this process only starts N rank processes (before touching the GPU),
 relays rank 0's JSON line and fails if any rank fails.  Under `python -m torch.distributed.run ... bench.py --gpus N` each
 process is one rank.  PYSPEEDY_AMD_BENCH_BACKEND=gloo rehearses the N-rank control flow when the ranks share one GPU.
@@ -73,6 +91,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+T_PROCESS_START = time.time()  # the wall-clock budget counts from here (PYSPEEDY_AMD_BENCH_T0: the launcher's own start)
 
 STEPS_PER_YEAR = 36 * 365  # model_control.f90:57-60, params.f90:32
 S_BYTES, G_BYTES = 15872, 36864  # one spectral / one grid field
@@ -122,8 +141,39 @@ def parse(argv=None):
     ap.add_argument("--one-process", action="store_true",
                     help="ONE process drives all --gpus devices through spd_parallel_step (the reference's own shape) and that is the "
                          "line's value; without it, an N > 1 line carries the same measurement as its `one_process` object")
+    ap.add_argument("--budget", type=float, default=300.0,
+                    help="wall-clock seconds for the whole run: secondary legs start only while the remaining time covers them")
     ap.add_argument("--cpu-worker", type=float, nargs=2, default=None, metavar=("T_START", "SECONDS"), help=argparse.SUPPRESS)
     return ap.parse_args(argv)
+
+
+class Budget:
+    """The run's wall-clock budget.  `allows(seconds)`: is there room for a leg with that allowance?  Every refusal is kept so
+    that the line can say what was left out and why."""
+
+    def __init__(self, seconds):
+        self.seconds = float(seconds)
+        self.t0 = float(os.environ.get("PYSPEEDY_AMD_BENCH_T0", T_PROCESS_START))
+        self.skipped = []
+
+    def left(self):
+        return self.seconds - (time.time() - self.t0)
+
+    def allows(self, what, allowance):
+        if self.left() >= allowance:
+            return True
+        self.skipped.append({"leg": what, "allowance_s": allowance, "left_s": round(self.left(), 1)})
+        return False
+
+    def record(self):
+        return {"budget_s": self.seconds, "used_s": round(time.time() - self.t0, 1), "skipped": self.skipped}
+
+
+# allowances of the secondary legs [s]: generous multiples of what they take on a healthy box (the whole default N = 1 line
+# runs in 40-60 s); ONE_PROCESS_* are also the timeouts of the child processes, and sum to 150 s
+LEG_ALLOWANCE = {"every_step_stores": 15, "drop_in_step": 25, "facade_run": 30, "cfg2_transforms": 10, "cfg3": 10, "cfg4_shard8": 10,
+                 "cfg5": 15, "cfg4_strong": 30}
+ONE_PROCESS_TIMEOUT, ONE_PROCESS_STRONG_TIMEOUT = 100, 50
 
 
 def load_bc():
@@ -153,17 +203,20 @@ def launch_ranks(args, argv):
             json.dump(cpu_baseline(args.cpu_seconds), fh)
     for r in range(args.gpus):
         env = dict(os.environ, WORLD_SIZE=str(args.gpus), RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=port)
+                   MASTER_PORT=port, PYSPEEDY_AMD_BENCH_T0=repr(T_PROCESS_START))
         if baseline_file:
             env["PYSPEEDY_AMD_BENCH_CPU_BASELINE"] = baseline_file
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE,
                                       text=True))
     failed = None
+    give_up = T_PROCESS_START + args.budget + 90.0  # (the ranks bound themselves by the budget; this is the launcher's backstop)
     while failed is None and any(p.poll() is None for p in procs):
         for r, p in enumerate(procs):
             if p.poll() not in (None, 0):
                 failed = r
+        if failed is None and time.time() > give_up:
+            failed = next(r for r, p in enumerate(procs) if p.poll() is None)
         time.sleep(0.05)
     if failed is None:
         failed = next((r for r, p in enumerate(procs) if p.returncode != 0), None)
@@ -272,7 +325,11 @@ def cpu_baseline(seconds):
                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(cores)]
     rate, steps, longest, ok = 0.0, 0, 0.0, 0
     for p in procs:
-        o = p.communicate()[0]
+        try:
+            o = p.communicate(timeout=max(5.0, t_start + seconds + 45.0 - time.time()))[0]
+        except subprocess.TimeoutExpired:  # (a worker that does not finish is left out of the sum, not waited for)
+            p.kill()
+            o = ""
         for ln in o.splitlines():
             if ln.startswith("CPUWORKER"):
                 _, _, n, el = ln.split()
@@ -699,6 +756,113 @@ def small_drop_in_legs(steps):
     return out
 
 
+def facade_leg():
+    """The reference's own entry points, as a user of pySPEEDY calls them (pyspeedy/speedy.py:572-586 and :398-405):
+    `SpeedyEns(64)` with `for member in ens: member.set_bc()` and `ens.run(callbacks)`, and `Speedy().set_bc(); run(callbacks)` --
+    the Python time loop, one parallel_step per model step with its range check, and (second figure) the default daily
+    XarrayExporter: u, v, t, q, phi, ps of every member, device -> host -> NetCDF-3 file, once per simulated day.  Wall time of
+    run() / model steps.  A one-day run of the same shape goes first, untimed (the runtime's one-off costs)."""
+    import tempfile
+    from datetime import datetime, timedelta
+    import torch
+    from pyspeedy_amd.callbacks import XarrayExporter
+    from pyspeedy_amd.speedy import Speedy, SpeedyEns
+    start = datetime(1982, 1, 1)
+
+    def make(members, days):
+        end = start + timedelta(days=days)
+        if members == 1:
+            model = Speedy(start_date=start, end_date=end)
+            model.set_bc()
+            return model
+        ens = SpeedyEns(members, start_date=start, end_date=end)
+        for member in ens:  # (the reference's way; SpeedyEns.set_bc, this library's extension, loads the file once)
+            member.set_bc()
+        return ens
+
+    def timed(members, days, export):
+        model = make(members, days)
+        with tempfile.TemporaryDirectory(prefix="pyspeedy_bench_") as tmp:
+            callbacks = [XarrayExporter(output_dir=tmp)] if export else []
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model.run(callbacks=callbacks)
+            torch.cuda.synchronize()
+            seconds = time.perf_counter() - t0
+            files = [os.path.join(tmp, f) for f in os.listdir(tmp)]
+            written = sum(os.path.getsize(f) for f in files)
+        assert model.get_current_step() == 36 * days
+        del model
+        return seconds / (36 * days) * 1e3, len(files), written
+
+    out = {}
+    for key, members, days_plain, days_export in (("ens64", 64, 10, 5), ("single", 1, 10, 10)):
+        timed(members, 1, False)
+        plain, _, _ = timed(members, days_plain, False)
+        exported, files, written = timed(members, days_export, True)
+        out[key] = {"members": members, "run_ms_per_step": plain, "run_steps": 36 * days_plain,
+                    "run_daily_export_ms_per_step": exported, "run_daily_export_steps": 36 * days_export, "files_written": files,
+                    "megabytes_written": written / 1e6}
+    out["note"] = ("SpeedyEns(64).run() / Speedy().run() of the facade (pyspeedy_amd/speedy.py = the reference's classes over the C "
+                   "boundary): wall time of run() per model step, Python loop + parallel_step begin / end + range check every step; "
+                   "run_daily_export = with callbacks=[XarrayExporter()] (defaults: every 36 steps, u v t q phi ps, NetCDF-3 files)")
+    return out
+
+
+def step_contract_keys(legs, headline_ms, members_total):
+    """The scalars of drop_in_step / facade_run / projected_8gpu_cfg4 once more, flat, for `config` (readers that keep the
+    contract's objects and scalar members only)."""
+    flat = {}
+    d = legs.get("drop_in_step") or {}
+    if "sync_ms_per_step" in d:
+        n = d["containers"]
+        flat["step_contract_ms_per_step_sync_%d" % n] = d["sync_ms_per_step"]
+        flat["step_contract_ms_per_step_begin_end_%d" % n] = d["begin_end_ms_per_step"]
+        for sub in ("containers_8", "containers_1"):
+            if sub in d and d[sub]["containers"] != n:
+                flat["step_contract_ms_per_step_sync_%d" % d[sub]["containers"]] = d[sub]["sync_ms_per_step"]
+                flat["step_contract_ms_per_step_begin_end_%d" % d[sub]["containers"]] = d[sub]["begin_end_ms_per_step"]
+        flat["step_contract_note"] = ("ms_per_step is spd_model_step(m, K), K steps per call; the reference's step() contract (one call "
+                                      "per step, range check, codes back) is step_contract_ms_per_step_* over that many containers")
+    f = legs.get("facade_run") or {}
+    for key in ("ens64", "single"):
+        if key in f:
+            flat["facade_%s_run_ms_per_step" % key] = f[key]["run_ms_per_step"]
+            flat["facade_%s_run_daily_export_ms_per_step" % key] = f[key]["run_daily_export_ms_per_step"]
+    pr = legs.get("projected_8gpu_cfg4") or {}
+    for key in ("value", "speedup_over_1gpu", "efficiency"):
+        if key in pr:
+            flat["projected_8gpu_cfg4_%s" % key] = pr[key]
+    return flat
+
+
+def projection_8gpu(shard8, headline_value, headline_members, all_cores):
+    """BASELINE cfg 4 as worded (64 members, 8 per GPU on 8 GPUs), PROJECTED from one GPU: members never exchange data in a step
+    (no collective: speedy_driver.f90.j2:71-77), so each GPU steps its 8 members in cfg4_shard8.ms_per_step whatever the other
+    seven do, and the node's throughput is 64 members / that time.  Against this line's 64 members on ONE GPU."""
+    from pyspeedy_amd import ensemble as E
+    ms = shard8["ms_per_step"]
+    value = E.simulated_years_per_day(64, ms * 1e-3, STEPS_PER_YEAR)
+    one_gpu_64 = headline_value * 64.0 / headline_members  # (the headline is 64 members on one GPU unless --members said otherwise)
+    out = {"projection": True, "n_gpus": 8, "members_total": 64, "members_per_gpu": 8, "ms_per_step": ms, "value": value,
+           "unit": "simulated-years/day", "speedup_over_1gpu": value / one_gpu_64, "efficiency": value / one_gpu_64 / 8.0,
+           "note": "PROJECTED, not measured: 64 members / cfg4_shard8.ms_per_step (8 members on this GPU; the step has no collective, "
+                   "the other GPUs do not enter), against 64 members on one GPU at this line's headline rate.  Strong scaling of 64 "
+                   "members tops out here because an 8-member launch fills a fraction of a GPU (DESIGN: small shards)"}
+    if all_cores:
+        out["vs_cpu_all_cores"] = value / all_cores["value"]
+    return out
+
+
+def agreed(dist, value):
+    """rank 0's `value` on every rank (decisions about what to run must not differ between ranks that meet in collectives)"""
+    if dist is None:
+        return value
+    box = [value]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
 def one_process_leg(n_devices, members_total, steps, what):
     """The reference's own shape (speedy_driver.f90.j2:58-79, SpeedyEns.run): ONE process owns every container and hands them all
     to parallel_step.  The containers are placed in blocks on the first `n_devices` GPUs this process can see
@@ -802,14 +966,14 @@ def dominant_kernel(kernels, M, config):
     return out
 
 
-def wait_for_ranks(rank, world, what):
+def wait_for_ranks(rank, world, what, seconds=600.0):
     """A file barrier under /tmp keyed by the rendezvous port: used ONCE, before any process group exists, so that rank 0
     measures the host baseline while the other ranks have finished importing torch and sit idle."""
     import tempfile
     # (the ranks of one job are children of one launcher process: its pid keeps the files of an earlier job apart)
     base = os.path.join(tempfile.gettempdir(), "pyspeedy_bench_%s_%d_%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid(), what))
     open("%s.%d" % (base, rank), "w").close()
-    deadline = time.time() + 600.0
+    deadline = time.time() + seconds
     while time.time() < deadline:
         if all(os.path.exists("%s.%d" % (base, r)) for r in range(world)):
             if rank != 0:  # (rank 0 reads the files last: it is the one that waits for all of them)
@@ -840,19 +1004,60 @@ def file_flag(what, set_it=False, wait_seconds=0.0):
     return False
 
 
-def one_process_child(n_gpus, extra, timeout=420):
-    """`bench.py --one-process --gpus N ...` as a child process; its `one_process` object, or {"error": ...}."""
+def run_bounded_child(cmd, env, timeout):
+    """Run `cmd` to completion or for `timeout` seconds, whichever comes first; -> (returncode or None, stdout, stderr).  Unlike
+    subprocess.run(timeout=...) this never waits for a child it could not end: output goes to files, not pipes, and a child that
+    survives SIGKILL for 10 s (stuck in the kernel on a wedged GPU) is left behind."""
+    import tempfile
+    with tempfile.TemporaryFile("w+") as out, tempfile.TemporaryFile("w+") as err:
+        child = subprocess.Popen(cmd, env=env, stdout=out, stderr=err, text=True, start_new_session=True)
+        deadline = time.time() + timeout
+        while child.poll() is None and time.time() < deadline:
+            time.sleep(0.05)
+        code = child.poll()
+        if code is None:
+            child.kill()  # (exactly the process started here)
+            try:
+                child.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pass
+        out.seek(0)
+        err.seek(0)
+        return code, out.read(), err.read()
+
+
+def one_process_child(n_gpus, extra, timeout=ONE_PROCESS_TIMEOUT):
+    """`bench.py --one-process --gpus N ...` as a child process; its `one_process` object, or {"error": ...}.
+    (PYSPEEDY_AMD_BENCH_ONE_PROCESS_CMD: a command to start instead -- the tests put a child there that never answers.)"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
-                                                             "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
-    cmd = [sys.executable, os.path.abspath(__file__), "--one-process", "--gpus", str(n_gpus), "--steps", "200", "--no-cpu-baseline"]
+                                                             "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "PYSPEEDY_AMD_BENCH_T0")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--one-process", "--gpus", str(n_gpus), "--steps", "200", "--no-cpu-baseline",
+           "--budget", str(int(timeout))]
+    if os.environ.get("PYSPEEDY_AMD_BENCH_ONE_PROCESS_CMD"):
+        import shlex
+        cmd, extra = shlex.split(os.environ["PYSPEEDY_AMD_BENCH_ONE_PROCESS_CMD"]), []
     try:
-        run = subprocess.run(cmd + extra, env=env, capture_output=True, text=True, timeout=timeout)
-        lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
-        if run.returncode != 0 or len(lines) != 1:
-            return {"error": "exit code %s: %s" % (run.returncode, (run.stderr or run.stdout)[-600:])}
+        t0 = time.time()
+        code, out, err = run_bounded_child(cmd + extra, env, timeout)
+        if code is None:
+            return {"error": "no answer within %d s (the child was killed after %.1f s); the line's other objects do not depend on it"
+                             % (timeout, time.time() - t0)}
+        lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+        if code != 0 or len(lines) != 1:
+            return {"error": "exit code %s: %s" % (code, (err or out)[-600:])}
         return json.loads(lines[0])["one_process"]
-    except (OSError, ValueError, KeyError, subprocess.TimeoutExpired) as exc:
+    except (OSError, ValueError, KeyError) as exc:
         return {"error": "%s: %s" % (type(exc).__name__, exc)}
+
+
+def one_process_timeouts(budget):
+    """(timeout of the one_process child, timeout of its cfg4_strong child) for the time that is left: at most 100 + 50 s, at most
+    a third and a sixth of the budget, and 0 = do not start when less than 20 s would remain for it."""
+    left = budget.left() - 15.0  # (what the line still needs afterwards: the last barrier, printing)
+    t1 = min(ONE_PROCESS_TIMEOUT, budget.seconds / 3.0, left)
+    t2 = min(ONE_PROCESS_STRONG_TIMEOUT, budget.seconds / 6.0, left - t1)
+    floor = min(20.0, budget.seconds / 15.0)
+    return (t1 if t1 >= floor else 0.0), (t2 if t1 >= floor and t2 >= floor / 2 else 0.0)
 
 
 def run_one_process(args):
@@ -891,6 +1096,7 @@ def run_one_process(args):
 
 def run_rank(args):
     baseline = None
+    budget = Budget(args.budget)
     world_env, rank_env = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     import torch  # (importing torch does not initialise the GPU; the first import on a fresh box takes a minute or two)
     if os.environ.get("PYSPEEDY_AMD_BENCH_CPU_BASELINE"):  # measured by bench.py's launcher before it started the ranks
@@ -901,7 +1107,7 @@ def run_rank(args):
         # spawns processes: must come before the first GPU call of this process.  Under torch.distributed.run rank 0 measures
         # it while the other ranks -- torch imported, GPU untouched -- wait for it in the rendezvous of the process group.
         if world_env > 1:
-            wait_for_ranks(rank_env, world_env, "imported")
+            wait_for_ranks(rank_env, world_env, "imported", seconds=max(30.0, budget.left() - 60.0))
         if rank_env == 0:
             baseline = cpu_baseline(args.cpu_seconds)
 
@@ -967,19 +1173,30 @@ def run_rank(args):
     sp.close()
     legs = {}
     if not args.no_legs:
+        def leg(name, fn):  # a secondary object of the one-GPU line: only while the budget covers its allowance
+            legs[name] = fn() if budget.allows(name, LEG_ALLOWANCE[name]) else {"skipped": "budget"}
+
         if n_gpus == 1 and args.config == "cfg4":
-            legs["every_step_stores"] = fidelity_leg(args, M, first_id, device, dist, rank, coll_device, barrier)
-            legs["drop_in_step"] = drop_in_leg(M, 360)
-            legs["drop_in_step"].update(small_drop_in_legs(360))
+            leg("every_step_stores", lambda: fidelity_leg(args, M, first_id, device, dist, rank, coll_device, barrier))
+
+            def drop_in():
+                out = drop_in_leg(M, 360)
+                out.update(small_drop_in_legs(360))
+                return out
+            leg("drop_in_step", drop_in)
+            leg("facade_run", facade_leg)
             # the other BASELINE configs on the same clock (SURVEY 8d "Configs as concrete inputs")
-            legs["cfg2_transforms"] = transforms_leg(args, device)
-            legs["cfg3"] = config_leg(args, "cfg4", 1, "BASELINE cfg 3: one member, fp64, the full step on the GPU", device, dist, rank,
-                                      coll_device, barrier)
-            legs["cfg4_shard8"] = config_leg(args, "cfg4", 8, "BASELINE cfg 4 as worded: one GPU's share of 64 members on 8 GPUs = 8 "
-                                             "members, fp64", device, dist, rank, coll_device, barrier)
-            legs["cfg5"] = config_leg(args, "cfg5", 32, "BASELINE cfg 5: one GPU's share of 256 members on 8 GPUs = 32 members, SPPT "
-                                      "on, fp32 arithmetic in the column physics (fp64 state)", device, dist, rank, coll_device, barrier)
-        if n_gpus > 1 and args.scaling == "weak" and args.config == "cfg4" and args.members is None:
+            leg("cfg2_transforms", lambda: transforms_leg(args, device))
+            leg("cfg3", lambda: config_leg(args, "cfg4", 1, "BASELINE cfg 3: one member, fp64, the full step on the GPU", device, dist, rank,
+                                           coll_device, barrier))
+            leg("cfg4_shard8", lambda: config_leg(args, "cfg4", 8, "BASELINE cfg 4 as worded: one GPU's share of 64 members on 8 GPUs = 8 "
+                                                  "members, fp64", device, dist, rank, coll_device, barrier))
+            leg("cfg5", lambda: config_leg(args, "cfg5", 32, "BASELINE cfg 5: one GPU's share of 256 members on 8 GPUs = 32 members, SPPT "
+                                           "on, fp32 arithmetic in the column physics (fp64 state)", device, dist, rank, coll_device, barrier))
+        if n_gpus > 1 and args.scaling == "weak" and args.config == "cfg4" and args.members is None and not agreed(
+                dist, budget.allows("cfg4_strong", LEG_ALLOWANCE["cfg4_strong"])):
+            legs["cfg4_strong"] = {"skipped": "budget"}
+        elif n_gpus > 1 and args.scaling == "weak" and args.config == "cfg4" and args.members is None:
             # BASELINE cfg 4 to the letter next to the weak headline: 64 members in total, block-sharded over the ranks
             strong = argparse.Namespace(**dict(vars(args), scaling="strong", members=None))
             Ms, first_s, total_s = workload(strong, world, rank)
@@ -1004,15 +1221,26 @@ def run_rank(args):
             # pending RCCL barrier would keep a kernel spinning on the very GPUs that are being measured).
             # The measurement runs in a CHILD process of rank 0 (`bench.py --one-process`): it is ONE process by construction,
             # and whatever its first contact with a second GPU does, the headline of this line survives it.
+            # Its children get timeouts cut from what is left of the budget (at most 100 + 50 s), rank 0 decides and tells the
+            # others, and they wait exactly that long: whatever the first contact with a second GPU does inside this SECONDARY
+            # object, every rank is back in time to print the line.
+            t_child, t_strong = agreed(dist, one_process_timeouts(budget))
+            if not (args.scaling == "weak" and args.members is None):
+                t_strong = 0.0
             barrier()
-            if rank == 0:
-                op = one_process_child(n_gpus, ["--scaling", "strong", "--members", str(total_members)])
-                if "error" not in op and args.scaling == "weak" and args.members is None:
-                    op["cfg4_strong"] = one_process_child(n_gpus, ["--scaling", "strong", "--members", "64"], timeout=240)
+            if t_child <= 0:
+                legs["one_process"] = {"skipped": "budget"}
+                if rank == 0:
+                    budget.skipped.append({"leg": "one_process", "allowance_s": ONE_PROCESS_TIMEOUT, "left_s": round(budget.left(), 1)})
+            elif rank == 0:
+                op = one_process_child(n_gpus, ["--scaling", "strong", "--members", str(total_members)], timeout=t_child)
+                if "error" not in op and t_strong > 0:
+                    op["cfg4_strong"] = one_process_child(n_gpus, ["--scaling", "strong", "--members", "64"], timeout=t_strong)
+                op["timeouts_s"] = [round(t_child, 1), round(t_strong, 1)]
                 legs["one_process"] = op
                 file_flag("one_process_done", set_it=True)
             else:
-                file_flag("one_process_done", wait_seconds=700.0)
+                file_flag("one_process_done", wait_seconds=t_child + t_strong + 25.0)  # (+ the grace of two killed children)
 
     if rank == 0:
         ms_step, ms_min = median(region_s) / args.steps * 1e3, min(region_s) / args.steps * 1e3
@@ -1065,9 +1293,15 @@ def run_rank(args):
                                 "serial_plan_ms_per_step by the gaps between dependent launches",
             },
         }
+        if "ms_per_step" in (legs.get("cfg4_shard8") or {}):
+            legs["projected_8gpu_cfg4"] = projection_8gpu(legs["cfg4_shard8"], value, total_members, all_cores)
+        line["config"].update(step_contract_keys(legs, ms_step, total_members))
         line.update(legs)
+        line["budget"] = budget.record()
         if baseline is not None:
             line["cpu_baseline"] = baseline
+            if all_cores:  # (flat, beside the one-core figure: the comparison north_star asks for is against all host cores)
+                baseline["all_cores_value"], baseline["all_cores_cores"] = all_cores["value"], all_cores["cores"]
             if "cfg4_strong" in legs and all_cores:
                 legs["cfg4_strong"]["vs_cpu_all_cores"] = legs["cfg4_strong"]["value"] / all_cores["value"]
         print(json.dumps(line), flush=True)

@@ -54,6 +54,55 @@ def test_a_failing_one_process_child_costs_the_line_an_object_not_its_headline()
     assert bench.file_flag("test_flag_%d" % os.getpid(), set_it=True) and bench.file_flag("test_flag_%d" % os.getpid(), wait_seconds=1.0)
 
 
+def test_budget_arithmetic():
+    """The wall-clock budget of the line: secondary legs are refused once the remaining time does not cover their allowance, and
+    the timeouts of the one_process children never sum to more than 150 s, whatever the budget."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.parse([]).budget == 300.0 and bench.parse(["--budget", "77"]).budget == 77.0
+    import time
+    b = bench.Budget(300.0)
+    assert b.t0 == bench.T_PROCESS_START and b.left() <= 300.0  # (counted from the moment the bench module was loaded)
+    b.t0 = time.time() - 150.0
+    assert b.allows("cfg3", 10) and not b.allows("big", 200)
+    assert b.record()["skipped"] == [{"leg": "big", "allowance_s": 200, "left_s": b.skipped[0]["left_s"]}] and 148 < b.skipped[0]["left_s"] < 151
+    assert bench.ONE_PROCESS_TIMEOUT + bench.ONE_PROCESS_STRONG_TIMEOUT <= 150
+    for seconds, used in ((300, 0), (300, 100), (300, 250), (300, 290), (600, 0), (60, 10), (30, 0), (10, 9)):
+        b = bench.Budget(float(seconds))
+        b.t0 = time.time() - used
+        t1, t2 = bench.one_process_timeouts(b)
+        assert 0 <= t1 <= bench.ONE_PROCESS_TIMEOUT and 0 <= t2 <= bench.ONE_PROCESS_STRONG_TIMEOUT and t1 + t2 <= 150
+        assert t1 + t2 + 15 <= max(seconds - used, 15) + 1e-6, (seconds, used, t1, t2)  # the children end inside what is left
+        if t1 == 0:
+            assert t2 == 0
+    fresh = bench.Budget(300.0)
+    fresh.t0 = time.time()
+    assert bench.one_process_timeouts(fresh) == (100, 50)
+    spent = bench.Budget(300.0)
+    spent.t0 = time.time() - 290
+    assert bench.one_process_timeouts(spent) == (0.0, 0.0)
+    assert sum(bench.LEG_ALLOWANCE.values()) < 200  # (all legs of the default one-GPU line fit the default budget)
+
+
+def test_a_child_that_never_answers_is_cut_off():
+    """The one_process object of an N-rank line is measured by a child process.  One that never answers (here: a sleeper put in
+    its place) is ended at its timeout and comes back as {"error": ...}; the caller is not kept any longer."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    os.environ["PYSPEEDY_AMD_BENCH_ONE_PROCESS_CMD"] = "%s -c 'import time; time.sleep(600)'" % sys.executable
+    try:
+        t0 = time.time()
+        op = bench.one_process_child(8, ["--scaling", "strong"], timeout=2)
+        waited = time.time() - t0
+    finally:
+        del os.environ["PYSPEEDY_AMD_BENCH_ONE_PROCESS_CMD"]
+    assert set(op) == {"error"} and "no answer within 2 s" in op["error"], op
+    assert 1.9 <= waited < 15.0
+    code, out, err = bench.run_bounded_child([sys.executable, "-c", "print('hello'); import sys; sys.exit(3)"], dict(os.environ), 30)
+    assert code == 3 and out.strip() == "hello"
+
+
 def _result(run):
     assert run.returncode == 0, run.stdout + run.stderr
     lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
@@ -85,6 +134,31 @@ def test_bench_two_ranks_share_the_gpu():
     names = {k["kernel"] for k in weak["roofline"]["kernels"]}
     assert {"spec2grid", "column_sw", "column", "grid2spec", "spectral_step"} <= names
     assert weak["roofline"]["serial_plan_ms_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_a_hanging_one_process_child_does_not_cost_the_line():
+    """First contact with a second GPU happens in the SECONDARY legs of an N-rank line (one process over all devices: peer
+    copies, RCCL inside the library).  Here the child that measures it never answers: the 2-rank line still comes out, inside
+    its wall-clock budget, with the reason in `one_process.error`, and rank 1 has waited no longer than rank 0's timeouts."""
+    import time
+    env = dict(os.environ, PYSPEEDY_AMD_BENCH_BACKEND="gloo",
+               PYSPEEDY_AMD_BENCH_ONE_PROCESS_CMD="%s -c 'import time; time.sleep(3600)'" % sys.executable)
+    env.pop("WORLD_SIZE", None)
+    t0 = time.time()
+    res = _result(subprocess.run([sys.executable, BENCH, "--gpus", "2", "--members", "4", "--steps", "6", "--warmup", "3", "--regions", "2",
+                                  "--no-cpu-baseline", "--budget", "75"], capture_output=True, text=True, timeout=600, env=env))
+    wall = time.time() - t0
+    assert wall < 75 + 30, wall
+    assert res["n_gpus"] == 2 and res["value"] > 0 and res["roofline"]["frac"] > 0
+    op = res["one_process"]
+    assert "no answer within" in op["error"] and op["timeouts_s"][0] <= 25.0 and op["timeouts_s"][1] == 0.0
+    assert res["budget"]["budget_s"] == 75.0 and res["budget"]["used_s"] < 75.0
+    # ... and with no time left at all nothing secondary is started: the headline alone
+    res = _result(subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "6", "--warmup", "3", "--regions", "2",
+                                  "--no-cpu-baseline", "--budget", "1"], capture_output=True, text=True, timeout=600, env=env))
+    assert res["value"] > 0 and res["one_process"] == {"skipped": "budget"} and res["cfg4_strong"] == {"skipped": "budget"}
+    assert {k["leg"] for k in res["budget"]["skipped"]} == {"cfg4_strong", "one_process"}
 
 
 @pytest.mark.gpu
@@ -136,6 +210,22 @@ def test_the_one_gpu_line_carries_the_drop_in_and_every_store_legs():
     assert d["containers"] == 8 and 0 < d["begin_end_ms_per_step"] and 0 < d["sync_ms_per_step"]
     assert d["containers_1"]["containers"] == 1 and 0 < d["containers_1"]["begin_end_ms_per_step"] < d["containers_1"]["sync_ms_per_step"]
     assert d["containers_8"]["containers"] == 8 and d["containers_8"]["device_models"] == 1
+    # the reference's own entry points on the same clock, and the step() contract's figures flat in `config`
+    f = res["facade_run"]
+    for key, members in (("ens64", 64), ("single", 1)):
+        assert f[key]["members"] == members and 0 < f[key]["run_ms_per_step"] < f[key]["run_daily_export_ms_per_step"]
+        assert f[key]["files_written"] == f[key]["run_daily_export_steps"] // 36 and f[key]["megabytes_written"] > 0.7 * members * f[key]["files_written"]
+    cfg = res["config"]
+    assert cfg["step_contract_ms_per_step_sync_8"] == d["sync_ms_per_step"] and cfg["step_contract_ms_per_step_begin_end_8"] == d["begin_end_ms_per_step"]
+    assert cfg["step_contract_ms_per_step_sync_1"] == d["containers_1"]["sync_ms_per_step"]
+    assert cfg["facade_ens64_run_ms_per_step"] == f["ens64"]["run_ms_per_step"]
+    assert cfg["facade_single_run_daily_export_ms_per_step"] == f["single"]["run_daily_export_ms_per_step"]
+    pr = res["projected_8gpu_cfg4"]
+    assert pr["projection"] is True and pr["n_gpus"] == 8 and pr["ms_per_step"] == res["cfg4_shard8"]["ms_per_step"]
+    assert abs(pr["value"] - 64 * 86400.0 / (pr["ms_per_step"] * 1e-3 * 13140)) < 1e-6 * pr["value"]
+    assert abs(pr["efficiency"] * 8 - pr["speedup_over_1gpu"]) < 1e-9 and cfg["projected_8gpu_cfg4_value"] == pr["value"]
+    assert res["budget"]["skipped"] == [] and res["budget"]["used_s"] < res["budget"]["budget_s"] == 300.0
+    assert res["cpu_baseline"]["all_cores_cores"] == res["cpu_baseline"]["all_cores"]["cores"]
     e = res["every_step_stores"]
     assert e["spec2grid_per_member"] == 91 and e["ms_per_step"] > 0
     dom = res["roofline"]["dominant"]  # the fused column kernel: the largest share of the step, priced like the line's kernel
