@@ -922,7 +922,7 @@ def plan_name(cfg, M):
         return "serial: one member group on one stream"
     plan = "%d member groups of %d / %d members on %d HIP streams" % (g, (M + g - 1) // g, M // g, g)
     if cfg.get("group_streams", 0) > 1:  # (csrc/stream_apart.hpp: measured when the streams were created)
-        plan += " (measured: side by side)" if cfg["group_streams_apart"] else " (MEASURED: NOT ALL SIDE BY SIDE -- two share a hardware queue)"
+        plan += " (measured: side by side)" if cfg["group_streams_apart"] else " (NOT measured to be all side by side -- two may share a hardware queue)"
     return plan
 
 
@@ -1096,7 +1096,7 @@ def run_one_process(args):
 
 def run_rank(args):
     baseline = None
-    budget = Budget(args.budget)
+    wall = Budget(args.budget)
     world_env, rank_env = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     import torch  # (importing torch does not initialise the GPU; the first import on a fresh box takes a minute or two)
     if os.environ.get("PYSPEEDY_AMD_BENCH_CPU_BASELINE"):  # measured by bench.py's launcher before it started the ranks
@@ -1107,7 +1107,7 @@ def run_rank(args):
         # spawns processes: must come before the first GPU call of this process.  Under torch.distributed.run rank 0 measures
         # it while the other ranks -- torch imported, GPU untouched -- wait for it in the rendezvous of the process group.
         if world_env > 1:
-            wait_for_ranks(rank_env, world_env, "imported", seconds=max(30.0, budget.left() - 60.0))
+            wait_for_ranks(rank_env, world_env, "imported", seconds=max(30.0, wall.left() - 60.0))
         if rank_env == 0:
             baseline = cpu_baseline(args.cpu_seconds)
 
@@ -1174,7 +1174,7 @@ def run_rank(args):
     legs = {}
     if not args.no_legs:
         def leg(name, fn):  # a secondary object of the one-GPU line: only while the budget covers its allowance
-            legs[name] = fn() if budget.allows(name, LEG_ALLOWANCE[name]) else {"skipped": "budget"}
+            legs[name] = fn() if wall.allows(name, LEG_ALLOWANCE[name]) else {"skipped": "budget"}
 
         if n_gpus == 1 and args.config == "cfg4":
             leg("every_step_stores", lambda: fidelity_leg(args, M, first_id, device, dist, rank, coll_device, barrier))
@@ -1194,7 +1194,7 @@ def run_rank(args):
             leg("cfg5", lambda: config_leg(args, "cfg5", 32, "BASELINE cfg 5: one GPU's share of 256 members on 8 GPUs = 32 members, SPPT "
                                            "on, fp32 arithmetic in the column physics (fp64 state)", device, dist, rank, coll_device, barrier))
         if n_gpus > 1 and args.scaling == "weak" and args.config == "cfg4" and args.members is None and not agreed(
-                dist, budget.allows("cfg4_strong", LEG_ALLOWANCE["cfg4_strong"])):
+                dist, wall.allows("cfg4_strong", LEG_ALLOWANCE["cfg4_strong"])):
             legs["cfg4_strong"] = {"skipped": "budget"}
         elif n_gpus > 1 and args.scaling == "weak" and args.config == "cfg4" and args.members is None:
             # BASELINE cfg 4 to the letter next to the weak headline: 64 members in total, block-sharded over the ranks
@@ -1224,14 +1224,14 @@ def run_rank(args):
             # Its children get timeouts cut from what is left of the budget (at most 100 + 50 s), rank 0 decides and tells the
             # others, and they wait exactly that long: whatever the first contact with a second GPU does inside this SECONDARY
             # object, every rank is back in time to print the line.
-            t_child, t_strong = agreed(dist, one_process_timeouts(budget))
+            t_child, t_strong = agreed(dist, one_process_timeouts(wall))
             if not (args.scaling == "weak" and args.members is None):
                 t_strong = 0.0
             barrier()
             if t_child <= 0:
                 legs["one_process"] = {"skipped": "budget"}
                 if rank == 0:
-                    budget.skipped.append({"leg": "one_process", "allowance_s": ONE_PROCESS_TIMEOUT, "left_s": round(budget.left(), 1)})
+                    wall.skipped.append({"leg": "one_process", "allowance_s": ONE_PROCESS_TIMEOUT, "left_s": round(wall.left(), 1)})
             elif rank == 0:
                 op = one_process_child(n_gpus, ["--scaling", "strong", "--members", str(total_members)], timeout=t_child)
                 if "error" not in op and t_strong > 0:
@@ -1297,7 +1297,7 @@ def run_rank(args):
             legs["projected_8gpu_cfg4"] = projection_8gpu(legs["cfg4_shard8"], value, total_members, all_cores)
         line["config"].update(step_contract_keys(legs, ms_step, total_members))
         line.update(legs)
-        line["budget"] = budget.record()
+        line["budget"] = wall.record()
         if baseline is not None:
             line["cpu_baseline"] = baseline
             if all_cores:  # (flat, beside the one-core figure: the comparison north_star asks for is against all host cores)

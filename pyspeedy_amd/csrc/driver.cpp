@@ -498,7 +498,26 @@ int spd_modelstate_init_on(int64_t *state_cnt, int32_t device) {
 }
 
 // n containers batched from the start over k devices (k = 0: the current device); (lock held)
+static int place_ensemble(int64_t *state_cnts, int32_t n_members, int k);
+
+// All n containers, or none: an ensemble is several device models (two per device from 32 members up, one or two on every
+// device of a one-process ensemble), and creating one of the later ones may fail -- a GPU out of memory, a device that does
+// not answer.  The containers of the models made before it are closed again (their device models go with them, the memory
+// returns to the context), every entry of state_cnts is 0, and the caller gets the error of the model that failed.
 static int init_ensemble(int64_t *state_cnts, int32_t n_members, int k) {
+    for (int i = 0; i < n_members; ++i) state_cnts[i] = 0;
+    const int rc = place_ensemble(state_cnts, n_members, k);
+    if (rc == SPD_OK) return rc;
+    const std::string why = spd_last_error();
+    regrouped();  // (no kept plan may hold on to a model that is about to go)
+    for (int i = 0; i < n_members; ++i) {
+        if (state_cnts[i]) g_states.erase(state_cnts[i]);
+        state_cnts[i] = 0;
+    }
+    return fail(rc, why);
+}
+
+static int place_ensemble(int64_t *state_cnts, int32_t n_members, int k) {
     if (k <= 1) {
         int dev = 0;
         if (k == 0) {

@@ -14,7 +14,9 @@
 
 namespace spd {
 constexpr int kApartTries = 4;
-// flags: hipStreamDefault or hipStreamNonBlocking.  *apart (may be null): whether the stream overlapped with all of `others` in
-// the end.  The current device must be the streams' device; a stream of `others` that is busy is not measured against.
+// flags: hipStreamDefault or hipStreamNonBlocking.  *apart (may be null): whether the stream was MEASURED to overlap with every one
+// of `others` in the end -- false also when one of them was busy and could not be measured against (it is not made to wait),
+// or when the measurement is switched off (PYSPEEDY_AMD_STREAMS_APART=0): nothing is claimed that was not seen.  The current
+// device must be the streams' device.  Durations come from HIP events on the streams, not from the host's clock.
 hipError_t create_stream_apart(hipStream_t *out, const hipStream_t *others, int n_others, unsigned flags, bool *apart = nullptr);
 }  // namespace spd

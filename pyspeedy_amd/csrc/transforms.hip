@@ -45,6 +45,8 @@ constexpr int kCStride = 63;                    // compact row: positions 0..60 
 constexpr int kCBufDoubles = kRows * kCStride;  // 3024 doubles = 24 192 B
 constexpr int kSpecPerLane = (NSPEC + kThreads - 1) / kThreads;      // 2 x 16 B per lane stage a spectral field
 constexpr int kGridPerLane = (NGRID / 2 + kThreads - 1) / kThreads;  // 5 x 16 B per lane stage a grid field
+constexpr int kPlanePerLane = (kRows * MX + kThreads - 1) / kThreads;  // 3 x 16 B per lane stage a Fourier plane (Legendre stage alone)
+constexpr int kHalfPlanePerLane = (IY * MX + kThreads - 1) / kThreads; // 2 x (16 + 16) B per lane: a wavenumber of a latitude and its mirror
 constexpr int kInvLanes = MX * 12;              // inverse Legendre tasks: (m, pair-of-latitude-pairs)
 constexpr size_t kLdsBytes = (kCBufDoubles + 2 * NSPEC) * sizeof(double);  // 40 064
 static_assert(kRows * kRowStride <= kCBufDoubles + 2 * NSPEC, "R must fit inside C + S");
@@ -196,11 +198,22 @@ __device__ __forceinline__ void spec2grid_body(const double *__restrict__ src, d
     }
 
     if (ST == Stage::LegendreOnly) {
-        double *g = dst;
-        for (int idx = tid; idx < NFOUR; idx += kThreads) {
-            const int row = idx / 62, r = idx - row * 62;
-            g[idx] = cbuf[row * kCStride + (r == 0 ? 0 : (r == 1 ? 61 : r - 1))];
+        // the Fourier plane (62, 48) leaves 16 B per lane = one zonal wavenumber (re, im) of one latitude, coalesced, all of a
+        // lane's LDS reads before its first store, past the L2 like every output a later kernel consumes
+        gd2_out g = (gd2_out)dst;
+        d2 v[kPlanePerLane];
+#pragma unroll
+        for (int it = 0; it < kPlanePerLane; ++it) {
+            const int item = tid + it * kThreads;
+            if (item < kRows * MX) {
+                const int row = item / MX, m = item - row * MX;
+                const double *c = cbuf + row * kCStride;
+                v[it] = d2{c[pos_re(m)], c[pos_im(m)]};
+            }
         }
+#pragma unroll
+        for (int it = 0; it < kPlanePerLane; ++it)
+            if (tid + it * kThreads < kRows * MX) __builtin_nontemporal_store(v[it], &g[tid + it * kThreads]);
         return;
     }
 
@@ -422,10 +435,41 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
         __syncthreads();
         TRACE_MARK(1, 2);
     } else {
-        const double *g = src;
-        for (int idx = tid; idx < NFOUR; idx += kThreads) {
-            const int r0 = idx / 62, r = idx - r0 * 62;
-            cbuf[r0 * kCStride + (r == 0 ? 0 : (r == 1 ? 61 : r - 1))] = g[idx];
+        // The Legendre stage on its own: the Fourier plane (62, 48) comes in 16 B per lane = one zonal wavenumber (re, im) of one
+        // latitude; the lane fetches the same wavenumber of the mirrored latitude with it and stores step 1 of the direct
+        // transform (legendre.f90:190-199): north row <- symmetric part, south row <- antisymmetric part, both times the
+        // Gaussian weight -- as the fused kernel does while it loads the grid.  All loads of a lane before its first LDS store.
+        gd2_in g = (gd2_in)src;
+        d2 nv[kHalfPlanePerLane], sv[kHalfPlanePerLane];
+        double w[kHalfPlanePerLane];
+#pragma unroll
+        for (int it = 0; it < kHalfPlanePerLane; ++it) {
+            const int item = tid + it * kThreads;
+            if (item < IY * MX) {
+                const int j = item / MX, m = item - j * MX;
+#ifdef SPD_LEG_PLAIN_LOAD
+                nv[it] = g[(kRows - 1 - j) * MX + m];
+                sv[it] = g[j * MX + m];
+#else
+                nv[it] = __builtin_nontemporal_load(&g[(kRows - 1 - j) * MX + m]);
+                sv[it] = __builtin_nontemporal_load(&g[j * MX + m]);
+#endif
+                w[it] = T.wt[j];
+            }
+        }
+        for (int idx = tid; idx < NSPEC; idx += kThreads) s[idx] = d2{0.0, 0.0};  // (step 2 only writes what the reference fills)
+#pragma unroll
+        for (int it = 0; it < kHalfPlanePerLane; ++it) {
+            const int item = tid + it * kThreads;
+            if (item < IY * MX) {
+                const int j = item / MX, m = item - j * MX;
+                const int pr = pos_re(m), pi = pos_im(m);
+                double *rn = cbuf + (kRows - 1 - j) * kCStride, *rs = cbuf + j * kCStride;
+                rn[pr] = (nv[it].x + sv[it].x) * w[it];
+                rs[pr] = (nv[it].x - sv[it].x) * w[it];
+                rn[pi] = (nv[it].y + sv[it].y) * w[it];
+                rs[pi] = (nv[it].y - sv[it].y) * w[it];
+            }
         }
         __syncthreads();
     }
@@ -440,24 +484,8 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
     }
 
     // ---- direct Legendre (legendre.f90:175-221) ----
-    // step 1 (Legendre stage on its own only; the fused kernel formed the two parts while it loaded the grid), in place:
-    // north row <- symmetric part, south row <- antisymmetric part, both times the Gaussian weight; the output staging area is
-    // cleared, step 2 only writes the coefficients the reference fills
-    if (ST == Stage::LegendreOnly) {
-        for (int idx = tid; idx < NSPEC; idx += kThreads) s[idx] = d2{0.0, 0.0};
-        for (int idx = tid; idx < MX * IY; idx += kThreads) {
-            const int j = idx / MX, m = idx - j * MX;
-            const int pr = pos_re(m), pi = pos_im(m);
-            double *rn = cbuf + (kRows - 1 - j) * kCStride, *rs = cbuf + j * kCStride;
-            const double w = T.wt[j];
-            const double nr = rn[pr], sr = rs[pr], ni = rn[pi], si = rs[pi];
-            rn[pr] = (nr + sr) * w;
-            rs[pr] = (nr - sr) * w;
-            rn[pi] = (ni + si) * w;
-            rs[pi] = (ni - si) * w;
-        }
-        __syncthreads();
-    }
+    // (step 1 -- north row <- symmetric part, south row <- antisymmetric part, both times the Gaussian weight -- happened while
+    // the input was staged, in both forms of the kernel)
     TRACE_MARK(1, 3);
     // step 2: lane = (m, parity, two valid n of that parity) from the work list of the context (capi.hip: dir_lanes);
     // sum over the 24 latitude pairs in reference order

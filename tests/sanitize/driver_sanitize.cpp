@@ -230,6 +230,29 @@ void single_thread() {
         EXPECT(entered->load() == 2);
         std::this_thread::sleep_for(std::chrono::milliseconds(20));  // (the thread's last lines run after the counter moved)
     }
+    // ---- an ensemble whose LATER device model cannot be created (a GPU out of memory): all containers or none.  40 members on
+    // one device are two device models, 12 over two devices one per device; the second creation fails -- the first model is
+    // given back, every container id of the call is 0, the error is the allocation's, and the next ensemble comes up as usual.
+    {
+        const int before = models_alive();
+        std::vector<int64_t> ens(40, -1);
+        stub_fail_model_create_in(2);
+        EXPECT(spd_modelstate_init_ensemble(ens.data(), 40) == SPD_E_DEVICE);
+        EXPECT(std::string(spd_last_error()).find("out of memory") != std::string::npos);
+        for (int64_t c : ens) EXPECT(c == 0);
+        EXPECT(models_alive() == before);
+        std::vector<int64_t> two(12, -1);
+        stub_fail_model_create_in(2);
+        EXPECT(spd_modelstate_init_ensemble_on(two.data(), 12, 2) == SPD_E_DEVICE);
+        for (int64_t c : two) EXPECT(c == 0);
+        EXPECT(models_alive() == before);
+        stub_fail_model_create_in(1);
+        int64_t single = -1;
+        EXPECT(spd_modelstate_init(&single) == SPD_E_DEVICE && models_alive() == before);
+        EXPECT(spd_modelstate_init_ensemble(ens.data(), 40) == 0 && models_alive() == before + 2);
+        for (int64_t c : ens) EXPECT(c > 0 && spd_modelstate_close(c) == 0);
+        EXPECT(models_alive() == before);
+    }
     // ---- uninitialised containers step with code -1 and keep their date
     {
         std::vector<Member *> ms = {&m[0], &m[1]};

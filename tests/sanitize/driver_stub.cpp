@@ -30,6 +30,7 @@ std::atomic<int> g_check_delay_us{0};
 std::atomic<int> g_fail_next_check_begin{0};
 std::atomic<long> g_device_syncs{0}, g_peer_copies{0}, g_local_copies{0}, g_collectives{0};
 std::atomic<int> g_collective_available{1};
+std::atomic<int> g_fail_model_create_in{0};  // n > 0: the n-th spd_model_create from now fails as a hipMalloc out of memory does
 thread_local int t_device = 0;
 thread_local std::string t_error;
 }  // namespace
@@ -42,6 +43,7 @@ long stub_peer_copies() { return g_peer_copies.load(); }
 long stub_local_copies() { return g_local_copies.load(); }
 long stub_collectives() { return g_collectives.load(); }
 void stub_set_collective_available(int yes) { g_collective_available = yes; }
+void stub_fail_model_create_in(int n) { g_fail_model_create_in = n; }
 int stub_current_device() { return t_device; }
 void stub_set_current_device(int d) { t_device = d; }
 
@@ -150,6 +152,8 @@ long spd_get_table_host(spd_handle, const char *name, double *buf, size_t n) {
 
 int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
     if (!h || !out || nmembers < 1) return spd_set_error(SPD_E_ARG, "spd_model_create: bad argument");
+    if (g_fail_model_create_in.load() > 0 && g_fail_model_create_in.fetch_sub(1) == 1)
+        return spd_set_error(SPD_E_DEVICE, "hipMalloc(&p, size): out of memory (injected)");
     spd_model *m = new spd_model();
     m->device = h->device;
     m->M = nmembers;

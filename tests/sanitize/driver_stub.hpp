@@ -11,6 +11,7 @@ long stub_device_syncs();
 long stub_peer_copies();
 long stub_local_copies();
 long stub_collectives();                      // collective broadcasts between device models
+void stub_fail_model_create_in(int n);  // the n-th spd_model_create from now fails like a hipMalloc that is out of memory (0: none)
 void stub_set_collective_available(int yes);  // 0: spd_model_broadcast_vars fails as it does when RCCL cannot be loaded; 1: it works;
                                               // 2: as when ncclCommInitAll does not come back inside its bound (SPD_E_DEVICE, nothing
                                               // enqueued); 3: as when the broadcast does not complete inside its bound (SPD_E_TIMEOUT)

@@ -651,3 +651,37 @@ def test_collective_broadcast_between_device_models_reaches_rccl(spectral, bc):
     assert L.spd_model_broadcast_vars((C.c_void_p * 1)(a._m), (C.c_int * 1)(0), 1, 0, bad, 1) < 0
     a.close()
     b.close()
+
+
+def test_an_ensemble_that_does_not_fit_is_refused_whole():
+    """An ensemble is several device models (two from 32 members of a device up).  Here it is sized from the free memory of the GPU
+    so that the FIRST model fits and the second cannot (model.hip: arena_alloc, 19 MB per member in one hipMalloc): the call fails
+    with the allocation's error, no container of it exists (every id 0), the first model's memory is back, and the next ensemble
+    comes up and steps.  (The all-or-nothing logic itself runs under ASan / LeakSanitizer with an injected failure:
+    tests/sanitize/driver_sanitize.cpp.)"""
+    import torch
+    from pyspeedy_amd import speedy_driver as drv
+    L = drv._L()
+    torch.cuda.synchronize()
+    alive0, _ = drv.driver_stats()
+    free0, total = torch.cuda.mem_get_info()
+    per_member = 19 << 20
+    n = int(1.3 * free0 / per_member)  # two models of 0.65 x the free memory each
+    assert n >= 64 and (n // 2) * per_member < 0.8 * free0
+    arr = (C.c_int64 * n)(*([-1] * n))
+    rc = L.spd_modelstate_init_ensemble(arr, n)
+    assert rc == -2, rc  # SPD_E_DEVICE
+    message = L.spd_last_error().decode()
+    assert "hipMalloc" in message and "memory" in message.lower(), message
+    assert not any(arr)
+    assert drv.driver_stats()[0] == alive0
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 > free0 - (2 << 30), (free0, free1)  # (a context keeps up to 1 GiB of released blocks for the next model)
+    from datetime import datetime
+    from pyspeedy_amd.speedy import SpeedyEns
+    ens = SpeedyEns(40, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 1, 2, 0))
+    ens.set_bc()
+    ens.run()
+    assert ens.get_current_step() == 3 and drv.driver_stats()[0] == alive0 + 2
+    del ens

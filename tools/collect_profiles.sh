@@ -41,6 +41,13 @@ for st in 1 0; do
   python3 $R/tools/pmc_summary.py $OUT/pmc5_$st $OUT/${TAG}_pmc_cfg5_storage32_$st.json "PYSPEEDY_AMD_PHYS_STORE32=$st python3 bench.py --config cfg5 $PMC (32 members)" 8
 done
 unset PYSPEEDY_AMD_PHYS_STORE32
+# the Legendre stage on its own at 16 384 fields (north_star's literal target): kernel stats, then the two PMC passes
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/leg -o run -- python3 $R/tools/perf_legendre_only.py > $OUT/${TAG}_legendre_only.txt 2>&1
+cp $OUT/leg/run_kernel_stats.csv $OUT/${TAG}_legendre_only_kernel_stats.csv
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmcleg/fetch -o run -- python3 $R/tools/perf_legendre_only.py 16384 20 > $OUT/pmcleg_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmcleg/write -o run -- python3 $R/tools/perf_legendre_only.py 16384 20 > $OUT/pmcleg_write.log 2>&1
+python3 $R/tools/pmc_summary.py $OUT/pmcleg $OUT/${TAG}_pmc_legendre_only.json "python3 tools/perf_legendre_only.py 16384 20 (16 384 fields per launch)" 5
+rm -rf $OUT/leg/run_kernel_trace.csv $OUT/pmcleg
 rm -rf $OUT/k64/run_kernel_trace.csv $OUT/k8/run_kernel_trace.csv $OUT/k1/run_kernel_trace.csv $OUT/k32c5/run_kernel_trace.csv $OUT/pmc/fetch $OUT/pmc/write $OUT/pmc5_0 $OUT/pmc5_1
 python3 $R/tools/copy_rate.py > $OUT/${TAG}_device_copy_rate.txt 2>&1 || true
 echo "all done"
