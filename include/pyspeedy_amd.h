@@ -194,10 +194,10 @@ int spd_model_check_end(spd_model_handle m, int slot, int32_t *error_codes_host)
  * state first -- spd_model_set, the export transforms, member copies, a call of several steps in member groups, spd_model_check_end
  * itself -- makes it a launch of its own there and then.  Returns the slot for spd_model_check_end. */
 int spd_model_check_defer(spd_model_handle m, int time_level, void *stream);
-/* launches a check put off by spd_model_check_defer now, if it is still waiting for a step to carry it: afterwards
- * spd_model_check_end of its slot is a pure wait (a host may then make that call outside the lock it serialises its other calls
- * on this model with) */
-int spd_model_check_settle(spd_model_handle m);
+/* launches the check spd_model_check_defer put off under `slot` (-1: whichever one is waiting) now, if it is still waiting for a
+ * step to carry it; a check put off under another slot keeps waiting for its step.  Afterwards spd_model_check_end of that slot
+ * is a pure wait (a host may then make that call outside the lock it serialises its other calls on this model with) */
+int spd_model_check_settle(spd_model_handle m, int slot);
 /* how many of the model's begun / deferred range checks went out as launches of their own and how many rode in a step's launch */
 int spd_model_check_counts(spd_model_handle m, int32_t *alone, int32_t *rode);
 int spd_model_checks_in_flight(spd_model_handle m); /* 0, 1 or 2: checks begun and not yet ended */

@@ -102,7 +102,7 @@ _SIGNATURES = {
     "spd_model_check_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "spd_model_check_end": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "spd_model_check_defer": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
-    "spd_model_check_settle": (C.c_int, [C.c_void_p]),
+    "spd_model_check_settle": (C.c_int, [C.c_void_p, C.c_int]),
     "spd_model_check_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "spd_model_init": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
     "spd_model_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

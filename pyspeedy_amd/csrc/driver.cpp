@@ -1064,7 +1064,7 @@ static void settle_deferred(const GroupPlan &g, GroupRun &r) {
     Batch &b = *g.batch;
     int rc = SPD_OK;
     if (!drvdev::set_device(b.device)) rc = fail(SPD_E_DEVICE, "speedy driver: hipSetDevice failed");
-    if (rc == SPD_OK) rc = spd_model_check_settle(b.model);
+    if (rc == SPD_OK) rc = spd_model_check_settle(b.model, r.slot);  // (only THIS step's check: the next one's waits for its step)
     if (rc != SPD_OK) {  // (collect_group still ends the slot; its codes no longer count)
         r.rc = rc;
         r.error = spd_last_error();

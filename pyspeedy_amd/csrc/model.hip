@@ -163,6 +163,9 @@ struct spd_model {
     int phys_fp32 = 0;
     bool phys_store32 = true;  // option physics_storage32 / PYSPEEDY_AMD_PHYS_STORE32: 0 keeps fp64 storage under the fp32 physics
     bool stored32 = false;     // how the RegEntry::f32 arrays are stored right now (= phys_fp32 && phys_store32)
+    // A change of that storage converts the arrays in place, one by one; a device error in the middle leaves some of them
+    // converted and `stored32` unable to say which.  The model then refuses every call that would read or advance its state.
+    std::string poisoned;
     // Dead-store elimination inside multi-step calls (PYSPEEDY_AMD_DIAG_EVERY_STEP=1 switches it off): only the LAST step
     // of a spd_model_step call stores the physics outputs that no later kernel reads -- the host can only look at the
     // state between calls, and every earlier value would be overwritten before that.
@@ -199,6 +202,10 @@ LaunchEvents &pending_launch_events() {
 }  // namespace spd
 
 static int m_fail(int code, const std::string &msg) { return spd_set_error(code, msg); }
+static int usable(const spd_model *m, const char *who) {
+    if (m->poisoned.empty()) return SPD_OK;
+    return m_fail(SPD_E_DEVICE, std::string(who) + ": this model is unusable: " + m->poisoned);
+}
 static int apply_storage(spd_model *m, bool want32);  // (with spd_model_set_physics_precision)
 static int settle_deferred_check(spd_model *m);        // (with spd_model_check_defer)
 
@@ -700,6 +707,7 @@ static int xfer(spd_model_handle m, const char *name, int member, void *host, si
     if (bytes != e.bytes_member)
         return m_fail(SPD_E_SIZE, std::string("spd_model_get/set: '") + name + "' needs exactly " + std::to_string(e.bytes_member) + " bytes per member");
     if (member < -1 || member >= m->M) return m_fail(SPD_E_ARG, "spd_model_get/set: member index out of range");
+    if (int rc = usable(m, "spd_model_get/set")) return rc;
     if (member == -1 && !to_device) return m_fail(SPD_E_ARG, "spd_model_get: member = -1 (broadcast) is only valid for set");
     M_HIP(hipSetDevice(m->ctx->device));
     if (to_device)  // (a range check that was put off looks at the state as it is NOW)
@@ -1075,11 +1083,13 @@ int spd_model_check_defer(spd_model_handle m, int time_level, void *stream) {
     return slot;
 }
 
-// Launch a check that spd_model_check_defer put off, now, if one is still waiting for a step to ride in.  After this call
+// Launch the check that spd_model_check_defer put off under `slot` (-1: whichever is waiting), now, if it is still waiting for a
+// step to ride in -- a check put off under ANOTHER slot is left waiting for its step.  After this call
 // spd_model_check_end of that slot only waits and reads: it changes nothing another host thread could be looking at, so a host
 // may call it without the lock it serialises its other calls on this model with (csrc/driver.cpp does).
-int spd_model_check_settle(spd_model_handle m) {
+int spd_model_check_settle(spd_model_handle m, int slot) {
     if (!m) return m_fail(SPD_E_ARG, "spd_model_check_settle: null model");
+    if (slot >= 0 && !(m->deferred.active && m->deferred.slot == slot)) return SPD_OK;  // (that one is out already, or rides)
     return settle_deferred_check(m);
 }
 
@@ -1159,6 +1169,7 @@ static int couple(spd_model *m, int day, hipStream_t s) { return couple_range(m,
 // orog, fmask_orig, alb0, veg_high, veg_low, stl12, snowd12, soil_wc_l1, soil_wc_l2, sst12, sea_ice_frac12 [, sst_anom].
 int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, int minute, void *stream) {
     if (!m) return m_fail(SPD_E_ARG, "spd_model_init: null model");
+    if (int rc = usable(m, "spd_model_init")) return rc;
     if (month < 1 || month > 12 || day < 1 || day > 31) return m_fail(SPD_E_ARG, "spd_model_init: bad start date");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int M = m->M;
@@ -1237,6 +1248,7 @@ int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, i
 // diagnostics.f90 is available separately through spd_model_check (the reference runs it after every step).
 int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
     if (!m) return m_fail(SPD_E_ARG, "spd_model_step: null model");
+    if (int rc = usable(m, "spd_model_step")) return rc;
     if (!m->initialized) return m_fail(SPD_E_ARG, "spd_model_step: model state not initialized (error code -1 of the reference)");
     if (!m->dyn) return m_fail(SPD_E_ARG, "spd_model_step: call spd_model_set_time_step first");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1394,6 +1406,7 @@ int spd_model_profile_read_kernels(spd_model_handle m, double *mean_ms, double *
 
 int spd_model_mark_initialized(spd_model_handle m, int current_step, int year, int month, int day, int hour, int minute) {
     if (!m) return m_fail(SPD_E_ARG, "spd_model_mark_initialized: null model");
+    if (int rc = usable(m, "spd_model_mark_initialized")) return rc;
     m->cal.set(year, month, day, hour, minute);
     m->current_step = current_step;
     m->surf_cache_valid = false;
@@ -1425,6 +1438,7 @@ int spd_model_get_control(spd_model_handle m, spd_model_control *out) {
 
 int spd_model_set_control(spd_model_handle m, const spd_model_control *in) {
     if (!m || !in) return m_fail(SPD_E_ARG, "spd_model_set_control: null argument");
+    if (int rc = usable(m, "spd_model_set_control")) return rc;
     if (in->month < 1 || in->month > 12 || in->day < 1 || in->day > 31 || in->month_idx < 1 || in->current_step < 0)
         return m_fail(SPD_E_ARG, "spd_model_set_control: bad date, month index or step counter");
     if (in->sppt_on && !m->sppt_spec)
@@ -1497,29 +1511,41 @@ int spd_model_set_option(spd_model_handle m, const char *name, int32_t value) {
 // bring the storage of the RegEntry::f32 arrays in line with what the model's settings ask for
 static int apply_storage(spd_model *m, bool want32) {
     if (want32 == m->stored32) return SPD_OK;
+    if (int rc = usable(m, "spd_model_set_physics_precision")) return rc;
     const int fp32 = want32 ? 1 : 0;
     // the arrays only the column physics reads back change their storage with its arithmetic: converted here, once (values
     // that came out of the fp32 physics are fp32 numbers already; what the fp64 physics left is rounded as that kernel's loads
     // would have rounded it)
     M_HIP(hipSetDevice(m->ctx->device));
     M_HIP(hipDeviceSynchronize());
+    // everything that can fail WITHOUT having touched an array comes first: the descriptor tables of the fp32 layout, the scratch
+    if (want32)
+        if (int rc = ensure_tables32(m)) return rc;
     size_t largest = 0;
     for (const auto &kv : m->reg)
         if (kv.second.f32) largest = std::max(largest, kv.second.bytes_member * static_cast<size_t>(m->M));
     void *scratch = nullptr;
     M_HIP(hipMalloc(&scratch, largest));
     hipError_t e = hipSuccess;
+    int converted = 0;
     for (const auto &kv : m->reg) {
         if (!kv.second.f32 || e != hipSuccess) continue;
         const long n = static_cast<long>(kv.second.bytes_member / sizeof(double)) * m->M;
         e = run_change_storage(static_cast<double *>(kv.second.ptr), n, fp32 != 0, scratch, nullptr);
+        ++converted;
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     (void)hipFree(scratch);
-    if (e != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_set_physics_precision: ") + hipGetErrorString(e));
-    m->stored32 = want32;
-    if (want32)
-        if (int rc = ensure_tables32(m)) return rc;
+    if (e != hipSuccess) {
+        // some arrays are in the new format, some in the old, and nothing records which: the state cannot be read any more
+        if (converted > 0) {
+            m->initialized = false;
+            m->poisoned = std::string("a device error (") + hipGetErrorString(e) + ") interrupted the change of its fp32 / fp64 storage; "
+                          "create and initialise a new model";
+        }
+        return m_fail(SPD_E_DEVICE, std::string("spd_model_set_physics_precision: ") + hipGetErrorString(e));
+    }
+    m->stored32 = want32;  // (only now: every array is in the new format)
     return SPD_OK;
 }
 
@@ -1643,6 +1669,8 @@ int spd_model_copy_member(spd_model_handle dst, int di, spd_model_handle src, in
     if (!dst || !src) return m_fail(SPD_E_ARG, "spd_model_copy_member: null model");
     if (di < 0 || di >= dst->M || si < 0 || si >= src->M) return m_fail(SPD_E_ARG, "spd_model_copy_member: member index out of range");
     if (dst->ctx->device != src->ctx->device) return m_fail(SPD_E_ARG, "spd_model_copy_member: models live on different devices");
+    if (int rc = usable(dst, "spd_model_copy_member")) return rc;
+    if (int rc = usable(src, "spd_model_copy_member")) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     M_HIP(hipSetDevice(dst->ctx->device));
     if (int rc = settle_deferred_check(dst)) return rc;

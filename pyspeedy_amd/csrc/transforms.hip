@@ -447,13 +447,10 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
             const int item = tid + it * kThreads;
             if (item < IY * MX) {
                 const int j = item / MX, m = item - j * MX;
-#ifdef SPD_LEG_PLAIN_LOAD
+                // (plain loads: with the streaming hint the same kernel is 20 % slower while its input still sits in the 256 MB
+                // Infinity Cache -- batches up to 4096 fields -- and no faster beyond, profiles/r05_legendre_only.txt)
                 nv[it] = g[(kRows - 1 - j) * MX + m];
                 sv[it] = g[j * MX + m];
-#else
-                nv[it] = __builtin_nontemporal_load(&g[(kRows - 1 - j) * MX + m]);
-                sv[it] = __builtin_nontemporal_load(&g[j * MX + m]);
-#endif
                 w[it] = T.wt[j];
             }
         }

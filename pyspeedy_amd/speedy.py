@@ -51,12 +51,15 @@ def _add_months(date, months):
 
 
 _last_file = [None, None]  # (path, mtime, size) and the fields of the file read last
+_CACHE_LIMIT_BYTES = 32 << 20  # a boundary-condition file is 7 MB as float64; a multi-decade SST-anomaly record is not kept
 
 
 def _load_fields(source):
-    """Mapping name -> array from an .npz file, a NetCDF-3 file, a Dataset or a plain mapping.  The file read last is kept
-    (read-only arrays): the reference's `for member in ens: member.set_bc()` reads the same file once per member, and
-    decompressing it costs more than everything else a member's set_bc does."""
+    """Mapping name -> array from an .npz file, a NetCDF-3 file, a Dataset or a plain mapping.  A FILE's arrays come back as
+    float64 in Fortran order and READ-ONLY (this module only copies them into state containers).  The file read last is kept
+    while it is small (a boundary-condition file: the reference's `for member in ens: member.set_bc()` reads the same file once
+    per member, and decompressing it costs more than everything else a member's set_bc does); anything larger than
+    _CACHE_LIMIT_BYTES -- an SST-anomaly record -- is read again when it is asked for again and pins no host memory."""
     if isinstance(source, (str, os.PathLike)):
         if not os.path.isfile(source):
             raise RuntimeError("The boundary conditions file does not exist.\nFile: %s" % source)
@@ -73,7 +76,10 @@ def _load_fields(source):
         fields = {k: np.asfortranarray(v, dtype=np.float64) if v.dtype.kind == "f" else v for k, v in fields.items()}
         for v in fields.values():
             v.setflags(write=False)
-        _last_file[0], _last_file[1] = key, fields
+        if sum(v.nbytes for v in fields.values()) <= _CACHE_LIMIT_BYTES:
+            _last_file[0], _last_file[1] = key, fields
+        elif _last_file[0] is not None and _last_file[0][0] == key[0]:
+            _last_file[0], _last_file[1] = None, None
         return dict(fields)
     if isinstance(source, Dataset):
         return {k: v.values for k, v in source.variables.items()}

@@ -346,10 +346,12 @@ int spd_model_check_defer(spd_model_handle m, int time_level, void *stream) {
     return slot;
 }
 
-int spd_model_check_settle(spd_model_handle m) {
-    if (!m) return spd_set_error(SPD_E_ARG, "spd_model_check_settle: null model");
-    Inside guard(m);
-    m->unsettled[0] = m->unsettled[1] = false;
+int spd_model_check_settle(spd_model_handle m, int slot) {
+    if (!m || slot > 1) return spd_set_error(SPD_E_ARG, "spd_model_check_settle: bad argument");
+    if (slot >= 0 && !m->unsettled[slot].load()) return SPD_OK;  // (out already: nothing to do inside the model)
+    const bool other = slot >= 0 && m->unsettled[1 - slot].load();
+    Inside guard(m);  // (entering the model settles both in the stub; the real one leaves the other slot's check waiting)
+    if (other) m->unsettled[1 - slot] = true;
     return SPD_OK;
 }
 

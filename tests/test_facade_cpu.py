@@ -188,3 +188,26 @@ def test_dataset_reductions_of_the_references_ensemble_notebook():
     low = ds.std(dim="ens").apply(np.sqrt).isel(lev=0)
     assert low["t"].dims == ("time", "lat", "lon") and np.allclose(low["t"].values, np.sqrt(t.astype(np.float64).std(axis=1))[:, 0])
     assert low["ps"].dims == ("time", "lat", "lon")
+
+
+def test_file_loader_keeps_small_files_only(tmp_path):
+    """speedy._load_fields: the boundary file read last is kept (the reference's per-member set_bc re-reads it), a large record -- an
+    SST-anomaly file -- is not, so that it pins no host memory after set_bc; arrays from files are float64, Fortran order, read-only."""
+    from pyspeedy_amd import speedy as S
+    small = S._load_fields(S.example_bc_file())
+    assert S._last_file[0] is not None and S._last_file[0][0] == os.path.realpath(S.example_bc_file())
+    again = S._load_fields(S.example_bc_file())
+    assert again["orog"] is small["orog"] and small["orog"].dtype == np.float64 and small["orog"].flags.f_contiguous
+    assert not small["orog"].flags.writeable
+    with pytest.raises(ValueError):
+        small["orog"][0, 0] = 1.0
+    big = tmp_path / "ssta_record.npz"
+    months = S._CACHE_LIMIT_BYTES // (96 * 48 * 8) + 8
+    np.savez(big, ssta=np.zeros((96, 48, months), dtype=np.float32), time=np.arange(months).astype("datetime64[M]").astype("datetime64[s]"))
+    rec = S._load_fields(str(big))
+    assert rec["ssta"].shape == (96, 48, months) and rec["ssta"].dtype == np.float64
+    assert S._last_file[0][0] == os.path.realpath(S.example_bc_file())  # (the small file is still the one that is kept)
+    assert S._load_fields(str(big))["ssta"] is not rec["ssta"]
+    assert S._load_fields({"a": 1}) == {"a": 1}
+    with pytest.raises(RuntimeError):
+        S._load_fields(str(tmp_path / "missing.npz"))
