@@ -273,18 +273,13 @@ def _reference_member():
     except (OSError, AttributeError):
         import oracle as orc
         orc.build()
-        g = np.load(os.path.join(ROOT, "tests", "golden", "step.npz"))
-        arr = {k[3:]: g[k] for k in g.files if k.startswith("s0_")}
-        arr["tcorh"], arr["qcorh"] = g["tab_tcorh"], g["tab_qcorh"]
-        st = orc.ModelState(arr, True, float(g["air_absortivity_co2"]))
-        d = orc.dyn_tables(2 * 2400.0)
-        count = [0]
+        m = orc.Model(n_months=12)  # the whole model restated in C (oracle/orc_model.c), bitwise the reference's trajectory
+        m.set_bc(bc)
+        assert m.init(1982, 1, 1) == 0
 
         def step():
-            st.set_shortwave(count[0] % 3 == 0)
-            orc.step(st, d, 2, 2, 2 * 2400.0)
-            count[0] += 1
-        return step, "port", "C port (oracle/liboracle.so) of time_stepping.f90 step incl. transforms and physics"
+            assert m.step() == 0
+        return step, "port", "C port (oracle/liboracle.so) of do_single_step: the whole model, bit for bit the reference's results"
 
 
 def _time_member(step, seconds, t_start=None):
@@ -761,7 +756,7 @@ def facade_leg():
     `SpeedyEns(64)` with `for member in ens: member.set_bc()` and `ens.run(callbacks)`, and `Speedy().set_bc(); run(callbacks)` --
     the Python time loop, one parallel_step per model step with its range check, and (second figure) the default daily
     XarrayExporter: u, v, t, q, phi, ps of every member, device -> host -> NetCDF-3 file, once per simulated day.  Wall time of
-    run() / model steps.  A one-day run of the same shape goes first, untimed (the runtime's one-off costs)."""
+    run() / model steps, the better of two runs.  A one-day run of the same shape goes first, untimed (one-off costs)."""
     import tempfile
     from datetime import datetime, timedelta
     import torch
@@ -798,8 +793,10 @@ def facade_leg():
     out = {}
     for key, members, days_plain, days_export in (("ens64", 64, 10, 5), ("single", 1, 10, 10)):
         timed(members, 1, False)
-        plain, _, _ = timed(members, days_plain, False)
-        exported, files, written = timed(members, days_export, True)
+        # the better of two runs each: the ROCm runtime stalls once per process for ~40 ms shortly after its first launches, and
+        # one such stall is a tenth of a millisecond per step of a 360-step run
+        plain = min(timed(members, days_plain, False)[0] for _ in range(2))
+        exported, files, written = min(timed(members, days_export, True) for _ in range(2))
         out[key] = {"members": members, "run_ms_per_step": plain, "run_steps": 36 * days_plain,
                     "run_daily_export_ms_per_step": exported, "run_daily_export_steps": 36 * days_export, "files_written": files,
                     "megabytes_written": written / 1e6}

@@ -377,3 +377,78 @@ def check_diagnostics(state, time_lev):
     lib().orc_check_diagnostics.restype = C.c_int
     rc = lib().orc_check_diagnostics(C.byref(tables()), C.byref(state.c), C.c_int(time_lev), _p(diag))
     return rc, diag
+
+
+# ---- the whole model (orc_model.c) ---------------------------------------------------------------------------------------
+MODEL_SHAPES = {"vor": (31, 32, 8, 2), "div": (31, 32, 8, 2), "t": (31, 32, 8, 2), "tr": (31, 32, 8, 2), "ps": (31, 32, 2),
+                "phi": (31, 32, 8), "phis": (31, 32), "tcorh": (31, 32), "qcorh": (31, 32)}  # complex; everything else is real
+BC_MAP = (("orog", "orog"), ("fmask_orig", "lsm"), ("alb0", "alb"), ("veg_high", "vegh"), ("veg_low", "vegl"), ("stl12", "stl"),
+          ("snowd12", "snowd"), ("soil_wc_l1", "swl1"), ("soil_wc_l2", "swl2"), ("soil_wc_l3", "swl3"), ("sst12", "sst"),
+          ("sea_ice_frac12", "icec"))  # pyspeedy/speedy.py:279-296
+
+
+class Model:
+    """One whole oracle model: boundary fields in, `init`, `step` (do_single_step), registry arrays out by name."""
+
+    def __init__(self, n_months=1):
+        L = lib()
+        L.orc_model_new.restype = C.c_void_p
+        L.orc_model_field.restype = C.POINTER(C.c_double)
+        L.orc_model_field.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_long)]
+        L.orc_model_get_scalar.restype = C.c_double
+        L.orc_model_get_scalar.argtypes = [C.c_void_p, C.c_char_p]
+        L.orc_model_set_scalar.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        L.orc_model_init.argtypes = [C.c_void_p] + [C.c_int] * 5
+        L.orc_model_step.argtypes = [C.c_void_p]
+        L.orc_model_free.argtypes = [C.c_void_p]
+        L.orc_model_calendar.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.planes = n_months + 2
+        self._m = C.c_void_p(L.orc_model_new(self.planes))
+
+    def __del__(self):
+        if getattr(self, "_m", None):
+            lib().orc_model_free(self._m)
+            self._m = None
+
+    def _view(self, name):
+        n = C.c_long(0)
+        p = lib().orc_model_field(self._m, name.encode(), C.byref(n))
+        if not p:
+            raise KeyError(name)
+        return np.ctypeslib.as_array(p, shape=(n.value,))
+
+    def get(self, name):
+        if name in ("current_step", "air_absortivity_co2", "ablco2_ref", "compute_shortwave"):
+            return lib().orc_model_get_scalar(self._m, name.encode())
+        flat = self._view(name).copy()
+        if name in MODEL_SHAPES:
+            return flat.view(np.complex128).reshape(MODEL_SHAPES[name], order="F")
+        return flat.reshape((96, 48) + ((flat.size // 4608,) if flat.size > 4608 else ()), order="F")
+
+    def set(self, name, value):
+        if name in ("land_coupling_flag", "sst_anomaly_coupling_flag", "increase_co2", "air_absortivity_co2"):
+            assert lib().orc_model_set_scalar(self._m, name.encode(), float(value)) == 0
+            return
+        view = self._view(name)
+        a = np.asfortranarray(value, dtype=np.complex128 if name in MODEL_SHAPES else np.float64)
+        flat = a.reshape(-1, order="F").view(np.float64)
+        assert flat.size == view.size, (name, flat.size, view.size)
+        view[:] = flat
+
+    def set_bc(self, bc, sst_anom=None):
+        for state_name, bc_name in BC_MAP:
+            self.set(state_name, np.asarray(bc[bc_name], dtype=np.float64))
+        if sst_anom is not None:
+            self.set("sst_anom", sst_anom)
+
+    def init(self, year, month, day, hour=0, minute=0):
+        return lib().orc_model_init(self._m, year, month, day, hour, minute)
+
+    def step(self):
+        return lib().orc_model_step(self._m)
+
+    def calendar(self):
+        ymdhm = (C.c_int * 5)()
+        mi, im, tm, ty = C.c_int(), C.c_int(), C.c_double(), C.c_double()
+        lib().orc_model_calendar(self._m, ymdhm, C.byref(mi), C.byref(im), C.byref(tm), C.byref(ty))
+        return list(ymdhm), mi.value, im.value, tm.value, ty.value

@@ -158,6 +158,20 @@ void orc_land_sea_init(const orc_tables *t, int n_anom_planes, const double *fma
                        double *rhcapl, double *cdland, double *rhcaps, double *rhcapi, double *cdsea, double *cdice,
                        double *fmean);
 
+/* ---- the whole model (orc_model.c): calendar, interpolation, daily forcing, land / sea / ice coupling, initialisation and
+ * do_single_step around the pieces above.  Boundary fields are written into the model's arrays by name (orc_model_field:
+ * orog, fmask_orig, alb0, veg_high, veg_low, stl12, snowd12, soil_wc_l1..3, sst12, sea_ice_frac12, sst_anom) before
+ * orc_model_init; every state array of the reference that the run touches can be read back the same way. */
+typedef struct orc_model orc_model;
+orc_model *orc_model_new(int n_anom_planes /* n_months + 2 */);
+void orc_model_free(orc_model *m);
+double *orc_model_field(orc_model *m, const char *name, long *n_doubles);
+int orc_model_set_scalar(orc_model *m, const char *name, double value); /* land_coupling_flag, sst_anomaly_coupling_flag, increase_co2, air_absortivity_co2 */
+double orc_model_get_scalar(const orc_model *m, const char *name);      /* current_step, air_absortivity_co2, ablco2_ref, compute_shortwave */
+int orc_model_init(orc_model *m, int year, int month, int day, int hour, int minute); /* initialize_state; 0 or -2 */
+int orc_model_step(orc_model *m);                                                      /* do_single_step; 0, -1, -2 */
+void orc_model_calendar(const orc_model *m, int *ymdhm /* 5 */, int *month_idx, int *imont1, double *tmonth, double *tyear);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,6 +97,51 @@ int main(void) {
         for (int p = 0; p < NG; ++p) acc += in12[2][p] + in12[4][p + 11 * NG] + soilw[p] + out2[0][p] + out2[9][p] + anom[p + 4 * NG];
         acc += fmean;
     }
+    /* the whole model (orc_model.c): a synthetic planet -- a mountain, a continent, a seasonal cycle, SST anomalies over 5 planes --
+     * initialised in late December and stepped across the year end with the CO2 trend on (daily forcing, coupling, calendar) */
+    {
+        orc_model *m = orc_model_new(5);
+        long n = 0;
+        double *orog = orc_model_field(m, "orog", &n), *lsm = orc_model_field(m, "fmask_orig", NULL), *alb = orc_model_field(m, "alb0", NULL);
+        double *vegh = orc_model_field(m, "veg_high", NULL), *vegl = orc_model_field(m, "veg_low", NULL);
+        double *stl = orc_model_field(m, "stl12", NULL), *snow = orc_model_field(m, "snowd12", NULL), *sst = orc_model_field(m, "sst12", NULL);
+        double *ice = orc_model_field(m, "sea_ice_frac12", NULL), *sw1 = orc_model_field(m, "soil_wc_l1", NULL),
+               *sw2 = orc_model_field(m, "soil_wc_l2", NULL), *anom = orc_model_field(m, "sst_anom", NULL);
+        if (n != NG || orc_model_field(m, "no_such_field", NULL) != NULL) return 2;
+        for (int j = 0; j < 48; ++j)
+            for (int i = 0; i < 96; ++i) {
+                const int p = i + 96 * j;
+                const double lat = -87.0 + 174.0 * j / 47.0, land = (i > 20 && i < 50 && j > 10 && j < 40) ? 1.0 : 0.0;
+                orog[p] = land * 1500.0 * exp(-0.01 * ((i - 35) * (i - 35) + (j - 25) * (j - 25)));
+                lsm[p] = land;
+                alb[p] = 0.2 + 0.3 * (fabs(lat) > 70.0);
+                vegh[p] = 0.3 * land;
+                vegl[p] = 0.4 * land;
+                for (int mo = 0; mo < 12; ++mo) {
+                    const double season = cos(6.283185307 * (mo - 0.5) / 12.0) * (lat > 0 ? -1.0 : 1.0);
+                    const size_t q = (size_t)mo * NG + p;
+                    stl[q] = 288.0 - 45.0 * (lat / 90.0) * (lat / 90.0) + 8.0 * season;
+                    sst[q] = 271.5 + 28.0 * (1.0 - (lat / 90.0) * (lat / 90.0)) + 2.0 * season;
+                    snow[q] = fabs(lat) > 55.0 ? 40.0 : 0.0;
+                    ice[q] = fabs(lat) > 72.0 ? 0.8 : 0.0;
+                    sw1[q] = 0.25;
+                    sw2[q] = 0.22;
+                }
+                for (int pl = 0; pl < 5; ++pl) anom[(size_t)pl * NG + p] = 0.5 * sin(0.1 * i + pl);
+            }
+        if (orc_model_set_scalar(m, "increase_co2", 1.0) != 0 || orc_model_set_scalar(m, "no_such_flag", 1.0) != -1) return 3;
+        if (orc_model_step(m) != -1) return 4;
+        if (orc_model_init(m, 1983, 12, 31, 0, 0) != 0) return 5;
+        int rc = 0, ymdhm[5], month_idx, imont1;
+        double tmonth, tyear;
+        for (int s = 0; s < 40 && rc == 0; ++s) rc = orc_model_step(m);
+        orc_model_calendar(m, ymdhm, &month_idx, &imont1, &tmonth, &tyear);
+        if (rc != 0 || ymdhm[0] != 1984 || ymdhm[1] != 1 || ymdhm[2] != 1 || month_idx != 2 || imont1 != 1) return 6;
+        const double *olr = orc_model_field(m, "olr", NULL), *sst_am = orc_model_field(m, "sst_am", NULL);
+        for (int p = 0; p < NG; ++p) acc += olr[p] + sst_am[p];
+        acc += orc_model_get_scalar(m, "air_absortivity_co2") + tyear + tmonth;
+        orc_model_free(m);
+    }
     printf("oracle sanitize ok %.6e\n", acc);
     return isfinite(acc) ? 0 : 1;
 }

@@ -213,8 +213,9 @@ def test_the_one_gpu_line_carries_the_drop_in_and_every_store_legs():
     # the reference's own entry points on the same clock, and the step() contract's figures flat in `config`
     f = res["facade_run"]
     for key, members in (("ens64", 64), ("single", 1)):
-        assert f[key]["members"] == members and 0 < f[key]["run_ms_per_step"] < f[key]["run_daily_export_ms_per_step"]
+        assert f[key]["members"] == members and 0 < f[key]["run_ms_per_step"] and 0 < f[key]["run_daily_export_ms_per_step"]
         assert f[key]["files_written"] == f[key]["run_daily_export_steps"] // 36 and f[key]["megabytes_written"] > 0.7 * members * f[key]["files_written"]
+    assert f["ens64"]["run_ms_per_step"] < f["ens64"]["run_daily_export_ms_per_step"]  # (48 MB per simulated day)
     cfg = res["config"]
     assert cfg["step_contract_ms_per_step_sync_8"] == d["sync_ms_per_step"] and cfg["step_contract_ms_per_step_begin_end_8"] == d["begin_end_ms_per_step"]
     assert cfg["step_contract_ms_per_step_sync_1"] == d["containers_1"]["sync_ms_per_step"]

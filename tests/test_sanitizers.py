@@ -37,7 +37,7 @@ def test_oracle_under_asan_ubsan(tmp_path):
     orc = os.path.join(ROOT, "oracle")
     run(["gcc", "-std=c11", "-ffp-contract=off", *SAN, "-I" + orc, os.path.join(ROOT, "tests", "sanitize", "oracle_sanitize.c"),
          os.path.join(orc, "orc_spectral.c"), os.path.join(orc, "orc_physics.c"), os.path.join(orc, "orc_dynamics.c"),
-         os.path.join(orc, "orc_surface.c"), "-lm", "-o",
+         os.path.join(orc, "orc_surface.c"), os.path.join(orc, "orc_model.c"), "-lm", "-o",
          "oracle_sanitize"], tmp_path)
     assert "oracle sanitize ok" in run([str(tmp_path / "oracle_sanitize")], tmp_path)
 
