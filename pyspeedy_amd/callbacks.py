@@ -92,7 +92,8 @@ class XarrayExporter(_GridOutput):
         target = os.path.join(self.output_dir, model_instance.current_date.strftime(self.filename_fmt))
         os.makedirs(self.output_dir, exist_ok=True)
         self.print_msg("Saving model output at: %s." % target)
-        self.snapshot(model_instance).to_netcdf(target)
+        # (the file's payload -- float32, big-endian, levels bottom-up -- is formed on the GPU and copied out as such: `packed`)
+        model_instance.to_dataframe(variables=self.variables, packed=True).to_netcdf(target)
 
 
 NetcdfExporter = XarrayExporter

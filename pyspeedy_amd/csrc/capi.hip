@@ -45,7 +45,10 @@ static int hip_fail(hipError_t e, const char *what) {
 #define SPD_HIP(call)                                  \
     do {                                               \
         hipError_t e_ = (call);                        \
-        if (e_ != hipSuccess) return hip_fail(e_, #call); \
+        if (e_ != hipSuccess) {                        \
+            (void)hipGetLastError(); /* reported here, once: not again by the next launch's hipGetLastError() */ \
+            return hip_fail(e_, #call);                \
+        }                                              \
     } while (0)
 
 static int upload(spd_context *c, const double *src, size_t n, const double **dst) {

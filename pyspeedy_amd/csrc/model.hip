@@ -209,10 +209,16 @@ static int usable(const spd_model *m, const char *who) {
 static int apply_storage(spd_model *m, bool want32);  // (with spd_model_set_physics_precision)
 static int settle_deferred_check(spd_model *m);        // (with spd_model_check_defer)
 
+// (A failed runtime call also leaves its code behind as the thread's "last error", and the launch wrappers of the kernels report
+// hipGetLastError(): a hipMalloc that ran out of memory would come back as the "failure" of the next launch of an unrelated model.
+// The code is reported HERE, once, and cleared.)
 #define M_HIP(call)                                                                   \
     do {                                                                              \
         hipError_t e_ = (call);                                                       \
-        if (e_ != hipSuccess) return m_fail(SPD_E_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
+        if (e_ != hipSuccess) {                                                       \
+            (void)hipGetLastError();                                                  \
+            return m_fail(SPD_E_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
+        }                                                                             \
     } while (0)
 
 // `bytes` of zero-filled device memory that lives as long as the model.  Every array starts on a 256-byte boundary.  The first

@@ -206,7 +206,7 @@ def _prepare(ds):
         if vals.dtype.kind in "iu":
             vals = vals.astype(">i4")
         elif vals.dtype.kind == "f":
-            vals = vals.astype(">f4")
+            vals = vals.astype(">f4", copy=False)  # (packed exports arrive in the file's byte order already)
         else:
             raise TypeError("%s: dtype %s cannot be written" % (name, vals.dtype))
         out.append((name, v.dims, vals, {k: a for k, a in attrs.items() if a is not None}))

@@ -284,9 +284,17 @@ class Speedy:
             raise RuntimeError(ERROR_CODES[code])
 
     # ---- export ----------------------------------------------------------------------------------------------
-    def to_dataframe(self, variables=None):
-        """Current model state as a Dataset following the export conventions of the reference (speedy.py:415-477)."""
+    def to_dataframe(self, variables=None, packed=False):
+        """Current model state as a Dataset following the export conventions of the reference (speedy.py:415-477).
+        packed=True (extension, what XarrayExporter asks for): the data variables come as they go into a NetCDF-3 file -- float32,
+        big-endian, narrowed and ordered on the GPU -- and alias a buffer that the next packed call overwrites."""
         variables = DEFAULT_OUTPUT_VARS if variables is None else variables
+        if packed:
+            for var in variables:
+                _exportable(var)
+            arrays = _speedy.ensemble_export_arrays([self._state_cnt], list(variables))
+            members = [self.member_id] if self.is_ensemble_member else None
+            return _build_dataset(self, arrays, members, self.current_date, packed=True)
         self.spectral2grid()
         arrays = {}
         for var in variables:
@@ -309,16 +317,18 @@ def _exportable(var):
     return meta
 
 
-def _build_dataset(model, arrays, members, date):
-    """arrays: var -> [member, (lev,) lat, lon] float64 in model level order; members: list of ids or None (single run)."""
+def _build_dataset(model, arrays, members, date, packed=False):
+    """arrays: var -> [member, (lev,) lat, lon] float64 in model level order -- or, packed, float32 with the levels already
+    bottom-up (speedy_driver.ensemble_export_arrays); members: list of ids or None (single run)."""
     lead = ("time", "ens") if members is not None else ("time",)
     data = {}
     for var, values in arrays.items():
         meta = _exportable(var)
         dims = tuple(reversed(meta.nc_dims))
-        if "lev" in dims:
-            values = values[:, ::-1]  # vertical levels increasing with height (lev coordinate reversed)
-        values = values.astype(np.float32)  # one pass: reversed view -> contiguous float32
+        if not packed:
+            if "lev" in dims:
+                values = values[:, ::-1]  # vertical levels increasing with height (lev coordinate reversed)
+            values = values.astype(np.float32)  # one pass: reversed view -> contiguous float32
         values = values[None] if members is not None else values  # -> (time, ens, ...) or (time, ...)
         attrs = {"long_name": meta.long_name, "standard_name": var}
         if meta.units is not None:
@@ -383,14 +393,15 @@ class SpeedyEns:
             member.spectral2grid()
             member._initialized_bc = True
 
-    def to_dataframe(self, variables=None):
+    def to_dataframe(self, variables=None, packed=False):
         """All members along the `ens` dimension: one batched spectral -> grid conversion and one device-to-host copy per
-        variable (the device layout [member][lev][lat][lon] is already the export order)."""
+        variable (the device layout [member][lev][lat][lon] is already the export order).  packed=True: see Speedy.to_dataframe."""
         variables = DEFAULT_OUTPUT_VARS if variables is None else variables
         for var in variables:
             _exportable(var)
-        arrays = _speedy.ensemble_grid_arrays([m._state_cnt for m in self], list(variables))
-        return _build_dataset(self.members[0], arrays, [m.member_id for m in self], self.current_date)
+        cnts = [m._state_cnt for m in self]
+        arrays = _speedy.ensemble_export_arrays(cnts, list(variables)) if packed else _speedy.ensemble_grid_arrays(cnts, list(variables))
+        return _build_dataset(self.members[0], arrays, [m.member_id for m in self], self.current_date, packed=packed)
 
     def _device_models(self):
         """[(EnsembleModel view, member_id of the container that is member 0 of that model)] for the device models the

@@ -315,6 +315,65 @@ def ensemble_grid_arrays(state_cnts, names):
     return {n: np.stack([models[key][n][member] for key, member in where]) for n in names}
 
 
+_export_buffers = {}  # (bytes, slot) -> pinned uint8 tensor, kept for the life of the process (a day's output of 64 members: 48 MB)
+
+
+def ensemble_export_arrays(state_cnts, names, slot=0):
+    """Extension, for writing files: the grid-space variables `names` of the given containers as they go into a NetCDF-3 file --
+    float32, BIG-endian, vertical levels bottom-up (the reference's export convention, speedy.py:415-477) -- dict name -> numpy
+    array of dtype '>f4' [member, (lev,) lat, lon] in the order of `state_cnts`.  Narrowing, level reversal and byte order happen
+    on the GPU; what crosses PCIe is the file's payload itself (half the bytes of the fp64 fields), into pinned host memory.
+    The arrays alias a buffer that the next call with the same `slot` overwrites."""
+    import torch
+    groups, order = {}, []
+    for pos, cnt in enumerate(state_cnts):
+        model, member = device_model(cnt)
+        key = model._m.value
+        if key not in groups:
+            groups[key] = (model, [], [])
+            order.append(key)
+        groups[key][1].append(pos)
+        groups[key][2].append(member)
+    n = len(state_cnts)
+    first = groups[order[0]][0]
+    shapes = {name: tuple(first.device_view(name).shape[1:]) for name in names}
+    sizes = {name: 4 * n * int(np.prod(shapes[name])) for name in names}
+    total = sum(sizes.values())
+    key = (total, slot)
+    if key not in _export_buffers:
+        _export_buffers[key] = torch.empty(total, dtype=torch.uint8).pin_memory()
+    buf = _export_buffers[key]
+    offsets, at = {}, 0
+    for name in names:
+        offsets[name] = at
+        at += sizes[name]
+    for k in order:
+        model, positions, members = groups[k]
+        model.spectral2grid()
+        whole = members == list(range(model.nmembers))
+        contiguous = positions == list(range(positions[0], positions[0] + len(positions)))
+        index = None if whole else torch.as_tensor(members, device=model.sp.device)
+        for name in names:
+            v = model.device_view(name)
+            if index is not None:
+                v = v.index_select(0, index)
+            if v.ndim == 4:
+                v = v.flip(1)  # lev increasing with height
+            be = v.to(torch.float32).contiguous().view(torch.uint8).view(-1, 4).flip(1)  # byte order of the file
+            per_member = sizes[name] // n
+            if contiguous:
+                start = offsets[name] + positions[0] * per_member
+                buf[start:start + len(positions) * per_member].copy_(be.reshape(-1), non_blocking=True)
+            else:
+                flat = be.reshape(len(positions), per_member)
+                for row, pos in enumerate(positions):
+                    buf[offsets[name] + pos * per_member:offsets[name] + (pos + 1) * per_member].copy_(flat[row], non_blocking=True)
+    for k in order:
+        torch.cuda.synchronize(groups[k][0].sp.device)
+    host = buf.numpy()
+    return {name: host[offsets[name]:offsets[name] + sizes[name]].view(">f4").reshape((n,) + shapes[name]) for name in names}
+
+
 def driver_stats(state_cnt=0):
     """(device models alive, members in the model of `state_cnt`)"""
     alive, members = C.c_int32(), C.c_int32()

@@ -344,3 +344,39 @@ def test_ensemble_set_bc_loads_once_and_hands_the_fields_on():
                 assert np.array_equal(once.members[i][name], each.members[i][name]), (n, i, name)
         assert np.abs(once.members[1]["sst_anom"]).max() > 0 if anomalies else True
 
+
+
+def test_packed_export_writes_the_same_file():
+    """XarrayExporter asks for `to_dataframe(packed=True)`: float32, big-endian, levels bottom-up formed on the GPU and copied out as
+    the file's payload (speedy_driver.ensemble_export_arrays).  The file is byte for byte the one the host-side path writes -- for a
+    single model, for 33 members in two device models, and for a selection of containers in another order."""
+    from pyspeedy_amd import speedy_driver as drv
+    from pyspeedy_amd.callbacks import XarrayExporter
+    from pyspeedy_amd.registry import DEFAULT_OUTPUT_VARS
+    from pyspeedy_amd.speedy import Speedy, SpeedyEns
+    start, end = datetime(1982, 1, 1), datetime(1982, 1, 1, 4, 0)
+    single = Speedy(start_date=start, end_date=end)
+    single.set_bc()
+    ens = SpeedyEns(33, start_date=start, end_date=end)
+    ens.set_bc()
+    for k, member in enumerate(ens):
+        member["t_grid"] = member["t_grid"] + 0.01 * k
+        member.grid2spectral()
+    for model in (single, ens):
+        with tempfile.TemporaryDirectory() as tmp:
+            model.run(callbacks=[XarrayExporter(output_dir=tmp, interval=6)])
+            written = os.path.join(tmp, end.strftime("%Y-%m-%d_%H%M.nc"))
+            plain = os.path.join(tmp, "plain.nc")
+            model.to_dataframe().to_netcdf(plain)
+            with open(written, "rb") as a, open(plain, "rb") as b:
+                assert a.read() == b.read()
+    packed = ens.to_dataframe(packed=True)
+    assert packed["t"].values.dtype == np.dtype(">f4") and packed["t"].values.shape == (1, 33, 8, 48, 96)
+    np.testing.assert_array_equal(packed["t"].values, ens.to_dataframe()["t"].values)
+    pick = [ens.members[k]._state_cnt for k in (20, 3, 32, 16)]  # members of both device models, out of order
+    some = drv.ensemble_export_arrays(pick, list(DEFAULT_OUTPUT_VARS), slot=1)
+    full = drv.ensemble_grid_arrays([m._state_cnt for m in ens], list(DEFAULT_OUTPUT_VARS))
+    for name in DEFAULT_OUTPUT_VARS:
+        want = full[name][[20, 3, 32, 16]]
+        want = want[:, ::-1] if want.ndim == 4 else want
+        np.testing.assert_array_equal(some[name], want.astype(np.float32))
