@@ -81,19 +81,69 @@ class ModelCheckpoint(_GridOutput):
 
 
 class XarrayExporter(_GridOutput):
-    """Writes the selected grid-space variables to `output_dir/<model date formatted with filename_fmt>`."""
+    """Writes the selected grid-space variables to `output_dir/<model date formatted with filename_fmt>`.
+
+    The file's payload (float32, big-endian, levels bottom-up) is formed on the GPU and copied out as such
+    (`to_dataframe(packed=True)`).  With `background=True` (the default) the file itself is written by a thread of this exporter
+    while the model goes on stepping: two output buffers alternate, a third output waits for the first file to be finished, and
+    `finish()` -- called by `Speedy.run` / `SpeedyEns.run` when the run ends, also when it ends with an exception -- returns when
+    every file is on disk (and raises what the writer could not do).  `background=False` writes inside the callback, as the
+    reference's exporter does."""
 
     def __init__(self, interval=36, verbose=False, spinup_date=None, variables=None, output_dir="./",
-                 filename_fmt="%Y-%m-%d_%H%M.nc"):
+                 filename_fmt="%Y-%m-%d_%H%M.nc", background=True):
         super().__init__(interval, verbose, spinup_date, variables, output_dir)
         self.filename_fmt = filename_fmt
+        self.background = background
+        self._pending = [None, None]  # per output buffer: the thread that is writing from it
+        self._turn = 0
+        self._failure = None
 
     def fire(self, model_instance):
         target = os.path.join(self.output_dir, model_instance.current_date.strftime(self.filename_fmt))
         os.makedirs(self.output_dir, exist_ok=True)
         self.print_msg("Saving model output at: %s." % target)
-        # (the file's payload -- float32, big-endian, levels bottom-up -- is formed on the GPU and copied out as such: `packed`)
-        model_instance.to_dataframe(variables=self.variables, packed=True).to_netcdf(target)
+        if not self.background:
+            model_instance.to_dataframe(variables=self.variables, packed=True).to_netcdf(target)
+            return
+        import threading
+        slot = self._turn
+        self._turn = 1 - slot
+        self._wait(slot)  # (the buffer this output goes into may still be on its way to disk)
+        frame = model_instance.to_dataframe(variables=self.variables, packed=True, slot=slot)
+
+        def write():
+            try:
+                frame.to_netcdf(target)
+            except BaseException as exc:  # noqa: B902 -- handed to the thread that owns the exporter
+                self._failure = exc
+        self._pending[slot] = threading.Thread(target=write, name="pyspeedy_amd-export", daemon=False)
+        self._pending[slot].start()
+
+    def _wait(self, slot):
+        thread, self._pending[slot] = self._pending[slot], None
+        if thread is not None:
+            thread.join()
+        if self._failure is not None:
+            failure, self._failure = self._failure, None
+            raise failure
+
+    def finish(self):
+        """Every file handed to the writer so far is complete when this returns."""
+        for slot in (0, 1):
+            self._wait(slot)
+
+    def copy(self):
+        self.finish()  # (threads do not copy)
+        return super().copy()
+
+    def __del__(self):
+        try:
+            for thread in self._pending:
+                if thread is not None:
+                    thread.join()
+        except Exception:
+            pass
 
 
 NetcdfExporter = XarrayExporter

@@ -253,6 +253,7 @@ class Speedy:
             self._collect(previous)
         finally:
             self._drain(pending)  # (a step that was begun behind the one that failed: end it, its code no longer matters)
+            _finish(callbacks)
 
     @staticmethod
     def _collect(token):
@@ -284,15 +285,15 @@ class Speedy:
             raise RuntimeError(ERROR_CODES[code])
 
     # ---- export ----------------------------------------------------------------------------------------------
-    def to_dataframe(self, variables=None, packed=False):
+    def to_dataframe(self, variables=None, packed=False, slot=0):
         """Current model state as a Dataset following the export conventions of the reference (speedy.py:415-477).
         packed=True (extension, what XarrayExporter asks for): the data variables come as they go into a NetCDF-3 file -- float32,
-        big-endian, narrowed and ordered on the GPU -- and alias a buffer that the next packed call overwrites."""
+        big-endian, narrowed and ordered on the GPU -- and alias a buffer that the next packed call with the same `slot` overwrites."""
         variables = DEFAULT_OUTPUT_VARS if variables is None else variables
         if packed:
             for var in variables:
                 _exportable(var)
-            arrays = _speedy.ensemble_export_arrays([self._state_cnt], list(variables))
+            arrays = _speedy.ensemble_export_arrays([self._state_cnt], list(variables), slot=slot)
             members = [self.member_id] if self.is_ensemble_member else None
             return _build_dataset(self, arrays, members, self.current_date, packed=True)
         self.spectral2grid()
@@ -303,6 +304,14 @@ class Speedy:
             arrays[var] = values.transpose(*range(values.ndim - 1, -1, -1))[None]
         members = [self.member_id] if self.is_ensemble_member else None
         return _build_dataset(self, arrays, members, self.current_date)
+
+
+def _finish(callbacks):
+    """end of a run: hooks that work in the background (XarrayExporter's file writer) complete what they hold"""
+    for cb in callbacks:
+        done = getattr(cb, "finish", None)
+        if callable(done):
+            done()
 
 
 def _callbacks_due(callbacks, model):
@@ -393,14 +402,15 @@ class SpeedyEns:
             member.spectral2grid()
             member._initialized_bc = True
 
-    def to_dataframe(self, variables=None, packed=False):
+    def to_dataframe(self, variables=None, packed=False, slot=0):
         """All members along the `ens` dimension: one batched spectral -> grid conversion and one device-to-host copy per
         variable (the device layout [member][lev][lat][lon] is already the export order).  packed=True: see Speedy.to_dataframe."""
         variables = DEFAULT_OUTPUT_VARS if variables is None else variables
         for var in variables:
             _exportable(var)
         cnts = [m._state_cnt for m in self]
-        arrays = _speedy.ensemble_export_arrays(cnts, list(variables)) if packed else _speedy.ensemble_grid_arrays(cnts, list(variables))
+        arrays = (_speedy.ensemble_export_arrays(cnts, list(variables), slot=slot) if packed else
+                  _speedy.ensemble_grid_arrays(cnts, list(variables)))
         return _build_dataset(self.members[0], arrays, [m.member_id for m in self], self.current_date, packed=packed)
 
     def _device_models(self):
@@ -459,6 +469,7 @@ class SpeedyEns:
             Speedy._collect(previous)
         finally:
             Speedy._drain(pending)
+            _finish(callbacks)
 
     def get_current_step(self):
         return self.members[0]["current_step"]

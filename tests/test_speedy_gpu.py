@@ -380,3 +380,30 @@ def test_packed_export_writes_the_same_file():
         want = full[name][[20, 3, 32, 16]]
         want = want[:, ::-1] if want.ndim == 4 else want
         np.testing.assert_array_equal(some[name], want.astype(np.float32))
+
+
+def test_background_writer_leaves_the_same_files():
+    """XarrayExporter writes its files from a thread of its own while the model steps on (two buffers in turn); `run` returns when
+    all of them are on disk.  Seven outputs of an 8-member ensemble, byte for byte the files of the in-callback writer; a writer
+    that cannot write makes `run` raise."""
+    from pyspeedy_amd.callbacks import XarrayExporter
+    from pyspeedy_amd.speedy import SpeedyEns
+    start, end = datetime(1982, 1, 1), datetime(1982, 1, 1, 14, 0)  # 21 steps, an output every third
+    files = {}
+    for background in (True, False):
+        ens = SpeedyEns(8, start_date=start, end_date=end)
+        ens.set_bc()
+        with tempfile.TemporaryDirectory() as tmp:
+            ens.run(callbacks=[XarrayExporter(output_dir=tmp, interval=3, background=background)])
+            names = sorted(os.listdir(tmp))
+            assert len(names) == 7, names
+            files[background] = {n: open(os.path.join(tmp, n), "rb").read() for n in names}
+    assert files[True] == files[False]
+    assert len({v for v in files[True].values()}) == 7  # (seven different states, not one buffer written seven times)
+    ens = SpeedyEns(2, start_date=start, end_date=end)
+    ens.set_bc()
+    with tempfile.TemporaryDirectory() as tmp:
+        blocked = os.path.join(tmp, "a_file")
+        open(blocked, "w").close()
+        with pytest.raises(OSError):
+            ens.run(callbacks=[XarrayExporter(output_dir=os.path.join(blocked, "below_a_file"), interval=3)])
