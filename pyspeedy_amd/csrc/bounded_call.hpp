@@ -9,11 +9,10 @@
 //
 // Host-only C++, no HIP: tests/sanitize/driver_sanitize.cpp runs it under ASan / UBSan / TSan with a call that never returns.
 #pragma once
+#include <atomic>
 #include <chrono>
-#include <condition_variable>
 #include <functional>
 #include <memory>
-#include <mutex>
 #include <thread>
 
 namespace spd {
@@ -23,26 +22,25 @@ struct BoundedResult {
     int rc = 0;             // ... with this value
 };
 
+// (The caller watches an atomic flag with short sleeps instead of waiting on a condition variable: the wait is once per process,
+// a fraction of a millisecond of latency does not matter to it, and a timed wait on the steady clock is pthread_cond_clockwait,
+// which the ThreadSanitizer of this toolchain does not know -- it reports the worker's lock of the mutex as a double lock.)
 inline BoundedResult run_bounded(std::function<int()> fn, double seconds) {
     struct Shared {
-        std::mutex m;
-        std::condition_variable cv;
-        bool done = false;
+        std::atomic<bool> done{false};
         int rc = 0;
         std::function<int()> fn;
     };
     auto shared = std::make_shared<Shared>();
     shared->fn = std::move(fn);
     std::thread([shared] {
-        const int rc = shared->fn();
-        std::lock_guard<std::mutex> lock(shared->m);
-        shared->rc = rc;
-        shared->done = true;
-        shared->cv.notify_all();
+        shared->rc = shared->fn();
+        shared->done.store(true, std::memory_order_release);
     }).detach();
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(seconds);
     BoundedResult out;
-    std::unique_lock<std::mutex> lock(shared->m);
-    out.finished = shared->cv.wait_for(lock, std::chrono::duration<double>(seconds), [&] { return shared->done; });
+    while (!(out.finished = shared->done.load(std::memory_order_acquire)) && std::chrono::steady_clock::now() < deadline)
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
     if (out.finished) out.rc = shared->rc;
     return out;
 }
