@@ -926,7 +926,8 @@ def plan_name(cfg, M):
 def load_traffic(nfields):
     """HBM bytes per spec2grid launch from the committed PMC measurement of this very kernel inside this bench (rocprofv3
     cannot run inside bench.py): FETCH_SIZE doubled as the gfx950 guide prescribes, scaled per field."""
-    for name in ("r04_pmc_model_step.json", "r03_pmc_model_step.json", "r02_pmc_model_step.json", "r01_pmc_model_step.json"):
+    for name in ("r05_pmc_model_step.json", "r04_pmc_model_step.json", "r03_pmc_model_step.json", "r02_pmc_model_step.json",
+                 "r01_pmc_model_step.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 tj = json.load(fh)["kernels"]["spd::spec2grid_table_kernel"]
@@ -952,8 +953,8 @@ def dominant_kernel(kernels, M, config):
            "share_of_kernel_time": t_us / all_us, "launches_timed": n, "avg_launch_us": t_us / n,
            "algorithmic_bytes_per_launch": int(round(nbytes / n)), "bound": "hbm", "achieved": nbytes / (t_us * 1e-6) / 1e9,
            "peak": 8000.0, "unit": "GB/s", "frac": nbytes / (t_us * 1e-6) / 1e9 / 8000.0, "traffic": None}
-    name, key, members = (("r04_pmc_model_step.json", "spd::physics_kernel<2, true, false, double, false>", 64) if config == "cfg4" else
-                          ("r04_pmc_cfg5_storage32_1.json", "spd::physics_kernel<3, true, true, float, true>", 32))
+    name, key, members = (("r05_pmc_model_step.json", "spd::physics_kernel<2, true, false, double, false>", 64) if config == "cfg4" else
+                          ("r05_pmc_cfg5_storage32_1.json", "spd::physics_kernel<3, true, true, float, true>", 32))
     try:
         with open(os.path.join(ROOT, "profiles", name)) as fh:
             out["traffic"] = json.load(fh)["kernels"][key]["hbm_bytes_per_launch"] / float(members) * M
