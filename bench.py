@@ -144,6 +144,7 @@ def parse(argv=None):
     ap.add_argument("--budget", type=float, default=300.0,
                     help="wall-clock seconds for the whole run: secondary legs start only while the remaining time covers them")
     ap.add_argument("--cpu-worker", type=float, nargs=2, default=None, metavar=("T_START", "SECONDS"), help=argparse.SUPPRESS)
+    ap.add_argument("--rccl-probe", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
 
@@ -1092,6 +1093,73 @@ def run_one_process(args):
     print(json.dumps(line), flush=True)
 
 
+def rccl_probe_child():
+    """`bench.py --rccl-probe` (a child of a rank, with the rank's environment and a rendezvous port of its own): the ranks' RCCL
+    world in miniature -- process group with a device id, an all-reduce and a broadcast on device buffers, a barrier."""
+    from datetime import timedelta
+    import torch
+    import torch.distributed as dist
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    local %= max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist.init_process_group("nccl", device_id=device, timeout=timedelta(seconds=60))
+    t = torch.full((1 << 16,), float(rank + 1), dtype=torch.float64, device=device)
+    dist.all_reduce(t)
+    dist.broadcast(t, src=0)
+    torch.cuda.synchronize()
+    ok = abs(float(t[0]) - world * (world + 1) / 2.0) < 1e-9
+    dist.barrier()
+    dist.destroy_process_group()
+    print("RCCL_PROBE_OK" if ok else "RCCL_PROBE_WRONG_SUM", flush=True)
+
+
+def rccl_preflight(rank, world, wall):
+    """Before the ranks commit to RCCL for their barriers, their all-reduced times and the start-up broadcast: every rank starts a
+    CHILD that forms the same RCCL world on another port and runs three collectives, bounded in time.  Rank 0 collects the
+    verdicts (files under /tmp, as for the other host-side meeting points) and decides for everybody: RCCL when every child came
+    back good, gloo otherwise -- with the reason in the line (`collective.backend_fallback`).  A node on which RCCL cannot be
+    initialised, or hangs at its first collective, then still produces the scaling line, timed the same way; the members never
+    exchange data in a step, so the transport of the barrier does not enter `value`.  -> (use RCCL?, reason, seconds spent)"""
+    t0 = time.time()
+    timeout = max(20.0, min(90.0, wall.left() / 4.0))
+    env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 1))
+    env.pop("PYSPEEDY_AMD_BENCH_T0", None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    code, out, err = run_bounded_child([sys.executable, os.path.abspath(__file__), "--rccl-probe"], env, timeout)
+    mine = "ok" if code == 0 and "RCCL_PROBE_OK" in out else (
+        "no answer within %d s" % timeout if code is None else "exit code %s: %s" % (code, (err or out).strip().splitlines()[-1][:300] if (err or out).strip() else ""))
+    import tempfile
+    base = os.path.join(tempfile.gettempdir(), "pyspeedy_bench_%s_%d_rccl" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+    with open("%s.%d" % (base, rank), "w") as fh:
+        fh.write(mine)
+    deadline = time.time() + timeout + 30.0
+    if rank == 0:
+        verdicts = {}
+        while time.time() < deadline and len(verdicts) < world:
+            for r in range(world):
+                if r not in verdicts and os.path.exists("%s.%d" % (base, r)):
+                    text = open("%s.%d" % (base, r)).read()
+                    if text:
+                        verdicts[r] = text
+            time.sleep(0.05)
+        bad = ["rank %d: %s" % (r, verdicts.get(r, "no verdict")) for r in range(world) if verdicts.get(r) != "ok"]
+        decision = "ok" if not bad else "; ".join(bad)
+        with open(base + ".decision.tmp", "w") as fh:
+            fh.write(decision)
+        os.replace(base + ".decision.tmp", base + ".decision")
+    else:
+        decision = None
+        while time.time() < deadline + 15.0 and decision is None:
+            if os.path.exists(base + ".decision"):
+                decision = open(base + ".decision").read()
+            else:
+                time.sleep(0.05)
+        if decision is None:
+            decision = "rank %d saw no decision of rank 0" % rank
+    return decision == "ok", decision, time.time() - t0
+
+
 def run_rank(args):
     baseline = None
     wall = Budget(args.budget)
@@ -1109,6 +1177,15 @@ def run_rank(args):
         if rank_env == 0:
             baseline = cpu_baseline(args.cpu_seconds)
 
+    backend = os.environ.get("PYSPEEDY_AMD_BENCH_BACKEND", "nccl")
+    preflight = None
+    if backend == "nccl" and world_env > 1 and os.environ.get("PYSPEEDY_AMD_BENCH_RCCL_PROBE", "1") != "0":
+        # starts a child process: like the host baseline, before this process makes its first GPU call
+        use_rccl, why, spent = rccl_preflight(rank_env, world_env, wall)
+        preflight = {"ok": use_rccl, "seconds": round(spent, 1)}
+        if not use_rccl:
+            backend, preflight["why"] = "gloo", why
+
     import pyspeedy_amd
     from pyspeedy_amd import ensemble as E
     pyspeedy_amd.lib()  # load (or fail loudly) before the GPU is initialised; there is no CPU fallback
@@ -1122,7 +1199,7 @@ def run_rank(args):
     device = torch.device("cuda", local)
     # RCCL ("nccl" on ROCm): barrier, max-over-ranks time and the start-up broadcast of the boundary fields.
     # PYSPEEDY_AMD_BENCH_BACKEND=gloo rehearses the same control flow when the ranks cannot each have their own GPU.
-    backend = os.environ.get("PYSPEEDY_AMD_BENCH_BACKEND", "nccl")
+    # (`backend`, `preflight`: decided above, before the first GPU call of this process)
     # the process group is also created for an explicit one-rank world (WORLD_SIZE=1 in the environment): RCCL end to end
     dist = E.init_process_group(backend, device, force="WORLD_SIZE" in os.environ)
     coll_device = device if backend == "nccl" else torch.device("cpu")
@@ -1137,6 +1214,11 @@ def run_rank(args):
     M, first_id, total_members = workload(args, world, rank)
     sp, model = build_ensemble(args, M, first_id, device, dist, rank, coll_device)
     collective = collective_record(dist, backend, device, coll_device, rank, model.bc_checksum, model.bc_bytes)
+    if preflight is not None:
+        collective["rccl_preflight"] = preflight
+        if not preflight["ok"]:
+            collective["backend_fallback"] = ("RCCL did not pass its pre-flight (%s): barriers, all-reduced times and the start-up "
+                                              "broadcast go through gloo; the step itself has no collective" % preflight["why"])
     if not collective["boundary_checksum_equal"] or collective["ranks_seen"] != n_gpus:
         raise SystemExit("bench.py: the start-up broadcast did not deliver the same boundary fields to %d ranks: %r" % (n_gpus, collective))
     if args.serial_plan:
@@ -1313,6 +1395,8 @@ def main():
     args = parse(argv)
     if args.cpu_worker is not None:
         return cpu_worker(*args.cpu_worker)
+    if args.rccl_probe:
+        return rccl_probe_child()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be at least 1")
     if args.one_process:

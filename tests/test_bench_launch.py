@@ -162,6 +162,22 @@ def test_a_hanging_one_process_child_does_not_cost_the_line():
 
 
 @pytest.mark.gpu
+def test_rccl_preflight_falls_back_to_gloo_when_rccl_cannot_form_the_world():
+    """Before the ranks commit to RCCL each of them forms the same RCCL world in a bounded child process; when that fails on any
+    rank, rank 0 decides for all and the line is produced over gloo with the reason in it.  Two ranks on the ONE GPU of this box
+    are a world RCCL refuses (two ranks on one device): exactly that case, with the backend left at its default."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "PYSPEEDY_AMD_BENCH_BACKEND"):
+        env.pop(k, None)
+    res = _result(subprocess.run([sys.executable, BENCH, "--gpus", "2", "--members", "4", "--steps", "6", "--warmup", "3", "--regions", "2",
+                                  "--no-cpu-baseline", "--no-legs"], capture_output=True, text=True, timeout=900, env=env))
+    c = res["collective"]
+    assert res["n_gpus"] == 2 and res["value"] > 0 and res["config"]["backend"] == "gloo" and c["backend"] == "gloo"
+    assert c["rccl_preflight"]["ok"] is False and c["rccl_preflight"]["why"] and "pre-flight" in c["backend_fallback"]
+    assert c["ranks_seen"] == 2 and c["boundary_checksum_equal"] is True
+
+
+@pytest.mark.gpu
 def test_the_n_rank_line_is_complete():
     """The driver's own command at N > 1 (default members: the weak headline, 64 per GPU) -- here with 2 ranks sharing the one
     GPU: the line carries the host baseline with its core count (measured by the launcher before any rank exists), the ratio to
