@@ -36,6 +36,9 @@ What the ONE JSON line of rank 0 holds:
   cfg4_strong (N > 1)   BASELINE cfg 4 to the letter beside the weak headline: 64 members in total, block-sharded.
   collective            what the collective layer saw, gathered through it (RCCL on the GPU box): ranks_seen, device_of_rank[],
                         the checksum of the boundary fields every rank received in the start-up broadcast and whether they agree.
+                        `rccl_preflight`: before the ranks commit to RCCL each forms the same RCCL world in a bounded CHILD process
+                        (all-reduce, broadcast, barrier on device buffers); rank 0 decides for all; when it fails the line is
+                        produced over gloo and `backend_fallback` says why (the step has no collective: `value` is unaffected).
   one_process (N > 1)   the reference's own shape beside the process-per-GPU headline: ONE process drives all N GPUs -- containers
                         in blocks per device, boundary fields device to device, spd_parallel_step[_begin / _end] once per model
                         step over all containers.  Measured by a child process of rank 0 (`bench.py --one-process`) after the
