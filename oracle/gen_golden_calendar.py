@@ -31,6 +31,9 @@ Stored per case `<c>`:
       stratospheric_correction.  (The compiled reference evaluates sin and cos of one argument with one `sincos` call -- flang
       and gfortran both merge them --, and glibc's sincos is not always its sin: 1 ulp on Jan 2.  Every day is here so that a
       host restatement is pinned to the bit on all of them.)
+  century_cal_* -- the calendar ALONE (advance_date without a model, shim_advance_date) after every step from 1899-12-30 to
+      1901-01-03: the model's leap rule is mod(year, 4) == 0 only, so its 1900 has a February 29 that the Gregorian calendar (and
+      Python's datetime, which the facade's `current_date` follows exactly as the reference's does) has not; month_idx counts to 14.
 Run in the build container:  python oracle/gen_golden_calendar.py
 """
 import ctypes as C
@@ -151,11 +154,28 @@ def forcing_sweep(bc, out):
     out["forcing_fields"] = fields
 
 
+def century_calendar(out):
+    m = R.RefModel(start=(1899, 12, 30, 0, 0), end=(1901, 1, 3, 0, 0))
+    n = 36 * (2 + 366 + 2)  # the model's 1900 has 366 days
+    cal = [control(m)]
+    for _ in range(n):
+        R.lib().shim_advance_date(m.ctl)
+        cal.append(control(m))
+    assert cal[-1][0] == [1901, 1, 3, 0, 0] and [1900, 2, 29, 0, 0] in [c[0] for c in cal]
+    out["century_cal_ymdhm"] = np.array([c[0] for c in cal], dtype=np.int32)
+    out["century_cal_month_idx"] = np.array([c[1] for c in cal], dtype=np.int32)
+    out["century_cal_imont1"] = np.array([c[2] for c in cal], dtype=np.int32)
+    out["century_cal_tmonth"] = np.array([c[3] for c in cal], dtype=np.float64)
+    out["century_cal_tyear"] = np.array([c[4] for c in cal], dtype=np.float64)
+    print("century: last", cal[-1][0], "month_idx", cal[-1][1])
+
+
 def main():
     bc = np.load(os.path.join(HERE, "..", "pyspeedy_amd", "data", "example_bc.npz"))
     lat = latitudes(bc)
     out = {"lat": lat}
     forcing_sweep(bc, out)
+    century_calendar(out)
     for name in CASES:
         run_case(name, bc, lat, out)
     dst = os.path.join(HERE, "..", "tests", "golden", "calendar.npz")

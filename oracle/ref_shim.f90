@@ -381,6 +381,15 @@ contains
         tyear = ptr%p%tyear
     end subroutine
 
+    !> One 40-minute step of the calendar alone (model_control.f90:114-160), without stepping a model.
+    subroutine shim_advance_date(ctl) bind(C, name = "shim_advance_date")
+        use model_control, only : ControlParams_Ptr_t, advance_date
+        integer(c_int64_t), value :: ctl
+        type(ControlParams_Ptr_t) :: ptr
+        ptr = transfer(ctl, ptr)
+        call advance_date(ptr%p)
+    end subroutine
+
     !> The zonally uniform daily forcing for an arbitrary fraction of the year (shortwave_radiation.f90:218-275), as
     !  set_forcing calls it once per simulated day (forcing.f90:84).
     subroutine shim_zonal_average_fields(cnt, tyear) bind(C, name = "shim_zonal_average_fields")

@@ -72,6 +72,20 @@ def test_leap_rule_against_the_gregorian_calendar(hip_lib):
     assert month_idx[-1] == 1 + (last.year - start.year) * 12 + last.month - start.month
 
 
+def test_a_century_year_bitwise(hip_lib, gold):
+    """1899-12-30 -> 1901-01-03 after every one of 13 320 steps against the reference's advance_date alone: its leap rule is
+    mod(year, 4) == 0 and nothing else, so the MODEL's 1900 has a February 29 (the Gregorian calendar has none), and month_idx
+    counts through 14 months."""
+    n = len(gold["century_cal_month_idx"]) - 1
+    ymdhm, month_idx, imont1, tmonth, tyear = walk(hip_lib, (1899, 12, 30, 0, 0), n)
+    assert np.array_equal(ymdhm, gold["century_cal_ymdhm"]) and np.array_equal(month_idx, gold["century_cal_month_idx"])
+    assert np.array_equal(imont1, gold["century_cal_imont1"])
+    assert np.array_equal(tmonth.view(np.uint64), gold["century_cal_tmonth"].view(np.uint64))
+    assert np.array_equal(tyear.view(np.uint64), gold["century_cal_tyear"].view(np.uint64))
+    days = {tuple(r[:3]) for r in gold["century_cal_ymdhm"]}
+    assert (1900, 2, 29) in days and (1901, 2, 29) not in days and gold["century_cal_month_idx"][-1] == 14
+
+
 def test_daily_forcing_every_day_of_the_year_bitwise(hip_lib, gold):
     out = np.zeros((5, 48))
     for d, tyear in enumerate(gold["forcing_tyear"]):
