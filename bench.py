@@ -883,6 +883,7 @@ def one_process_leg(n_devices, members_total, steps, what):
     cnts = [m._state_cnt for m in ens.members]
     ens.set_bc()  # member 0 reads the packaged boundary file; every other member receives the fields device to device
     peer, local, collective = drv.broadcast_boundary_stats()
+    transport_note = drv.broadcast_boundary_note()  # (in words, with the reason when the collective was not used)
     bc = load_bc()
     probe = ens.members[-1]["orog"]  # what arrived in the last container (on the last device) is what the file holds
     arrived = bool(np.array_equal(probe, np.asarray(bc["orog"], dtype=np.float64)))
@@ -899,7 +900,7 @@ def one_process_leg(n_devices, members_total, steps, what):
            "members_per_device": [sum(1 for c in cnts if drv.modelstate_device(c) == d) for d in devices],
            "device_models": models, "boundary_broadcast": {"collective_devices": collective, "peer_copies": peer, "local_copies": local,
                                                          "transport": "rccl" if collective else ("peer copies" if peer else "local copies only"),
-                                                         "arrived_intact": arrived},
+                                                         "arrived_intact": arrived, "note": transport_note},
            "setup_seconds": t_setup, "ms_per_step": ms,
            "value": members_total * 86400.0 / (ms * 1e-3 * STEPS_PER_YEAR), "unit": "simulated-years/day",
            "current_device_preserved": torch.cuda.current_device() == before}

@@ -207,7 +207,8 @@ def test_the_n_rank_line_is_complete():
     assert op["processes"] == 1 and op["devices_asked"] == 2 and op["devices_used"] == 1 and op["containers"] == 128
     assert op["device_models"] == 2 and op["members_per_device"] == [128] and op["current_device_preserved"] is True
     assert op["boundary_broadcast"] == {"collective_devices": 0, "peer_copies": 0, "local_copies": 127,
-                                        "transport": "local copies only", "arrived_intact": True}
+                                        "transport": "local copies only", "arrived_intact": True,
+                                        "note": "local copies only (one device)"}
     assert 0 < op["begin_end_ms_per_step"] == op["ms_per_step"] and 0 < op["sync_ms_per_step"]
     assert abs(op["value"] - 128 * 86400.0 / (op["ms_per_step"] * 1e-3 * 13140)) < 1e-6 * op["value"]
     assert op["cfg4_strong"]["containers"] == 64 and op["cfg4_strong"]["device_models"] == 2

@@ -115,6 +115,41 @@ def test_members_of_a_large_batch_equal_single_member_runs(spectral, bc):
     assert not np.array_equal(ens.get("t", 1), ens.get("t", 2))
 
 
+def test_four_thousand_members_on_one_gpu(spectral, bc):
+    """Sized for the 288 GB of the card: 4096 members in ONE device model (76 GB, descriptor tables of 315 392 fields per launch),
+    initialised and stepped together.  Members at the far end of every array -- element offsets beyond 2^31 bytes from member
+    1821 on -- stay bit for bit on the trajectory of a one-member model, perturbed or not, and every member passes the check."""
+    import torch
+    from pyspeedy_amd.model import EnsembleModel
+    if torch.cuda.mem_get_info()[0] < 100 << 30:
+        pytest.skip("needs 100 GB of free device memory")
+    M = 4096
+    ens = EnsembleModel(spectral, M)
+    ens.set_bc(bc)
+    reserved, used = ens.memory()
+    assert 17.0e6 * M < used <= reserved < 21.0e6 * M
+    t0 = ens.get("t", 0)
+    rng = np.random.default_rng(7)
+    bump = t0 * (1.0 + 1e-4 * rng.standard_normal((31, 32, 8, 1)))
+    bump[0] = bump[0].real
+    for i in (1900, M - 1):
+        ens.set("t", bump, member=i)
+    ens.run(6)  # two shortwave steps
+    assert (ens.check(2) == 0).all()
+    plain, bumped = EnsembleModel(spectral, 1), EnsembleModel(spectral, 1)
+    for single, t in ((plain, None), (bumped, bump)):
+        single.set_bc(bc)
+        if t is not None:
+            single.set("t", t)
+        single.run(6)
+    for i, single in ((0, plain), (1899, plain), (1900, bumped), (M - 2, plain), (M - 1, bumped)):
+        for n in SPEC + ("phi", "land_temp", "sst_am", "olr", "precnv", "hfluxn", "rad_tau2", "tt_rsw"):
+            assert np.array_equal(ens.get(n, i), single.get(n, 0)), (i, n)
+    ens.close()
+    plain.close()
+    bumped.close()
+
+
 def test_initialisation_with_distinct_boundary_sets(spectral, bc):
     """spd_model_init preprocesses every member's boundary fields on the device.  Six members, two of
     them with their own SST / soil climatologies: every member is bitwise the one-member model initialised from the same fields,
