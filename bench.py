@@ -1131,8 +1131,12 @@ def rccl_preflight(rank, world, wall):
     env.pop("PYSPEEDY_AMD_BENCH_T0", None)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     code, out, err = run_bounded_child([sys.executable, os.path.abspath(__file__), "--rccl-probe"], env, timeout)
+    def reason(text):  # the exception's own line, not the warnings the runtime prints on its way out
+        lines = [ln.strip() for ln in text.splitlines() if ln.strip() and not ln.lstrip().startswith(("[W", "[I", "warnings.warn"))]
+        errors = [ln for ln in lines if "Error" in ln or "error" in ln]
+        return (errors or lines or [""])[-1][:240]
     mine = "ok" if code == 0 and "RCCL_PROBE_OK" in out else (
-        "no answer within %d s" % timeout if code is None else "exit code %s: %s" % (code, (err or out).strip().splitlines()[-1][:300] if (err or out).strip() else ""))
+        "no answer within %d s" % timeout if code is None else "exit code %s: %s" % (code, reason(err or out)))
     import tempfile
     base = os.path.join(tempfile.gettempdir(), "pyspeedy_bench_%s_%d_rccl" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
     with open("%s.%d" % (base, rank), "w") as fh:
