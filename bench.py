@@ -1127,8 +1127,10 @@ def rccl_preflight(rank, world, wall):
     exchange data in a step, so the transport of the barrier does not enter `value`.  -> (use RCCL?, reason, seconds spent)"""
     t0 = time.time()
     timeout = max(20.0, min(90.0, wall.left() / 4.0))
-    env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 1))
-    env.pop("PYSPEEDY_AMD_BENCH_T0", None)
+    # (without torchrun's own variables: under TORCHELASTIC_USE_AGENT_STORE the ranks expect the launcher's agent to host the
+    # rendezvous store, and nobody hosts one on the probe's port -- the children would wait for it until their time is up)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_") and k != "PYSPEEDY_AMD_BENCH_T0"}
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     code, out, err = run_bounded_child([sys.executable, os.path.abspath(__file__), "--rccl-probe"], env, timeout)
     def reason(text):  # the exception's own line, not the warnings the runtime prints on its way out
