@@ -1135,8 +1135,10 @@ def rccl_preflight(rank, world, wall):
     code, out, err = run_bounded_child([sys.executable, os.path.abspath(__file__), "--rccl-probe"], env, timeout)
     def reason(text):  # the exception's own line, not the warnings the runtime prints on its way out
         lines = [ln.strip() for ln in text.splitlines() if ln.strip() and not ln.lstrip().startswith(("[W", "[I", "warnings.warn"))]
-        errors = [ln for ln in lines if "Error" in ln or "error" in ln]
-        return (errors or lines or [""])[-1][:240]
+        import re
+        named = [ln for ln in lines if re.search(r"\b\w+(Error|Exception)\b", ln)]  # "torch.distributed.DistBackendError: ..."
+        errors = [ln for ln in lines if "error" in ln.lower() and not ln.lower().startswith("last error")]
+        return (named or errors or lines or [""])[-1][:240]
     mine = "ok" if code == 0 and "RCCL_PROBE_OK" in out else (
         "no answer within %d s" % timeout if code is None else "exit code %s: %s" % (code, reason(err or out)))
     import tempfile
