@@ -1,8 +1,9 @@
-"""GPU tier: the whole model step of a batch of DIFFERENT members against the CPU oracle's whole model (oracle/orc_model.c, bit for
-bit the reference: tests/test_model_oracle.py) on the same seeded inputs -- six members of one device model, each with its own
+"""GPU tier: the whole model step of DIFFERENT states against the CPU oracle's whole model (oracle/orc_model.c, bit for bit the
+reference: tests/test_model_oracle.py) on the same seeded inputs -- six containers stepped through `spd_step`, each with its own
 temperature perturbation (numpy default_rng(seed = member)), its own start date (through the coupling flags and the CO2 trend for two
-of them) and 12 model steps (four shortwave steps, a midnight coupling for the member started at 20:00).  The goldens pin one
-unperturbed trajectory; this pins the batch: every member against an oracle run of its own.  Tolerance 1e-11 of each field's
+of them) and 12 model steps (four shortwave steps, a midnight coupling for the member started at 20:00).  The goldens pin
+unperturbed trajectories; this pins perturbed ones, at other dates and flag settings: every member against an oracle run of its own
+(observed 6.4e-14).  Tolerance 1e-11 of each field's
 max norm (12 steps, fp64; one step is held to 1e-12 in tests/test_step_gpu.py)."""
 from datetime import datetime
 
