@@ -34,6 +34,22 @@ module pyspeedy_amd_c
             real(c_double), intent(out) :: buf(*)
             integer(c_size_t), value :: buf_elems
         end function
+        ! host only (no device): initialize_control + nsteps x advance_date / update_forcing_params, model_control.f90:79-185;
+        ! row 1 of every output = after initialize_control, row s + 1 = after s steps; ymdhm(5, nsteps + 1)
+        integer(c_int) function spd_calendar_walk(year, month, day, hour, minute, nsteps, ymdhm, month_idx, imont1, tmonth, tyear) &
+                bind(C, name="spd_calendar_walk")
+            import :: c_int, c_int32_t, c_double
+            integer(c_int), value :: year, month, day, hour, minute, nsteps
+            integer(c_int32_t), intent(out) :: ymdhm(5, *), month_idx(*), imont1(*)
+            real(c_double), intent(out) :: tmonth(*), tyear(*)
+        end function
+        ! host only: get_zonal_average_fields (shortwave_radiation.f90:218-322) for a fraction of the year; out(48, 5) =
+        ! flux_solar_in, flux_ozone_upper, flux_ozone_lower, zenit_correction, stratospheric_correction by latitude
+        integer(c_int) function spd_daily_forcing_host(tyear, out) bind(C, name="spd_daily_forcing_host")
+            import :: c_int, c_double
+            real(c_double), value :: tyear
+            real(c_double), intent(out) :: out(48, 5)
+        end function
 
         ! ---- operator level: device pointers, explicit batch count, stream ------------------------------------------
         integer(c_int) function spd_spec2grid(handle, spec, grid, kcos, nfields, stream) bind(C, name="spd_spec2grid")
