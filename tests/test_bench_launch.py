@@ -307,7 +307,8 @@ def test_bench_one_process_mode():
     assert res["n_gpus"] == 1 and res["value"] == op["value"] and res["ms_per_step"] == op["begin_end_ms_per_step"]
     assert op["containers"] == 40 and op["device_models"] == 2 and op["devices_used"] == 1 and op["steps_timed"] == 30
     assert op["boundary_broadcast"] == {"collective_devices": 0, "peer_copies": 0, "local_copies": 39,
-                                        "transport": "local copies only", "arrived_intact": True}
+                                        "transport": "local copies only", "arrived_intact": True,
+                                        "note": "local copies only (one device)"}
     assert op["current_device_preserved"] is True and res["vs_baseline"] is None
 
 
