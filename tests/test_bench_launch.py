@@ -147,13 +147,13 @@ def test_a_hanging_one_process_child_does_not_cost_the_line():
     env.pop("WORLD_SIZE", None)
     t0 = time.time()
     res = _result(subprocess.run([sys.executable, BENCH, "--gpus", "2", "--members", "4", "--steps", "6", "--warmup", "3", "--regions", "2",
-                                  "--no-cpu-baseline", "--budget", "75"], capture_output=True, text=True, timeout=600, env=env))
+                                  "--no-cpu-baseline", "--budget", "90"], capture_output=True, text=True, timeout=600, env=env))
     wall = time.time() - t0
-    assert wall < 75 + 30, wall
+    assert wall < 90 + 30, wall
     assert res["n_gpus"] == 2 and res["value"] > 0 and res["roofline"]["frac"] > 0
     op = res["one_process"]
-    assert "no answer within" in op["error"] and op["timeouts_s"][0] <= 25.0 and op["timeouts_s"][1] == 0.0
-    assert res["budget"]["budget_s"] == 75.0 and res["budget"]["used_s"] < 75.0
+    assert "no answer within" in op["error"] and op["timeouts_s"][0] <= 30.0 and op["timeouts_s"][1] == 0.0
+    assert res["budget"]["budget_s"] == 90.0 and res["budget"]["used_s"] < 90.0
     # ... and with no time left at all nothing secondary is started: the headline alone
     res = _result(subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "6", "--warmup", "3", "--regions", "2",
                                   "--no-cpu-baseline", "--budget", "1"], capture_output=True, text=True, timeout=600, env=env))
