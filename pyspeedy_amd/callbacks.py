@@ -95,6 +95,7 @@ class XarrayExporter(_GridOutput):
         super().__init__(interval, verbose, spinup_date, variables, output_dir)
         self.filename_fmt = filename_fmt
         self.background = background
+        self._buffers = {}            # this exporter's own two pinned output buffers (speedy_driver.ensemble_export_arrays)
         self._pending = [None, None]  # per output buffer: the thread that is writing from it
         self._turn = 0
         self._failure = None
@@ -104,13 +105,13 @@ class XarrayExporter(_GridOutput):
         os.makedirs(self.output_dir, exist_ok=True)
         self.print_msg("Saving model output at: %s." % target)
         if not self.background:
-            model_instance.to_dataframe(variables=self.variables, packed=True).to_netcdf(target)
+            model_instance.to_dataframe(variables=self.variables, packed=True, buffers=self._buffers).to_netcdf(target)
             return
         import threading
         slot = self._turn
         self._turn = 1 - slot
         self._wait(slot)  # (the buffer this output goes into may still be on its way to disk)
-        frame = model_instance.to_dataframe(variables=self.variables, packed=True, slot=slot)
+        frame = model_instance.to_dataframe(variables=self.variables, packed=True, slot=slot, buffers=self._buffers)
 
         def write():
             try:
@@ -134,8 +135,12 @@ class XarrayExporter(_GridOutput):
             self._wait(slot)
 
     def copy(self):
-        self.finish()  # (threads do not copy)
-        return super().copy()
+        self.finish()  # (threads do not copy, and a copy gets buffers of its own)
+        buffers, self._buffers = self._buffers, {}
+        try:
+            return super().copy()
+        finally:
+            self._buffers = buffers
 
     def __del__(self):
         try:

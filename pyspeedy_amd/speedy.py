@@ -285,15 +285,16 @@ class Speedy:
             raise RuntimeError(ERROR_CODES[code])
 
     # ---- export ----------------------------------------------------------------------------------------------
-    def to_dataframe(self, variables=None, packed=False, slot=0):
+    def to_dataframe(self, variables=None, packed=False, slot=0, buffers=None):
         """Current model state as a Dataset following the export conventions of the reference (speedy.py:415-477).
         packed=True (extension, what XarrayExporter asks for): the data variables come as they go into a NetCDF-3 file -- float32,
-        big-endian, narrowed and ordered on the GPU -- and alias a buffer that the next packed call with the same `slot` overwrites."""
+        big-endian, narrowed and ordered on the GPU -- and alias a buffer that the next packed call with the same `slot` (of the same
+        `buffers` dict, when the caller brings its own) overwrites."""
         variables = DEFAULT_OUTPUT_VARS if variables is None else variables
         if packed:
             for var in variables:
                 _exportable(var)
-            arrays = _speedy.ensemble_export_arrays([self._state_cnt], list(variables), slot=slot)
+            arrays = _speedy.ensemble_export_arrays([self._state_cnt], list(variables), slot=slot, buffers=buffers)
             members = [self.member_id] if self.is_ensemble_member else None
             return _build_dataset(self, arrays, members, self.current_date, packed=True)
         self.spectral2grid()
@@ -402,14 +403,14 @@ class SpeedyEns:
             member.spectral2grid()
             member._initialized_bc = True
 
-    def to_dataframe(self, variables=None, packed=False, slot=0):
+    def to_dataframe(self, variables=None, packed=False, slot=0, buffers=None):
         """All members along the `ens` dimension: one batched spectral -> grid conversion and one device-to-host copy per
         variable (the device layout [member][lev][lat][lon] is already the export order).  packed=True: see Speedy.to_dataframe."""
         variables = DEFAULT_OUTPUT_VARS if variables is None else variables
         for var in variables:
             _exportable(var)
         cnts = [m._state_cnt for m in self]
-        arrays = (_speedy.ensemble_export_arrays(cnts, list(variables), slot=slot) if packed else
+        arrays = (_speedy.ensemble_export_arrays(cnts, list(variables), slot=slot, buffers=buffers) if packed else
                   _speedy.ensemble_grid_arrays(cnts, list(variables)))
         return _build_dataset(self.members[0], arrays, [m.member_id for m in self], self.current_date, packed=packed)
 

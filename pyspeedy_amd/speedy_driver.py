@@ -318,12 +318,13 @@ def ensemble_grid_arrays(state_cnts, names):
 _export_buffers = {}  # (bytes, slot) -> pinned uint8 tensor, kept for the life of the process (a day's output of 64 members: 48 MB)
 
 
-def ensemble_export_arrays(state_cnts, names, slot=0):
+def ensemble_export_arrays(state_cnts, names, slot=0, buffers=None):
     """Extension, for writing files: the grid-space variables `names` of the given containers as they go into a NetCDF-3 file --
     float32, BIG-endian, vertical levels bottom-up (the reference's export convention, speedy.py:415-477) -- dict name -> numpy
     array of dtype '>f4' [member, (lev,) lat, lon] in the order of `state_cnts`.  Narrowing, level reversal and byte order happen
     on the GPU; what crosses PCIe is the file's payload itself (half the bytes of the fp64 fields), into pinned host memory.
-    The arrays alias a buffer that the next call with the same `slot` overwrites."""
+    The arrays alias a pinned buffer that the next call with the same `slot` overwrites: the process-wide one of that slot, or --
+    `buffers`, a dict the caller owns (an exporter that writes its files in the background keeps two of its own) -- buffers[slot]."""
     import torch
     groups, order = {}, []
     for pos, cnt in enumerate(state_cnts):
@@ -339,10 +340,10 @@ def ensemble_export_arrays(state_cnts, names, slot=0):
     shapes = {name: tuple(first.device_view(name).shape[1:]) for name in names}
     sizes = {name: 4 * n * int(np.prod(shapes[name])) for name in names}
     total = sum(sizes.values())
-    key = (total, slot)
-    if key not in _export_buffers:
-        _export_buffers[key] = torch.empty(total, dtype=torch.uint8).pin_memory()
-    buf = _export_buffers[key]
+    pool, key = (_export_buffers, (total, slot)) if buffers is None else (buffers, slot)
+    if key not in pool or pool[key].numel() != total:
+        pool[key] = torch.empty(total, dtype=torch.uint8).pin_memory()
+    buf = pool[key]
     offsets, at = {}, 0
     for name in names:
         offsets[name] = at

@@ -400,6 +400,18 @@ def test_background_writer_leaves_the_same_files():
             files[background] = {n: open(os.path.join(tmp, n), "rb").read() for n in names}
     assert files[True] == files[False]
     assert len({v for v in files[True].values()}) == 7  # (seven different states, not one buffer written seven times)
+    # two exporters in one run whose outputs have the same size but not the same content: each has buffers of its own
+    ens = SpeedyEns(3, start_date=start, end_date=datetime(1982, 1, 1, 4, 0))
+    ens.set_bc()
+    with tempfile.TemporaryDirectory() as tmp:
+        a, b = os.path.join(tmp, "a"), os.path.join(tmp, "b")
+        ens.run(callbacks=[XarrayExporter(output_dir=a, interval=2, variables=("t_grid", "ps_grid")),
+                           XarrayExporter(output_dir=b, interval=2, variables=("u_grid", "ps_grid"))])
+        from pyspeedy_amd.dataset import open_dataset
+        for name in sorted(os.listdir(a)):
+            da, db = open_dataset(os.path.join(a, name)), open_dataset(os.path.join(b, name))
+            assert "t" in da.variables and "u" in db.variables and "u" not in da.variables
+            assert 150.0 < float(da["t"].values.min()) and abs(float(db["u"].values.mean())) < 50.0 < float(da["t"].values.mean())
     ens = SpeedyEns(2, start_date=start, end_date=end)
     ens.set_bc()
     with tempfile.TemporaryDirectory() as tmp:
