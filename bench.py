@@ -922,7 +922,12 @@ def plan_name(cfg, M):
     g = cfg["chunks"]
     if g <= 1:
         return "serial: one member group on one stream"
-    plan = "%d member groups of %d / %d members on %d HIP streams" % (g, (M + g - 1) // g, M // g, g)
+    rounds = cfg.get("rounds", 1)
+    if rounds > 1:  # (multi-step calls of large ensembles: model.hip, block_members)
+        per = (M + rounds - 1) // rounds
+        plan = "%d rounds of %d members, each through all steps of a call in %d member groups on %d HIP streams" % (rounds, per, g, g)
+    else:
+        plan = "%d member groups of %d / %d members on %d HIP streams" % (g, (M + g - 1) // g, M // g, g)
     if cfg.get("group_streams", 0) > 1:  # (csrc/stream_apart.hpp: measured when the streams were created)
         plan += " (measured: side by side)" if cfg["group_streams_apart"] else " (NOT measured to be all side by side -- two may share a hardware queue)"
     return plan

@@ -284,12 +284,18 @@ int spd_model_group_streams(spd_model_handle m, int32_t *created, int32_t *apart
  *   "split_dyn"            0 / 1   separate launches for grid-point dynamics and column physics
  *   "member_groups"        1 ... 4 the members are stepped in that many groups on separate HIP streams (default: 1 below 20
  *                                  members, 2 for 20 ... 23 and from 64 up, 3 for 24 ... 63; always 1 while spd_model_profile is on, for calls of a single step and with split_dyn)
+ *   "block_members"        0, n    (default 32, PYSPEEDY_AMD_BLOCK_MEMBERS) from 4 n members up a multi-step spd_model_step takes the
+ *                                  members in rounds of member_groups x n, a round through all steps of the call before the next
+ *                                  starts (the cross-step hand-over of a group's spectral state then stays in the Infinity Cache;
+ *                                  bitwise the same state); 0: everybody together
  *   "physics_storage32"    0 / 1   (default 1, PYSPEEDY_AMD_PHYS_STORE32) with spd_model_set_physics_precision(m, 1): keep the arrays
  *                                  only the column physics reads back as fp32 in memory (1) or as fp64 (0: same arithmetic, same
  *                                  bits in the state, 13 % more bytes in the column kernel); converts the arrays when it changes
  * Returns SPD_E_ARG for an unknown name or a value outside the list.  What is fixed at creation (the pruned transform
  * table, the geopotential fold) is read from the environment only. */
 int spd_model_set_option(spd_model_handle m, const char *name, int32_t value);
+/* ... and read back, by the same names */
+int spd_model_get_option(spd_model_handle m, const char *name, int32_t *value);
 /* BASELINE cfg 5: fp32 != 0 runs the arithmetic of the column physics (physics.f90:107-256 and the schemes it calls) in
  * single precision; the model state, the grid-point dynamics and the tendencies handed to the transforms stay fp64 (the
  * physics increment is formed in fp32 and added to the fp64 dynamics tendency).  Not bitwise comparable with the reference:

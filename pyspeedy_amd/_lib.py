@@ -167,6 +167,7 @@ _SIGNATURES = {
     "spd_model_get_config": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "spd_model_group_streams": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "spd_model_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
+    "spd_model_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -155,6 +155,14 @@ struct spd_model {
     // kx; every registry variable stays bitwise identical, tests/test_run_gpu.py).  PYSPEEDY_AMD_PRUNE_DEAD=0 restores all 91.
     int inv_per_member = 77;
     int nchunks = 1;
+    // Large ensembles in multi-step calls: from 4 x `block_members` members up, spd_model_step(m, n) takes the members in ROUNDS of
+    // nchunks x block_members -- a round through ALL n steps before the next round starts (members never exchange data).  A group's
+    // spectral step is then followed on its stream by the spectral -> grid launch of its own next step, which reads what was just
+    // written while it is still in the 256 MB Infinity Cache, as in a 64-member ensemble; with 128 members per group it is not,
+    // and a member-step costs 5-10 % more (profiles/r05_members_per_gpu.txt).  The host-side state of the step (calendar, step
+    // counter, geopotential buffer, SPPT counter, CO2) is rewound for every round.  0: off (PYSPEEDY_AMD_BLOCK_MEMBERS, option
+    // "block_members").
+    int block_members = 32;
     hipStream_t cstream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t cev[4] = {nullptr, nullptr, nullptr, nullptr}, ev_start = nullptr, ev_offset = nullptr;
     bool split_dyn_physics = false;  // PYSPEEDY_AMD_SPLIT_DYN=1: separate dynamics and physics launches (for measurements)
@@ -528,6 +536,7 @@ int spd_model_create(spd_handle h, int nmembers, spd_model_handle *out) {
     if (m->nchunks < 1) m->nchunks = 1;
     if (m->nchunks > 4) m->nchunks = 4;
     if (m->nchunks > nmembers) m->nchunks = nmembers;
+    if (const char *env = getenv("PYSPEEDY_AMD_BLOCK_MEMBERS")) m->block_members = atoi(env) > 0 ? atoi(env) : 0;
     const size_t M = nmembers, S = NSPEC * C, G3 = static_cast<size_t>(8) * NG;
     ModelPtrs &P = m->P;
     spd_physics_args &pa = m->pa;
@@ -1308,49 +1317,78 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
     static const int offset_from = getenv("PYSPEEDY_AMD_GROUP_OFFSET") ? atoi(getenv("PYSPEEDY_AMD_GROUP_OFFSET")) : 72;
     const bool offset = offset_from > 0 && G == 2 && nsteps >= offset_from;
     if (offset && !m->ev_offset) M_HIP(hipEventCreateWithFlags(&m->ev_offset, hipEventDisableTiming));
-    const int base = m->M / G, extra = m->M % G;
+    // rounds (see block_members): the members of a round go through all steps of the call before the next round starts
+    int rounds = 1;
+    if (G > 1 && nsteps > 1 && m->block_members > 0 && m->M >= 4 * m->block_members)
+        rounds = (m->M + G * m->block_members - 1) / (G * m->block_members);
+    struct HostState {  // what a step changes on the host side of the model
+        Calendar cal;
+        int current_step, phi_cur;
+        bool surf_cache_valid, phi_ahead, sppt_first;
+        long long sppt_step;
+        double co2;
+    };
+    const HostState start{m->cal, m->current_step, m->phi_cur, m->surf_cache_valid, m->phi_ahead, m->sppt_first, m->sppt_step,
+                          m->air_absortivity_co2};
     int rc = SPD_OK;
-    for (int it = 0; it < nsteps && rc == SPD_OK; ++it) {
-        const bool new_day = m->current_step % 36 == 0;
-        ZonalDevice zd{};
-        if (new_day) zd = forcing_host(m, 1);
-        const int sw = (m->current_step % 3 == 0) ? 1 : 0;
-        const int diag = (m->diag_every_step || it == nsteps - 1) ? 1 : 0;
-        // The land / sea-ice coupling that follows the step (speedy.f90:72) happens at the date AFTER the step and for the
-        // incremented step counter.  The interpolation weights of the climatologies change at midnight only: the first
-        // coupling of a day (or of a state the host touched) interpolates, the others re-use what it stored (surface.hip).
-        Calendar next = m->cal;
-        next.advance();
-        const TimeInterp w = time_interp(next);
-        const int fresh = (!m->surf_cache_valid || (next.hour == 0 && next.minute == 0)) ? 1 : 0;
-        if (m->sst_anomaly_flag && (w.a0 < 0 || w.a1 < 0 || w.a0 >= m->anom_planes || w.a1 >= m->anom_planes))
-            return m_fail(SPD_E_ARG, "SST anomaly planes do not cover the simulated period (speedy.py:338-372)");
-        const bool run_geo = begin_step_geopotential(m);
-        for (int g = 0, first = 0; g < G && rc == SPD_OK; ++g) {
-            const int count = base + (g < extra ? 1 : 0);
-            if (new_day) rc = forcing_range(m, zd, first, count, gs[g]);
-            CouplerArgs cpl{m->S, w, first, count, 1 + (m->current_step + 1) / 36, m->land_coupling_flag, m->sst_anomaly_flag,
-                            m->anom_planes, fresh};
-            const bool ride = m->coupler_in_spectral;
-            if (rc == SPD_OK) {
-                if (offset && it == 0 && g == 1) M_HIP(hipStreamWaitEvent(gs[1], m->ev_offset, 0));
-                const hipError_t e = step_range(m, 2, 2, 2 * delt, sw, first, count, diag, run_geo, ride ? &cpl : nullptr, gs[g],
-                                                (offset && it == 0 && g == 0) ? m->ev_offset : nullptr);
-                if (e != hipSuccess) rc = m_fail(SPD_E_DEVICE, std::string("spd_model_step: ") + hipGetErrorString(e));
-            }
-            if (rc == SPD_OK && !ride) {
-                ProfScope ps(m, SPD_K_COUPLER, count, gs[g]);
-                const hipError_t e = run_coupler(m->S, first, count, w, 1 + (m->current_step + 1) / 36, m->land_coupling_flag,
-                                                 m->sst_anomaly_flag, m->anom_planes, fresh, gs[g]);
-                if (e != hipSuccess) rc = m_fail(SPD_E_DEVICE, std::string("couple_sea_land: ") + hipGetErrorString(e));
-            }
-            first += count;
+    for (int round = 0, round_first = 0; round < rounds && rc == SPD_OK; ++round) {
+        const int round_count = m->M / rounds + (round < m->M % rounds ? 1 : 0);
+        if (round > 0) {  // the same steps again, for the next members
+            m->cal = start.cal;
+            m->current_step = start.current_step;
+            m->phi_cur = start.phi_cur;
+            m->surf_cache_valid = start.surf_cache_valid;
+            m->phi_ahead = start.phi_ahead;
+            m->sppt_first = start.sppt_first;
+            m->sppt_step = start.sppt_step;
+            m->air_absortivity_co2 = start.co2;
         }
-        if (rc != SPD_OK) break;
-        sppt_advance(m);
-        m->current_step += 1;
-        m->cal = next;
-        m->surf_cache_valid = true;
+        const int base = round_count / G, extra = round_count % G;
+        for (int it = 0; it < nsteps && rc == SPD_OK; ++it) {
+            const bool new_day = m->current_step % 36 == 0;
+            ZonalDevice zd{};
+            if (new_day) zd = forcing_host(m, 1);
+            const int sw = (m->current_step % 3 == 0) ? 1 : 0;
+            const int diag = (m->diag_every_step || it == nsteps - 1) ? 1 : 0;
+            // The land / sea-ice coupling that follows the step (speedy.f90:72) happens at the date AFTER the step and for the
+            // incremented step counter.  The interpolation weights of the climatologies change at midnight only: the first
+            // coupling of a day (or of a state the host touched) interpolates, the others re-use what it stored (surface.hip).
+            Calendar next = m->cal;
+            next.advance();
+            const TimeInterp w = time_interp(next);
+            const int fresh = (!m->surf_cache_valid || (next.hour == 0 && next.minute == 0)) ? 1 : 0;
+            if (m->sst_anomaly_flag && (w.a0 < 0 || w.a1 < 0 || w.a0 >= m->anom_planes || w.a1 >= m->anom_planes))
+                return m_fail(SPD_E_ARG, "SST anomaly planes do not cover the simulated period (speedy.py:338-372)");
+            const bool run_geo = begin_step_geopotential(m);
+            const bool first_of_call = it == 0 && round == 0;
+            for (int g = 0, first = round_first; g < G && rc == SPD_OK; ++g) {
+                const int count = base + (g < extra ? 1 : 0);
+                if (count == 0) continue;
+                if (new_day) rc = forcing_range(m, zd, first, count, gs[g]);
+                CouplerArgs cpl{m->S, w, first, count, 1 + (m->current_step + 1) / 36, m->land_coupling_flag, m->sst_anomaly_flag,
+                                m->anom_planes, fresh};
+                const bool ride = m->coupler_in_spectral;
+                if (rc == SPD_OK) {
+                    if (offset && first_of_call && g == 1) M_HIP(hipStreamWaitEvent(gs[1], m->ev_offset, 0));
+                    const hipError_t e = step_range(m, 2, 2, 2 * delt, sw, first, count, diag, run_geo, ride ? &cpl : nullptr, gs[g],
+                                                    (offset && first_of_call && g == 0) ? m->ev_offset : nullptr);
+                    if (e != hipSuccess) rc = m_fail(SPD_E_DEVICE, std::string("spd_model_step: ") + hipGetErrorString(e));
+                }
+                if (rc == SPD_OK && !ride) {
+                    ProfScope ps(m, SPD_K_COUPLER, count, gs[g]);
+                    const hipError_t e = run_coupler(m->S, first, count, w, 1 + (m->current_step + 1) / 36, m->land_coupling_flag,
+                                                     m->sst_anomaly_flag, m->anom_planes, fresh, gs[g]);
+                    if (e != hipSuccess) rc = m_fail(SPD_E_DEVICE, std::string("couple_sea_land: ") + hipGetErrorString(e));
+                }
+                first += count;
+            }
+            if (rc != SPD_OK) break;
+            sppt_advance(m);
+            m->current_step += 1;
+            m->cal = next;
+            m->surf_cache_valid = true;
+        }
+        round_first += round_count;
     }
     return rc;
 }
@@ -1497,6 +1535,20 @@ int spd_model_get_config(spd_model_handle m, int32_t *cfg) {
     return SPD_OK;
 }
 
+int spd_model_get_option(spd_model_handle m, const char *name, int32_t *value) {
+    if (!m || !name || !value) return m_fail(SPD_E_ARG, "spd_model_get_option: null argument");
+    const std::string key(name);
+    if (key == "diag_every_step") *value = m->diag_every_step ? 1 : 0;
+    else if (key == "coupler_in_spectral") *value = m->coupler_in_spectral ? 1 : 0;
+    else if (key == "split_dyn") *value = m->split_dyn_physics ? 1 : 0;
+    else if (key == "spectral_early") *value = m->spectral_early;
+    else if (key == "member_groups") *value = m->nchunks;
+    else if (key == "block_members") *value = m->block_members;
+    else if (key == "physics_storage32") *value = m->phys_store32 ? 1 : 0;
+    else return m_fail(SPD_E_ARG, "spd_model_get_option: unknown option: " + key);
+    return SPD_OK;
+}
+
 int spd_model_set_option(spd_model_handle m, const char *name, int32_t value) {
     if (!m || !name) return m_fail(SPD_E_ARG, "spd_model_set_option: null argument");
     const std::string key(name);
@@ -1506,6 +1558,7 @@ int spd_model_set_option(spd_model_handle m, const char *name, int32_t value) {
     else if (key == "split_dyn" && flag) m->split_dyn_physics = value != 0;
     else if (key == "spectral_early" && value >= -1 && value <= 1) m->spectral_early = value;
     else if (key == "member_groups" && value >= 1 && value <= 4) m->nchunks = value < m->M ? value : m->M;
+    else if (key == "block_members" && value >= 0) m->block_members = value;
     else if (key == "physics_storage32" && flag) {
         m->phys_store32 = value != 0;
         return apply_storage(m, m->phys_fp32 && m->phys_store32);

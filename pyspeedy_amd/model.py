@@ -255,13 +255,21 @@ class EnsembleModel:
         check(self._lib.spd_model_get_config(self._m, cfg), "spd_model_get_config")
         created, apart = C.c_int32(0), C.c_int32(1)
         check(self._lib.spd_model_group_streams(self._m, C.byref(created), C.byref(apart)), "spd_model_group_streams")
+        block = C.c_int32(0)
+        check(self._lib.spd_model_get_option(self._m, b"block_members", C.byref(block)), "spd_model_get_option")
+        streams, M = cfg[2], self.nmembers
+        # (as spd_model_step forms them: rounds of `chunks` x `block_members` members from 4 x block_members members up)
+        rounds = 1
+        if streams > 1 and block.value > 0 and M >= 4 * block.value:
+            rounds = (M + streams * block.value - 1) // (streams * block.value)
         return dict(inv_per_member=cfg[0], diag_every_step=bool(cfg[1]), chunks=cfg[2], split_dyn=bool(cfg[3]),
                     fold_geo=bool(cfg[4]), coupler_in_spectral=bool(cfg[5]), physics_fp32=bool(cfg[6]),
-                    physics_storage32=bool(cfg[7]), group_streams=created.value, group_streams_apart=bool(apart.value))
+                    physics_storage32=bool(cfg[7]), group_streams=created.value, group_streams_apart=bool(apart.value),
+                    block_members=block.value, rounds=rounds)
 
     def set_option(self, name, value):
         """A launch-plan switch of the live model by name (spd_model_set_option: diag_every_step, coupler_in_spectral,
-        spectral_early, split_dyn, member_groups, physics_storage32); none of them changes the state a step leaves behind.
+        spectral_early, split_dyn, member_groups, block_members, physics_storage32); none of them changes the state a step leaves behind.
         ValueError for an unknown name."""
         rc = self._lib.spd_model_set_option(self._m, name.encode(), int(value))
         if rc == _lib.SPD_E_ARG:

@@ -377,6 +377,49 @@ def test_member_groups_on_separate_streams_are_bitwise(spectral, bc, monkeypatch
             assert np.array_equal(a, b), n
 
 
+def test_rounds_of_a_large_ensemble_are_bitwise(spectral, bc):
+    """From 128 members up a multi-step call takes the members in rounds of 64 -- a round through ALL steps of the call before the
+    next one starts, with the host side of the step (calendar, step counter, geopotential buffer, SPPT counter, CO2) rewound in
+    between (option block_members).  Bitwise the state of the call that steps everybody together: 150 members (three uneven
+    rounds), 50 steps across a midnight and the January / February boundary, SST anomalies, the CO2 trend -- and, second pass, SPPT
+    with the fp32 column physics -- then a second call on top (the rewound state must end where a single pass ends)."""
+    from pyspeedy_amd.model import EnsembleModel
+    M = 150
+    i_ = np.arange(96)[:, None, None]
+    ssta = 1.5 * np.sin(2 * np.pi * i_ / 96 + 0.7 * np.arange(4)[None, None, :]) * np.ones((1, 48, 1)) - 0.4
+    for cfg5 in (False, True):
+        states = []
+        for block in (0, 32):
+            model = EnsembleModel(spectral, M)
+            model.init_sst_anom(2)
+            model.set("sst_anom", ssta)
+            model.set_flags(increase_co2=True)
+            model.set_bc(bc, start_date=(1982, 1, 31, 8, 0))
+            model.set_option("block_members", block)
+            assert model.config()["block_members"] == block
+            t0 = model.get("t", 0)
+            for i in (1, 63, 64, 100, M - 1):
+                t = t0 * (1.0 + 1e-4 * np.random.default_rng(i).standard_normal((31, 32, 8, 1)))
+                t[0] = t[0].real
+                model.set("t", t, member=i)
+            if cfg5:
+                model.set_sppt(True, seed=11)
+                model.set_physics_precision(True)
+            model.run(50)
+            model.run(7)
+            assert model.current_step == 57 and model.current_date == (1982, 2, 1, 22, 0)
+            assert (model.check(2) == 0).all()
+            states.append({n: [model.get(n, i) for i in (0, 1, 49, 50, 63, 64, 100, M - 1)] for n in model.variables()
+                           if n not in ("lon", "lat", "lev")})
+            c = model.control()
+            states[-1]["__control__"] = [np.array([float(getattr(c, name)) for name, _ in c._fields_])]
+            assert model.config()["rounds"] == (3 if block else 1)
+            model.close()
+        for n, per_member in states[0].items():
+            for a, b in zip(per_member, states[1][n]):
+                assert np.array_equal(a, b), (cfg5, n)
+
+
 def test_multi_step_calls_leave_the_same_state_as_single_steps(spectral, bc, monkeypatch):
     """Inside a multi-step spd_model_step call only the last step stores the physics outputs no later kernel reads, and the
     coupler re-uses the day's interpolated climatologies: every registry variable after run(n) equals, bit for bit, the
