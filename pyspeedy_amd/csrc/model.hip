@@ -1390,6 +1390,10 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
         }
         round_first += round_count;
     }
+    if (rc != SPD_OK && rounds > 1) {  // some members have taken steps of this call that the others have not
+        m->initialized = false;
+        m->poisoned = "a device error interrupted a multi-step call that steps its members in rounds; initialise a new model";
+    }
     return rc;
 }
 
