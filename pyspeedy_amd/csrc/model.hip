@@ -1357,8 +1357,10 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
             next.advance();
             const TimeInterp w = time_interp(next);
             const int fresh = (!m->surf_cache_valid || (next.hour == 0 && next.minute == 0)) ? 1 : 0;
-            if (m->sst_anomaly_flag && (w.a0 < 0 || w.a1 < 0 || w.a0 >= m->anom_planes || w.a1 >= m->anom_planes))
-                return m_fail(SPD_E_ARG, "SST anomaly planes do not cover the simulated period (speedy.py:338-372)");
+            if (m->sst_anomaly_flag && (w.a0 < 0 || w.a1 < 0 || w.a0 >= m->anom_planes || w.a1 >= m->anom_planes)) {
+                rc = m_fail(SPD_E_ARG, "SST anomaly planes do not cover the simulated period (speedy.py:338-372)");
+                break;
+            }
             const bool run_geo = begin_step_geopotential(m);
             const bool first_of_call = it == 0 && round == 0;
             for (int g = 0, first = round_first; g < G && rc == SPD_OK; ++g) {
