@@ -1330,6 +1330,15 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
     };
     const HostState start{m->cal, m->current_step, m->phi_cur, m->surf_cache_valid, m->phi_ahead, m->sppt_first, m->sppt_step,
                           m->air_absortivity_co2};
+    if (rounds > 1 && m->sst_anomaly_flag) {  // (what can refuse a step is asked for ALL steps before the first round goes out)
+        Calendar ahead = m->cal;
+        for (int it = 0; it < nsteps; ++it) {
+            ahead.advance();
+            const TimeInterp w = time_interp(ahead);
+            if (w.a0 < 0 || w.a1 < 0 || w.a0 >= m->anom_planes || w.a1 >= m->anom_planes)
+                return m_fail(SPD_E_ARG, "SST anomaly planes do not cover the simulated period (speedy.py:338-372)");
+        }
+    }
     int rc = SPD_OK;
     for (int round = 0, round_first = 0; round < rounds && rc == SPD_OK; ++round) {
         const int round_count = m->M / rounds + (round < m->M % rounds ? 1 : 0);
