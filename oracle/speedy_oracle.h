@@ -1,11 +1,14 @@
 /* TEST INFRASTRUCTURE -- CPU oracle for the pySPEEDY hot path.  NOT PART OF THE PRODUCT.
  *
  * Plain-C restatement of the reference algorithm for the spectral-transform path
- * (speedy.f90/legendre.f90, fourier.f90, fftpack.f90, spectral.f90, geometry.f90) and of the
- * per-column physics (physics.f90 and the scheme files it calls).  Each function cites the
- * reference file:line it follows.  Parity is PINNED: tests/test_oracle.py checks every function
- * against golden vectors captured from the flang-compiled reference itself
- * (oracle/build_ref.sh -> oracle/_ref/libspeedy_ref.so, vectors by oracle/gen_golden.py).
+ * (speedy.f90/legendre.f90, fourier.f90, fftpack.f90, spectral.f90, geometry.f90), of the
+ * per-column physics (physics.f90 and the scheme files it calls) and -- orc_dynamics.c, orc_surface.c,
+ * orc_model.c -- of everything around them, up to the whole model (initialisation, do_single_step).
+ * Each function cites the reference file:line it follows.  Parity is PINNED: tests/test_oracle_golden.py,
+ * test_schemes_oracle.py, test_physics_oracle.py, test_step_oracle.py, test_oracle_init.py and
+ * test_model_oracle.py compare every function, and whole runs, BIT FOR BIT with golden vectors captured from
+ * the flang-compiled reference itself (oracle/build_ref.sh -> oracle/_ref/libspeedy_ref.so, vectors by
+ * oracle/gen_golden*.py).
  *
  * Only tests/, __graft_entry__.smoke() and the cpu_baseline leg of bench.py may use this library,
  * and only as the checker / baseline -- never on the product path.
