@@ -321,6 +321,12 @@ int spd_model_set_flags(spd_model_handle m, int land_coupling_flag, int sst_anom
 int spd_model_spectral2grid(spd_model_handle m, int first, int count, void *stream);
 int spd_model_grid2spectral(spd_model_handle m, int first, int count, void *stream);
 int spd_model_grid_filter(spd_model_handle m, int first, int count, void *stream);
+/* One grid-space registry variable ((ix, il) or (ix, il, kx) per member, e.g. "t_grid" after spd_model_spectral2grid) of the
+ * members [first, first + count) as a NetCDF-3 file carries it -- float32, BIG-endian, vertical levels bottom-up (the reference's
+ * export conventions, pyspeedy/speedy.py:415-477) -- into dst_device[count][levels][48][96] (4 bytes each), stream-ordered.  For
+ * hosts that write files: narrowing, level order and byte order happen on the GPU, and what crosses PCIe is the file's payload. */
+int spd_model_export_pack(spd_model_handle m, const char *name, int first, int count, void *dst_device, size_t dst_bytes,
+                          void *stream);
 /* modelstate_init_sst_anom (speedy_driver.f90.j2:225-237): sst_anom(ix, il, 0:n_months+1) per member, zero-filled */
 int spd_model_init_sst_anom(spd_model_handle m, int n_months);
 /* Stochastically perturbed parametrisation tendencies (sppt.f90; compile-time off and non-functional in the reference:

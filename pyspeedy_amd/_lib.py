@@ -115,6 +115,7 @@ _SIGNATURES = {
     "spd_model_spectral2grid": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "spd_model_grid2spectral": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "spd_model_grid_filter": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "spd_model_export_pack": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "spd_model_init_sst_anom": (C.c_int, [C.c_void_p, C.c_int]),
     "spd_model_set_sppt": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_int64]),
     "spd_model_copy_member": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

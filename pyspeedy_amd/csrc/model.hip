@@ -64,6 +64,7 @@ SpptArgs sppt_args(double *spec, const DeviceTables &T, int M, unsigned long lon
                    int first);
 hipError_t run_sppt_update(const SpptArgs &a, hipStream_t s);
 hipError_t run_export_units(double *q, double *phi, double *ps, long n2d, hipStream_t s);
+hipError_t run_export_pack(const void *src, bool src_is_float, void *dst, int levels, int count, hipStream_t s);
 hipError_t run_log_ps(const double *ps_grid, double *out, long n2d, hipStream_t s);
 hipError_t run_vort2vel(const DeviceTables &T, const double *vor, const double *div, double *ucos, double *vcos, int nfields,
                         hipStream_t s);
@@ -1644,6 +1645,32 @@ int spd_model_set_flags(spd_model_handle m, int land_coupling_flag, int sst_anom
 static int member_range(spd_model_handle m, int first, int count, const char *who) {
     if (!m) return m_fail(SPD_E_ARG, std::string(who) + ": null model");
     if (first < 0 || count < 0 || first + count > m->M) return m_fail(SPD_E_ARG, std::string(who) + ": member range out of bounds");
+    return SPD_OK;
+}
+
+// One grid-space registry variable ((ix, il) or (ix, il, kx) per member) of the members [first, first + count) as a NetCDF-3
+// file carries it: float32, BIG-endian, levels bottom-up -- into `dst_device` (count * levels * 4608 * 4 bytes), on `stream`.
+// For hosts that write files: what crosses PCIe afterwards is the file's payload itself.
+int spd_model_export_pack(spd_model_handle m, const char *name, int first, int count, void *dst_device, size_t dst_bytes, void *stream) {
+    if (!name || !dst_device) return m_fail(SPD_E_ARG, "spd_model_export_pack: null argument");
+    if (int rc = member_range(m, first, count, "spd_model_export_pack")) return rc;
+    if (int rc = usable(m, "spd_model_export_pack")) return rc;
+    auto it = m->reg.find(name);
+    if (it == m->reg.end()) return m_fail(SPD_E_ARG, std::string("spd_model_export_pack: unknown variable '") + name + "'");
+    const RegEntry &e = it->second;
+    const size_t plane = static_cast<size_t>(NG) * sizeof(double);
+    const int levels = static_cast<int>(e.bytes_member / plane);
+    if (e.bytes_member % plane != 0 || (levels != 1 && levels != KX))
+        return m_fail(SPD_E_ARG, std::string("spd_model_export_pack: '") + name + "' is not a grid-space (ix, il[, kx]) variable");
+    const size_t need = static_cast<size_t>(count) * levels * NG * sizeof(float);
+    if (dst_bytes < need) return m_fail(SPD_E_SIZE, "spd_model_export_pack: destination too small");
+    if (count == 0) return SPD_OK;
+    M_HIP(hipSetDevice(m->ctx->device));
+    if (int rc = settle_deferred_check(m)) return rc;
+    const bool narrow = e.f32 && m->stored32;  // (stored as fp32 in the first half of the allocation)
+    const char *src = static_cast<const char *>(e.ptr) + static_cast<size_t>(first) * (narrow ? e.bytes_member / 2 : e.bytes_member);
+    const hipError_t err = run_export_pack(src, narrow, dst_device, levels, count, static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return m_fail(SPD_E_DEVICE, std::string("spd_model_export_pack: ") + hipGetErrorString(err));
     return SPD_OK;
 }
 

@@ -377,6 +377,30 @@ __global__ __launch_bounds__(kT) void export_spec_units_kernel(double *tr, doubl
     }
 }
 
+// One grid-space variable of `count` members as it goes into a NetCDF-3 file (pyspeedy/speedy.py:415-477: float32, levels counted
+// upwards from the surface; the classic format is big-endian): dst[member][levels - 1 - k][point] <- bswap32(float(src[member][k][point])).
+// Coalesced 8- (or 4-) byte reads, coalesced 4-byte writes; the output is consumed by a copy to the host: streamed past the L2.
+template <typename SRC>
+__global__ __launch_bounds__(kT) void export_pack_kernel(const SRC *__restrict__ src, unsigned *__restrict__ dst, int levels, long n) {
+    const long i = static_cast<long>(blockIdx.x) * kT + threadIdx.x;
+    if (i >= n) return;
+    const long plane = i / NG, p = i - plane * NG;
+    const long mem = plane / levels, k = plane - mem * levels;
+    const float v = static_cast<float>(src[(mem * levels + (levels - 1 - k)) * NG + p]);
+    __builtin_nontemporal_store(__builtin_bswap32(__float_as_uint(v)), &dst[i]);
+}
+
+hipError_t run_export_pack(const void *src, bool src_is_float, void *dst, int levels, int count, hipStream_t s) {
+    const long n = static_cast<long>(count) * levels * NG;
+    if (n == 0) return hipSuccess;
+    const dim3 grid(static_cast<unsigned>((n + kT - 1) / kT));
+    if (src_is_float)
+        hipLaunchKernelGGL(export_pack_kernel<float>, grid, dim3(kT), 0, s, static_cast<const float *>(src), static_cast<unsigned *>(dst), levels, n);
+    else
+        hipLaunchKernelGGL(export_pack_kernel<double>, grid, dim3(kT), 0, s, static_cast<const double *>(src), static_cast<unsigned *>(dst), levels, n);
+    return hipGetLastError();
+}
+
 hipError_t run_export_units(double *q, double *phi, double *ps, long n2d, hipStream_t s) {
     hipLaunchKernelGGL(export_units_kernel, dim3((8 * n2d + kT - 1) / kT), dim3(kT), 0, s, q, phi, ps, n2d);
     return hipGetLastError();

@@ -315,6 +315,17 @@ def ensemble_grid_arrays(state_cnts, names):
     return {n: np.stack([models[key][n][member] for key, member in where]) for n in names}
 
 
+_export_stages = {}  # device -> uint8 staging tensor on that device (grown on demand)
+
+
+def _export_stage(device, nbytes):
+    import torch
+    have = _export_stages.get(device)
+    if have is None or have.numel() < nbytes:
+        have = _export_stages[device] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return have
+
+
 _export_buffers = {}  # (bytes, slot) -> pinned uint8 tensor, kept for the life of the process (a day's output of 64 members: 48 MB)
 
 
@@ -351,13 +362,27 @@ def ensemble_export_arrays(state_cnts, names, slot=0, buffers=None):
     for k in order:
         model, positions, members = groups[k]
         model.spectral2grid()
-        whole = members == list(range(model.nmembers))
         contiguous = positions == list(range(positions[0], positions[0] + len(positions)))
-        index = None if whole else torch.as_tensor(members, device=model.sp.device)
+        run = members == list(range(members[0], members[0] + len(members)))  # consecutive members of the model, in order
+        if contiguous and run:
+            # the usual case (all members of a model, in order): one kernel per variable forms the payload on the device
+            # (spd_model_export_pack), one copy takes it to the pinned buffer
+            stage = _export_stage(model.sp.device, sum(sizes[name] // n for name in names) * len(members))
+            at = 0
+            with torch.cuda.device(model.sp.device):
+                stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                for name in names:
+                    per_member = sizes[name] // n
+                    nbytes = per_member * len(members)
+                    _ok(_L().spd_model_export_pack(model._m, name.encode(), members[0], len(members),
+                                                   C.c_void_p(stage.data_ptr() + at), nbytes, stream), "export_pack")
+                    start = offsets[name] + positions[0] * per_member
+                    buf[start:start + nbytes].copy_(stage[at:at + nbytes], non_blocking=True)
+                    at += nbytes
+            continue
+        index = torch.as_tensor(members, device=model.sp.device)
         for name in names:
-            v = model.device_view(name)
-            if index is not None:
-                v = v.index_select(0, index)
+            v = model.device_view(name).index_select(0, index)
             if v.ndim == 4:
                 v = v.flip(1)  # lev increasing with height
             be = v.to(torch.float32).contiguous().view(torch.uint8).view(-1, 4).flip(1)  # byte order of the file

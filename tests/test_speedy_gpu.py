@@ -370,6 +370,16 @@ def test_packed_export_writes_the_same_file():
             model.to_dataframe().to_netcdf(plain)
             with open(written, "rb") as a, open(plain, "rb") as b:
                 assert a.read() == b.read()
+    # ... and of variables the fp32 column physics keeps as fp32 in memory (BASELINE cfg 5): narrowed where they are stored
+    cfg5 = SpeedyEns(3, start_date=start, end_date=end)
+    cfg5.set_bc()
+    cfg5.set_physics_precision(True)
+    cfg5.run()
+    some = ("t_grid", "tt_rsw", "precnv", "olr", "ssrd")
+    a, b = cfg5.to_dataframe(variables=some, packed=True), cfg5.to_dataframe(variables=some)
+    for name in ("t", "tt_rsw", "precnv", "olr", "ssrd"):
+        np.testing.assert_array_equal(a[name].values, b[name].values)
+    assert np.abs(a["olr"].values).max() > 100.0 and a["tt_rsw"].values.shape == (1, 3, 8, 48, 96)
     packed = ens.to_dataframe(packed=True)
     assert packed["t"].values.dtype == np.dtype(">f4") and packed["t"].values.shape == (1, 33, 8, 48, 96)
     np.testing.assert_array_equal(packed["t"].values, ens.to_dataframe()["t"].values)
