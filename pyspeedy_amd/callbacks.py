@@ -84,8 +84,8 @@ class XarrayExporter(_GridOutput):
     """Writes the selected grid-space variables to `output_dir/<model date formatted with filename_fmt>`.
 
     The file's payload (float32, big-endian, levels bottom-up) is formed on the GPU and copied out as such
-    (`to_dataframe(packed=True)`).  With `background=True` (the default) the file itself is written by a thread of this exporter
-    while the model goes on stepping: two output buffers alternate, a third output waits for the first file to be finished, and
+    (`to_dataframe(packed=True)`).  With `background=True` (the default) the file of an ensemble of 8 members or more is written by
+    a thread of this exporter while the model goes on stepping: two output buffers alternate, a third output waits for the first file to be finished, and
     `finish()` -- called by `Speedy.run` / `SpeedyEns.run` when the run ends, also when it ends with an exception -- returns when
     every file is on disk (and raises what the writer could not do).  `background=False` writes inside the callback, as the
     reference's exporter does."""
@@ -104,7 +104,8 @@ class XarrayExporter(_GridOutput):
         target = os.path.join(self.output_dir, model_instance.current_date.strftime(self.filename_fmt))
         os.makedirs(self.output_dir, exist_ok=True)
         self.print_msg("Saving model output at: %s." % target)
-        if not self.background:
+        # (a single model's day is 0.8 MB: handing it to a thread costs more than writing it)
+        if not self.background or getattr(model_instance, "n_members", 1) < 8:
             model_instance.to_dataframe(variables=self.variables, packed=True, buffers=self._buffers).to_netcdf(target)
             return
         import threading

@@ -134,6 +134,16 @@ class Speedy:
     def _get_date(container):
         return datetime(*_speedy.get_datetime(container))
 
+    def _date(self, which):
+        """the date held by the container `which` (as the reference: a driver-side datetime object); the value is remembered on the
+        Python side, so that a time loop that compares dates every step does not ask the driver for it every time"""
+        cached = self.__dict__.get("_value" + which)
+        return cached if cached is not None else self._get_date(getattr(self, which))
+
+    def _assign_date(self, which, value):
+        setattr(self, which, self._set_date(getattr(self, which), value))
+        self.__dict__["_value" + which] = value
+
     @staticmethod
     def _set_date(container, value):
         Speedy._dealloc_date(container)
@@ -141,12 +151,9 @@ class Speedy:
             raise TypeError("The input value is not a datetime object.")
         return _speedy.create_datetime(value.year, value.month, value.day, value.hour, value.minute)
 
-    start_date = property(lambda self: self._get_date(self._start_date),
-                          lambda self, v: setattr(self, "_start_date", self._set_date(self._start_date, v)))
-    end_date = property(lambda self: self._get_date(self._end_date),
-                        lambda self, v: setattr(self, "_end_date", self._set_date(self._end_date, v)))
-    current_date = property(lambda self: self._get_date(self._model_date),
-                            lambda self, v: setattr(self, "_model_date", self._set_date(self._model_date, v)))
+    start_date = property(lambda self: self._date("_start_date"), lambda self, v: self._assign_date("_start_date", v))
+    end_date = property(lambda self: self._date("_end_date"), lambda self, v: self._assign_date("_end_date", v))
+    current_date = property(lambda self: self._date("_model_date"), lambda self, v: self._assign_date("_model_date", v))
 
     # ---- state access --------------------------------------------------------------------------------------
     def __getitem__(self, var_name):
@@ -176,7 +183,8 @@ class Speedy:
         return setter(self._state_cnt, value)
 
     def get_current_step(self):
-        return self["current_step"]
+        inside_run = self.__dict__.get("_step_in_run")  # (the time loop counts along: hooks ask for the step several times a step)
+        return self["current_step"] if inside_run is None else inside_run
 
     # ---- boundary conditions and initialisation ----------------------------------------------------------
     def set_bc(self, bc_file=None, sst_anomaly=None):
@@ -237,21 +245,26 @@ class Speedy:
         if not self._initialized_bc:
             raise RuntimeError("The SPEEDY model was not initialized. Call the `set_bc` method to initialize the model.")
         self.current_date = self.start_date
+        end_date = self.end_date
         pending = None  # the range check of a step is collected after the next step has been enqueued (GPU never idles)
+        self._step_in_run = self["current_step"]
         try:
-            while self.current_date < self.end_date:
+            while self.current_date < end_date:
                 token = _speedy.parallel_step_begin([self._state_cnt], [self._control_cnt])
                 previous, pending = pending, token
                 self._collect(previous)
+                self._step_in_run += 1
                 self.current_date += _DT_STEP
-                if _callbacks_due(callbacks, self):
+                due = _callbacks_due(callbacks, self)
+                if due:
                     previous, pending = pending, None
                     self._collect(previous)
-                for callback in callbacks:
-                    callback(self)
+                    for act in due:
+                        act(self)
             previous, pending = pending, None
             self._collect(previous)
         finally:
+            self._step_in_run = None
             self._drain(pending)  # (a step that was begun behind the one that failed: end it, its code no longer matters)
             _finish(callbacks)
 
@@ -316,8 +329,18 @@ def _finish(callbacks):
 
 
 def _callbacks_due(callbacks, model):
-    """Whether any hook will act at this step (plain callables have no gating: they always act)."""
-    return any(not cb.skip_flag(model) if hasattr(cb, "skip_flag") else True for cb in callbacks)
+    """What acts at this step, in order: for a hook with the reference's gating (BaseCallback: skip_flag / fire) the gate is asked
+    ONCE and its `fire` is what is due; anything else -- a plain callable, a hook that overrides __call__ -- always acts, through
+    its own __call__."""
+    from .callbacks import BaseCallback
+    due = []
+    for cb in callbacks:
+        if isinstance(cb, BaseCallback) and type(cb).__call__ is BaseCallback.__call__:
+            if not cb.skip_flag(model):
+                due.append(cb.fire)
+        else:
+            due.append(cb)
+    return due
 
 
 def _exportable(var):
@@ -453,24 +476,30 @@ class SpeedyEns:
             if not member._initialized_bc:
                 raise RuntimeError("The SPEEDY model was not initialized. Call the `set_bc` method of every member.")
         pending = None
+        step = self.members[0]["current_step"]
         try:
             while self.current_date < end_date:
                 token = _speedy.parallel_step_begin(state_cnts, control_cnts)
                 previous, pending = pending, token
                 Speedy._collect(previous)
+                step += 1
                 self.current_date += _DT_STEP
                 for member in self:
                     member.current_date = self.current_date
-                if _callbacks_due(callbacks, self):
+                    member._step_in_run = step
+                due = _callbacks_due(callbacks, self)
+                if due:
                     previous, pending = pending, None
                     Speedy._collect(previous)
-                for callback in callbacks:
-                    callback(self)
+                    for act in due:
+                        act(self)
             previous, pending = pending, None
             Speedy._collect(previous)
         finally:
+            for member in self:
+                member._step_in_run = None
             Speedy._drain(pending)
             _finish(callbacks)
 
     def get_current_step(self):
-        return self.members[0]["current_step"]
+        return self.members[0].get_current_step()

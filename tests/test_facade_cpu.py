@@ -211,3 +211,40 @@ def test_file_loader_keeps_small_files_only(tmp_path):
     assert S._load_fields({"a": 1}) == {"a": 1}
     with pytest.raises(RuntimeError):
         S._load_fields(str(tmp_path / "missing.npz"))
+
+
+def test_what_is_due_at_a_step():
+    """The time loops ask every hook's gate ONCE per step (speedy._callbacks_due): a hook with the reference's gating contributes its
+    `fire` when it is due, a plain callable or a hook that overrides __call__ always acts through its own __call__."""
+    from pyspeedy_amd.callbacks import BaseCallback
+    from pyspeedy_amd.speedy import _callbacks_due
+
+    class Fake:
+        current_date = datetime(1982, 1, 5)
+        asked = 0
+
+        def get_current_step(self):
+            Fake.asked += 1
+            return 72
+
+    class Counts(BaseCallback):
+        fired = 0
+
+        def fire(self, model_instance):
+            Counts.fired += 1
+
+    class OwnCall(BaseCallback):
+        called = 0
+
+        def __call__(self, model_instance):
+            OwnCall.called += 1
+
+    seen = []
+    hooks = [Counts(interval=36), Counts(interval=5), OwnCall(interval=1000), seen.append, Counts(interval=36, spinup_date=datetime(1982, 2, 1))]
+    model = Fake()
+    due = _callbacks_due(hooks, model)
+    assert len(due) == 3 and Fake.asked == 2  # (the gate of the hook that is still spinning up never gets to the step counter)
+    for act in due:
+        act(model)
+    assert Counts.fired == 1 and OwnCall.called == 1 and seen == [model]
+    assert _callbacks_due([], model) == []
