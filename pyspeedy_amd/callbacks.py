@@ -113,10 +113,13 @@ class XarrayExporter(_GridOutput):
         self._turn = 1 - slot
         self._wait(slot)  # (the buffer this output goes into may still be on its way to disk)
         frame = model_instance.to_dataframe(variables=self.variables, packed=True, slot=slot, buffers=self._buffers)
+        # (the header is made here: a thread that runs Python code competes with the time loop for the interpreter lock, one that
+        # only writes bytes does not)
+        prepared = _dataset.prepare_netcdf(frame)
 
         def write():
             try:
-                frame.to_netcdf(target)
+                _dataset.write_prepared(target, prepared)
             except BaseException as exc:  # noqa: B902 -- handed to the thread that owns the exporter
                 self._failure = exc
         self._pending[slot] = threading.Thread(target=write, name="pyspeedy_amd-export", daemon=False)

@@ -213,10 +213,10 @@ def _prepare(ds):
     return ds.dims, out
 
 
-def write_netcdf(ds, path):
-    """NetCDF-3 classic (CDF-1) writer: header, then every variable as one contiguous big-endian block.  Written directly
-    (one tofile per variable) because it is on the path of every model output; files are read back by scipy / netCDF4 /
-    xarray like any other classic file (tests/test_facade_cpu.py compares with scipy.io.netcdf_file)."""
+def prepare_netcdf(ds):
+    """Everything of a NetCDF-3 classic (CDF-1) file that takes Python work -- the header and the list of big-endian blocks behind
+    it -- without touching the disk: (header bytes, [(contiguous array, padding bytes)]).  `write_prepared` then only moves bytes,
+    which a background thread can do without holding the interpreter lock for more than a few calls."""
     import struct
 
     NC_DIMENSION, NC_VARIABLE, NC_ATTRIBUTE, NC_CHAR, NC_INT, NC_FLOAT, NC_DOUBLE = 10, 11, 12, 2, 4, 5, 6
@@ -263,11 +263,24 @@ def write_netcdf(ds, path):
         size += vals.nbytes + (-vals.nbytes % 4)
     if size >= 2 ** 31:
         raise ValueError("dataset too large for the NetCDF-3 classic format (2 GiB offsets)")
+    return head + var_headers(begins), [(np.ascontiguousarray(vals), b"\0" * (-vals.nbytes % 4)) for _, _, vals, _ in variables]
+
+
+def write_prepared(path, prepared):
+    header, blocks = prepared
     with open(str(path), "wb") as f:
-        f.write(head + var_headers(begins))
-        for _, _, vals, _ in variables:
-            np.ascontiguousarray(vals).tofile(f)
-            f.write(b"\0" * (-vals.nbytes % 4))
+        f.write(header)
+        for vals, padding in blocks:
+            vals.tofile(f)
+            if padding:
+                f.write(padding)
+
+
+def write_netcdf(ds, path):
+    """NetCDF-3 classic (CDF-1) writer: header, then every variable as one contiguous big-endian block.  Written directly
+    (one tofile per variable) because it is on the path of every model output; files are read back by scipy / netCDF4 /
+    xarray like any other classic file (tests/test_facade_cpu.py compares with scipy.io.netcdf_file)."""
+    write_prepared(path, prepare_netcdf(ds))
 
 
 def open_dataset(path):
