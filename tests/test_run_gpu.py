@@ -578,3 +578,35 @@ def test_the_default_plan_overlaps_member_groups_and_profiling_is_serial(spectra
         a.set_option("member_groups", 5)
     a.close()
     b.close()
+
+
+def test_export_pack_entry_point(spectral, bc):
+    """spd_model_export_pack through the C ABI: a grid variable of a member range as a NetCDF-3 file carries it (float32, big-endian,
+    levels bottom-up) against numpy on the values spd_model_get returns; what it refuses."""
+    import ctypes as C
+    import torch
+    from pyspeedy_amd.model import EnsembleModel
+    model = EnsembleModel(spectral, 5)
+    model.set_bc(bc)
+    model.run(4)
+    model.spectral2grid()
+    L = model._lib
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for name, levels in (("t_grid", 8), ("ps_grid", 1), ("olr", 1), ("tt_rsw", 8)):
+        n = 3 * levels * 4608
+        out = torch.zeros(n, dtype=torch.int32, device="cuda")
+        rc = L.spd_model_export_pack(model._m, name.encode(), 1, 3, C.c_void_p(out.data_ptr()), n * 4, stream)
+        assert rc == 0, L.spd_last_error()
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(">f4").reshape(3, levels, 48, 96)
+        for k, member in enumerate((1, 2, 3)):
+            ref = model.get(name, member)  # (lon, lat[, lev]) fp64, levels top-down
+            ref = ref.transpose(2, 1, 0)[::-1] if levels == 8 else ref.T[None]
+            np.testing.assert_array_equal(got[k], ref.astype(np.float32))
+    small = torch.zeros(16, dtype=torch.int32, device="cuda")
+    assert L.spd_model_export_pack(model._m, b"t_grid", 0, 5, C.c_void_p(small.data_ptr()), 64, stream) == -3  # SPD_E_SIZE
+    assert L.spd_model_export_pack(model._m, b"vor", 0, 1, C.c_void_p(small.data_ptr()), 64, stream) == -1     # spectral: refused
+    assert L.spd_model_export_pack(model._m, b"no_such", 0, 1, C.c_void_p(small.data_ptr()), 64, stream) == -1
+    assert L.spd_model_export_pack(model._m, b"t_grid", 4, 2, C.c_void_p(small.data_ptr()), 64, stream) == -1  # member range
+    assert L.spd_model_export_pack(model._m, b"t_grid", 2, 0, C.c_void_p(small.data_ptr()), 0, stream) == 0
+    model.close()
