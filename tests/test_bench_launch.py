@@ -103,6 +103,34 @@ def test_a_child_that_never_answers_is_cut_off():
     assert code == 3 and out.strip() == "hello"
 
 
+PREFLIGHT_CHILD = r"""
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import bench
+ok, why, spent = bench.rccl_preflight(int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), bench.Budget(120.0))
+print(json.dumps({"ok": ok, "why": why, "spent": spent}))
+"""
+
+
+def test_rccl_preflight_reaches_one_decision_for_all_ranks():
+    """The pre-flight's meeting point without a GPU: every rank's probe child fails here (no device), rank 0 collects the verdicts
+    and writes the decision, the other ranks read it -- all of them come back with the same answer (gloo) and the same reason."""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("needs a machine without a GPU (on a GPU box the GPU tier runs the real thing)")
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = [subprocess.Popen([sys.executable, "-c", PREFLIGHT_CHILD, ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1",
+                                       MASTER_PORT=str(port))) for r in range(3)]
+    outs = [json.loads(p.communicate(timeout=300)[0].strip().splitlines()[-1]) for p in procs]
+    assert [o["ok"] for o in outs] == [False] * 3
+    assert len({o["why"] for o in outs}) == 1 and "rank 0:" in outs[0]["why"] and "rank 2:" in outs[0]["why"]
+    assert all(o["spent"] < 120 for o in outs)
+
+
 def _result(run):
     assert run.returncode == 0, run.stdout + run.stderr
     lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
