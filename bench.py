@@ -59,6 +59,11 @@ What the ONE JSON line of rank 0 holds:
   facade_run (N = 1)    the reference's own entry points on the same clock: SpeedyEns(64).run() and Speedy().run()
                         (pyspeedy/speedy.py:572-586, :398-405) over ten simulated days, without callbacks and with the default daily
                         XarrayExporter; ms per model step, Python loop, range check and file output included.
+  roofline.stream_ceiling   what kernels of this library that only move bytes reach on this box (spd_stream_probe: copy, 2r:1w,
+                        3r:2w, read, write; best shape and the column kernel's shape; TB/s) and `column_twin`, the column kernel's
+                        launch with the arithmetic taken out; every kernel row carries frac_of_stream_ceiling beside its frac of 8 TB/s.
+  roofline.frac_beyond_infinity_cache   the line's kernel at 256 members in the serial plan: `frac` at 64 members is HBM + Infinity
+                        Cache.  roofline.traffic_stale: the committed PMC figure was taken with other device sources than this tree's.
   projected_8gpu_cfg4   (N = 1) BASELINE cfg 4 as worded on 8 GPUs, PROJECTED from this box: 8 members per GPU step in
                         cfg4_shard8.ms_per_step whatever the other 7 GPUs do (no collective in the step), so the node's
                         throughput is 64 members / that time; speedup and efficiency against this line's 64-members-on-one-GPU
@@ -176,7 +181,7 @@ class Budget:
 # allowances of the secondary legs [s]: generous multiples of what they take on a healthy box (the whole default N = 1 line
 # runs in 40-60 s); ONE_PROCESS_* are also the timeouts of the child processes, and sum to 150 s
 LEG_ALLOWANCE = {"every_step_stores": 15, "drop_in_step": 25, "facade_run": 30, "cfg2_transforms": 10, "cfg3": 10, "cfg4_shard8": 10,
-                 "cfg5": 15, "cfg4_strong": 30}
+                 "cfg5": 15, "cfg4_strong": 30, "stream_ceiling": 8, "beyond_infinity_cache": 12}
 ONE_PROCESS_TIMEOUT, ONE_PROCESS_STRONG_TIMEOUT = 100, 50
 
 
@@ -933,22 +938,94 @@ def plan_name(cfg, M):
     return plan
 
 
+def stream_ceiling_object(sp, kernels):
+    """roofline.stream_ceiling: what kernels of this library that only move bytes reach on THIS box, in the shapes of the step's
+    kernels (pyspeedy_amd/stream_probe.py, spd_stream_probe) -- the ceiling to read the fractions of 8 TB/s against -- and the
+    column kernel's twin: its own launch (streams, bytes per lane, occupancy, rows per wavefront, size) with the arithmetic taken
+    out.  Every row of `kernels` gets `frac_of_stream_ceiling` (the best shape of its stream mix)."""
+    from pyspeedy_amd import stream_probe as P
+    L = sp._lib
+    out = P.ceiling(L, sp.handle)
+    mix_of = {"column": "column_2r1w", "column_sw": "column_2r1w", "physics": "column_2r1w", "physics_sw": "column_2r1w",
+              "spec2grid": "copy_1r1w", "grid2spec": "copy_1r1w", "spectral_step": "copy_1r1w", "geopotential": "read",
+              "coupler": "copy_1r1w", "forcing": "write", "dyn_grid": "copy_1r1w", "sppt": "copy_1r1w"}
+    for k in kernels or []:
+        mix = mix_of.get(k["kernel"])
+        if mix:
+            k["frac_of_stream_ceiling"] = k["achieved"] / 1e3 / out[mix]
+            k["stream_ceiling_mix"] = mix
+    col = [k for k in kernels or [] if k["kernel"] == "column"]
+    if col:
+        twin = P.column_twin(L, sp.handle, col[0]["algorithmic_bytes_per_launch"])
+        out["column_twin"] = {
+            "us": round(twin["us"], 2), "us_best": round(twin["us_best"], 2), "tb_s": round(twin["tb_s"], 3), "bytes": twin["bytes"],
+            "column_kernel_us": col[0]["avg_launch_us"], "column_kernel_over_twin": col[0]["avg_launch_us"] / twin["us"],
+            "note": "the column kernel's launch with the arithmetic taken out: 2 reads : 1 write, one double per lane, two "
+                    "wavefronts per SIMD, 243 rows per wavefront each in an array of its own, non-temporal, the same bytes"}
+    return out
+
+
+def beyond_infinity_cache_leg(args, device, dist, rank, coll_device, barrier):
+    """roofline.frac_beyond_infinity_cache: the line's kernel (spec2grid_table_kernel) at 256 members, serial plan, no rounds -- its
+    input (the spectral state the previous launch wrote) and output are then far beyond the 256 MB Infinity Cache, which at 64
+    members still holds a part of them (FETCH_SIZE counts such hits as fabric reads: `frac` is HBM + Infinity Cache)."""
+    M = 256
+    sp, model = build_ensemble(args, M, 0, device, dist, rank, coll_device)
+    model.set_option("member_groups", 1)
+    model.set_option("block_members", 0)
+    model.run(36)
+    model.profile(1)
+    model.run(36)
+    import torch
+    torch.cuda.synchronize()
+    kern_ms, launches, nfields = model.profile_read()
+    model.profile(0)
+    ok = (model.check(2) == 0).all()
+    model.close()
+    sp.close()
+    if not ok:
+        raise SystemExit("bench.py: members left the accepted range in the beyond_infinity_cache leg")
+    nbytes = (S_BYTES + G_BYTES) * nfields
+    return {"members": M, "fields_per_launch": nfields, "avg_launch_ms": kern_ms, "launches_timed": launches,
+            "achieved": nbytes / (kern_ms * 1e-3) / 1e9, "unit": "GB/s", "frac": nbytes / (kern_ms * 1e-3) / 1e9 / 8000.0}
+
+
+def kernel_sources_sha():
+    """sha256 over the device sources of the library (csrc/*.hip, *.hpp in name order): what a committed PMC measurement was taken
+    with (tools/pmc_summary.py writes it into every profiles/*_pmc_*.json) against what this tree holds"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "pyspeedy_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "pyspeedy_amd", "csrc", "*.hpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+PMC_FILES = ("r06_pmc_model_step.json", "r05_pmc_model_step.json", "r04_pmc_model_step.json", "r03_pmc_model_step.json",
+             "r02_pmc_model_step.json", "r01_pmc_model_step.json")
+
+
 def load_traffic(nfields):
     """HBM bytes per spec2grid launch from the committed PMC measurement of this very kernel inside this bench (rocprofv3
     cannot run inside bench.py): FETCH_SIZE doubled as the gfx950 guide prescribes, scaled per field."""
-    for name in ("r05_pmc_model_step.json", "r04_pmc_model_step.json", "r03_pmc_model_step.json", "r02_pmc_model_step.json",
-                 "r01_pmc_model_step.json"):
+    for name in PMC_FILES:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
-                tj = json.load(fh)["kernels"]["spd::spec2grid_table_kernel"]
+                doc = json.load(fh)
+            tj = doc["kernels"]["spd::spec2grid_table_kernel"]
             per_field = tj["hbm_bytes_per_launch"] / float(tj.get("fields_per_launch", 5824))
-            return per_field * nfields, "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py)" % name
+            # (the PMC passes cannot run inside bench.py: the figure is the committed one -- stale when the device sources have
+            # changed since it was taken; None: the file is older than the stamp)
+            taken_with = doc.get("kernel_sources_sha")
+            stale = None if taken_with is None else taken_with != kernel_sources_sha()
+            return per_field * nfields, "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py)" % name, stale
         except (OSError, KeyError, ValueError):
             continue
-    return None, None
+    return None, None, None
 
 
-def dominant_kernel(kernels, M, config):
+def dominant_kernel(kernels, M, config, stream_ceiling=None):
     """The kernel that takes the largest share of the step -- the fused column kernel (grid-point dynamics + physics) -- priced
     like `roofline`: the launches of one simulated day (shortwave and other steps together), algorithmic bytes of its argument
     list / its dispatch-attached HIP-event time, and the committed PMC traffic of the same kernel per member."""
@@ -963,14 +1040,21 @@ def dominant_kernel(kernels, M, config):
            "share_of_kernel_time": t_us / all_us, "launches_timed": n, "avg_launch_us": t_us / n,
            "algorithmic_bytes_per_launch": int(round(nbytes / n)), "bound": "hbm", "achieved": nbytes / (t_us * 1e-6) / 1e9,
            "peak": 8000.0, "unit": "GB/s", "frac": nbytes / (t_us * 1e-6) / 1e9 / 8000.0, "traffic": None}
-    name, key, members = (("r05_pmc_model_step.json", "spd::physics_kernel<2, true, false, double, false>", 64) if config == "cfg4" else
-                          ("r05_pmc_cfg5_storage32_1.json", "spd::physics_kernel<3, true, true, float, true>", 32))
-    try:
-        with open(os.path.join(ROOT, "profiles", name)) as fh:
-            out["traffic"] = json.load(fh)["kernels"][key]["hbm_bytes_per_launch"] / float(members) * M
-        out["traffic_source"] = "profiles/%s (%d members per launch there; scaled per member)" % (name, members)
-    except (OSError, KeyError, ValueError):
-        pass
+    if stream_ceiling and "column_2r1w" in stream_ceiling:  # (against this box's own 2r : 1w copy kernels, best shape / the kernel's shape)
+        out["frac_of_stream_ceiling"] = out["achieved"] / 1e3 / stream_ceiling["column_2r1w"]
+        out["frac_of_stream_ceiling_in_its_shape"] = out["achieved"] / 1e3 / stream_ceiling["column_2r1w_column_shape"]
+    names, key, members = ((PMC_FILES[:2], "spd::physics_kernel<2, true, false, double, false>", 64) if config == "cfg4" else
+                           (("r06_pmc_cfg5_storage32_1.json", "r05_pmc_cfg5_storage32_1.json"), "spd::physics_kernel<3, true, true, float, true>", 32))
+    for name in names:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                doc = json.load(fh)
+            out["traffic"] = doc["kernels"][key]["hbm_bytes_per_launch"] / float(members) * M
+            out["traffic_source"] = "profiles/%s (%d members per launch there; scaled per member)" % (name, members)
+            out["traffic_stale"] = None if doc.get("kernel_sources_sha") is None else doc["kernel_sources_sha"] != kernel_sources_sha()
+            break
+        except (OSError, KeyError, ValueError):
+            continue
     return out
 
 
@@ -1267,6 +1351,10 @@ def run_rank(args):
     model.profile(0)
     kernels = kernel_table(model, M, nfields // M, sppt) if rank == 0 or dist is None else None
     model.close()
+    stream_ceiling = None
+    if rank == 0:  # (own probe kernels on the idle GPU of rank 0; the other ranks' GPUs have nothing timed in flight either)
+        stream_ceiling = (stream_ceiling_object(sp, kernels) if wall.allows("stream_ceiling", LEG_ALLOWANCE["stream_ceiling"])
+                          else {"skipped": "budget"})
     sp.close()
     legs = {}
     if not args.no_legs:
@@ -1275,6 +1363,7 @@ def run_rank(args):
 
         if n_gpus == 1 and args.config == "cfg4":
             leg("every_step_stores", lambda: fidelity_leg(args, M, first_id, device, dist, rank, coll_device, barrier))
+            leg("beyond_infinity_cache", lambda: beyond_infinity_cache_leg(args, device, dist, rank, coll_device, barrier))
 
             def drop_in():
                 out = drop_in_leg(M, 360)
@@ -1345,7 +1434,8 @@ def run_rank(args):
         # (cfg 5 stores 27 of a member's fields as fp32: those count S + G / 2)
         s2g_bytes = (S_BYTES + G_BYTES) * nfields - (G_BYTES // 2) * S2G_FLOAT_FIELDS * M * (1 if cfg["physics_storage32"] else 0)
         achieved = s2g_bytes / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_src = load_traffic(nfields)
+        traffic, traffic_src, traffic_stale = load_traffic(nfields)
+        beyond = legs.pop("beyond_infinity_cache", None)
         physics = "fp64 column physics" if args.config == "cfg4" else "SPPT on, fp32 arithmetic in the column physics (fp64 state)"
         all_cores = (baseline or {}).get("all_cores")
         line = {
@@ -1383,8 +1473,14 @@ def run_rank(args):
                                "duration of a kernel that shares the GPU with another group's kernels is not its own); HIP events "
                                "attached to the dispatch of every spec2grid launch of those regions" % (len(serial_s), args.steps),
                 "serial_plan_ms_per_step": median(serial_s) / args.steps * 1e3,
-                "traffic": traffic, "traffic_source": traffic_src,
-                "dominant": dominant_kernel(kernels, M, args.config), "kernels": kernels,
+                "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+                "kernel_sources_sha": kernel_sources_sha(),
+                # `frac` is HBM + Infinity Cache at 64 members (a part of what this launch reads and writes is still in the 256 MB
+                # cache); the same kernel where nothing is: 256 members, serial plan
+                "frac_beyond_infinity_cache": (beyond or {}).get("frac"), "beyond_infinity_cache": beyond,
+                "stream_ceiling": stream_ceiling,
+                "frac_of_stream_ceiling": (achieved / 1e3 / stream_ceiling["copy_1r1w"]) if stream_ceiling and "copy_1r1w" in stream_ceiling else None,
+                "dominant": dominant_kernel(kernels, M, args.config, stream_ceiling), "kernels": kernels,
                 "kernels_note": "one simulated day (36 steps, serial plan) with events attached to every kernel's dispatch (the "
                                 "kernels' own begin / end time stamps, as in rocprofv3's kernel trace); the rows sum to less than "
                                 "serial_plan_ms_per_step by the gaps between dependent launches",

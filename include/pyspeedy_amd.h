@@ -136,6 +136,32 @@ typedef struct spd_physics_args {
 
 int spd_physics(spd_handle h, const spd_physics_args *args, int nmembers, void *stream);
 
+/* ---- streaming-rate probe (measurement infrastructure; no counterpart in the reference -- SURVEY.md section 8d: "report
+ *      measured copy / triad bandwidth on the box and use the spec peak for the contract fraction") -------------------------
+ * What a kernel that only moves bytes reaches on this device in a given SHAPE, with kernels of this library (csrc/
+ * stream_probe.hip): one wavefront per 64-thread workgroup; a wavefront requests `in_flight` rows (64 lanes x lane_bytes,
+ * contiguous) of each of its `reads` input streams back to back, adds them and stores `in_flight` rows to each of its
+ * `writes` output streams, and repeats until it has touched about `rows_per_wave` rows of all its streams together (1: a
+ * plain copy kernel's one row and out; 243: the column kernel's life).  The streams lie far apart in memory.  The probe
+ * allocates total_bytes itself, launches 2 + reps times and times every launch by the time stamps of its dispatch packet.
+ * The step's kernels are priced against 8 TB/s in bench.py's `roofline`; this is the ceiling to read those fractions against. */
+typedef struct spd_stream_probe_args {
+    int32_t reads, writes;  /* streams: 1:1 (copy), 2:1 (the column kernel's mix), 3:2, 1:0 (read only), 0:1 (write only) */
+    int32_t lane_bytes;     /* 8 (the column kernel: one double per lane) or 16 (the transforms' staging) */
+    int32_t in_flight;      /* rows per stream requested before the first use: 1, 2, 4, 8, 16 */
+    int32_t nontemporal;    /* 0 / 1: the non-temporal hint on loads and stores (csrc/stream_store.hpp) */
+    int32_t waves_per_simd; /* 1 ... 8 wavefronts per SIMD, held there by dynamic LDS (2: the column kernel at 256 VGPRs) */
+    int32_t rows_per_wave;  /* rows of all streams together a wavefront works through before it ends */
+    int32_t reps;           /* timed launches, 1 ... 1000 */
+    int32_t layout;         /* 0: a wavefront walks a contiguous chunk of its own in every stream; 1: the column kernel's -- row r of every
+                             * wavefront lies in array r of the stream, consecutive wavefronts side by side inside each array */
+    int32_t reserved;
+    uint64_t total_bytes;   /* bytes one launch moves, reads + writes (rounded down to whole wavefronts) */
+} spd_stream_probe_args;
+/* mean and minimum duration of a launch in microseconds; optionally the bytes a launch really moved and its workgroups */
+int spd_stream_probe(spd_handle h, const spd_stream_probe_args *args, double *mean_us, double *min_us, uint64_t *bytes_moved,
+                     uint64_t *workgroups);
+
 /* ---- ensemble model object: device-resident state of M members and the model time step ------------------------
  * Replaces, for M members at once, the reference's ModelState_t container (model_state.f90) and
  * time_stepping.f90:38-147 `step` (get_tendencies -> horizontal diffusion -> leapfrog + Robert/Williams filter), i.e. what
@@ -215,6 +241,17 @@ int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, i
  * sure they sit on different hardware queues (it measures: HIP's hand-out depends on every stream the process created before,
  * and two group streams on one queue run one after the other); that first call blocks the host for that long. */
 int spd_model_step(spd_model_handle m, int nsteps, void *stream);
+/* The same `nsteps` steps with the range check of EVERY step (diagnostics.f90:16-76, which the reference's time loop runs after each
+ * do_single_step: pyspeedy/speedy.py:396-405) recorded by the device: for hosts that know they will not look at the state before
+ * nsteps steps have passed (no callback due before).  One call instead of nsteps -- with the member groups and rounds of the
+ * multi-step plan -- and still every step's code: the check of step k rides in the spectral -> grid launch of step k + 1, the last
+ * one is a launch of its own.  _begin enqueues everything and returns; _end waits and reports per member the first step of the call
+ * whose check failed (0-based; -1: none) and, in `accepted` ([members][7], may be NULL), the model's step counter, date (year,
+ * month, day, hour, minute) and month index after the member's last ACCEPTED step (the one before its first failure, else the
+ * last of the call).  The device does not stop at a failed check: the steps behind it run on a state the model does not accept;
+ * after a failure the only defined continuation is spd_model_init.  One such call may be in flight per model; nsteps <= 4096. */
+int spd_model_step_checked_begin(spd_model_handle m, int nsteps, void *stream);
+int spd_model_step_checked_end(spd_model_handle m, int32_t *first_failed_step, int32_t *accepted);
 int spd_model_current_step(spd_model_handle m);
 int spd_model_get_date(spd_model_handle m, int *ymdhm /* 5 ints */);
 /* declare a state loaded through spd_model_set as initialised at the START of a run: step counter and date as given, month

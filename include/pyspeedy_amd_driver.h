@@ -120,6 +120,18 @@ int spd_parallel_step(const int64_t *state_cnts, const int64_t *control_cnts, in
  * else touches the state first -- spd_set, a regrouping, the _end that collects it -- sends it out there and then). */
 int spd_parallel_step_begin(const int64_t *state_cnts, const int64_t *control_cnts, int32_t n_members, int64_t *token);
 int spd_parallel_step_end(int64_t token, int32_t *error_codes /* n_members of the matching _begin */);
+/* Extension: n_steps steps (1 ... 4096) of the same containers as ONE call, for the stretch of a time loop in which nothing looks at
+ * the state (the reference's Speedy.run / SpeedyEns.run between two due callbacks, pyspeedy/speedy.py:396-405, 572-586).  Every
+ * device model takes the steps as one multi-step device call -- member groups on streams of their own, large ensembles in rounds --
+ * and the range check of EVERY step is recorded on the device.  _begin enqueues and returns a token, the model dates move n_steps
+ * steps; _end waits and hands out, per member, the code of the first step whose check failed (0 when none did; the reference's loop
+ * stops at the first code) and in steps_done (may be NULL) the steps it completed before that one (n_steps when none failed).  For a
+ * member with -2 the reference's text goes to stderr with the step counter of the failing step, and its date is the one after its
+ * last accepted step (speedy.f90:57-71 returns before advance_date).  The device does NOT stop at the failed check: the member's
+ * state is what the remaining steps made of a state outside the accepted range -- as after every -2, the only defined
+ * continuation is a new spd_init.  No single step (spd_parallel_step_begin) may be in flight on the same containers. */
+int spd_parallel_steps_begin(const int64_t *state_cnts, const int64_t *control_cnts, int32_t n_members, int32_t n_steps, int64_t *token);
+int spd_parallel_steps_end(int64_t token, int32_t *error_codes /* n_members */, int32_t *steps_done /* n_members or NULL */);
 int spd_check(int64_t state_cnt, int32_t *error_code); /* diagnostics on time level 1 */
 int spd_transform_spectral2grid(int64_t state_cnt);
 int spd_transform_grid2spectral(int64_t state_cnt);

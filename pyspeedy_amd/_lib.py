@@ -60,7 +60,17 @@ class ModelControl(C.Structure):
         ("air_absortivity_co2", C.c_double), ("ablco2_ref", C.c_double)]
 
 
+class StreamProbeArgs(C.Structure):
+    """Mirror of spd_stream_probe_args (include/pyspeedy_amd.h)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "reads", "writes", "lane_bytes", "in_flight", "nontemporal", "waves_per_simd", "rows_per_wave", "reps", "layout",
+        "reserved")] + [
+        ("total_bytes", C.c_uint64)]
+
+
 _SIGNATURES = {
+    "spd_stream_probe": (C.c_int, [C.c_void_p, C.POINTER(StreamProbeArgs), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "spd_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "spd_destroy": (C.c_int, [C.c_void_p]),
     "spd_device": (C.c_int, [C.c_void_p]),
@@ -149,6 +159,10 @@ _SIGNATURES = {
     "spd_parallel_step": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int32]),
     "spd_parallel_step_begin": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_int64)]),
     "spd_parallel_step_end": (C.c_int, [C.c_int64, C.POINTER(C.c_int32)]),
+    "spd_parallel_steps_begin": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
+    "spd_parallel_steps_end": (C.c_int, [C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "spd_model_step_checked_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "spd_model_step_checked_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "spd_driver_model": (C.c_int, [C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "spd_check": (C.c_int, [C.c_int64, C.POINTER(C.c_int32)]),
     "spd_transform_spectral2grid": (C.c_int, [C.c_int64]),

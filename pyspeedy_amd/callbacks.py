@@ -84,14 +84,15 @@ class XarrayExporter(_GridOutput):
     """Writes the selected grid-space variables to `output_dir/<model date formatted with filename_fmt>`.
 
     The file's payload (float32, big-endian, levels bottom-up) is formed on the GPU and copied out as such
-    (`to_dataframe(packed=True)`).  With `background=True` (the default) the file of an ensemble of 8 members or more is written by
-    a thread of this exporter while the model goes on stepping: two output buffers alternate, a third output waits for the first file to be finished, and
-    `finish()` -- called by `Speedy.run` / `SpeedyEns.run` when the run ends, also when it ends with an exception -- returns when
-    every file is on disk (and raises what the writer could not do).  `background=False` writes inside the callback, as the
-    reference's exporter does."""
+    (`to_dataframe(packed=True)`).  `background=None` (the default): while a `Speedy.run` / `SpeedyEns.run` owns the hook, the file
+    of an ensemble of 8 members or more is written by a thread of this exporter while the model goes on stepping -- two output
+    buffers alternate, a third output waits for the first file to be finished -- and the run calls `finish()` when it ends, also
+    when it ends with an exception: every file is on disk then (and what the writer could not do is raised).  Called by hand,
+    outside a run, the hook writes inside the call, as the reference's exporter does: the file is complete when it returns.
+    `background=True` writes in the background wherever it is called (the caller owes a `finish()`), `background=False` never."""
 
     def __init__(self, interval=36, verbose=False, spinup_date=None, variables=None, output_dir="./",
-                 filename_fmt="%Y-%m-%d_%H%M.nc", background=True):
+                 filename_fmt="%Y-%m-%d_%H%M.nc", background=None):
         super().__init__(interval, verbose, spinup_date, variables, output_dir)
         self.filename_fmt = filename_fmt
         self.background = background
@@ -99,13 +100,15 @@ class XarrayExporter(_GridOutput):
         self._pending = [None, None]  # per output buffer: the thread that is writing from it
         self._turn = 0
         self._failure = None
+        self._in_run = False  # set by the time loops of speedy.py around the run that owns this hook
 
     def fire(self, model_instance):
         target = os.path.join(self.output_dir, model_instance.current_date.strftime(self.filename_fmt))
         os.makedirs(self.output_dir, exist_ok=True)
         self.print_msg("Saving model output at: %s." % target)
         # (a single model's day is 0.8 MB: handing it to a thread costs more than writing it)
-        if not self.background or getattr(model_instance, "n_members", 1) < 8:
+        behind = self._in_run if self.background is None else bool(self.background)
+        if not behind or getattr(model_instance, "n_members", 1) < 8:
             model_instance.to_dataframe(variables=self.variables, packed=True, buffers=self._buffers).to_netcdf(target)
             return
         import threading

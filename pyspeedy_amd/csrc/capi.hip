@@ -62,14 +62,15 @@ static int upload(spd_context *c, const double *src, size_t n, const double **ds
 
 // kernel-friendly polynomial layouts (device_tables.hpp, transforms.hip)
 static std::vector<double> make_pinv(const HostTables &h) {
-    // [n = 32][lane = m*12 + jq][2]: latitude pairs 2jq, 2jq+1; zero outside the triangle (nsh2, legendre.f90:73)
+    // [n = 32][lane = m*12 + jq][2]: latitude pairs jq, jq + 12 (transforms.hip: the lanes of one LDS store cycle then sit on
+    // different banks); zero outside the triangle (nsh2, legendre.f90:73)
     std::vector<double> p(static_cast<size_t>(NX) * MX * 12 * 2, 0.0);
     for (int n = 0; n < NX; ++n)
         for (int m = 0; m < MX; ++m)
             for (int jq = 0; jq < 12; ++jq)
                 for (int q = 0; q < 2; ++q)
                     if (m + n <= TRUNC + 1)
-                        p[((static_cast<size_t>(n) * MX + m) * 12 + jq) * 2 + q] = h.poly[m + MX * (n + NX * (2 * jq + q))];
+                        p[((static_cast<size_t>(n) * MX + m) * 12 + jq) * 2 + q] = h.poly[m + MX * (n + NX * SPD_INV_PAIR(jq, q))];
     return p;
 }
 
@@ -202,6 +203,7 @@ int spd_destroy(spd_handle h) {
     for (void *p : h->allocations) (void)hipFree(p);
     for (const spd_context::IdleBlock &b : h->idle_blocks) (void)hipFree(b.base);
     if (h->scratch) (void)hipFree(h->scratch);
+    if (h->probe_buf) (void)hipFree(h->probe_buf);
     delete h;
     return SPD_OK;
 }

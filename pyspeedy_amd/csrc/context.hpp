@@ -28,6 +28,10 @@ struct spd_context {
     double *scratch = nullptr;
     size_t scratch_bytes = 0;
     std::mutex scratch_mutex;
+    // buffer of spd_stream_probe (stream_probe.hip): grows on demand, lives as long as the context; one probe at a time
+    void *probe_buf = nullptr;
+    size_t probe_bytes = 0;
+    std::mutex probe_mutex;
     // Memory blocks of models that have died, kept for the next model of the same size (model.hip: arena_alloc / spd_model_destroy):
     // a host with the reference's call sequence creates and closes one-member models by the hundred, and hipFree costs 0.22 ms.
     struct IdleBlock {

@@ -19,6 +19,7 @@ struct CheckArgs {
     int *err;                     // [M], pinned host memory
     double *diag;                 // [M][3][8] or nullptr
     int ticket;
+    int first = 0;                // block i of a launch checks member first + i (err and diag are indexed by the member itself)
 };
 
 // kBatch: how many of a lane's 16 rounds of loads are requested before anything is summed (the order of the sum is the same for

@@ -783,12 +783,15 @@ struct GroupRun {
     int slot = -1;     // pending check; -1: the members were not initialised; -2: the step could not be issued
     int32_t step = 0;  // the model's step counter after the step: what the range check reports on stderr
     bool behind = false;  // enqueued while the check of the step before it was still out
+    int nsteps = 1;    // > 1 or `checked`: a multi-step call with the check of every step recorded on the device (spd_parallel_steps_begin)
+    bool checked = false;
     int rc = SPD_OK;   // status of this group's device calls
     std::string error; // ... and its message
 };
 struct PendingStep {
     std::shared_ptr<const Plan> plan;
     std::vector<GroupRun> run;
+    int nsteps = 0;  // 0: spd_parallel_step_begin; k >= 1: spd_parallel_steps_begin of k steps
 };
 std::map<int64_t, PendingStep> g_pending;
 // Host-side order of the device work of the multi-group paths, for tests: (kind, group) pairs, kind 1 = step + check
@@ -932,11 +935,37 @@ constexpr int32_t kStepFailed = -3;
 // Everything that can refuse is asked BEFORE the step is enqueued (a free check slot, the control block); what fails from the
 // step on is a device error, and it leaves the model marked: its state has moved while its date and codes say it has not, and
 // it is not stepped again until its members are initialised anew.
-static void issue_group(const GroupPlan &g, GroupRun &r, bool defer_check) {
+static void issue_group(const GroupPlan &g, GroupRun &r, bool defer_check, int nsteps_checked = 0) {
     Batch &b = *g.batch;
     if (!all_initialized(b)) return;  // slot stays -1: E_STATE_NOT_INITIALIZED
     int rc = SPD_OK;
     bool step_enqueued = false;
+    if (nsteps_checked > 0) {  // k steps as ONE device call, every step's range check recorded by the device
+        r.nsteps = nsteps_checked;
+        r.checked = true;
+        if (b.advanced_without_check)
+            rc = fail(SPD_E_ARG, "speedy driver: an earlier step of this device model was enqueued but could not be checked; initialise its members again");
+        if (rc == SPD_OK && !drvdev::set_device(b.device)) rc = fail(SPD_E_DEVICE, "speedy driver: hipSetDevice failed");
+        if (rc == SPD_OK && !b.stream) rc = fail(SPD_E_DEVICE, "speedy driver: hipStreamCreate failed");
+        if (rc == SPD_OK && spd_model_checks_in_flight(b.model) != 0)
+            rc = fail(SPD_E_ARG, "speedy driver: a step of this device model is in flight; end it with spd_parallel_step_end first");
+        if (rc == SPD_OK) rc = push_date(b, r.before);
+        if (rc == SPD_OK) {
+            rc = spd_model_step_checked_begin(b.model, nsteps_checked, b.stream);
+            // (a refusal leaves the model as it was; a device error in the middle marks the model itself: spd_model_step)
+            step_enqueued = rc == SPD_OK;
+        }
+        if (rc == SPD_OK) rc = pull_date(b, r.advanced, &r.step);
+        if (rc == SPD_OK) {
+            r.slot = 0;  // (no check slot: the codes wait in the model until spd_model_step_checked_end)
+        } else {
+            r.rc = rc;
+            r.error = spd_last_error();
+            r.slot = -2;
+            if (step_enqueued) b.advanced_without_check = true;
+        }
+        return;
+    }
     if (b.advanced_without_check)
         rc = fail(SPD_E_ARG, "speedy driver: an earlier step of this device model was enqueued but could not be checked; initialise its members again");
     if (rc == SPD_OK && !drvdev::set_device(b.device)) rc = fail(SPD_E_DEVICE, "speedy driver: hipSetDevice failed");
@@ -1016,7 +1045,7 @@ static IssueWorker *issue_worker(int key) {
 }
 
 // Enqueue the step and check of every group; after_issue(i) runs on the CALLING thread for every group, in order.  (lock held)
-static void issue_all(const std::vector<GroupPlan> &groups, std::vector<GroupRun> &run, bool defer_check) {
+static void issue_all(const std::vector<GroupPlan> &groups, std::vector<GroupRun> &run, bool defer_check, int nsteps_checked = 0) {
     static const int mode = [] {
         const char *e = getenv("PYSPEEDY_AMD_ISSUE_THREADS");
         return e ? atoi(e) : 1;
@@ -1029,7 +1058,7 @@ static void issue_all(const std::vector<GroupPlan> &groups, std::vector<GroupRun
     for (size_t i = 0; i < groups.size(); ++i) by_key[mode == 2 ? static_cast<int>(i) : groups[i].batch->device].push_back(i);
     if (mode == 0 || by_key.size() < 2) {
         for (size_t i = 0; i < groups.size(); ++i) {
-            issue_group(groups[i], run[i], defer_check);
+            issue_group(groups[i], run[i], defer_check, nsteps_checked);
             trace(1, static_cast<int>(i));
         }
         return;
@@ -1040,16 +1069,16 @@ static void issue_all(const std::vector<GroupPlan> &groups, std::vector<GroupRun
         if (kv.first == mine) continue;
         IssueWorker *w = issue_worker(kv.first);
         const std::vector<size_t> *list = &kv.second;
-        w->submit([list, &groups, &run, defer_check] {
+        w->submit([list, &groups, &run, defer_check, nsteps_checked] {
             for (size_t i : *list) {
-                issue_group(groups[i], run[i], defer_check);
+                issue_group(groups[i], run[i], defer_check, nsteps_checked);
                 trace(1, static_cast<int>(i));
             }
         });
         busy.push_back(w);
     }
     for (size_t i : by_key[mine]) {
-        issue_group(groups[i], run[i], defer_check);
+        issue_group(groups[i], run[i], defer_check, nsteps_checked);
         trace(1, static_cast<int>(i));
     }
     for (IssueWorker *w : busy) w->wait();
@@ -1189,7 +1218,7 @@ int spd_parallel_step_end(int64_t token, int32_t *error_codes) {
     drvdev::DeviceGuard guard;
     std::unique_lock<std::recursive_mutex> lock(g_mutex);
     auto it = g_pending.find(token);
-    if (it == g_pending.end() || !error_codes) return fail(SPD_E_ARG, "spd_parallel_step_end: not a pending step");
+    if (it == g_pending.end() || !error_codes || it->second.nsteps != 0) return fail(SPD_E_ARG, "spd_parallel_step_end: not a pending step");
     PendingStep p = std::move(it->second);
     g_pending.erase(it);
     for (size_t i = 0; i < p.plan->groups.size(); ++i) settle_deferred(p.plan->groups[i], p.run[i]);
@@ -1210,6 +1239,106 @@ int spd_parallel_step_end(int64_t token, int32_t *error_codes) {
         }
         settle_group(g, p.run[i], codes[i], error_codes, true);
     }
+    return first_failure(p.run);
+}
+
+// k steps of the same containers as ONE device call per device model, with the range check of EVERY step recorded on the device
+// (spd_model_step_checked_begin): what a host with the reference's time loop (pyspeedy/speedy.py:396-405, 572-586) may do for the
+// steps between two due callbacks -- nothing looks at the state in between.  The dates in the control containers move k steps at
+// _begin; _end waits, hands out per member the code of the FIRST step whose check failed (the reference's loop stops there) and
+// how many steps the member completed before it, writes the reference's stderr text for that step and puts the member's date
+// back to the one after its last accepted step (speedy.f90:57-71 returns before advance_date).
+int spd_parallel_steps_begin(const int64_t *state_cnts, const int64_t *control_cnts, int32_t n, int32_t n_steps, int64_t *token) {
+    if (n < 0 || !token || (n > 0 && (!state_cnts || !control_cnts))) return fail(SPD_E_ARG, "spd_parallel_steps_begin: bad argument");
+    if (n_steps < 1 || n_steps > 4096) return fail(SPD_E_ARG, "spd_parallel_steps_begin: 1 ... 4096 steps per call");
+    drvdev::DeviceGuard guard;
+    LOCK;
+    PendingStep p;
+    p.nsteps = n_steps;
+    if (int rc = plan_step(state_cnts, control_cnts, n, p.plan, p.run, "spd_parallel_steps_begin")) return rc;
+    issue_all(p.plan->groups, p.run, false, n_steps);  // (a group that cannot be issued reports at _end; the others go ahead)
+    for (size_t i = 0; i < p.run.size(); ++i) {
+        const GroupPlan &g = p.plan->groups[i];
+        GroupRun &r = p.run[i];
+        if (r.slot < 0) continue;
+        for (int64_t id : g.control_ids) {  // the dates run ahead of the checks; _end puts a failed member's date back
+            auto ci = g_controls.find(id);
+            if (ci == g_controls.end()) continue;
+            ci->second.now = r.advanced.now;
+            ci->second.month_idx = r.advanced.month_idx;
+        }
+    }
+    *token = g_next++;
+    g_pending[*token] = std::move(p);
+    return SPD_OK;
+}
+
+int spd_parallel_steps_end(int64_t token, int32_t *error_codes, int32_t *steps_done) {
+    drvdev::DeviceGuard guard;
+    std::unique_lock<std::recursive_mutex> lock(g_mutex);
+    auto it = g_pending.find(token);
+    if (it == g_pending.end() || !error_codes || it->second.nsteps < 1) return fail(SPD_E_ARG, "spd_parallel_steps_end: not a pending multi-step call");
+    PendingStep p = std::move(it->second);
+    g_pending.erase(it);
+    lock.unlock();  // (other host threads may step THEIR containers while this one waits)
+    const std::vector<GroupPlan> &groups = p.plan->groups;
+    std::vector<std::vector<int32_t>> failed(groups.size()), accepted(groups.size());
+    for (size_t i = 0; i < groups.size(); ++i) {
+        GroupRun &r = p.run[i];
+        Batch &b = *groups[i].batch;
+        if (r.slot < 0) continue;
+        trace(2, static_cast<int>(i));
+        failed[i].assign(b.members, -1);
+        accepted[i].assign(static_cast<size_t>(b.members) * 7, 0);
+        int rc = SPD_OK;
+        if (!drvdev::set_device(b.device)) rc = fail(SPD_E_DEVICE, "speedy driver: hipSetDevice failed");
+        if (rc == SPD_OK) rc = spd_model_step_checked_end(b.model, failed[i].data(), accepted[i].data());
+        if (rc != SPD_OK && r.rc == SPD_OK) {
+            r.rc = rc;
+            r.error = spd_last_error();
+        }
+        trace(3, static_cast<int>(i));
+    }
+    lock.lock();
+    bool any_failed = false;
+    for (size_t i = 0; i < groups.size(); ++i) {
+        const GroupPlan &g = groups[i];
+        const GroupRun &r = p.run[i];
+        for (size_t k = 0; k < g.positions.size(); ++k) {
+            const int pos = g.positions[k], mem = g.members[k];
+            int32_t code = 0, done = p.nsteps;
+            if (r.slot == -1) {  // not initialised: nothing was touched
+                code = -1;
+                done = 0;
+            } else if (r.slot == -2 || r.rc != SPD_OK) {  // could not be issued, or its codes could not be collected
+                code = kStepFailed;
+                done = 0;
+            } else if (failed[i][mem] >= 0) {
+                code = -2;
+                done = failed[i][mem];
+            }
+            error_codes[pos] = code;
+            if (steps_done) steps_done[pos] = done;
+            any_failed = any_failed || code != 0;
+            auto ci = g_controls.find(g.control_ids[k]);
+            if (code == -2) {
+                const int32_t *a = accepted[i].data() + 7 * static_cast<size_t>(mem);
+                report_out_of_range(a[0] + 1);  // the step counter of the step that failed (diagnostics.f90:70)
+                std::vector<int32_t> &told = g.batch->failed_step;
+                if (told.size() != static_cast<size_t>(g.batch->members)) told.assign(g.batch->members, -1);
+                told[mem] = a[0] + 1;
+                if (ci != g_controls.end()) {  // the date after the last accepted step (speedy.f90:57-71 returns before advance_date)
+                    for (int d = 0; d < 5; ++d) ci->second.now.ymdhm[d] = a[1 + d];
+                    ci->second.month_idx = a[6];
+                }
+            } else if (code == kStepFailed && r.slot != -1 && ci != g_controls.end()) {  // the dates stay (see the header)
+                ci->second.now = r.before.now;
+                ci->second.month_idx = r.before.month_idx;
+            }
+        }
+        if (r.rc != SPD_OK && r.slot >= 0) g.batch->advanced_without_check = true;  // (stepped, and the checks could not be collected)
+    }
+    if (any_failed) regrouped();  // the members of a model may now disagree about the date
     return first_failure(p.run);
 }
 

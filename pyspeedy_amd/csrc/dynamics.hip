@@ -422,7 +422,7 @@ __global__ __launch_bounds__(kT) void spectral_step_kernel(ModelPtrs P, DeviceTa
 // memory alone, the moment the store lands (model.hip: wait_codes), instead of waiting for a completion event behind the kernel.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * KX) void diagnostics_kernel(CheckArgs c, DeviceTables T) {
-    diagnostics_block(c, T, blockIdx.x);
+    diagnostics_block(c, T, c.first + static_cast<int>(blockIdx.x));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -477,6 +477,13 @@ hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const Dy
 hipError_t run_diagnostics(const ModelPtrs &P, const DeviceTables &T, int M, int tl, int *err, double *diag, int ticket,
                            hipStream_t s) {
     hipLaunchKernelGGL(diagnostics_kernel, dim3(M), dim3(64 * KX), 0, s, CheckArgs{P.vor, P.div, P.t, tl, err, diag, ticket}, T);
+    return hipGetLastError();
+}
+// ... of the members [first, first + count) only (err, diag: the whole model's arrays)
+hipError_t run_diagnostics_range(const ModelPtrs &P, const DeviceTables &T, int first, int count, int tl, int *err, double *diag,
+                                 int ticket, hipStream_t s) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(diagnostics_kernel, dim3(count), dim3(64 * KX), 0, s, CheckArgs{P.vor, P.div, P.t, tl, err, diag, ticket, first}, T);
     return hipGetLastError();
 }
 

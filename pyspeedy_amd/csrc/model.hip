@@ -41,6 +41,8 @@ hipError_t run_spectral_step(const ModelPtrs &P, const DeviceTables &T, const Dy
                              int j1, double dt, double eps, const CouplerArgs *cpl, bool early, hipStream_t s);
 hipError_t run_diagnostics(const ModelPtrs &P, const DeviceTables &T, int M, int tl, int *err, double *diag, int ticket,
                            hipStream_t s);
+hipError_t run_diagnostics_range(const ModelPtrs &P, const DeviceTables &T, int first, int count, int tl, int *err, double *diag,
+                                 int ticket, hipStream_t s);
 hipError_t run_coupler(const SurfacePtrs &S, int first, int count, const TimeInterp &w, int day, int land_coupling,
                        int sst_anomaly, int anom_planes, int fresh, hipStream_t s);
 hipError_t run_forcing(const SurfacePtrs &S, int first, int count, const ZonalDevice &Z, double gamlat, double *corh_t,
@@ -175,6 +177,18 @@ struct spd_model {
     // A change of that storage converts the arrays in place, one by one; a device error in the middle leaves some of them
     // converted and `stored32` unable to say which.  The model then refuses every call that would read or advance its state.
     std::string poisoned;
+    // ... and a device error in the middle of a step (some launches of it out, others not; or one member group a step ahead of
+    // another): the STATE is then inconsistent, not the storage -- spd_model_init, which rebuilds every array from the boundary
+    // fields, makes the model usable again; nothing else does.
+    std::string step_poison;
+    int fail_launch_after = -1;  // fault injection for tests (option "fail_launch_after"): the n-th step_range of the next call fails
+    // spd_model_step_checked_begin / _end: the range check of EVERY step of a multi-step call, recorded by the device into pinned
+    // host memory [steps][M] (4 * ticket + flag, as the single checks do) by check blocks that ride in the next step's
+    // spectral -> grid launch; the last step's check is a launch of its own behind the call.
+    int *h_steps_err = nullptr;
+    int steps_cap = 0, steps_pending = 0, steps_ticket = 0;
+    hipEvent_t steps_event = nullptr;
+    std::vector<int32_t> steps_accepted;  // [steps + 1][7]: step counter, y, m, d, h, min, month_idx before the call and after each step
     // Dead-store elimination inside multi-step calls (PYSPEEDY_AMD_DIAG_EVERY_STEP=1 switches it off): only the LAST step
     // of a spd_model_step call stores the physics outputs that no later kernel reads -- the host can only look at the
     // state between calls, and every earlier value would be overwritten before that.
@@ -211,9 +225,11 @@ LaunchEvents &pending_launch_events() {
 }  // namespace spd
 
 static int m_fail(int code, const std::string &msg) { return spd_set_error(code, msg); }
-static int usable(const spd_model *m, const char *who) {
-    if (m->poisoned.empty()) return SPD_OK;
-    return m_fail(SPD_E_DEVICE, std::string(who) + ": this model is unusable: " + m->poisoned);
+static int usable(const spd_model *m, const char *who, bool about_to_init = false) {
+    if (!m->poisoned.empty()) return m_fail(SPD_E_DEVICE, std::string(who) + ": this model is unusable: " + m->poisoned);
+    if (!about_to_init && !m->step_poison.empty())
+        return m_fail(SPD_E_ARG, std::string(who) + ": this model is unusable until it is initialised again (spd_model_init): " + m->step_poison);
+    return SPD_OK;
 }
 static int apply_storage(spd_model *m, bool want32);  // (with spd_model_set_physics_precision)
 static int settle_deferred_check(spd_model *m);        // (with spd_model_check_defer)
@@ -673,6 +689,8 @@ int spd_model_destroy(spd_model_handle m) {
     if (m->ev_start) (void)hipEventDestroy(m->ev_start);
     if (m->ev_offset) (void)hipEventDestroy(m->ev_offset);
     if (m->h_err_sync) (void)hipHostFree(m->h_err_sync);
+    if (m->h_steps_err) (void)hipHostFree(m->h_steps_err);
+    if (m->steps_event) (void)hipEventDestroy(m->steps_event);
     for (int i = 0; i < 2; ++i) {
         if (m->h_err[i]) (void)hipHostFree(m->h_err[i]);
         if (m->err_event[i]) (void)hipEventDestroy(m->err_event[i]);
@@ -785,6 +803,7 @@ int spd_model_get(spd_model_handle m, const char *name, int member, void *host, 
 //    they are dropped here, and a caller that writes through a pointer it took EARLIER must call spd_model_invalidate.
 void *spd_model_device_ptr(spd_model_handle m, const char *name) {
     if (!m || !name) return nullptr;
+    if (usable(m, "spd_model_device_ptr") != SPD_OK) return nullptr;  // (spd_last_error says why)
     auto it = m->reg.find(name);
     if (it == m->reg.end()) return nullptr;
     if (settle_deferred_check(m) != SPD_OK) return nullptr;
@@ -878,11 +897,14 @@ static void sppt_advance(spd_model *m) {
 }
 
 // cpl != nullptr: the coupling that follows the step is part of the last launch
+// ride != nullptr: the range check of the PREVIOUS step of these members rides in this step's spectral -> grid launch
 static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int compute_shortwave, int first, int count, int diag,
-                             bool run_geo, const CouplerArgs *cpl, hipStream_t s, hipEvent_t after_grid2spec = nullptr) {
+                             bool run_geo, const CouplerArgs *cpl, hipStream_t s, hipEvent_t after_grid2spec = nullptr,
+                             const CheckArgs *ride = nullptr) {
     const DeviceTables &T = m->ctx->dev;
     const int M = m->M;
     hipError_t e = hipSuccess;
+    if (m->fail_launch_after >= 0 && m->fail_launch_after-- == 0) return hipErrorLaunchFailure;  // (fault injection, tests only)
     // physics.f90:234-236: a new SPPT pattern for every call of the physics, here for the members of this launch (the generator
     // is keyed by the global member id, so a group of members advances exactly its own part of the pattern; the caller moves
     // the generator's step counter once per model step, after all groups have been issued).  The AR(1) update rides in the
@@ -915,6 +937,9 @@ static hipError_t step_range(spd_model *m, int j1, int j2, double dt, int comput
             e = run_spec2grid_table_check(T, table, per * count, chk, M, s);
             m->deferred.active = false;
             m->slot_rode[slot] = true;
+            ++m->checks_rode;
+        } else if (ride) {
+            e = run_spec2grid_table_check(T, table + static_cast<size_t>(first) * per, per * count, *ride, count, s);
             ++m->checks_rode;
         } else {
             e = run_spec2grid_table(T, table + static_cast<size_t>(first) * per, per * count, s);
@@ -1004,6 +1029,7 @@ static int wait_codes(spd_model *m, const int *pinned, int ticket, hipEvent_t ev
 // diagnostics.f90 check_diagnostics for every member; synchronises the stream and returns the reference's codes.
 int spd_model_check(spd_model_handle m, int time_level, int32_t *error_codes_host, double *diag_host, void *stream) {
     if (!m || !error_codes_host) return m_fail(SPD_E_ARG, "spd_model_check: null argument");
+    if (int rc = usable(m, "spd_model_check")) return rc;
     if (time_level < 1 || time_level > 2) return m_fail(SPD_E_ARG, "spd_model_check: time level is 1 or 2");
     hipStream_t s = static_cast<hipStream_t>(stream);
     // The kernel writes the codes straight into pinned, coherent host memory (one 4-byte store per member over the fabric): a
@@ -1072,6 +1098,7 @@ static int settle_deferred_check(spd_model *m) {
 
 int spd_model_check_begin(spd_model_handle m, int time_level, void *stream) {
     if (!m) return m_fail(SPD_E_ARG, "spd_model_check_begin: null model");
+    if (int rc = usable(m, "spd_model_check_begin")) return rc;
     if (time_level < 1 || time_level > 2) return m_fail(SPD_E_ARG, "spd_model_check_begin: time level is 1 or 2");
     if (int rc = settle_deferred_check(m)) return rc;
     const int slot = reserve_check_slot(m, "spd_model_check_begin");
@@ -1087,6 +1114,7 @@ int spd_model_check_begin(spd_model_handle m, int time_level, void *stream) {
 // For hosts that collect the check of step k after they have enqueued step k + 1 (spd_parallel_step_begin / _end).
 int spd_model_check_defer(spd_model_handle m, int time_level, void *stream) {
     if (!m) return m_fail(SPD_E_ARG, "spd_model_check_defer: null model");
+    if (int rc = usable(m, "spd_model_check_defer")) return rc;
     if (time_level < 1 || time_level > 2) return m_fail(SPD_E_ARG, "spd_model_check_defer: time level is 1 or 2");
     if (int rc = settle_deferred_check(m)) return rc;
     const int slot = reserve_check_slot(m, "spd_model_check_defer");
@@ -1185,7 +1213,7 @@ static int couple(spd_model *m, int day, hipStream_t s) { return couple_range(m,
 // orog, fmask_orig, alb0, veg_high, veg_low, stl12, snowd12, soil_wc_l1, soil_wc_l2, sst12, sea_ice_frac12 [, sst_anom].
 int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, int minute, void *stream) {
     if (!m) return m_fail(SPD_E_ARG, "spd_model_init: null model");
-    if (int rc = usable(m, "spd_model_init")) return rc;
+    if (int rc = usable(m, "spd_model_init", true)) return rc;
     if (month < 1 || month > 12 || day < 1 || day > 31) return m_fail(SPD_E_ARG, "spd_model_init: bad start date");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int M = m->M;
@@ -1196,6 +1224,9 @@ int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, i
     m->cal.set(year, month, day, hour, minute);
     m->current_step = 0;
     m->surf_cache_valid = m->phi_ahead = false;
+    m->step_poison.clear();  // (every array of the state is rebuilt below)
+    m->steps_pending = 0;
+    m->fail_launch_after = -1;
     // ---- land_model_init / sea_model_init: every member's boundary fields preprocessed where they lie (surface.hip)
     {
         LandSeaPtrs L{};
@@ -1262,11 +1293,14 @@ int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, i
 
 // do_single_step (speedy.f90:20-74) `nsteps` times for all members.  Nothing synchronises; the range check of
 // diagnostics.f90 is available separately through spd_model_check (the reference runs it after every step).
-int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
-    if (!m) return m_fail(SPD_E_ARG, "spd_model_step: null model");
-    if (int rc = usable(m, "spd_model_step")) return rc;
-    if (!m->initialized) return m_fail(SPD_E_ARG, "spd_model_step: model state not initialized (error code -1 of the reference)");
-    if (!m->dyn) return m_fail(SPD_E_ARG, "spd_model_step: call spd_model_set_time_step first");
+// record: the range check of every step is left in m->h_steps_err[step][member] (spd_model_step_checked_begin) -- the check of step
+// k rides in the spectral -> grid launch of step k + 1 of the same members, the last one is a launch of its own behind the call.
+static int step_impl(spd_model *m, int nsteps, void *stream, bool record, const char *who) {
+    if (!m) return m_fail(SPD_E_ARG, std::string(who) + ": null model");
+    if (int rc = usable(m, who)) return rc;
+    if (!m->initialized) return m_fail(SPD_E_ARG, std::string(who) + ": model state not initialized (error code -1 of the reference)");
+    if (!m->dyn) return m_fail(SPD_E_ARG, std::string(who) + ": call spd_model_set_time_step first");
+    if (m->steps_pending) return m_fail(SPD_E_ARG, std::string(who) + ": a checked multi-step call is in flight; end it with spd_model_step_checked_end first");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double delt = 86400.0 / 36;
     // Members never exchange data, so the step is issued group by group on separate streams: every group runs the same
@@ -1277,7 +1311,7 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
     const int G = (m->split_dyn_physics || m->profile > 0 || nsteps == 1) ? 1 : m->nchunks;
     // a range check that was put off rides in the first spectral -> grid launch of this call -- when that is ONE launch over all
     // members on the stream the check was put off on; otherwise it goes out on its own first
-    if (m->deferred.active && (G > 1 || s != m->deferred.stream))
+    if (m->deferred.active && (G > 1 || s != m->deferred.stream || record))
         if (int rc = settle_deferred_check(m)) return rc;
     hipStream_t gs[4] = {s, nullptr, nullptr, nullptr};
     if (G > 1) {
@@ -1341,6 +1375,16 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
         }
     }
     int rc = SPD_OK;
+    auto note_accepted = [&](int row) {  // (record: what the host side of the model looks like after `row` steps of the call)
+        if (!record) return;
+        int32_t *a = m->steps_accepted.data() + 7 * static_cast<size_t>(row);
+        a[0] = m->current_step; a[1] = m->cal.year; a[2] = m->cal.month; a[3] = m->cal.day; a[4] = m->cal.hour; a[5] = m->cal.minute;
+        a[6] = m->cal.month_idx;
+    };
+    if (record) m->steps_accepted.assign(7 * static_cast<size_t>(nsteps + 1), 0);
+    note_accepted(0);
+    bool launched = false, device_failed = false;  // a launch of this call went out / a device call of it failed
+    const int tl_check = 1;  // the check looks at time level 2 (do_single_step checks the state the step has just produced)
     for (int round = 0, round_first = 0; round < rounds && rc == SPD_OK; ++round) {
         const int round_count = m->M / rounds + (round < m->M % rounds ? 1 : 0);
         if (round > 0) {  // the same steps again, for the next members
@@ -1376,21 +1420,46 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
             for (int g = 0, first = round_first; g < G && rc == SPD_OK; ++g) {
                 const int count = base + (g < extra ? 1 : 0);
                 if (count == 0) continue;
-                if (new_day) rc = forcing_range(m, zd, first, count, gs[g]);
+                launched = true;
+                if (new_day) {
+                    rc = forcing_range(m, zd, first, count, gs[g]);
+                    device_failed = device_failed || rc != SPD_OK;
+                }
                 CouplerArgs cpl{m->S, w, first, count, 1 + (m->current_step + 1) / 36, m->land_coupling_flag, m->sst_anomaly_flag,
                                 m->anom_planes, fresh};
                 const bool ride = m->coupler_in_spectral;
                 if (rc == SPD_OK) {
-                    if (offset && first_of_call && g == 1) M_HIP(hipStreamWaitEvent(gs[1], m->ev_offset, 0));
-                    const hipError_t e = step_range(m, 2, 2, 2 * delt, sw, first, count, diag, run_geo, ride ? &cpl : nullptr, gs[g],
-                                                    (offset && first_of_call && g == 0) ? m->ev_offset : nullptr);
-                    if (e != hipSuccess) rc = m_fail(SPD_E_DEVICE, std::string("spd_model_step: ") + hipGetErrorString(e));
+                    hipError_t e = hipSuccess;
+                    if (offset && first_of_call && g == 1) e = hipStreamWaitEvent(gs[1], m->ev_offset, 0);
+                    // (the check of the step before this one, for these members: written to that step's row)
+                    const CheckArgs chk{m->P.vor, m->P.div, m->P.t, tl_check, record && it > 0 ? m->h_steps_err + static_cast<size_t>(it - 1) * m->M : nullptr,
+                                        nullptr, m->steps_ticket, first};
+                    if (e == hipSuccess)
+                        e = step_range(m, 2, 2, 2 * delt, sw, first, count, diag, run_geo, ride ? &cpl : nullptr, gs[g],
+                                       (offset && first_of_call && g == 0) ? m->ev_offset : nullptr, record && it > 0 ? &chk : nullptr);
+                    if (e != hipSuccess) {
+                        (void)hipGetLastError();
+                        rc = m_fail(SPD_E_DEVICE, std::string(who) + ": " + hipGetErrorString(e));
+                        device_failed = true;
+                    }
                 }
                 if (rc == SPD_OK && !ride) {
                     ProfScope ps(m, SPD_K_COUPLER, count, gs[g]);
                     const hipError_t e = run_coupler(m->S, first, count, w, 1 + (m->current_step + 1) / 36, m->land_coupling_flag,
                                                      m->sst_anomaly_flag, m->anom_planes, fresh, gs[g]);
-                    if (e != hipSuccess) rc = m_fail(SPD_E_DEVICE, std::string("couple_sea_land: ") + hipGetErrorString(e));
+                    if (e != hipSuccess) {
+                        rc = m_fail(SPD_E_DEVICE, std::string("couple_sea_land: ") + hipGetErrorString(e));
+                        device_failed = true;
+                    }
+                }
+                if (rc == SPD_OK && record && it == nsteps - 1) {  // the last step's check: nothing comes behind it to carry it
+                    const hipError_t e = run_diagnostics_range(m->P, m->ctx->dev, first, count, tl_check,
+                                                               m->h_steps_err + static_cast<size_t>(it) * m->M, nullptr, m->steps_ticket, gs[g]);
+                    if (e != hipSuccess) {
+                        rc = m_fail(SPD_E_DEVICE, std::string(who) + ": " + hipGetErrorString(e));
+                        device_failed = true;
+                    }
+                    ++m->checks_alone;
                 }
                 first += count;
             }
@@ -1399,15 +1468,83 @@ int spd_model_step(spd_model_handle m, int nsteps, void *stream) {
             m->current_step += 1;
             m->cal = next;
             m->surf_cache_valid = true;
+            if (round == 0) note_accepted(it + 1);
         }
         round_first += round_count;
     }
-    if (rc != SPD_OK && rounds > 1) {  // some members have taken steps of this call that the others have not
+    // A device error after the first launch of the call went out: a member group may have taken a step (or a part of one: the
+    // launches of a step write its work arrays one after the other) that the others -- and the host side of the model, whose step
+    // counter and date only move with complete steps -- have not.  Whatever the plan (one group, several, rounds), the model is
+    // unusable until spd_model_init has rebuilt its state; the message of the failure itself stays the call's error text.
+    if (rc != SPD_OK && launched && device_failed) {
+        const std::string text = spd_last_error();
         m->initialized = false;
-        m->poisoned = "a device error interrupted a multi-step call that steps its members in rounds; initialise a new model";
+        m->step_poison = "a device error interrupted a model step after some of its launches had gone out (" + text + ")";
+        (void)m_fail(rc, text);
     }
     return rc;
 }
+
+int spd_model_step(spd_model_handle m, int nsteps, void *stream) { return step_impl(m, nsteps, stream, false, "spd_model_step"); }
+
+// The same call with the range check of EVERY step recorded on the device (diagnostics.f90:16-76 after each do_single_step, as the
+// reference's time loop sees it: pyspeedy/speedy.py:396-405), for hosts that know they will not look at the state before `nsteps`
+// steps have passed (no callback due): one call instead of nsteps, the member groups and rounds of the multi-step plan, and still
+// every step's code.  _begin enqueues everything and returns; _end waits and reports, per member, the first step of the call whose
+// check failed (0-based; -1: none).  The device does not stop at a failed check -- the steps behind it run on a state the model
+// does not accept, as the second step of spd_parallel_step_begin does; after a failure the only defined continuation is
+// spd_model_init.  One such call may be in flight per model; nsteps <= 4096.
+int spd_model_step_checked_begin(spd_model_handle m, int nsteps, void *stream) {
+    const char *who = "spd_model_step_checked_begin";
+    if (!m) return m_fail(SPD_E_ARG, std::string(who) + ": null model");
+    if (nsteps < 1 || nsteps > 4096) return m_fail(SPD_E_ARG, std::string(who) + ": 1 ... 4096 steps per call");
+    if (m->steps_pending) return m_fail(SPD_E_ARG, std::string(who) + ": a checked multi-step call is in flight already");
+    M_HIP(hipSetDevice(m->ctx->device));
+    if (m->steps_cap < nsteps) {
+        if (m->h_steps_err) M_HIP(hipHostFree(m->h_steps_err));
+        m->h_steps_err = nullptr;
+        m->steps_cap = 0;
+        void *p = nullptr;
+        const int cap = nsteps < 64 ? 64 : nsteps;
+        M_HIP(hipHostMalloc(&p, sizeof(int) * static_cast<size_t>(cap) * m->M, hipHostMallocCoherent));
+        m->h_steps_err = static_cast<int *>(p);
+        m->steps_cap = cap;
+        std::memset(m->h_steps_err, 0, sizeof(int) * static_cast<size_t>(cap) * m->M);
+    }
+    if (!m->steps_event) M_HIP(hipEventCreateWithFlags(&m->steps_event, hipEventDisableTiming));
+    m->steps_ticket = next_ticket(m);
+    if (int rc = step_impl(m, nsteps, stream, true, who)) return rc;
+    // (step_impl has joined the group streams into the caller's stream: the event is behind every launch of the call)
+    M_HIP(hipEventRecord(m->steps_event, static_cast<hipStream_t>(stream)));
+    m->steps_pending = nsteps;
+    return SPD_OK;
+}
+
+int spd_model_step_checked_end(spd_model_handle m, int32_t *first_failed_step, int32_t *accepted) {
+    const char *who = "spd_model_step_checked_end";
+    if (!m || !first_failed_step) return m_fail(SPD_E_ARG, std::string(who) + ": null argument");
+    if (!m->steps_pending) return m_fail(SPD_E_ARG, std::string(who) + ": no checked multi-step call is in flight");
+    const int K = m->steps_pending, M = m->M;
+    m->steps_pending = 0;
+    M_HIP(hipSetDevice(m->ctx->device));
+    M_HIP(hipEventSynchronize(m->steps_event));
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const volatile int *codes = m->h_steps_err;
+    for (int i = 0; i < M; ++i) first_failed_step[i] = -1;
+    for (int k = K - 1; k >= 0; --k)
+        for (int i = 0; i < M; ++i) {
+            const int c = codes[static_cast<size_t>(k) * M + i];
+            if ((c >> 2) != m->steps_ticket) return m_fail(SPD_E_DEVICE, std::string(who) + ": a range check finished without publishing its code");
+            if (c & 1) first_failed_step[i] = k;
+        }
+    if (accepted)  // a member's last accepted step: the one before its first failure, or the last of the call
+        for (int i = 0; i < M; ++i)
+            std::memcpy(accepted + 7 * static_cast<size_t>(i),
+                        m->steps_accepted.data() + 7 * static_cast<size_t>(first_failed_step[i] < 0 ? K : first_failed_step[i]), 7 * sizeof(int32_t));
+    return SPD_OK;
+}
+
+
 
 int spd_model_current_step(spd_model_handle m) { return m ? m->current_step : SPD_E_ARG; }
 
@@ -1575,6 +1712,7 @@ int spd_model_set_option(spd_model_handle m, const char *name, int32_t value) {
     else if (key == "spectral_early" && value >= -1 && value <= 1) m->spectral_early = value;
     else if (key == "member_groups" && value >= 1 && value <= 4) m->nchunks = value < m->M ? value : m->M;
     else if (key == "block_members" && value >= 0) m->block_members = value;
+    else if (key == "fail_launch_after" && value >= -1) m->fail_launch_after = value;  // (fault injection: tests)
     else if (key == "physics_storage32" && flag) {
         m->phys_store32 = value != 0;
         return apply_storage(m, m->phys_fp32 && m->phys_store32);
@@ -1645,7 +1783,7 @@ int spd_model_set_flags(spd_model_handle m, int land_coupling_flag, int sst_anom
 static int member_range(spd_model_handle m, int first, int count, const char *who) {
     if (!m) return m_fail(SPD_E_ARG, std::string(who) + ": null model");
     if (first < 0 || count < 0 || first + count > m->M) return m_fail(SPD_E_ARG, std::string(who) + ": member range out of bounds");
-    return SPD_OK;
+    return usable(m, who);
 }
 
 // One grid-space registry variable ((ix, il) or (ix, il, kx) per member) of the members [first, first + count) as a NetCDF-3

@@ -224,6 +224,19 @@ class EnsembleModel:
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(self._lib.spd_model_step(self._m, int(nsteps), stream), "spd_model_step")
 
+    def run_checked(self, nsteps):
+        """`nsteps` steps as ONE device call with the range check of EVERY step recorded by the device
+        (spd_model_step_checked_begin / _end); waits for it.  -> (first_failed, accepted): per member the first step of the call
+        (0-based) whose check failed, -1 for none, and [members, 7] the model's step counter, date (y, m, d, h, min) and month index
+        after the member's last accepted step."""
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(self._lib.spd_model_step_checked_begin(self._m, int(nsteps), stream), "spd_model_step_checked_begin")
+        failed = np.zeros(self.nmembers, dtype=np.int32)
+        accepted = np.zeros((self.nmembers, 7), dtype=np.int32)
+        check(self._lib.spd_model_step_checked_end(self._m, failed.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                   accepted.ctypes.data_as(C.POINTER(C.c_int32))), "spd_model_step_checked_end")
+        return failed, accepted
+
     @property
     def current_step(self):
         return int(self._lib.spd_model_current_step(self._m))

@@ -142,7 +142,8 @@ class Speedy:
 
     def _assign_date(self, which, value):
         setattr(self, which, self._set_date(getattr(self, which), value))
-        self.__dict__["_value" + which] = value
+        # (what the container holds, as the reference's getter returns it: year ... minute, no seconds, no time zone)
+        self.__dict__["_value" + which] = datetime(value.year, value.month, value.day, value.hour, value.minute)
 
     @staticmethod
     def _set_date(container, value):
@@ -246,8 +247,28 @@ class Speedy:
             raise RuntimeError("The SPEEDY model was not initialized. Call the `set_bc` method to initialize the model.")
         self.current_date = self.start_date
         end_date = self.end_date
-        pending = None  # the range check of a step is collected after the next step has been enqueued (GPU never idles)
         self._step_in_run = self["current_step"]
+        _own(callbacks, True)
+        intervals = _hook_intervals(callbacks)
+        if intervals is not None:  # the hooks' schedule is known: the steps between two due hooks are one device call
+            try:
+                while self.current_date < end_date:
+                    k = _stretch(self._step_in_run, intervals, self.current_date, end_date)
+                    token = _speedy.parallel_steps_begin([self._state_cnt], [self._control_cnt], k)
+                    codes, done = _speedy.parallel_steps_end(token)
+                    if (codes < 0).any():  # the date of the step before the one that failed, as the reference's loop leaves it
+                        self._step_in_run += int(done[0])
+                        self.current_date += int(done[0]) * _DT_STEP
+                        _raise_step_failure(codes)
+                    self._step_in_run += k
+                    self.current_date += k * _DT_STEP
+                    for act in _callbacks_due(callbacks, self):
+                        act(self)
+            finally:
+                self._step_in_run = None
+                _finish_all(callbacks)
+            return
+        pending = None  # the range check of a step is collected after the next step has been enqueued (GPU never idles)
         try:
             while self.current_date < end_date:
                 token = _speedy.parallel_step_begin([self._state_cnt], [self._control_cnt])
@@ -266,15 +287,14 @@ class Speedy:
         finally:
             self._step_in_run = None
             self._drain(pending)  # (a step that was begun behind the one that failed: end it, its code no longer matters)
-            _finish(callbacks)
+            _finish_all(callbacks)
 
     @staticmethod
     def _collect(token):
         if token is not None:
             codes = _speedy.parallel_step_end(token)
             if (codes < 0).any():
-                raise RuntimeError("".join("Member%d: %s\n" % (n, ERROR_CODES[int(c)]) for n, c in enumerate(codes))
-                                   if len(codes) > 1 else ERROR_CODES[int(codes[0])])
+                _raise_step_failure(codes)
 
     @staticmethod
     def _drain(token):
@@ -320,12 +340,78 @@ class Speedy:
         return _build_dataset(self, arrays, members, self.current_date)
 
 
+# The time loops below take the steps between two due callbacks as ONE device call (speedy_driver.parallel_steps_begin / _end): the
+# device then runs its multi-step plan -- member groups on streams of their own, large ensembles in rounds -- instead of being
+# asked once per 40 simulated minutes, and the range check the reference makes after every step (speedy.py:398-400) is still
+# made after every step, by the device.  That needs the schedule of the hooks: known for a BaseCallback with the stock gating
+# (`interval` / `spinup_date`: it can only act where current_step is a multiple of its interval); a plain callable, a hook that
+# overrides __call__ or skip_flag, or an interval that is not a positive integer may act at every step, and the loop then asks
+# step by step as before.  A stretch is at most _MAX_STRETCH steps long (ten model days).
+_MAX_STRETCH = 360
+
+
+def _hook_intervals(callbacks):
+    """[interval of every hook] when the schedule of all of them is known, else None"""
+    from .callbacks import BaseCallback
+    intervals = []
+    for cb in callbacks:
+        stock = (isinstance(cb, BaseCallback) and type(cb).__call__ is BaseCallback.__call__
+                 and type(cb).skip_flag is BaseCallback.skip_flag)
+        interval = getattr(cb, "interval", None)
+        if not stock or isinstance(interval, bool) or not isinstance(interval, (int, np.integer)) or interval < 1:
+            return None
+        intervals.append(int(interval))
+    return intervals
+
+
+def _stretch(step, intervals, current_date, end_date):
+    """steps until the next one at which a hook may act, the end of the run or _MAX_STRETCH, whichever comes first"""
+    remaining = -((current_date - end_date) // _DT_STEP)  # ceil((end - current) / dt)
+    k = min(int(remaining), _MAX_STRETCH)
+    for interval in intervals:
+        k = min(k, interval - step % interval)
+    return max(k, 1)
+
+
+def _raise_step_failure(codes):
+    raise RuntimeError("".join("Member%d: %s\n" % (n, ERROR_CODES[int(c)]) for n, c in enumerate(codes))
+                       if len(codes) > 1 else ERROR_CODES[int(codes[0])])
+
+
+def _own(callbacks, yes):
+    """tell the hooks that a run owns them (XarrayExporter then writes behind the time loop: the run will call finish())"""
+    for cb in callbacks:
+        if hasattr(cb, "_in_run"):
+            cb._in_run = yes
+
+
 def _finish(callbacks):
     """end of a run: hooks that work in the background (XarrayExporter's file writer) complete what they hold"""
+    failure = None
     for cb in callbacks:
         done = getattr(cb, "finish", None)
         if callable(done):
-            done()
+            try:
+                done()
+            except BaseException as exc:  # noqa: B902 -- every hook gets its turn; the first failure is reported
+                failure = failure or exc
+    if failure is not None:
+        raise failure
+
+
+def _finish_all(callbacks):
+    """_finish from the `finally` of a time loop: a failure of the run itself is not replaced by what a writer could not do -- the
+    writer's error is attached to it (__context__ does that) and the run's exception travels on; without one, the writer's is raised"""
+    import sys
+    running = sys.exc_info()[1]
+    _own(callbacks, False)
+    try:
+        _finish(callbacks)
+    except BaseException as exc:  # noqa: B902
+        if running is None:
+            raise
+        if running.__context__ is None and exc is not running:
+            running.__context__ = exc
 
 
 def _callbacks_due(callbacks, model):
@@ -475,8 +561,37 @@ class SpeedyEns:
         for member in self:
             if not member._initialized_bc:
                 raise RuntimeError("The SPEEDY model was not initialized. Call the `set_bc` method of every member.")
-        pending = None
         step = self.members[0]["current_step"]
+        _own(callbacks, True)
+        intervals = _hook_intervals(callbacks)
+        if intervals is not None:  # (see Speedy.run)
+            try:
+                while self.current_date < end_date:
+                    k = _stretch(step, intervals, self.current_date, end_date)
+                    token = _speedy.parallel_steps_begin(state_cnts, control_cnts, k)
+                    codes, done = _speedy.parallel_steps_end(token)
+                    if (codes < 0).any():
+                        # the reference's loop stops at the first step any member fails: the ensemble's date is the one before it
+                        first = int(done[codes < 0].min())
+                        step += first
+                        self.current_date += first * _DT_STEP
+                        for member, d in zip(self, done):
+                            member.current_date = member.current_date + int(d) * _DT_STEP
+                            member._step_in_run = None
+                        _raise_step_failure(codes)
+                    step += k
+                    self.current_date += k * _DT_STEP
+                    for member in self:
+                        member.current_date = self.current_date
+                        member._step_in_run = step
+                    for act in _callbacks_due(callbacks, self):
+                        act(self)
+            finally:
+                for member in self:
+                    member._step_in_run = None
+                _finish_all(callbacks)
+            return
+        pending = None
         try:
             while self.current_date < end_date:
                 token = _speedy.parallel_step_begin(state_cnts, control_cnts)
@@ -499,7 +614,7 @@ class SpeedyEns:
             for member in self:
                 member._step_in_run = None
             Speedy._drain(pending)
-            _finish(callbacks)
+            _finish_all(callbacks)
 
     def get_current_step(self):
         return self.members[0].get_current_step()

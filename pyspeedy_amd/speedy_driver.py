@@ -241,6 +241,29 @@ def parallel_step_end(token):
     return codes
 
 
+# Extension: n_steps steps as ONE call (spd_parallel_steps_begin / _end): the stretch of a time loop in which no callback is due.
+# Every device model takes them as one multi-step device call -- member groups on streams of their own, large ensembles in rounds
+# -- and the range check of every step is recorded on the device.  parallel_steps_end(token) -> (codes, steps_done): per member the
+# code of the FIRST step whose check failed (0: none) and the steps it completed before that one.
+def parallel_steps_begin(state_cnts, control_cnts, n_steps):
+    s, n = _cnts(state_cnts)
+    c, nc = _cnts(control_cnts)
+    if n != nc:
+        raise ValueError("parallel_steps: one control container per state container")
+    token = C.c_int64()
+    _ok(_L().spd_parallel_steps_begin(s, c, n, int(n_steps), C.byref(token)), "parallel_steps_begin")
+    _pending_sizes[token.value] = n
+    return token.value
+
+
+def parallel_steps_end(token):
+    n = _pending_sizes.pop(int(token))
+    codes, done = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+    _ok(_lib.lib().spd_parallel_steps_end(int(token), codes.ctypes.data_as(C.POINTER(C.c_int32)), done.ctypes.data_as(C.POINTER(C.c_int32))),
+        "parallel_steps_end")
+    return codes, done
+
+
 def check(state_cnt):
     code = C.c_int32(0)
     _ok(_L().spd_check(int(state_cnt), C.byref(code)), "check")
@@ -348,7 +371,9 @@ def ensemble_export_arrays(state_cnts, names, slot=0, buffers=None):
         groups[key][2].append(member)
     n = len(state_cnts)
     first = groups[order[0]][0]
-    shapes = {name: tuple(first.device_view(name).shape[1:]) for name in names}
+    # (from the registry, not from a device view: spd_model_device_ptr drops what the model derived from its state -- the day's
+    # interpolated climatologies, the look-ahead geopotential -- and a packed export never writes the state)
+    shapes = {name: tuple(reversed(first.shape(name)[1])) for name in names}
     sizes = {name: 4 * n * int(np.prod(shapes[name])) for name in names}
     total = sum(sizes.values())
     pool, key = (_export_buffers, (total, slot)) if buffers is None else (buffers, slot)

@@ -383,6 +383,64 @@ void single_thread() {
         for (auto &x : m) verify(x);
         (void)alive;
     }
+    // ---- k steps as one call (spd_parallel_steps_begin / _end): every step's check is there; a failure in the MIDDLE of a stretch
+    //      gives the member the code of that step, the steps before it and the date after its last accepted step
+    {
+        Lists l(everyone);
+        std::vector<int32_t> done(6, -7);
+        int64_t t = 0;
+        EXPECT(spd_parallel_steps_begin(l.s.data(), l.c.data(), 6, 0, &t) < 0);     // at least one step
+        EXPECT(spd_parallel_steps_begin(l.s.data(), l.c.data(), 6, 5000, &t) < 0);  // at most 4096
+        EXPECT(spd_parallel_steps_begin(l.s.data(), l.c.data(), 6, 9, &t) == 0);
+        EXPECT(spd_parallel_step_end(t, l.codes.data()) < 0);                       // (not a token of the single-step form)
+        {   // no single step on the same containers while the stretch is in flight
+            int64_t t2 = 0;
+            std::vector<int32_t> c2(6, 99);
+            EXPECT(spd_parallel_steps_begin(l.s.data(), l.c.data(), 6, 2, &t2) == 0);
+            EXPECT(spd_parallel_steps_end(t2, c2.data(), nullptr) < 0 && c2[0] == -3);
+            EXPECT(std::strstr(spd_last_error(), "in flight") != nullptr);
+        }
+        EXPECT(spd_parallel_steps_end(t, l.codes.data(), done.data()) == 0);
+        EXPECT(spd_parallel_steps_end(t, l.codes.data(), done.data()) < 0);  // a token is good for one _end
+        for (int i = 0; i < 6; ++i) {
+            EXPECT(l.codes[i] == 0 && done[i] == 9);
+            for (int k = 0; k < 9; ++k) m[i].predict_step();
+        }
+        for (auto &x : m) verify(x);
+        // member 3 leaves the accepted range once its step counter reaches steps + 4: the 4th step of a stretch of 7 fails
+        std::vector<double> olr(NG);
+        EXPECT(spd_get(m[3].state, "olr", olr.data(), NG * sizeof(double)) == 0);
+        olr[2] = 1.0;
+        olr[3] = static_cast<double>(m[3].steps + 4);
+        EXPECT(spd_set(m[3].state, "olr", olr.data(), NG * sizeof(double)) == 0);
+        EXPECT(spd_parallel_steps_begin(l.s.data(), l.c.data(), 6, 7, &t) == 0);
+        EXPECT(spd_parallel_steps_end(t, l.codes.data(), done.data()) == 0);
+        for (int i = 0; i < 6; ++i) {
+            EXPECT(l.codes[i] == (i == 3 ? -2 : 0) && done[i] == (i == 3 ? 3 : 7));
+            if (i != 3)
+                for (int k = 0; k < 7; ++k) m[i].predict_step();
+        }
+        for (int k = 0; k < 3; ++k) m[3].predict_step();  // its date: after the three steps it completed
+        int32_t now[5], midx;
+        EXPECT(spd_controlparams_get_model_datetime(m[3].control, now, &midx) == 0 && std::memcmp(now, m[3].date, sizeof(now)) == 0 &&
+               midx == m[3].month_idx);
+        for (int i = 0; i < 6; ++i)
+            if (i != 3) verify(m[i]);
+        set_seed(m[3], 777.0);
+        init(m[3]);  // a new start is the only defined continuation
+        step_all(everyone);
+        for (auto &x : m) verify(x);
+        // a device error while the stretch is enqueued: -3 for that model's members, the date stays, initialise again
+        Lists l2({&m[1], &m[3]});
+        stub_fail_next_steps_begin(2);  // (the two may be two device models by now: both refuse)
+        EXPECT(spd_parallel_steps_begin(l2.s.data(), l2.c.data(), 2, 4, &t) == 0);
+        EXPECT(spd_parallel_steps_end(t, l2.codes.data(), done.data()) < 0 && l2.codes[0] == -3 && l2.codes[1] == -3 && done[0] == 0);
+        stub_fail_next_steps_begin(0);
+        EXPECT(std::strstr(spd_last_error(), "injected") != nullptr);
+        EXPECT(spd_controlparams_get_model_datetime(m[1].control, now, &midx) == 0 && std::memcmp(now, m[1].date, sizeof(now)) == 0);
+        step_all({&m[1], &m[3]});  // (the refusal left the model as it was: nothing had been enqueued)
+        for (auto &x : m) verify(x);
+    }
     // ---- scalars are per device model: a member that wants its own leaves the batch
     {
         const int before = models_alive();

@@ -28,6 +28,7 @@ namespace {
 std::atomic<int> g_devices{2};
 std::atomic<int> g_check_delay_us{0};
 std::atomic<int> g_fail_next_check_begin{0};
+std::atomic<int> g_fail_next_steps_begin{0};
 std::atomic<long> g_device_syncs{0}, g_peer_copies{0}, g_local_copies{0}, g_collectives{0};
 std::atomic<int> g_collective_available{1};
 std::atomic<int> g_fail_model_create_in{0};  // n > 0: the n-th spd_model_create from now fails as a hipMalloc out of memory does
@@ -38,6 +39,7 @@ thread_local std::string t_error;
 void stub_set_device_count(int n) { g_devices = n; }
 void stub_set_check_delay_us(int us) { g_check_delay_us = us; }
 void stub_fail_next_check_begin(int count) { g_fail_next_check_begin = count; }
+void stub_fail_next_steps_begin(int count) { g_fail_next_steps_begin = count; }
 long stub_device_syncs() { return g_device_syncs.load(); }
 long stub_peer_copies() { return g_peer_copies.load(); }
 long stub_local_copies() { return g_local_copies.load(); }
@@ -96,6 +98,8 @@ struct spd_model {
     std::atomic<bool> unsettled[2] = {{false}, {false}};
     int next_slot = 0;
     std::vector<int32_t> slot_codes[2];
+    std::atomic<int> steps_pending{0};  // spd_model_step_checked_begin / _end
+    std::vector<int32_t> steps_failed, steps_accepted;
     // a model is driven by one host thread at a time (the contract of the boundary): two threads inside one model are a bug of
     // the DRIVER, and this counter catches it even where ThreadSanitizer's happens-before would not
     std::atomic<int> inside{0};
@@ -312,6 +316,54 @@ int spd_model_step(spd_model_handle m, int nsteps, void *) {
         m->ctl.current_step += 1;
         advance_date(m->ctl);
     }
+    return SPD_OK;
+}
+
+// k steps with the range check of every step: the stub evaluates the check after each step (a member whose olr[2] is set fails
+// from the step on at which olr[3] says so: olr[3] = n means "fails once its step counter reaches n", 0 = at once)
+int spd_model_step_checked_begin(spd_model_handle m, int nsteps, void *) {
+    if (!m) return spd_set_error(SPD_E_ARG, "spd_model_step_checked_begin: null model");
+    if (nsteps < 1 || nsteps > 4096) return spd_set_error(SPD_E_ARG, "spd_model_step_checked_begin: 1 ... 4096 steps per call");
+    if (!m->initialized) return spd_set_error(SPD_E_ARG, "spd_model_step_checked_begin: model state not initialized");
+    if (m->steps_pending) return spd_set_error(SPD_E_ARG, "spd_model_step_checked_begin: a checked multi-step call is in flight already");
+    Inside guard(m);
+    if (t_device != m->device) return spd_set_error(SPD_E_DEVICE, "spd_model_step_checked_begin: wrong current device");
+    if (g_fail_next_steps_begin.load() > 0 && g_fail_next_steps_begin.fetch_sub(1) > 0)
+        return spd_set_error(SPD_E_DEVICE, "spd_model_step_checked_begin: injected device error");
+    m->steps_failed.assign(m->M, -1);
+    m->steps_accepted.assign(static_cast<size_t>(m->M) * 7, 0);
+    auto note = [&](int i) {
+        int32_t *a = m->steps_accepted.data() + 7 * static_cast<size_t>(i);
+        a[0] = m->ctl.current_step; a[1] = m->ctl.year; a[2] = m->ctl.month; a[3] = m->ctl.day; a[4] = m->ctl.hour; a[5] = m->ctl.minute;
+        a[6] = m->ctl.month_idx;
+    };
+    for (int i = 0; i < m->M; ++i) note(i);
+    for (int it = 0; it < nsteps; ++it) {
+        for (int i = 0; i < m->M; ++i) {
+            double *olr = reinterpret_cast<double *>(var(m, i, "olr", kOlrBytes).data());
+            olr[0] += 1.0;
+            olr[1] = stub_fingerprint(olr[1], m->ctl.current_step);
+        }
+        m->ctl.current_step += 1;
+        advance_date(m->ctl);
+        for (int i = 0; i < m->M; ++i) {
+            const double *olr = reinterpret_cast<const double *>(var(m, i, "olr", kOlrBytes).data());
+            if (m->steps_failed[i] < 0 && olr[2] != 0.0 && m->ctl.current_step >= static_cast<int>(olr[3])) m->steps_failed[i] = it;
+            if (m->steps_failed[i] < 0) note(i);
+        }
+    }
+    m->steps_pending = nsteps;
+    return SPD_OK;
+}
+
+// (waits and reads only: outside the model, like spd_model_check_end of a check that is out)
+int spd_model_step_checked_end(spd_model_handle m, int32_t *first_failed_step, int32_t *accepted) {
+    if (!m || !first_failed_step) return spd_set_error(SPD_E_ARG, "spd_model_step_checked_end: null argument");
+    if (!m->steps_pending) return spd_set_error(SPD_E_ARG, "spd_model_step_checked_end: no checked multi-step call is in flight");
+    if (const int us = g_check_delay_us.load()) std::this_thread::sleep_for(std::chrono::microseconds(us));
+    m->steps_pending = 0;
+    std::memcpy(first_failed_step, m->steps_failed.data(), sizeof(int32_t) * m->M);
+    if (accepted) std::memcpy(accepted, m->steps_accepted.data(), sizeof(int32_t) * 7 * m->M);
     return SPD_OK;
 }
 

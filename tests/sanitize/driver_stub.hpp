@@ -7,6 +7,7 @@
 void stub_set_device_count(int n);
 void stub_set_check_delay_us(int us);         // how long spd_model_check_end "waits for the GPU"
 void stub_fail_next_check_begin(int count);   // the next `count` range checks cannot be enqueued (a device error after the step)
+void stub_fail_next_steps_begin(int count);   // the next `count` spd_model_step_checked_begin calls fail before anything is enqueued
 long stub_device_syncs();
 long stub_peer_copies();
 long stub_local_copies();

@@ -610,3 +610,121 @@ def test_export_pack_entry_point(spectral, bc):
     assert L.spd_model_export_pack(model._m, b"t_grid", 4, 2, C.c_void_p(small.data_ptr()), 64, stream) == -1  # member range
     assert L.spd_model_export_pack(model._m, b"t_grid", 2, 0, C.c_void_p(small.data_ptr()), 0, stream) == 0
     model.close()
+
+
+def _oracle_first_failure(bc, nmax=40):
+    """A member that leaves the accepted range a few steps into its run: SST + 80 K, the global mean of the two lowest levels
+    + 30 K.  The step at which it does is what the CPU oracle's whole model says (oracle/orc_model.c)."""
+    import oracle as orc
+    hot = {k: bc[k] for k in bc.files}
+    hot["sst"] = bc["sst"] + 80.0
+    cpu = orc.Model()
+    cpu.set_bc(hot)
+    assert cpu.init(1982, 1, 1) == 0
+    t = cpu.get("t").copy()
+    t[0, 0, 6:8, :] += 30.0 * np.sqrt(2.0)
+    cpu.set("t", t)
+    for k in range(nmax):
+        if cpu.step() != 0:
+            return k
+    raise AssertionError("the perturbed oracle member never left the accepted range")
+
+
+@pytest.mark.parametrize("plan", ["one_group", "two_groups", "rounds"])
+def test_checked_multi_step_call_records_every_steps_range_check(spectral, bc, plan):
+    """spd_model_step_checked_begin / _end: k steps as ONE device call, the range check of every step recorded by the device
+    (the check of step i rides in the spectral -> grid launch of step i + 1, the last one is a launch of its own).  The state is
+    bitwise the state of k single steps; a member that leaves the accepted range in the MIDDLE of the call is reported with the
+    step at which the CPU oracle's whole model reports it, its last accepted step counter and date; the others with -1 -- in the
+    serial plan, with two member groups on streams of their own, and with the members taken in rounds."""
+    from pyspeedy_amd.model import EnsembleModel
+    M, K, bad = 8, 30, 5
+    f = _oracle_first_failure(bc)
+    assert 0 < f < K - 1, f
+    hot = {k: bc[k] for k in bc.files}
+    hot["sst"] = bc["sst"] + 80.0
+    states = []
+    for checked in (False, True):
+        model = EnsembleModel(spectral, M)
+        model.set_bc(bc)
+        # (member `bad` gets boundary fields of its own and everybody is initialised again)
+        from pyspeedy_amd.model import BC_MAP
+        for state_name, file_name in BC_MAP:
+            model.set(state_name, np.asarray(hot[file_name], dtype=np.float64), member=bad)
+        model.init((1982, 1, 1, 0, 0))
+        t = model.get("t", bad)
+        t[0, 0, 6:8, :] += 30.0 * np.sqrt(2.0)
+        model.set("t", t, member=bad)
+        if plan == "one_group":
+            model.set_option("member_groups", 1)
+        else:
+            model.set_option("member_groups", 2)
+            model.set_option("block_members", 1 if plan == "rounds" else 0)
+        if checked:
+            alone0, rode0 = model.check_counts()
+            failed, accepted = model.run_checked(K)
+            alone1, rode1 = model.check_counts()
+            assert model.config()["rounds"] == (4 if plan == "rounds" else 1)
+            expect = np.full(M, -1)
+            expect[bad] = f
+            assert (failed == expect).all(), (failed, f)
+            groups = 1 if plan == "one_group" else 2
+            rounds = 4 if plan == "rounds" else 1
+            assert rode1 - rode0 == (K - 1) * groups * rounds and alone1 - alone0 == groups * rounds
+            for i in range(M):
+                steps = f if i == bad else K
+                total_minutes = 40 * steps
+                assert accepted[i, 0] == steps
+                assert tuple(accepted[i, 1:6]) == (1982, 1, 1 + total_minutes // 1440, (total_minutes % 1440) // 60, total_minutes % 60)
+            # a second call on top: the codes of the new call are its own
+            failed2, _ = model.run_checked(3)
+            assert failed2[bad] in (-1, 0, 1, 2) and (np.delete(failed2, bad) == -1).all()
+            with pytest.raises(Exception):
+                model.run_checked(5000)
+        else:
+            codes = []
+            for _ in range(K):
+                model.run(1)
+                codes.append(model.check(2))
+            codes = np.array(codes)
+            assert (codes[:, bad][:f] == 0).all() and codes[f, bad] == -2
+            assert (np.delete(codes, bad, axis=1) == 0).all()
+            model.run(3)
+        states.append({n: [model.get(n, i) for i in range(M) if i != bad] for n in model.variables() if n not in ("lon", "lat", "lev")})
+        model.close()
+    for n, per_member in states[0].items():
+        for a, b in zip(per_member, states[1][n]):
+            assert np.array_equal(a, b), n
+
+
+def test_a_device_error_in_the_middle_of_a_step_leaves_the_model_unusable_until_it_is_initialised_again(spectral, bc):
+    """A launch of step k fails after another member group's launches of the same step went out (fault injection: option
+    fail_launch_after): whatever the plan -- two groups and ONE round here, the case the rounds-only rule of round 5 missed --
+    the model refuses to be stepped, read or transformed until spd_model_init has rebuilt its state, and then runs as a new one."""
+    from pyspeedy_amd._lib import SpeedyHipError
+    from pyspeedy_amd.model import EnsembleModel
+    model = EnsembleModel(spectral, 4)
+    model.set_bc(bc)
+    model.set_option("member_groups", 2)
+    model.set_option("block_members", 0)
+    model.run(2)
+    model.set_option("fail_launch_after", 5)  # the 6th per-group launch sequence: group 1 of the third step of the call
+    with pytest.raises(SpeedyHipError):
+        model.run(6)
+    for call in (lambda: model.run(1), lambda: model.run_checked(2), lambda: model.check(2), lambda: model.spectral2grid(),
+                 lambda: model.get("t", 0)):
+        with pytest.raises(SpeedyHipError, match="initialised again"):
+            call()
+    with pytest.raises(KeyError):
+        model.device_view("t")
+    model.init((1982, 1, 1, 0, 0))
+    model.run(5)
+    fresh = EnsembleModel(spectral, 4)
+    fresh.set_bc(bc)
+    fresh.set_option("member_groups", 2)
+    fresh.set_option("block_members", 0)
+    fresh.run(5)
+    for n in SPEC:
+        assert np.array_equal(model.get(n, 3), fresh.get(n, 3)), n
+    model.close()
+    fresh.close()

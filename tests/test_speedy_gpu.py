@@ -429,3 +429,126 @@ def test_background_writer_leaves_the_same_files():
         open(blocked, "w").close()
         with pytest.raises(OSError):
             ens.run(callbacks=[XarrayExporter(output_dir=os.path.join(blocked, "below_a_file"), interval=3)])
+
+
+def _hot_boundary():
+    bc = np.load(os.path.join(os.path.dirname(os.path.dirname(GOLD)), "pyspeedy_amd", "data", "example_bc.npz"))
+    hot = {k: bc[k] for k in bc.files}
+    hot["sst"] = bc["sst"] + 80.0
+    return hot
+
+
+def _heat(t):
+    t = t.copy()
+    t[0, 0, 6:8, :] += 30.0 * np.sqrt(2.0)  # the global mean of the two lowest levels + 30 K, both time levels
+    return t
+
+
+def test_a_range_failure_in_the_middle_of_a_stretch_is_the_reference_loops_failure(capfd):
+    """Speedy.run / SpeedyEns.run take the steps between two due callbacks as ONE device call (parallel_steps_begin / _end) with the
+    range check of every step recorded on the device.  A member that leaves the accepted range in the middle of such a stretch
+    ends the run as the reference's loop does (speedy.py:396-405): RuntimeError with the reference's text, the reference's two
+    lines on stderr with the step counter of the step that failed -- the step at which the CPU oracle's whole model fails --, the
+    date of the step before, and no callback sees the failed state.  The step-by-step loop (a plain callable in the list) ends in
+    exactly the same way."""
+    import oracle as orc
+    from pyspeedy_amd.callbacks import BaseCallback, DiagnosticCheck
+    from pyspeedy_amd.error_codes import ERROR_CODES
+    from pyspeedy_amd.speedy import Speedy, SpeedyEns
+    hot = _hot_boundary()
+    cpu = orc.Model()
+    cpu.set_bc(hot)
+    assert cpu.init(1982, 1, 1) == 0
+    cpu.set("t", _heat(cpu.get("t")))
+    f = next(k for k in range(40) if cpu.step() != 0)
+    assert 0 < f < 35, f
+    start, dt = datetime(1982, 1, 1), timedelta(minutes=40)
+
+    class Probe(BaseCallback):
+        def __init__(self, interval):
+            super().__init__(interval=interval)
+            self.seen = []
+
+        def fire(self, model):
+            self.seen.append(model.get_current_step())
+
+    outcomes = []
+    for stepwise in (False, True):
+        model = Speedy(start_date=start, end_date=datetime(1982, 1, 3))
+        model.set_bc(bc_file=hot)
+        model["t"] = _heat(model["t"])
+        probe = Probe(2)  # acts at steps 2, 4, ...: before the failure too
+        hooks = [DiagnosticCheck(interval=36), probe] + ([lambda m: None] if stepwise else [])
+        capfd.readouterr()
+        with pytest.raises(RuntimeError) as failure:
+            model.run(callbacks=hooks)
+        assert str(failure.value) == ERROR_CODES[-2]
+        assert capfd.readouterr().err == " Model variables out of accepted range\n step =%12d\n" % (f + 1)
+        assert model.current_date == start + f * dt
+        assert probe.seen == list(range(2, f + 1, 2))  # nobody saw step f + 1
+        outcomes.append((model.current_date, tuple(probe.seen)))
+    assert outcomes[0] == outcomes[1]
+    # an ensemble: the member that fails is named, the others are not, and the ensemble's date is the one before the failing step
+    ens = SpeedyEns(3, start_date=start, end_date=datetime(1982, 1, 3))
+    for i, member in enumerate(ens):
+        member.set_bc(bc_file=hot if i == 1 else None)
+    ens.members[1]["t"] = _heat(ens.members[1]["t"])
+    probe = Probe(36)
+    capfd.readouterr()
+    with pytest.raises(RuntimeError) as failure:
+        ens.run(callbacks=[probe])
+    assert str(failure.value) == "Member0: %s\nMember1: %s\nMember2: %s\n" % (ERROR_CODES[0], ERROR_CODES[-2], ERROR_CODES[0])
+    assert capfd.readouterr().err == " Model variables out of accepted range\n step =%12d\n" % (f + 1)
+    assert ens.current_date == start + f * dt and ens.members[1].current_date == start + f * dt and probe.seen == []
+
+
+def test_stretches_between_due_callbacks_leave_the_state_of_the_step_by_step_loop():
+    """The same run three ways -- hooks with a known schedule (stretches of 7, 36 and 1 steps, one device call each), a plain callable
+    in the list (one call per step), no hooks at all (one stretch) --: every prognostic variable bitwise equal, the same dates and
+    step counters seen by the hooks, at the steps the reference's gating (callbacks.py:52-70) lets them act."""
+    from pyspeedy_amd.callbacks import BaseCallback, ModelCheckpoint
+    from pyspeedy_amd.speedy import Speedy, SpeedyEns
+    start, end = datetime(1982, 1, 1), datetime(1982, 1, 3, 8, 0)  # 84 steps
+
+    class Probe(BaseCallback):
+        def __init__(self, **kw):
+            super().__init__(**kw)
+            self.seen = []
+
+        def fire(self, model):
+            self.seen.append((model.get_current_step(), model.current_date))
+
+    results = []
+    for mode in ("stretches", "stepwise", "bare"):
+        model = Speedy(start_date=start, end_date=end)
+        model.set_bc()
+        seven, daily = Probe(interval=7), Probe(interval=36, spinup_date=datetime(1982, 1, 2, 12, 0))
+        keep = ModelCheckpoint(interval=36, variables=["t_grid", "ps_grid"])
+        hooks = {"stretches": [seven, daily, keep], "stepwise": [seven, daily, keep, lambda m: None], "bare": None}[mode]
+        model.run(callbacks=hooks)
+        assert model.current_date == end and model["current_step"] == 84
+        if hooks:
+            assert [s for s, _ in seven.seen] == list(range(7, 85, 7)) and seven.seen[2][1] == start + 21 * timedelta(minutes=40)
+            assert [s for s, _ in daily.seen] == [72]  # (36 falls before the spin-up date)
+            assert keep.dataframe["t"].values.shape[0] == 2
+        results.append({v: model[v] for v in ("vor", "div", "t", "tr", "ps", "olr", "precnv", "land_temp", "sst_am")})
+        if hooks:
+            results[-1]["kept"] = np.asarray(keep.dataframe["t"].values)
+    for v in results[0]:
+        for other in results[1:]:
+            if v in other:
+                assert np.array_equal(results[0][v], other[v]), v
+    # an ensemble across two device models, with an hourly hook that perturbs nothing
+    ens_states = []
+    for stepwise in (False, True):
+        ens = SpeedyEns(34, start_date=start, end_date=datetime(1982, 1, 1, 12, 0))
+        ens.set_bc()
+        t = ens.members[33]["t"]
+        t[3, 3] *= 1.001
+        ens.members[33]["t"] = t
+        hourly = Probe(interval=3)
+        ens.run(callbacks=[hourly] + ([lambda m: None] if stepwise else []))
+        assert [s for s, _ in hourly.seen] == list(range(3, 19, 3)) and ens.get_current_step() == 18
+        ens_states.append([ens.members[i]["vor"] for i in (0, 16, 17, 33)])
+    for a, b in zip(*ens_states):
+        assert np.array_equal(a, b)

@@ -1,34 +1,35 @@
 #!/bin/bash
-# Builds a variant of libpyspeedy_amd.so with extra compiler flags into build_variants/lib_<name>.so (not committed; travels
-# to the GPU box).  Used for A/B measurements in one gpurun session: PYSPEEDY_AMD_LIB=build_variants/lib_<name>.so python bench.py
-#     tools/build_variant.sh <name> [extra hipcc flags, e.g. -DSPD_EXP=3] [-- file.hip ...  (only these get the flags)]
+# Builds another copy of the library for A/B measurements in one GPU session:
+#     tools/build_variant.sh NAME [GIT_REF [FILE ...]] [-- EXTRA_HIPCC_FLAGS]
+# copies pyspeedy_amd/csrc to build_variants/NAME/csrc, replaces FILE ... (paths relative to pyspeedy_amd/csrc; default: every
+# tracked source) by their content at GIT_REF, builds there and leaves build_variants/lib_NAME.so.  Select it at run time with
+# PYSPEEDY_AMD_LIB=build_variants/lib_NAME.so (pyspeedy_amd/_lib.py).  build_variants/ is git-ignored and travels with gpurun.
 set -e
-NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-SRC=$ROOT/pyspeedy_amd/csrc
-OBJ=$ROOT/build_variants/obj_$NAME
-mkdir -p $OBJ
-FLAGS=()
-ONLY=()
+NAME=$1; shift
+REF=""; FILES=(); EXTRA=""
 while [ $# -gt 0 ]; do
-  if [ "$1" == "--" ]; then shift; ONLY=("$@"); break; fi
-  FLAGS+=("$1"); shift
+  if [ "$1" = "--" ]; then shift; EXTRA="$*"; break; fi
+  if [ -z "$REF" ]; then REF=$1; else FILES+=("$1"); fi
+  shift
 done
-BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=on"
-pids=()
-for f in capi transforms specops physics dynamics model surface sppt stream_apart driver_backend_hip; do
-  extra="${FLAGS[*]}"
-  if [ ${#ONLY[@]} -gt 0 ]; then
-    extra=""
-    for o in "${ONLY[@]}"; do [ "$o" == "$f.hip" ] && extra="${FLAGS[*]}"; done
-    # unchanged objects are reused from the main build
-    if [ -z "$extra" ] && [ -f $SRC/$f.o ]; then cp $SRC/$f.o $OBJ/$f.o; continue; fi
+D=$ROOT/build_variants/$NAME
+rm -rf "$D" && mkdir -p "$D/pyspeedy_amd" "$D/include"
+cp -r "$ROOT/pyspeedy_amd/csrc" "$D/pyspeedy_amd/csrc"
+cp "$ROOT"/include/*.h "$D/include/"
+rm -f "$D"/pyspeedy_amd/csrc/*.o
+if [ -n "$REF" ]; then
+  if [ ${#FILES[@]} -eq 0 ]; then
+    mapfile -t FILES < <(cd "$ROOT" && git ls-tree --name-only "$REF" pyspeedy_amd/csrc/ | sed 's|pyspeedy_amd/csrc/||')
+    for h in $(cd "$ROOT" && git ls-tree --name-only "$REF" include/ | grep '\.h$'); do git -C "$ROOT" show "$REF:$h" > "$D/$h"; done
   fi
-  /opt/rocm/bin/hipcc $BASE $extra -c $SRC/$f.hip -o $OBJ/$f.o &
-  pids+=($!)
-done
-for p in "${pids[@]}"; do wait $p; done
-cp $SRC/tables.o $SRC/surface_host.o $SRC/driver.o $OBJ/   # (host-only C++: always the main build's objects)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $ROOT/build_variants/lib_$NAME.so $OBJ/*.o
-rm -rf $OBJ
+  for f in "${FILES[@]}"; do git -C "$ROOT" show "$REF:pyspeedy_amd/csrc/$f" > "$D/pyspeedy_amd/csrc/$f"; done
+fi
+if [ -n "$EXTRA" ]; then
+  make -s -C "$D/pyspeedy_amd/csrc" -j8 CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=on $EXTRA"
+else
+  make -s -C "$D/pyspeedy_amd/csrc" -j8
+fi
+cp "$D/pyspeedy_amd/libpyspeedy_amd.so" "$ROOT/build_variants/lib_$NAME.so"
+rm -rf "$D"
 echo "built build_variants/lib_$NAME.so"
