@@ -738,8 +738,9 @@ def drop_in_leg(M, steps):
     ens = SpeedyEns(M, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 3, 1))
     for member in ens:
         member.set_bc()
-    out = {"containers": M, "device_models": len({drv.device_model(m._state_cnt)[0]._m.value for m in ens.members})}
+    out = {"containers": M}
     out.update(_time_container_loop(ens, steps))
+    out["device_models"] = len({drv.device_model(m._state_cnt)[0]._m.value for m in ens.members})  # (as this loop's habit left them)
     del ens
     out["note"] = ("spd_parallel_step(state_cnts, control_cnts, error_codes, n) once per model step over independent containers "
                    "(one device model up to 31 containers, two from 32 up, both enqueued before either is waited for): every "
@@ -780,7 +781,10 @@ def facade_leg():
             model.set_bc()
             return model
         ens = SpeedyEns(members, start_date=start, end_date=end)
-        for member in ens:  # (the reference's way; SpeedyEns.set_bc, this library's extension, loads the file once)
+        if members > 64:
+            ens.set_bc()  # (this library's extension: the file is read once and handed on device to device)
+            return ens
+        for member in ens:  # (the reference's way)
             member.set_bc()
         return ens
 
@@ -800,7 +804,12 @@ def facade_leg():
         return seconds / (36 * days) * 1e3, len(files), written
 
     out = {}
-    for key, members, days_plain, days_export in (("ens64", 64, 10, 5), ("single", 1, 10, 10)):
+    for key, members, days_plain, days_export in (("ens64", 64, 10, 5), ("single", 1, 10, 10), ("ens256", 256, 4, 0)):
+        if key == "ens256":  # (large ensembles through the facade: the 64-member rate per member-step, no file output)
+            timed(members, 1, False)
+            plain = min(timed(members, days_plain, False)[0] for _ in range(2))
+            out[key] = {"members": members, "run_ms_per_step": plain, "run_steps": 36 * days_plain, "us_per_member_step": plain / members * 1e3}
+            continue
         timed(members, 1, False)
         # the better of two runs each: the ROCm runtime stalls once per process for ~40 ms shortly after its first launches, and
         # one such stall is a tenth of a millisecond per step of a 360-step run
@@ -810,8 +819,10 @@ def facade_leg():
                     "run_daily_export_ms_per_step": exported, "run_daily_export_steps": 36 * days_export, "files_written": files,
                     "megabytes_written": written / 1e6}
     out["note"] = ("SpeedyEns(64).run() / Speedy().run() of the facade (pyspeedy_amd/speedy.py = the reference's classes over the C "
-                   "boundary): wall time of run() per model step, Python loop + parallel_step begin / end + range check every step; "
-                   "run_daily_export = with callbacks=[XarrayExporter()] (defaults: every 36 steps, u v t q phi ps, NetCDF-3 files)")
+                   "boundary): wall time of run() per model step; the steps between two due callbacks are ONE call "
+                   "(spd_parallel_steps_begin / _end) with the range check of every step recorded on the device; "
+                   "run_daily_export = with callbacks=[XarrayExporter()] (defaults: every 36 steps, u v t q phi ps, NetCDF-3 files, "
+                   "written behind the time loop); ens256: the same for 256 members (rounds of 64 inside every call)")
     return out
 
 
@@ -831,14 +842,44 @@ def step_contract_keys(legs, headline_ms, members_total):
         flat["step_contract_note"] = ("ms_per_step is spd_model_step(m, K), K steps per call; the reference's step() contract (one call "
                                       "per step, range check, codes back) is step_contract_ms_per_step_* over that many containers")
     f = legs.get("facade_run") or {}
-    for key in ("ens64", "single"):
+    for key in ("ens64", "single", "ens256"):
         if key in f:
             flat["facade_%s_run_ms_per_step" % key] = f[key]["run_ms_per_step"]
-            flat["facade_%s_run_daily_export_ms_per_step" % key] = f[key]["run_daily_export_ms_per_step"]
+            if "run_daily_export_ms_per_step" in f[key]:
+                flat["facade_%s_run_daily_export_ms_per_step" % key] = f[key]["run_daily_export_ms_per_step"]
     pr = legs.get("projected_8gpu_cfg4") or {}
     for key in ("value", "speedup_over_1gpu", "efficiency"):
         if key in pr:
             flat["projected_8gpu_cfg4_%s" % key] = pr[key]
+    return flat
+
+
+def scaling_keys(collective, legs):
+    """What tools/check_scale.py reads of an N-rank line, once more as flat scalars in `config` (a reader that keeps the contract's
+    objects only -- the driver's SCALE records -- still holds them): what the collective layer saw, BASELINE cfg 4 as worded
+    (cfg4_strong) and the one-process shape."""
+    flat = {}
+    c = collective or {}
+    for key in ("backend", "ranks_seen", "distinct_gpus", "boundary_checksum_equal"):
+        if key in c:
+            flat["collective_" + key] = c[key]
+    if "rccl_preflight" in c:
+        flat["collective_rccl_preflight_ok"] = bool(c["rccl_preflight"].get("ok"))
+    flat["collective_backend_fallback"] = c.get("backend_fallback")
+    st = legs.get("cfg4_strong") or {}
+    for key in ("value", "ms_per_step", "members_per_gpu"):
+        if key in st:
+            flat["cfg4_strong_" + key] = st[key]
+    op = legs.get("one_process") or {}
+    for key in ("ms_per_step", "value", "devices_used", "containers"):
+        if key in op:
+            flat["one_process_" + key] = op[key]
+    if "boundary_broadcast" in op:
+        flat["one_process_boundary_broadcast_note"] = op["boundary_broadcast"].get("note")
+    if "error" in op:
+        flat["one_process_error"] = str(op["error"])[:200]
+    if "value" in (op.get("cfg4_strong") or {}):
+        flat["one_process_cfg4_strong_value"] = op["cfg4_strong"]["value"]
     return flat
 
 
@@ -898,8 +939,10 @@ def one_process_leg(n_devices, members_total, steps, what):
         member.grid2spectral()
     t_setup = time.perf_counter() - t0
     devices = sorted({drv.modelstate_device(c) for c in cnts})
-    models = len({drv.device_model(c)[0]._m.value for c in cnts})
     timing = _time_container_loop(ens, steps)
+    # (counted after the loop: SpeedyEns makes one device model per GPU for its own multi-step stretches, and a host that steps one
+    # by one -- this loop -- gets two per GPU from 32 containers up at its first step, csrc/driver.cpp: regroup)
+    models = len({drv.device_model(c)[0]._m.value for c in cnts})
     ms = timing["begin_end_ms_per_step"]
     out = {"workload": what, "processes": 1, "devices_asked": n_devices, "devices_used": len(devices), "containers": members_total,
            "members_per_device": [sum(1 for c in cnts if drv.modelstate_device(c) == d) for d in devices],
@@ -1058,12 +1101,20 @@ def dominant_kernel(kernels, M, config, stream_ceiling=None):
     return out
 
 
+def job_file(what):
+    """path under /tmp of a host-side meeting point of the ranks of ONE launch: keyed by the rendezvous port, the launcher's pid
+    (the ranks of one job are children of one launcher process) and -- a worker group that torchrun restarts keeps both -- the
+    launcher's restart count and run id, so that the ranks of a restarted group never read what an earlier attempt left there"""
+    import tempfile
+    nonce = "%s_%s" % (os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"))
+    nonce = "".join(ch if ch.isalnum() else "-" for ch in nonce)[:48]
+    return os.path.join(tempfile.gettempdir(), "pyspeedy_bench_%s_%d_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid(), nonce, what))
+
+
 def wait_for_ranks(rank, world, what, seconds=600.0):
     """A file barrier under /tmp keyed by the rendezvous port: used ONCE, before any process group exists, so that rank 0
     measures the host baseline while the other ranks have finished importing torch and sit idle."""
-    import tempfile
-    # (the ranks of one job are children of one launcher process: its pid keeps the files of an earlier job apart)
-    base = os.path.join(tempfile.gettempdir(), "pyspeedy_bench_%s_%d_%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid(), what))
+    base = job_file(what)
     open("%s.%d" % (base, rank), "w").close()
     deadline = time.time() + seconds
     while time.time() < deadline:
@@ -1083,8 +1134,7 @@ def wait_for_ranks(rank, world, what, seconds=600.0):
 
 def file_flag(what, set_it=False, wait_seconds=0.0):
     """A flag file shared by the ranks of one job (keyed like wait_for_ranks): set it, or wait on the HOST until it is there."""
-    import tempfile
-    path = os.path.join(tempfile.gettempdir(), "pyspeedy_bench_%s_%d_%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid(), what))
+    path = job_file(what)
     if set_it:
         open(path, "w").close()
         return True
@@ -1221,6 +1271,11 @@ def rccl_preflight(rank, world, wall):
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_") and k != "PYSPEEDY_AMD_BENCH_T0"}
     env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for stale in ["%s.%d" % (job_file("rccl"), rank), "%s.ack.%d" % (job_file("rccl"), rank)] + ([job_file("rccl") + ".decision"] if rank == 0 else []):
+        try:  # (what an earlier attempt under the same key may have left: a rank's own verdict and acknowledgement, rank 0's decision)
+            os.unlink(stale)
+        except OSError:
+            pass
     code, out, err = run_bounded_child([sys.executable, os.path.abspath(__file__), "--rccl-probe"], env, timeout)
     def reason(text):  # the exception's own line, not the warnings the runtime prints on its way out
         lines = [ln.strip() for ln in text.splitlines() if ln.strip() and not ln.lstrip().startswith(("[W", "[I", "warnings.warn"))]
@@ -1230,10 +1285,10 @@ def rccl_preflight(rank, world, wall):
         return (named or errors or lines or [""])[-1][:240]
     mine = "ok" if code == 0 and "RCCL_PROBE_OK" in out else (
         "no answer within %d s" % timeout if code is None else "exit code %s: %s" % (code, reason(err or out)))
-    import tempfile
-    base = os.path.join(tempfile.gettempdir(), "pyspeedy_bench_%s_%d_rccl" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
-    with open("%s.%d" % (base, rank), "w") as fh:
+    base = job_file("rccl")
+    with open("%s.%d.tmp" % (base, rank), "w") as fh:
         fh.write(mine)
+    os.replace("%s.%d.tmp" % (base, rank), "%s.%d" % (base, rank))  # (never seen half written)
     deadline = time.time() + timeout + 30.0
     if rank == 0:
         verdicts = {}
@@ -1249,6 +1304,15 @@ def rccl_preflight(rank, world, wall):
         with open(base + ".decision.tmp", "w") as fh:
             fh.write(decision)
         os.replace(base + ".decision.tmp", base + ".decision")
+        # everybody acknowledges the decision; then the files go (a later launch that ends up with the same key finds nothing)
+        seen = time.time() + 20.0
+        while time.time() < seen and not all(os.path.exists("%s.ack.%d" % (base, r)) for r in range(1, world)):
+            time.sleep(0.05)
+        for path in [base + ".decision"] + ["%s.%d" % (base, r) for r in range(world)] + ["%s.ack.%d" % (base, r) for r in range(1, world)]:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
     else:
         decision = None
         while time.time() < deadline + 15.0 and decision is None:
@@ -1258,6 +1322,7 @@ def rccl_preflight(rank, world, wall):
                 time.sleep(0.05)
         if decision is None:
             decision = "rank %d saw no decision of rank 0" % rank
+        open("%s.ack.%d" % (base, rank), "w").close()
     return decision == "ok", decision, time.time() - t0
 
 
@@ -1489,6 +1554,8 @@ def run_rank(args):
         if "ms_per_step" in (legs.get("cfg4_shard8") or {}):
             legs["projected_8gpu_cfg4"] = projection_8gpu(legs["cfg4_shard8"], value, total_members, all_cores)
         line["config"].update(step_contract_keys(legs, ms_step, total_members))
+        if n_gpus > 1:
+            line["config"].update(scaling_keys(collective, legs))
         line.update(legs)
         line["budget"] = wall.record()
         if baseline is not None:

@@ -328,6 +328,9 @@ int spd_model_group_streams(spd_model_handle m, int32_t *created, int32_t *apart
  *   "physics_storage32"    0 / 1   (default 1, PYSPEEDY_AMD_PHYS_STORE32) with spd_model_set_physics_precision(m, 1): keep the arrays
  *                                  only the column physics reads back as fp32 in memory (1) or as fp64 (0: same arithmetic, same
  *                                  bits in the state, 13 % more bytes in the column kernel); converts the arrays when it changes
+ *   "prepare_multi_step"   1       create the streams of the member groups now instead of at the first multi-step call (write-only)
+ *   "fail_launch_after"    n, -1   fault injection for tests: the (n + 1)-th launch sequence of a member group from now on fails like a
+ *                                  device error (-1: off); spd_model_init clears it (write-only)
  * Returns SPD_E_ARG for an unknown name or a value outside the list.  What is fixed at creation (the pruned transform
  * table, the geopotential fold) is read from the environment only. */
 int spd_model_set_option(spd_model_handle m, const char *name, int32_t value);

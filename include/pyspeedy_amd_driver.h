@@ -61,6 +61,12 @@ int spd_modelstate_init_ensemble(int64_t *state_cnts, int32_t n_members);
 /* the same with the number of devices as an argument (0: the calling thread's current device; k: devices 0 .. k-1 in blocks):
  * the process-wide placement below is neither read nor changed */
 int spd_modelstate_init_ensemble_on(int64_t *state_cnts, int32_t n_members, int32_t n_devices);
+/* ... and as ONE device model per device whatever the number of members (n_devices < 0: the process-wide placement, 0: the current
+ * device, k: devices 0 .. k-1 in blocks): for hosts that hand over many steps at once (spd_parallel_steps_begin; what SpeedyEns
+ * creates), whose device model forms its member groups, offsets and rounds itself.  Either way the grouping follows the host: a
+ * multi-step call over the two halves of a device merges them into one model, single steps over a model that was made or merged
+ * whole halve it -- device-to-device copies, a few milliseconds, once per change of habit (csrc/driver.cpp: regroup). */
+int spd_modelstate_init_ensemble_whole(int64_t *state_cnts, int32_t n_members, int32_t n_devices);
 int spd_modelstate_init_sst_anom(int64_t state_cnt, int32_t n_months);    /* sst_anom(ix, il, 0:n_months+1), zero-filled */
 int spd_modelstate_close(int64_t state_cnt);
 

@@ -159,6 +159,7 @@ _SIGNATURES = {
     "spd_parallel_step": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int32]),
     "spd_parallel_step_begin": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_int64)]),
     "spd_parallel_step_end": (C.c_int, [C.c_int64, C.POINTER(C.c_int32)]),
+    "spd_modelstate_init_ensemble_whole": (C.c_int, [C.POINTER(C.c_int64), C.c_int32, C.c_int32]),
     "spd_parallel_steps_begin": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
     "spd_parallel_steps_end": (C.c_int, [C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "spd_model_step_checked_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

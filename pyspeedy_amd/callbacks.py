@@ -30,10 +30,14 @@ class BaseCallback:
 
     def __call__(self, model_instance):
         if not self.skip_flag(model_instance):
-            self.fire(model_instance)
+            rest = self.fire(model_instance)
+            if callable(rest):  # (called by hand there is no time loop to hand the rest to: it happens here)
+                rest()
 
     def fire(self, model_instance):
-        """What the hook does when it is due (nothing in the base class)."""
+        """What the hook does when it is due (nothing in the base class).  It may return a callable: the part of its work that no
+        longer needs the model's state (a file header, handing data to a writer).  `Speedy.run` / `SpeedyEns.run` call it after they
+        have handed the next stretch of steps to the device, so that it runs beside the GPU instead of in front of it."""
 
     # -- helpers -----------------------------------------------------------------------------------------------
     def print_msg(self, msg):
@@ -115,18 +119,27 @@ class XarrayExporter(_GridOutput):
         slot = self._turn
         self._turn = 1 - slot
         self._wait(slot)  # (the buffer this output goes into may still be on its way to disk)
-        frame = model_instance.to_dataframe(variables=self.variables, packed=True, slot=slot, buffers=self._buffers)
-        # (the header is made here: a thread that runs Python code competes with the time loop for the interpreter lock, one that
-        # only writes bytes does not)
-        prepared = _dataset.prepare_netcdf(frame)
+        # (wait=False: the transforms and pack kernels are enqueued, the copies to this slot's pinned buffer run on a stream of their
+        # own beside the next stretch of the time loop; the writer waits for them)
+        frame = model_instance.to_dataframe(variables=self.variables, packed=True, slot=slot, buffers=self._buffers, wait=False)
+        ready = list(getattr(frame, "ready", ()))
+        def hand_over():
+            # (the header is made here, not in the writer: a thread that runs Python code competes with the time loop for the
+            # interpreter lock, one that only waits and writes bytes does not)
+            prepared = _dataset.prepare_netcdf(frame)
 
-        def write():
-            try:
-                _dataset.write_prepared(target, prepared)
-            except BaseException as exc:  # noqa: B902 -- handed to the thread that owns the exporter
-                self._failure = exc
-        self._pending[slot] = threading.Thread(target=write, name="pyspeedy_amd-export", daemon=False)
-        self._pending[slot].start()
+            def write():
+                try:
+                    for event in ready:
+                        event.synchronize()
+                    _dataset.write_prepared(target, prepared)
+                except BaseException as exc:  # noqa: B902 -- handed to the thread that owns the exporter
+                    self._failure = exc
+            self._pending[slot] = threading.Thread(target=write, name="pyspeedy_amd-export", daemon=False)
+            self._pending[slot].start()
+        # (what needed the state -- transforms, pack kernels, the copies behind them -- is enqueued; the rest is the time loop's to
+        # call once the next stretch is on the device)
+        return hand_over
 
     def _wait(self, slot):
         thread, self._pending[slot] = self._pending[slot], None

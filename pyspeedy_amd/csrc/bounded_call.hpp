@@ -7,15 +7,42 @@
 // when the time is up the caller goes on (and takes the point-to-point path); the thread is left behind, detached, with
 // everything it touches kept alive by the shared state it owns -- so `fn` must capture by VALUE.
 //
+// A thread that was left behind is still somewhere inside the call when the process ends, and exit() then runs the static
+// destructors of every library in the process -- RCCL's and the HIP runtime's among them -- under its feet.  From the first call
+// that ran out of time the process therefore leaves through _exit() once exit() is under way: an on_exit handler (registered then,
+// so it runs before the destructors of everything constructed earlier) flushes the C streams and ends the process with the
+// status exit() was given, without further teardown.  What Python or the host program do before they call exit() has happened.
+//
 // Host-only C++, no HIP: tests/sanitize/driver_sanitize.cpp runs it under ASan / UBSan / TSan with a call that never returns.
 #pragma once
 #include <atomic>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
+#include <unistd.h>
 
 namespace spd {
+
+inline std::atomic<int> &abandoned_calls() {  // calls that ran out of time and whose threads were left behind
+    static std::atomic<int> n{0};
+    return n;
+}
+
+inline void leave_without_teardown_at_exit() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)on_exit([](int status, void *) {
+            if (abandoned_calls().load() > 0) {
+                std::fflush(nullptr);
+                _exit(status);
+            }
+        }, nullptr);
+    });
+}
 
 struct BoundedResult {
     bool finished = false;  // the call returned inside the bound
@@ -41,7 +68,12 @@ inline BoundedResult run_bounded(std::function<int()> fn, double seconds) {
     BoundedResult out;
     while (!(out.finished = shared->done.load(std::memory_order_acquire)) && std::chrono::steady_clock::now() < deadline)
         std::this_thread::sleep_for(std::chrono::microseconds(200));
-    if (out.finished) out.rc = shared->rc;
+    if (out.finished) {
+        out.rc = shared->rc;
+    } else {
+        abandoned_calls().fetch_add(1);
+        leave_without_teardown_at_exit();
+    }
     return out;
 }
 

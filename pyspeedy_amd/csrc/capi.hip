@@ -12,6 +12,7 @@
 #include "context.hpp"
 #include "device_tables.hpp"
 #include "surface_host.hpp"
+#include "vertical_consts.hpp"
 
 namespace spd {
 hipError_t run_spec2grid(const DeviceTables &T, int stage, const double *src, double *dst, int kcos, int nfields,
@@ -62,15 +63,14 @@ static int upload(spd_context *c, const double *src, size_t n, const double **ds
 
 // kernel-friendly polynomial layouts (device_tables.hpp, transforms.hip)
 static std::vector<double> make_pinv(const HostTables &h) {
-    // [n = 32][lane = m*12 + jq][2]: latitude pairs jq, jq + 12 (transforms.hip: the lanes of one LDS store cycle then sit on
-    // different banks); zero outside the triangle (nsh2, legendre.f90:73)
+    // [n = 32][lane = m*12 + jq][2]: latitude pairs 2jq, 2jq+1; zero outside the triangle (nsh2, legendre.f90:73)
     std::vector<double> p(static_cast<size_t>(NX) * MX * 12 * 2, 0.0);
     for (int n = 0; n < NX; ++n)
         for (int m = 0; m < MX; ++m)
             for (int jq = 0; jq < 12; ++jq)
                 for (int q = 0; q < 2; ++q)
                     if (m + n <= TRUNC + 1)
-                        p[((static_cast<size_t>(n) * MX + m) * 12 + jq) * 2 + q] = h.poly[m + MX * (n + NX * SPD_INV_PAIR(jq, q))];
+                        p[((static_cast<size_t>(n) * MX + m) * 12 + jq) * 2 + q] = h.poly[m + MX * (n + NX * (2 * jq + q))];
     return p;
 }
 
@@ -117,6 +117,27 @@ static std::vector<int> make_dirmeta(const std::vector<DirLane> &lanes, int stri
     return meta;
 }
 
+// The column kernel carries the vertical-structure tables as compile-time constants (vertical_consts.hpp, generated by
+// tools/gen_vertical_consts.py from these very host tables).  Whoever changes the levels, or the arithmetic that makes the tables,
+// and forgets to regenerate the header is told here, bit for bit, before a single kernel runs.
+static int verify_vertical_consts(const HostTables &h) {
+    const DynHostTables d(h);
+    struct Row {
+        const char *name;
+        const double *have, *want;
+        int n;
+    };
+    const Row rows[] = {{"fsg", vc::fsg, h.fsg.data(), 8},       {"dhs", vc::dhs, h.dhs.data(), 8},       {"sigl", vc::sigl, h.sigl.data(), 8},
+                        {"sigh", vc::sigh, h.sigh.data(), 9},    {"grdsig", vc::grdsig, h.grdsig.data(), 8}, {"grdscp", vc::grdscp, h.grdscp.data(), 8},
+                        {"wvi", vc::wvi, h.wvi.data(), 16},      {"dhsr", vc::dhsr, h.dhsr.data(), 8},    {"fsgr", vc::fsgr, h.fsgr.data(), 8},
+                        {"tref", vc::tref, d.tref.data(), 8},    {"tref3", vc::tref3, d.tref3.data(), 8}};
+    for (const Row &r : rows)
+        if (std::memcmp(r.have, r.want, sizeof(double) * r.n) != 0)
+            return fail(SPD_E_ARG, std::string("csrc/vertical_consts.hpp does not hold the table '") + r.name +
+                                       "' this library builds: run tools/gen_vertical_consts.py and rebuild");
+    return SPD_OK;
+}
+
 extern "C" {
 
 const char *spd_version(void) { return "pyspeedy_amd 0.1 (gfx950)"; }
@@ -136,7 +157,11 @@ int spd_create(spd_handle *out, int device) {
     c->device = device;
     const HostTables &h = c->host;
     DeviceTables &d = c->dev;
-    int rc = SPD_OK;
+    int rc = verify_vertical_consts(h);
+    if (rc != SPD_OK) {
+        delete c;
+        return rc;
+    }
     auto up = [&](const double *src, size_t n, const double **dst) {
         if (rc == SPD_OK) rc = upload(c, src, n, dst);
     };
@@ -233,6 +258,12 @@ long spd_get_table_host(spd_handle h, const char *name, double *buf, size_t buf_
     else if (s == "uvdx") arr(t.uvdx); else if (s == "uvdym") arr(t.uvdym); else if (s == "uvdyp") arr(t.uvdyp);
     else if (s == "vddym") arr(t.vddym); else if (s == "vddyp") arr(t.vddyp); else if (s == "gradx") arr(t.gradx);
     else if (s == "fband") arr(t.fband);
+    else if (s == "tref" || s == "tref3") {  // implicit.f90:71-78 (independent of the time step)
+        const DynHostTables d(t);
+        const auto &a = s == "tref" ? d.tref : d.tref3;
+        tmp.assign(a.begin(), a.end());
+        arr(tmp);
+    }
     else if (s == "cpol") { tmp = t.cpol(); arr(tmp); }
     else if (s == "nsh2") { tmp.assign(t.nsh2.begin(), t.nsh2.end()); arr(tmp); }
     else if (s == "ifac") { tmp.assign(t.ifac.begin(), t.ifac.end()); arr(tmp); }

@@ -1,17 +1,6 @@
 // Device-resident constant tables, passed by value to every kernel (all pointers are device memory owned by
 // the spd_context).  Layouts are chosen for the kernels, not for the reference: see the comments.
 #pragma once
-// Lane maps of the transform kernels (transforms.hip; experiment switches of round 6, profiles/r06_lds_conflicts.txt):
-//   SPD_LDS_MAP bit 1: inverse Legendre with 16 lanes per zonal wavenumber (12 at work), 2: grid read-out split over adjacent
-//   rows, 4: grid staging stores split over adjacent latitude pairs, 8: the same for the Fourier plane of the Legendre stage alone;
-//   SPD_LDS_PAIRS 1: an inverse-Legendre lane owns the latitude pairs jq and jq + 12, 0: 2 jq and 2 jq + 1.
-#ifndef SPD_LDS_MAP
-#define SPD_LDS_MAP 15
-#endif
-#ifndef SPD_LDS_PAIRS
-#define SPD_LDS_PAIRS 1
-#endif
-#define SPD_INV_PAIR(jq, q) (SPD_LDS_PAIRS ? (jq) + 12 * (q) : 2 * (jq) + (q))
 #include "tables.hpp"
 
 namespace spd {

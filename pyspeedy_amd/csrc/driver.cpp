@@ -138,6 +138,7 @@ struct Batch {  // one device model shared by the containers of its members
     bool advanced_without_check = false;
     // step counter of the last range failure each member was told about on stderr (-1: none); see report_out_of_range
     std::vector<int32_t> failed_step;
+    bool merged = false;  // made by regroup() out of several device models for a multi-step call (spd_parallel_steps_begin)
     ~Batch() {
         --g_models_alive;
         drvdev::DeviceGuard guard;  // (may run from any entry point that drops the last reference, or from a host's garbage collector)
@@ -187,6 +188,7 @@ struct Plan {
     std::vector<int64_t> states, controls;  // the argument list it was made for
     std::vector<GroupPlan> groups;
     uint64_t epoch = 0;
+    bool stretch = false;  // made for a multi-step call (the device models of a device merged into one) or for single steps
 };
 // A host with the reference's loop hands parallel_step the same two lists at every model step: the plans of the last few
 // argument lists are kept (several host threads may each step a list of their own) and used again while nothing has happened
@@ -401,6 +403,72 @@ int gather(const std::vector<std::shared_ptr<State>> &states, bool *done) {
     return SPD_OK;
 }
 
+// Re-cut the device models of ONE device: `states` (in this order; all the members of the models they come from, initialised,
+// with equal control blocks) become `parts` new batched models, device to device.  The outer boundary keeps 32 or more containers
+// of a device in TWO models because a host that calls once per step gets the overlap of two member groups that way without any
+// stream hand-over per step (device_model_parts); a host that hands over MANY steps at once (spd_parallel_steps_begin: the
+// stretches of Speedy.run / SpeedyEns.run) is better served by ONE model, whose own multi-step plan then forms the groups, offsets
+// them against each other and takes a large ensemble in rounds (measured at 64 members: 0.256 ms per step against 0.294 with the
+// two halves side by side, profiles/r06_facade_plans.txt).  So the first multi-step call over the two halves merges them (parts =
+// 1), and a single step over a model that was merged halves it again (parts = 2): a few milliseconds, once per change of habit.
+// *done = false when the models turn out not to be re-cuttable (SPPT: its generator is keyed by the member ids of the model it
+// was set up for; unequal control blocks; a model that is marked) -- they are then stepped as they are.
+int regroup(const std::vector<std::shared_ptr<State>> &states, int parts, bool *done) {
+    *done = false;
+    const int n = static_cast<int>(states.size());
+    if (n < 2 || parts < 1 || parts > n) return SPD_OK;
+    const Batch &b0 = *states[0]->batch;
+    spd_model_control first{};
+    std::vector<const Batch *> seen;
+    for (int i = 0; i < n; ++i) {
+        const Batch &b = *states[i]->batch;
+        if (!b.initialized[states[i]->member] || b.advanced_without_check) return SPD_OK;
+        if (b.device != b0.device || b.n_months != b0.n_months || b.sst_anom_allocated != b0.sst_anom_allocated) return SPD_OK;
+        if (std::find(seen.begin(), seen.end(), &b) != seen.end()) continue;
+        seen.push_back(&b);
+        if (spd_model_checks_in_flight(b.model) != 0) return SPD_OK;
+        spd_model_control mc;
+        if (int rc = spd_model_get_control(b.model, &mc)) return rc;
+        if (seen.size() == 1) first = mc;
+        else if (std::memcmp(&mc, &first, sizeof(mc)) != 0) return SPD_OK;
+    }
+    if (first.sppt_on) return SPD_OK;
+    regrouped();  // (first: a copy that fails below leaves some containers moved already, and no kept plan may outlive that)
+    std::vector<std::shared_ptr<Batch>> made;
+    for (int part = 0, at = 0; part < parts; ++part) {
+        const int count = n / parts + (part < n % parts ? 1 : 0);
+        std::shared_ptr<Batch> big;
+        if (int rc = new_batch(count, b0.device, &big)) return rc;
+        if (b0.sst_anom_allocated) {
+            if (int rc = spd_model_init_sst_anom(big->model, b0.n_months)) return rc;
+            big->n_months = b0.n_months;
+            big->sst_anom_allocated = true;
+        }
+        for (int i = 0; i < count; ++i)
+            if (int rc = spd_model_copy_member(big->model, i, states[at + i]->batch->model, states[at + i]->member, nullptr)) return rc;
+        big->merged = parts == 1;
+        if (big->merged) (void)spd_model_set_option(big->model, "prepare_multi_step", 1);
+        made.push_back(big);
+        at += count;
+    }
+    if (!drvdev::device_synchronize()) return fail(SPD_E_DEVICE, "speedy driver: device error while regrouping device models");
+    for (auto &big : made) {
+        if (int rc = spd_model_set_control(big->model, &first)) return rc;
+        if (int rc = spd_model_set_time_step(big->model, 2 * kDelt)) return rc;
+    }
+    for (int part = 0, at = 0; part < parts; ++part) {
+        const int count = made[part]->members;
+        for (int i = 0; i < count; ++i) {
+            states[at + i]->batch = made[part];  // (a model none of whose members is left dies with its last reference)
+            states[at + i]->member = i;
+            made[part]->initialized[i] = 1;
+        }
+        at += count;
+    }
+    *done = true;
+    return SPD_OK;
+}
+
 int table_values(const RegVar &v, spd_handle ctx, std::vector<double> &out64, std::vector<float> &out32) {
     auto tab = [&](const char *name, std::vector<double> &dst) -> int {
         const long n = spd_get_table_host(ctx, name, nullptr, 0);
@@ -452,11 +520,13 @@ extern "C" {
 // ModelState
 // ---------------------------------------------------------------------------------------------------------------------
 // the n members that share a device live in one device model up to 31 members and in two from 32 up (plan_step has the why)
-static int make_device_containers(int64_t *state_cnts, int n, int device);
+static int make_device_containers(int64_t *state_cnts, int n, int device, bool whole);
 
-static int make_containers(int64_t *state_cnts, int n, int device) {
+static int make_containers(int64_t *state_cnts, int n, int device, bool whole = false) {
     std::shared_ptr<Batch> b;
     if (int rc = new_batch(n, device, &b)) return rc;
+    b->merged = whole;  // (one model for a host that steps many steps at once: halved when it turns out to step one by one)
+    if (whole) (void)spd_model_set_option(b->model, "prepare_multi_step", 1);  // (its group streams now, not inside the first stretch)
     for (int i = 0; i < n; ++i) {
         auto st = std::make_shared<State>();
         st->batch = b;
@@ -468,7 +538,8 @@ static int make_containers(int64_t *state_cnts, int n, int device) {
     return SPD_OK;
 }
 
-static int make_device_containers(int64_t *state_cnts, int n, int device) {
+static int make_device_containers(int64_t *state_cnts, int n, int device, bool whole) {
+    if (whole) return make_containers(state_cnts, n, device, true);
     const int parts = static_cast<int>(device_model_parts(static_cast<size_t>(n)));
     for (int part = 0, first = 0; part < parts; ++part) {
         const int count = n / parts + (part < n % parts ? 1 : 0);
@@ -498,15 +569,15 @@ int spd_modelstate_init_on(int64_t *state_cnt, int32_t device) {
 }
 
 // n containers batched from the start over k devices (k = 0: the current device); (lock held)
-static int place_ensemble(int64_t *state_cnts, int32_t n_members, int k);
+static int place_ensemble(int64_t *state_cnts, int32_t n_members, int k, bool whole);
 
 // All n containers, or none: an ensemble is several device models (two per device from 32 members up, one or two on every
 // device of a one-process ensemble), and creating one of the later ones may fail -- a GPU out of memory, a device that does
 // not answer.  The containers of the models made before it are closed again (their device models go with them, the memory
 // returns to the context), every entry of state_cnts is 0, and the caller gets the error of the model that failed.
-static int init_ensemble(int64_t *state_cnts, int32_t n_members, int k) {
+static int init_ensemble(int64_t *state_cnts, int32_t n_members, int k, bool whole = false) {
     for (int i = 0; i < n_members; ++i) state_cnts[i] = 0;
-    const int rc = place_ensemble(state_cnts, n_members, k);
+    const int rc = place_ensemble(state_cnts, n_members, k, whole);
     if (rc == SPD_OK) return rc;
     const std::string why = spd_last_error();
     regrouped();  // (no kept plan may hold on to a model that is about to go)
@@ -517,20 +588,20 @@ static int init_ensemble(int64_t *state_cnts, int32_t n_members, int k) {
     return fail(rc, why);
 }
 
-static int place_ensemble(int64_t *state_cnts, int32_t n_members, int k) {
+static int place_ensemble(int64_t *state_cnts, int32_t n_members, int k, bool whole) {
     if (k <= 1) {
         int dev = 0;
         if (k == 0) {
             if (int rc = current_device(&dev)) return rc;
         }
-        return make_device_containers(state_cnts, n_members, dev);
+        return make_device_containers(state_cnts, n_members, dev, whole);
     }
     // block partition: member e on device e k / n, one batched model per device
     for (int d = 0, first = 0; d < k; ++d) {
         int last = first;
         while (last < n_members && static_cast<long>(last) * k / n_members == d) ++last;
         if (last > first)
-            if (int rc = make_device_containers(state_cnts + first, last - first, d)) return rc;
+            if (int rc = make_device_containers(state_cnts + first, last - first, d, whole)) return rc;
         first = last;
     }
     return SPD_OK;
@@ -541,6 +612,16 @@ int spd_modelstate_init_ensemble(int64_t *state_cnts, int32_t n_members) {
     drvdev::DeviceGuard guard;
     LOCK;
     return init_ensemble(state_cnts, n_members, placement_devices());
+}
+
+// ONE device model per device whatever the size: for hosts that hand over many steps at once (spd_parallel_steps_begin).
+// n_devices < 0: the process-wide placement.
+int spd_modelstate_init_ensemble_whole(int64_t *state_cnts, int32_t n_members, int32_t n_devices) {
+    if (!state_cnts || n_members < 1) return fail(SPD_E_ARG, "spd_modelstate_init_ensemble_whole: bad argument");
+    if (n_devices > device_count()) return fail(SPD_E_ARG, "spd_modelstate_init_ensemble_whole: more devices than the process can see");
+    drvdev::DeviceGuard guard;
+    LOCK;
+    return init_ensemble(state_cnts, n_members, n_devices < 0 ? placement_devices() : n_devices, true);
 }
 
 // the same with the number of devices as an argument: the process-wide placement is neither read nor changed
@@ -809,7 +890,8 @@ static void trace(int kind, int group) {
 // Resolve the containers; gather independent one-member models into batched models -- per device and per set of members that
 // agree in date, control flags and anomaly length, so one odd member or a second device never de-batches the rest --; split
 // batches that are asked for in a different grouping; make the groups to step.
-static int make_plan(const int64_t *state_cnts, const int64_t *control_cnts, int n, std::shared_ptr<const Plan> &out, const char *who) {
+static int make_plan(const int64_t *state_cnts, const int64_t *control_cnts, int n, bool stretch, std::shared_ptr<const Plan> &out,
+                     const char *who) {
     std::vector<std::shared_ptr<State>> states(n);
     std::vector<Control *> controls(n);
     {
@@ -858,7 +940,57 @@ static int make_plan(const int64_t *state_cnts, const int64_t *control_cnts, int
             }
         }
     }
+    // Device models that are whole in the list: for a multi-step call the models of a device that agree in everything become ONE
+    // (regroup has the why); for single steps a model that was merged that way is halved again.
+    {
+        static const size_t merge_up_to = [] {  // (the merged model exists beside its parts while the members are copied)
+            const char *e = getenv("PYSPEEDY_AMD_DRIVER_MERGE");
+            return static_cast<size_t>(e ? atoi(e) : 1024);
+        }();
+        std::map<const Batch *, std::vector<int>> of;  // model -> its positions in the argument list, in order
+        std::vector<const Batch *> order;
+        for (int i = 0; i < n; ++i) {
+            const Batch *b = states[i]->batch.get();
+            if (of.find(b) == of.end()) order.push_back(b);
+            of[b].push_back(i);
+        }
+        auto whole = [&](const Batch *b) {
+            const std::vector<int> &mine = of[b];
+            if (static_cast<int>(mine.size()) != b->members) return false;
+            for (int j : mine)
+                if (!same_date(*controls[mine[0]], *controls[j])) return false;
+            return true;
+        };
+        if (stretch) {
+            std::map<int, std::vector<const Batch *>> by_device;
+            for (const Batch *b : order)
+                if (whole(b)) by_device[b->device].push_back(b);
+            for (auto &kv : by_device) {
+                // (models that agree in the date of their containers: the first such class of the device)
+                std::vector<std::shared_ptr<State>> all;
+                const Batch *lead = kv.second[0];
+                int models = 0;
+                for (const Batch *b : kv.second) {
+                    if (!same_date(*controls[of[lead][0]], *controls[of[b][0]])) continue;
+                    ++models;
+                    for (int j : of[b]) all.push_back(states[j]);
+                }
+                if (models < 2 || all.size() > merge_up_to) continue;
+                bool done = false;
+                if (int rc = regroup(all, 1, &done)) return rc;
+            }
+        } else {
+            for (const Batch *b : order) {
+                if (!b->merged || !whole(b) || device_model_parts(static_cast<size_t>(b->members)) < 2) continue;
+                std::vector<std::shared_ptr<State>> all;
+                for (int j : of[b]) all.push_back(states[j]);
+                bool done = false;
+                if (int rc = regroup(all, 2, &done)) return rc;
+            }
+        }
+    }
     auto plan = std::make_shared<Plan>();
+    plan->stretch = stretch;
     plan->states.assign(state_cnts, state_cnts + n);
     plan->controls.assign(control_cnts, control_cnts + n);
     // (containers of one device model are found through a map from the model to its group: linear in n)
@@ -894,12 +1026,12 @@ static int make_plan(const int64_t *state_cnts, const int64_t *control_cnts, int
 
 // The plan of this argument list (the last call's, when it still holds) and a fresh run record per group.  (lock held)
 static int plan_step(const int64_t *state_cnts, const int64_t *control_cnts, int n, std::shared_ptr<const Plan> &plan,
-                     std::vector<GroupRun> &run, const char *who) {
+                     std::vector<GroupRun> &run, const char *who, bool stretch = false) {
     const size_t bytes = static_cast<size_t>(n) * sizeof(int64_t);
     plan.reset();
     for (size_t k = 0; k < g_plans.size(); ++k) {
         const Plan &p = *g_plans[k];
-        if (p.epoch == g_epoch && static_cast<int>(p.states.size()) == n &&
+        if (p.epoch == g_epoch && p.stretch == stretch && static_cast<int>(p.states.size()) == n &&
             (n == 0 || (std::memcmp(p.states.data(), state_cnts, bytes) == 0 && std::memcmp(p.controls.data(), control_cnts, bytes) == 0))) {
             plan = g_plans[k];
             if (k > 0) std::rotate(g_plans.begin(), g_plans.begin() + k, g_plans.begin() + k + 1);  // most recently used first
@@ -907,7 +1039,7 @@ static int plan_step(const int64_t *state_cnts, const int64_t *control_cnts, int
         }
     }
     if (!plan) {
-        if (int rc = make_plan(state_cnts, control_cnts, n, plan, who)) return rc;
+        if (int rc = make_plan(state_cnts, control_cnts, n, stretch, plan, who)) return rc;
         // (making the plan may have regrouped containers and emptied the list)
         if (g_plans.size() >= kKeptPlans) g_plans.pop_back();
         g_plans.insert(g_plans.begin(), plan);
@@ -935,7 +1067,7 @@ constexpr int32_t kStepFailed = -3;
 // Everything that can refuse is asked BEFORE the step is enqueued (a free check slot, the control block); what fails from the
 // step on is a device error, and it leaves the model marked: its state has moved while its date and codes say it has not, and
 // it is not stepped again until its members are initialised anew.
-static void issue_group(const GroupPlan &g, GroupRun &r, bool defer_check, int nsteps_checked = 0) {
+static void issue_group(const GroupPlan &g, GroupRun &r, bool defer_check, int nsteps_checked = 0, bool shares_device = false) {
     Batch &b = *g.batch;
     if (!all_initialized(b)) return;  // slot stays -1: E_STATE_NOT_INITIALIZED
     int rc = SPD_OK;
@@ -951,7 +1083,14 @@ static void issue_group(const GroupPlan &g, GroupRun &r, bool defer_check, int n
             rc = fail(SPD_E_ARG, "speedy driver: a step of this device model is in flight; end it with spd_parallel_step_end first");
         if (rc == SPD_OK) rc = push_date(b, r.before);
         if (rc == SPD_OK) {
+            // Several device models of ONE device in the call (the two halves an ensemble of 32 or more containers is kept in): they
+            // are each other's member groups already -- each is stepped as ONE group on its own stream (in rounds of its own when it
+            // is large), instead of splitting every half again into groups that would share the GPU six or eight ways.
+            int32_t groups = 0;
+            const bool one_group = shares_device && spd_model_get_option(b.model, "member_groups", &groups) == SPD_OK && groups > 1;
+            if (one_group) (void)spd_model_set_option(b.model, "member_groups", 1);
             rc = spd_model_step_checked_begin(b.model, nsteps_checked, b.stream);
+            if (one_group) (void)spd_model_set_option(b.model, "member_groups", groups);
             // (a refusal leaves the model as it was; a device error in the middle marks the model itself: spd_model_step)
             step_enqueued = rc == SPD_OK;
         }
@@ -1056,9 +1195,12 @@ static void issue_all(const std::vector<GroupPlan> &groups, std::vector<GroupRun
     }
     std::map<int, std::vector<size_t>> by_key;  // worker key -> groups, in argument order
     for (size_t i = 0; i < groups.size(); ++i) by_key[mode == 2 ? static_cast<int>(i) : groups[i].batch->device].push_back(i);
+    std::map<int, int> models_on;  // device -> device models of this call that live there
+    for (const GroupPlan &g : groups) ++models_on[g.batch->device];
+    auto shares = [&](size_t i) { return models_on[groups[i].batch->device] > 1; };
     if (mode == 0 || by_key.size() < 2) {
         for (size_t i = 0; i < groups.size(); ++i) {
-            issue_group(groups[i], run[i], defer_check, nsteps_checked);
+            issue_group(groups[i], run[i], defer_check, nsteps_checked, shares(i));
             trace(1, static_cast<int>(i));
         }
         return;
@@ -1069,16 +1211,16 @@ static void issue_all(const std::vector<GroupPlan> &groups, std::vector<GroupRun
         if (kv.first == mine) continue;
         IssueWorker *w = issue_worker(kv.first);
         const std::vector<size_t> *list = &kv.second;
-        w->submit([list, &groups, &run, defer_check, nsteps_checked] {
+        w->submit([list, &groups, &run, defer_check, nsteps_checked, &models_on] {
             for (size_t i : *list) {
-                issue_group(groups[i], run[i], defer_check, nsteps_checked);
+                issue_group(groups[i], run[i], defer_check, nsteps_checked, models_on.at(groups[i].batch->device) > 1);
                 trace(1, static_cast<int>(i));
             }
         });
         busy.push_back(w);
     }
     for (size_t i : by_key[mine]) {
-        issue_group(groups[i], run[i], defer_check, nsteps_checked);
+        issue_group(groups[i], run[i], defer_check, nsteps_checked, shares(i));
         trace(1, static_cast<int>(i));
     }
     for (IssueWorker *w : busy) w->wait();
@@ -1255,7 +1397,7 @@ int spd_parallel_steps_begin(const int64_t *state_cnts, const int64_t *control_c
     LOCK;
     PendingStep p;
     p.nsteps = n_steps;
-    if (int rc = plan_step(state_cnts, control_cnts, n, p.plan, p.run, "spd_parallel_steps_begin")) return rc;
+    if (int rc = plan_step(state_cnts, control_cnts, n, p.plan, p.run, "spd_parallel_steps_begin", true)) return rc;
     issue_all(p.plan->groups, p.run, false, n_steps);  // (a group that cannot be issued reports at _end; the others go ahead)
     for (size_t i = 0; i < p.run.size(); ++i) {
         const GroupPlan &g = p.plan->groups[i];

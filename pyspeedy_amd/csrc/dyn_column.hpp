@@ -5,6 +5,7 @@
 
 #include "model.hpp"
 #include "stream_store.hpp"
+#include "vertical_consts.hpp"
 
 namespace spd {
 
@@ -13,6 +14,7 @@ namespace spd {
 // wind tendencies of the lowest level in registers (the physics adds to exactly those) -- or stores them too when STORE_ALL.
 // `before_products` is called once the tendencies are formed, in front of the 40 product stores: the fused kernel issues the
 // loads of its next phase there, so that they travel while the stores are issued (nothing, for the stand-alone kernel).
+// (dhs, dhsr, fsgr, tref, tref3: the compile-time tables of vertical_consts.hpp, not D's copies -- see physics.hip: ColTables)
 struct NoPrefetch {
     __device__ void operator()() const {}
 };
@@ -43,9 +45,9 @@ __device__ __forceinline__ void dyn_column(const ModelPtrs &P, const DynDeviceTa
     double umean = 0.0, vmean = 0.0, dmean = 0.0;
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
-        umean = umean + ug[k] * D.dhs[k];
-        vmean = vmean + vg[k] * D.dhs[k];
-        dmean = dmean + divg[k] * D.dhs[k];
+        umean = umean + ug[k] * vc::dhs[k];
+        vmean = vmean + vg[k] * vc::dhs[k];
+        dmean = dmean + divg[k] * vc::dhs[k];
     }
     stream_store(&P.psdtg[o2], -umean * px - vmean * py);
     double puv[KX], sigdt[KX + 1], sigm[KX + 1], tgg[KX], temp[KX + 1];
@@ -55,13 +57,13 @@ __device__ __forceinline__ void dyn_column(const ModelPtrs &P, const DynDeviceTa
     for (int k = 0; k < KX; ++k) puv[k] = (ug[k] - umean) * px + (vg[k] - vmean) * py;
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
-        sigdt[k + 1] = sigdt[k] - D.dhs[k] * (puv[k] + divg[k] - dmean);
-        sigm[k + 1] = sigm[k] - D.dhs[k] * puv[k];
+        sigdt[k + 1] = sigdt[k] - vc::dhs[k] * (puv[k] + divg[k] - dmean);
+        sigm[k + 1] = sigm[k] - vc::dhs[k] * puv[k];
     }
     // (tendencies.f90:153-156 zeroes level kx+1 BEFORE this loop; the loop's last iteration stores it again, so the
     //  value used below is the accumulated one, ~1e-17, exactly as in the reference)
 #pragma unroll
-    for (int k = 0; k < KX; ++k) tgg[k] = tg[k] - D.tref[k];
+    for (int k = 0; k < KX; ++k) tgg[k] = tg[k] - vc::tref[k];
     temp[0] = 0.0;
     temp[KX] = 0.0;
     // zonal wind
@@ -69,7 +71,7 @@ __device__ __forceinline__ void dyn_column(const ModelPtrs &P, const DynDeviceTa
     for (int k = 1; k < KX; ++k) temp[k] = sigdt[k] * (ug[k] - ug[k - 1]);
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
-        const double v = vg[k] * vorg[k] - tgg[k] * RGASd * px - (temp[k + 1] + temp[k]) * D.dhsr[k];
+        const double v = vg[k] * vorg[k] - tgg[k] * RGASd * px - (temp[k + 1] + temp[k]) * vc::dhsr[k];
         if (STORE_ALL || k < KX - 1) stream_store(&P.utend[o3 + NG * k], v);
         if (k == KX - 1) utend_kx = v;
     }
@@ -78,17 +80,17 @@ __device__ __forceinline__ void dyn_column(const ModelPtrs &P, const DynDeviceTa
     for (int k = 1; k < KX; ++k) temp[k] = sigdt[k] * (vg[k] - vg[k - 1]);
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
-        const double v = -ug[k] * vorg[k] - tgg[k] * RGASd * py - (temp[k + 1] + temp[k]) * D.dhsr[k];
+        const double v = -ug[k] * vorg[k] - tgg[k] * RGASd * py - (temp[k + 1] + temp[k]) * vc::dhsr[k];
         if (STORE_ALL || k < KX - 1) stream_store(&P.vtend[o3 + NG * k], v);
         if (k == KX - 1) vtend_kx = v;
     }
     // temperature
 #pragma unroll
-    for (int k = 1; k < KX; ++k) temp[k] = sigdt[k] * (tgg[k] - tgg[k - 1]) + sigm[k] * (D.tref[k] - D.tref[k - 1]);
+    for (int k = 1; k < KX; ++k) temp[k] = sigdt[k] * (tgg[k] - tgg[k - 1]) + sigm[k] * (vc::tref[k] - vc::tref[k - 1]);
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
-        ttend[k] = tgg[k] * divg[k] - (temp[k + 1] + temp[k]) * D.dhsr[k] + D.fsgr[k] * tgg[k] * (sigdt[k + 1] + sigdt[k]) +
-                   D.tref3[k] * (sigm[k + 1] + sigm[k]) + AKAPd * (tg[k] * puv[k] - tgg[k] * dmean);
+        ttend[k] = tgg[k] * divg[k] - (temp[k + 1] + temp[k]) * vc::dhsr[k] + vc::fsgr[k] * tgg[k] * (sigdt[k + 1] + sigdt[k]) +
+                   vc::tref3[k] * (sigm[k + 1] + sigm[k]) + AKAPd * (tg[k] * puv[k] - tgg[k] * dmean);
         if (STORE_ALL) stream_store(&P.ttend[o3 + NG * k], ttend[k]);
     }
     // tracer
@@ -98,7 +100,7 @@ __device__ __forceinline__ void dyn_column(const ModelPtrs &P, const DynDeviceTa
     temp[2] = 0.0;
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
-        trtend[k] = trg[k] * divg[k] - (temp[k + 1] + temp[k]) * D.dhsr[k];
+        trtend[k] = trg[k] * divg[k] - (temp[k + 1] + temp[k]) * vc::dhsr[k];
         if (STORE_ALL) stream_store(&P.trtend[o3 + NG * k], trtend[k]);
     }
     before_products();

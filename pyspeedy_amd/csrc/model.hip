@@ -233,6 +233,7 @@ static int usable(const spd_model *m, const char *who, bool about_to_init = fals
 }
 static int apply_storage(spd_model *m, bool want32);  // (with spd_model_set_physics_precision)
 static int settle_deferred_check(spd_model *m);        // (with spd_model_check_defer)
+static int ensure_group_streams(spd_model *m, int G);  // (with spd_model_step)
 
 // (A failed runtime call also leaves its code behind as the thread's "last error", and the launch wrappers of the kernels report
 // hipGetLastError(): a hipMalloc that ran out of memory would come back as the "failure" of the next launch of an unrelated model.
@@ -1291,6 +1292,24 @@ int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, i
     return SPD_OK;
 }
 
+// The streams the member groups of multi-step calls are issued on (and their events), made once per model: at its first multi-step
+// call, or before when a host that knows it will make such calls says so (option "prepare_multi_step": a millisecond per stream
+// and the measurement that it runs side by side with the others then belong to setting the model up, not to the first stretch of
+// its time loop).  Not for every model: an idle stream holds its place among the device's few hardware queues.
+static int ensure_group_streams(spd_model *m, int G) {
+    M_HIP(hipSetDevice(m->ctx->device));
+    if (!m->ev_start) M_HIP(hipEventCreateWithFlags(&m->ev_start, hipEventDisableTiming));
+    for (int g = 0; g < G && g < 4; ++g) {
+        if (m->cstream[g]) continue;
+        // on a hardware queue none of the groups before it is on (stream_apart.hpp: measured, not assumed)
+        bool apart = true;
+        M_HIP(create_stream_apart(&m->cstream[g], m->cstream, g, hipStreamNonBlocking, &apart));
+        m->groups_apart = m->groups_apart && apart;
+        M_HIP(hipEventCreateWithFlags(&m->cev[g], hipEventDisableTiming));
+    }
+    return SPD_OK;
+}
+
 // do_single_step (speedy.f90:20-74) `nsteps` times for all members.  Nothing synchronises; the range check of
 // diagnostics.f90 is available separately through spd_model_check (the reference runs it after every step).
 // record: the range check of every step is left in m->h_steps_err[step][member] (spd_model_step_checked_begin) -- the check of step
@@ -1315,17 +1334,9 @@ static int step_impl(spd_model *m, int nsteps, void *stream, bool record, const 
         if (int rc = settle_deferred_check(m)) return rc;
     hipStream_t gs[4] = {s, nullptr, nullptr, nullptr};
     if (G > 1) {
-        M_HIP(hipSetDevice(m->ctx->device));
-        if (!m->ev_start) M_HIP(hipEventCreateWithFlags(&m->ev_start, hipEventDisableTiming));
+        if (int rc = ensure_group_streams(m, G)) return rc;
         M_HIP(hipEventRecord(m->ev_start, s));
         for (int g = 0; g < G; ++g) {
-            if (!m->cstream[g]) {
-                // on a hardware queue none of the groups before it is on (stream_apart.hpp: measured, not assumed)
-                bool apart = true;
-                M_HIP(create_stream_apart(&m->cstream[g], m->cstream, g, hipStreamNonBlocking, &apart));
-                m->groups_apart = m->groups_apart && apart;
-                M_HIP(hipEventCreateWithFlags(&m->cev[g], hipEventDisableTiming));
-            }
             gs[g] = m->cstream[g];
             M_HIP(hipStreamWaitEvent(gs[g], m->ev_start, 0));
         }
@@ -1353,8 +1364,12 @@ static int step_impl(spd_model *m, int nsteps, void *stream, bool record, const 
     const bool offset = offset_from > 0 && G == 2 && nsteps >= offset_from;
     if (offset && !m->ev_offset) M_HIP(hipEventCreateWithFlags(&m->ev_offset, hipEventDisableTiming));
     // rounds (see block_members): the members of a round go through all steps of the call before the next round starts
+    // (also with ONE group when the caller says so by setting member_groups to 1 on a large model -- the outer boundary does for
+    // the two device models it keeps a large ensemble in, which are each other's groups: csrc/driver.cpp -- but never while profiling
+    // or in the split-launch mode, whose single group is the whole model by definition)
     int rounds = 1;
-    if (G > 1 && nsteps > 1 && m->block_members > 0 && m->M >= 4 * m->block_members)
+    const bool may_round = G > 1 || (m->nchunks == 1 && m->profile == 0 && !m->split_dyn_physics);
+    if (may_round && nsteps > 1 && m->block_members > 0 && m->M >= 4 * m->block_members)
         rounds = (m->M + G * m->block_members - 1) / (G * m->block_members);
     struct HostState {  // what a step changes on the host side of the model
         Calendar cal;
@@ -1713,6 +1728,9 @@ int spd_model_set_option(spd_model_handle m, const char *name, int32_t value) {
     else if (key == "member_groups" && value >= 1 && value <= 4) m->nchunks = value < m->M ? value : m->M;
     else if (key == "block_members" && value >= 0) m->block_members = value;
     else if (key == "fail_launch_after" && value >= -1) m->fail_launch_after = value;  // (fault injection: tests)
+    else if (key == "prepare_multi_step" && value == 1) {  // the group streams of multi-step calls now, not at the first such call
+        if (m->nchunks > 1 && !m->split_dyn_physics) return ensure_group_streams(m, m->nchunks);
+    }
     else if (key == "physics_storage32" && flag) {
         m->phys_store32 = value != 0;
         return apply_storage(m, m->phys_fp32 && m->phys_store32);

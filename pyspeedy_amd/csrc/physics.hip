@@ -27,6 +27,7 @@
 #include "dyn_column.hpp"
 #include "launch_events.hpp"
 #include "stream_store.hpp"
+#include "vertical_consts.hpp"
 
 namespace spd {
 
@@ -79,13 +80,22 @@ __device__ __forceinline__ R fband_at(const R *fband, R temp, int band /*0-based
     return fband[(it - 100) + 301 * band];
 }
 
-// the vertical-structure tables of DeviceTables in the arithmetic type of the kernel (built per launch on the host)
+// The tables the column physics indexes at run time, in the arithmetic type of the kernel.  The vertical-structure tables (fsg,
+// dhs, sigl, sigh, grdsig, grdscp, wvi of geometry.f90:89-140) are compile-time constants (vertical_consts.hpp, generated from the
+// host tables and checked against them when a context is made): every level loop is unrolled, so they reach the instructions as
+// literals, and what depends on them alone -- the entrainment profile, 1 / dhs, the diffusion coefficients -- is folded by the
+// compiler.  As kernel arguments they were 104 SGPRs (of 102 a wavefront has) that the register allocator kept alive by spilling
+// them into VGPR lanes: 590 v_readlane / 130 v_writelane / 390 s_nop of the 7950 instructions of the fp64 kernel.
 template <typename R>
 struct ColTables {
-    R fsg[8], dhs[8], sigl[8], sigh[9], grdsig[8], grdscp[8], wvi[16];
     const R *fband;  // (301,4)
     const R *coa;    // 48, cos(latitude)
 };
+
+template <typename R>
+__device__ __forceinline__ constexpr R vert(const double *table, int i) {
+    return static_cast<R>(table[i]);
+}
 
 template <typename R> struct TablePtrs;
 template <> struct TablePtrs<double> {
@@ -100,12 +110,6 @@ template <> struct TablePtrs<float> {
 template <typename R>
 ColTables<R> col_tables(const DeviceTables &T) {
     ColTables<R> c;
-    for (int k = 0; k < 8; ++k) {
-        c.fsg[k] = static_cast<R>(T.fsg[k]); c.dhs[k] = static_cast<R>(T.dhs[k]); c.sigl[k] = static_cast<R>(T.sigl[k]);
-        c.grdsig[k] = static_cast<R>(T.grdsig[k]); c.grdscp[k] = static_cast<R>(T.grdscp[k]);
-    }
-    for (int k = 0; k < 9; ++k) c.sigh[k] = static_cast<R>(T.sigh[k]);
-    for (int k = 0; k < 16; ++k) c.wvi[k] = static_cast<R>(T.wvi[k]);
     c.fband = TablePtrs<R>::fband(T);
     c.coa = TablePtrs<R>::coa(T);
     return c;
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         phi[k] = R(in_phi[k]);
         qa[k] = rmax<R>(R(in_q[k]), 0.0f);
         se[k] = C::CP * ta[k] + phi[k];
-        qsat[k] = qsat_point<R>(ta[k], CT.fsg[k] * psa);
+        qsat[k] = qsat_point<R>(ta[k], vert<R>(vc::fsg, k) * psa);
         rh[k] = qa[k] / qsat[k];
     }
     // ------------------------------------------------------------------ deep convection, convection.f90
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
 #pragma unroll
         for (int k = KX - 3; k >= 3; --k) {  // 1-based k
             const R mss_k = se[k - 1] + C::ALHC * qsat[k - 1], mss_k1 = se[k] + C::ALHC * qsat[k];
-            const R mss2 = mss_k + CT.wvi[8 + k - 1] * (mss_k1 - mss_k);
+            const R mss2 = mss_k + vert<R>(vc::wvi, 8 + k - 1) * (mss_k1 - mss_k);
             if (mss0 > mss2) ktop1 = k;
             if (mse1 > mss2) {
                 ktop2 = k;
@@ -277,13 +281,13 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
     }
     if (itop != KX + 1) {  // convection.f90:78-156
         const R fqmax = 5.0f;
-        const R fm0 = C::P0 * CT.dhs[KX - 1] / (C::GRAV * trcnv * 3600.0f);
+        const R fm0 = C::P0 * vert<R>(vc::dhs, KX - 1) / (C::GRAV * trcnv * 3600.0f);
         const R rdps = 2.0f / (1.0f - psmin);
         R entr[KX];  // entr(2:kx-1), 0-based index k-1
         R sentr = R(0.0f);
 #pragma unroll
         for (int k = 2; k <= nl1; ++k) {
-            const R d = rmax<R>(0.0f, CT.fsg[k - 1] - 0.5f);
+            const R d = rmax<R>(0.0f, vert<R>(vc::fsg, k - 1) - 0.5f);
             entr[k - 1] = d * d;
             sentr = sentr + entr[k - 1];
         }
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
 #pragma unroll
         for (int k = 2; k <= nl1; ++k) entr[k - 1] = entr[k - 1] * sentr;
 
-        const R wv_nl1 = CT.wvi[8 + nl1 - 1];
+        const R wv_nl1 = vert<R>(vc::wvi, 8 + nl1 - 1);
         const R qmax = rmax<R>(1.01f * qa[KX - 1], qsat[KX - 1]);
         R sb = se[nl1 - 1] + wv_nl1 * (se[KX - 1] - se[nl1 - 1]);
         R qb = qa[nl1 - 1] + wv_nl1 * (qa[KX - 1] - qa[nl1 - 1]);
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
                 fmass = fmass + enmass;
                 fus = fus + enmass * se[k - 1];
                 fuq = fuq + enmass * qa[k - 1];
-                const R wv = CT.wvi[8 + k - 2];
+                const R wv = vert<R>(vc::wvi, 8 + k - 2);
                 sb = se[k - 2] + wv * (se[k - 1] - se[k - 2]);
                 qb = qa[k - 2] + wv * (qa[k - 1] - qa[k - 2]);
                 fds = fmass * sb;
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
             if (k == itop) {
                 qs_t = qsat[k - 1];
                 qs_t1 = qsat[k];
-                wv_t = CT.wvi[8 + k - 1];
+                wv_t = vert<R>(vc::wvi, 8 + k - 1);
             }
         const R qsatb = qs_t + wv_t * (qs_t1 - qs_t);
         precnv = rmax<R>(fuq - fmass * qsatb, R(0.0f));
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         const R psa2 = psa * psa;
 #pragma unroll
         for (int k = 2; k <= KX; ++k) {
-            const R sig2 = CT.fsg[k - 1] * CT.fsg[k - 1];
+            const R sig2 = vert<R>(vc::fsg, k - 1) * vert<R>(vc::fsg, k - 1);
             R rhref = rhlsc + drhlsc * (sig2 - 1.0f);
             if (k == KX) rhref = rmax<R>(rhref, rhblsc);
             const R dqmax = qsmax * sig2 * rtlsc;
@@ -378,9 +382,9 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
                 dt = tfact * rmin<R>(-dq, dqmax * psa2);
             }
             // physics.f90:127-130, 138-139: ttend = ttend + tt_cnv + tt_lsc
-            ttend[k - 1] = ttend[k - 1] + dfse[k - 1] * rps * CT.grdscp[k - 1] + dt;
-            qtend[k - 1] = qtend[k - 1] + dfqa[k - 1] * rps * CT.grdsig[k - 1] + dq;
-            precls = precls - (CT.dhs[k - 1] * prg) * dq;
+            ttend[k - 1] = ttend[k - 1] + dfse[k - 1] * rps * vert<R>(vc::grdscp, k - 1) + dt;
+            qtend[k - 1] = qtend[k - 1] + dfqa[k - 1] * rps * vert<R>(vc::grdsig, k - 1) + dq;
+            precls = precls - (vert<R>(vc::dhs, k - 1) * prg) * dq;
         }
         // level 1: tt_cnv(1) = dfse(1) (unscaled, zero), tt_lsc(1) = 0
         ttend[0] = ttend[0] + dfse[0] + R(0.0f);
@@ -396,17 +400,17 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
     // depends on se, rh, qa, qsat, phi and icnv, and computing it now lets those 40 per-column values die before the
     // register-hungry radiation sweeps.  Its tendencies are ADDED in the reference's order at the end.
     const R trshc = 6.0f, trvdi = 24.0f, trvds = 6.0f, redshc = 0.5f, rhgrad = 0.5f, segrad = 0.1f;
-    const R cshc = CT.dhs[KX - 1] / 3600.0f;
-    const R cvdi = (CT.sigh[nl1] - CT.sigh[1]) / (static_cast<float>(nl1 - 1) * 3600.0f);
+    const R cshc = vert<R>(vc::dhs, KX - 1) / 3600.0f;
+    const R cvdi = (vert<R>(vc::sigh, nl1) - vert<R>(vc::sigh, 1)) / (static_cast<float>(nl1 - 1) * 3600.0f);
     const R fshcq = cshc / trshc, fshcse = cshc / (trshc * C::CP);
     const R fvdiq = cvdi / trvdi, fvdise = cvdi / (trvds * C::CP);
     R ttv[KX], qtv[KX];
 #pragma unroll
     for (int k = 0; k < KX; ++k) ttv[k] = qtv[k] = R(0.0f);
     {
-        const R rs_nl1 = 1.0f / CT.dhs[nl1 - 1], rs_kx = 1.0f / CT.dhs[KX - 1];
-        const R drh0 = rhgrad * (CT.fsg[KX - 1] - CT.fsg[nl1 - 1]);
-        const R fvdiq2 = fvdiq * CT.sigh[nl1];
+        const R rs_nl1 = 1.0f / vert<R>(vc::dhs, nl1 - 1), rs_kx = 1.0f / vert<R>(vc::dhs, KX - 1);
+        const R drh0 = rhgrad * (vert<R>(vc::fsg, KX - 1) - vert<R>(vc::fsg, nl1 - 1));
+        const R fvdiq2 = fvdiq * vert<R>(vc::sigh, nl1);
         const R dmse = se[KX - 1] - se[nl1 - 1] + C::ALHC * (qa[KX - 1] - qsat[nl1 - 1]);
         const R drh = rh[KX - 1] - rh[nl1 - 1];
         if (dmse >= R(0.0f)) {
@@ -427,14 +431,14 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
     }
 #pragma unroll
     for (int k = 3; k <= KX - 2; ++k) {
-        if (CT.sigh[k] > 0.5f) {
-            const R drh0 = rhgrad * (CT.fsg[k] - CT.fsg[k - 1]);
-            const R fvdiq2 = fvdiq * CT.sigh[k];
+        if (vert<R>(vc::sigh, k) > 0.5f) {
+            const R drh0 = rhgrad * (vert<R>(vc::fsg, k) - vert<R>(vc::fsg, k - 1));
+            const R fvdiq2 = fvdiq * vert<R>(vc::sigh, k);
             const R drh = rh[k] - rh[k - 1];
             if (drh >= drh0) {
                 const R fluxq = fvdiq2 * qsat[k - 1] * drh;
-                qtv[k - 1] = qtv[k - 1] + fluxq * (1.0f / CT.dhs[k - 1]);
-                qtv[k] = qtv[k] - fluxq * (1.0f / CT.dhs[k]);
+                qtv[k - 1] = qtv[k - 1] + fluxq * (1.0f / vert<R>(vc::dhs, k - 1));
+                qtv[k] = qtv[k] - fluxq * (1.0f / vert<R>(vc::dhs, k));
             }
         }
     }
@@ -443,8 +447,8 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         const R se0 = se[k] + segrad * (phi[k - 1] - phi[k]);
         if (se[k - 1] < se0) {
             const R fluxse = fvdise * (se0 - se[k - 1]);
-            ttv[k - 1] = ttv[k - 1] + fluxse * (1.0f / CT.dhs[k - 1]);
-            const R r1 = 1.0f / (1.0f - CT.sigh[k]);
+            ttv[k - 1] = ttv[k - 1] + fluxse * (1.0f / vert<R>(vc::dhs, k - 1));
+            const R r1 = 1.0f / (1.0f - vert<R>(vc::sigh, k));
 #pragma unroll
             for (int k1 = k + 1; k1 <= KX; ++k1) ttv[k1 - 1] = ttv[k1 - 1] - fluxse * r1;
         }
@@ -526,20 +530,20 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         const R psaz = psa * zenit;
         R acloud = cloudc * rmin<R>(abscl1 * qcloud, abscl2);
         R tsw1[KX], tsw2[KX];  // shortwave transmissivities, bands 1 and 2
-        tsw1[0] = rexp(-psaz * CT.dhs[0] * absdry);
+        tsw1[0] = rexp(-psaz * vert<R>(vc::dhs, 0) * absdry);
         tsw2[0] = R(0.0f);
 #pragma unroll
         for (int k = 2; k <= nl1; ++k) {
-            const R abs1 = absdry + absaer * (CT.fsg[k - 1] * CT.fsg[k - 1]);
-            tsw1[k - 1] = (k >= icltop) ? rexp(-psaz * CT.dhs[k - 1] * (abs1 + abswv1 * qa[k - 1] + acloud))
-                                        : rexp(-psaz * CT.dhs[k - 1] * (abs1 + abswv1 * qa[k - 1]));
+            const R abs1 = absdry + absaer * (vert<R>(vc::fsg, k - 1) * vert<R>(vc::fsg, k - 1));
+            tsw1[k - 1] = (k >= icltop) ? rexp(-psaz * vert<R>(vc::dhs, k - 1) * (abs1 + abswv1 * qa[k - 1] + acloud))
+                                        : rexp(-psaz * vert<R>(vc::dhs, k - 1) * (abs1 + abswv1 * qa[k - 1]));
         }
         {
-            const R abs1 = absdry + absaer * (CT.fsg[KX - 1] * CT.fsg[KX - 1]);
-            tsw1[KX - 1] = rexp(-psaz * CT.dhs[KX - 1] * (abs1 + abswv1 * qa[KX - 1]));
+            const R abs1 = absdry + absaer * (vert<R>(vc::fsg, KX - 1) * vert<R>(vc::fsg, KX - 1));
+            tsw1[KX - 1] = rexp(-psaz * vert<R>(vc::dhs, KX - 1) * (abs1 + abswv1 * qa[KX - 1]));
         }
 #pragma unroll
-        for (int k = 2; k <= KX; ++k) tsw2[k - 1] = rexp(-psaz * CT.dhs[k - 1] * abswv2 * qa[k - 1]);
+        for (int k = 2; k <= KX; ++k) tsw2[k - 1] = rexp(-psaz * vert<R>(vc::dhs, k - 1) * abswv2 * qa[k - 1]);
 
         R tsr = solar;
         R tt_rsw[KX];
@@ -579,7 +583,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         // physics.f90:166-168
 #pragma unroll
         for (int k = 0; k < KX; ++k) {
-            tt_rsw[k] = tt_rsw[k] * rps * CT.grdscp[k];
+            tt_rsw[k] = tt_rsw[k] * rps * vert<R>(vc::grdscp, k);
             st_stream(a.tt_rsw, o3 + NG * k, tt_rsw[k]);
             ttend[k] = ttend[k] + tt_rsw[k];
         }
@@ -587,8 +591,8 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         // longwave transmissivities, shortwave_radiation.f90:170-208
         const R co2 = a.air_absortivity_co2;
         const size_t NGs = static_cast<size_t>(NG);
-        tau_s[0][lane] = rexp(-psa * CT.dhs[0] * ablwin);
-        tau_s[KX][lane] = rexp(-psa * CT.dhs[0] * co2);
+        tau_s[0][lane] = rexp(-psa * vert<R>(vc::dhs, 0) * ablwin);
+        tau_s[KX][lane] = rexp(-psa * vert<R>(vc::dhs, 0) * co2);
         st_stream(a.rad_tau2, ot + NGs * (0 + KX * 0), tau_s[0][lane]);
         st_stream(a.rad_tau2, ot + NGs * (0 + KX * 1), tau_s[KX][lane]);
         st_stream(a.rad_tau2, ot + NGs * (0 + KX * 2), R(1.0f));
@@ -598,12 +602,12 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         for (int k = 2; k <= KX; ++k) {
             R t0, t1, t2, t3;
             if (k == 2 || k == KX) {
-                t0 = rexp(-psa * CT.dhs[k - 1] * ablwin);
-                t1 = rexp(-psa * CT.dhs[k - 1] * co2);
-                t2 = rexp(-psa * CT.dhs[k - 1] * ablwv1 * qa[k - 1]);
-                t3 = rexp(-psa * CT.dhs[k - 1] * ablwv2 * qa[k - 1]);
+                t0 = rexp(-psa * vert<R>(vc::dhs, k - 1) * ablwin);
+                t1 = rexp(-psa * vert<R>(vc::dhs, k - 1) * co2);
+                t2 = rexp(-psa * vert<R>(vc::dhs, k - 1) * ablwv1 * qa[k - 1]);
+                t3 = rexp(-psa * vert<R>(vc::dhs, k - 1) * ablwv2 * qa[k - 1]);
             } else {
-                const R deltap = psa * CT.dhs[k - 1];
+                const R deltap = psa * vert<R>(vc::dhs, k - 1);
                 const R acloud1 = (k < icltop) ? acloud : ablcl1 * cloudc;
                 t0 = rexp(-deltap * (ablwin + acloud1));
                 t1 = rexp(-deltap * co2);
@@ -619,7 +623,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
             tau_s[k - 1 + KX * 2][lane] = t2;
             tau_s[k - 1 + KX * 3][lane] = t3;
         }
-        const R eps1 = C::EPSLW / (CT.dhs[0] + CT.dhs[1]);
+        const R eps1 = C::EPSLW / (vert<R>(vc::dhs, 0) + vert<R>(vc::dhs, 1));
         strat1 = R(a.stratospheric_correction[o2]) * psa;  // (requested here: one more live value above costs the kernel scratch)
         strat2 = eps1 * psa;
         st_stream(a.rad_strat_corr, oc, strat1);
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
     {
         const R anis = 1.0f;
 #pragma unroll
-        for (int k = 1; k <= nl1; ++k) st4a[k - 1][0] = ta[k - 1] + CT.wvi[8 + k - 1] * (ta[k] - ta[k - 1]);
+        for (int k = 1; k <= nl1; ++k) st4a[k - 1][0] = ta[k - 1] + vert<R>(vc::wvi, 8 + k - 1) * (ta[k] - ta[k - 1]);
         st4a[0][1] = 0.75f * ta[0] + 0.25f * st4a[0][0];
         st4a[1][1] = 0.50f * ta[1] + 0.25f * (st4a[0][0] + st4a[1][0]);
 #pragma unroll
@@ -719,9 +723,9 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         const R forog = R(a.forog[o2]), snowc = R(a.snowc[o2]), alb_sea = R(a.alb_sea[o2]);
         const R u0 = fwind0 * ua, v0 = fwind0 * va;
         const R gtemp0 = 1.0f - ftemp0, rcp = 1.0f / C::CP;
-        const R dt1 = CT.wvi[8 + KX - 1] * (ta[KX - 1] - ta[nl1 - 1]);
+        const R dt1 = vert<R>(vc::wvi, 8 + KX - 1) * (ta[KX - 1] - ta[nl1 - 1]);
         R t1l = ta[KX - 1] + dt1;
-        R t1s = t1l - phi0 * dt1 / (C::RGAS * 288.0f * CT.sigl[KX - 1]);
+        R t1s = t1l - phi0 * dt1 / (C::RGAS * 288.0f * vert<R>(vc::sigl, KX - 1));
         const R t2s = ta[KX - 1] + rcp * phi_kx;
         const R t2l = t2s - rcp * phi0;
         if (ta[KX - 1] > ta[nl1 - 1]) {
@@ -823,8 +827,8 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
             flux[b] = tau0[b] * flux[b] + emis * brad;
             dfabs[0] = dfabs[0] - flux[b];
         }
-        const R corlw1 = CT.dhs[0] * strat2 * st4a[0][0] + strat1;
-        const R corlw2 = CT.dhs[1] * strat2 * st4a[1][0];
+        const R corlw1 = vert<R>(vc::dhs, 0) * strat2 * st4a[0][0] + strat1;
+        const R corlw2 = vert<R>(vc::dhs, 1) * strat2 * st4a[1][0];
         dfabs[0] = dfabs[0] - corlw1;
         dfabs[1] = dfabs[1] - corlw2;
         R olr = corlw1 + corlw2;
@@ -837,15 +841,15 @@ __global__ __launch_bounds__(kPhysThreads, W) void physics_kernel(spd_physics_ar
         }
         // physics.f90:207-211: ttend = ttend + tt_rsw + tt_rlw
 #pragma unroll
-        for (int k = 0; k < KX; ++k) ttend[k] = ttend[k] + dfabs[k] * rps * CT.grdscp[k];
+        for (int k = 0; k < KX; ++k) ttend[k] = ttend[k] + dfabs[k] * rps * vert<R>(vc::grdscp, k);
 
         // physics.f90:223-231: surface-flux tendencies at the lowest level, then accumulate
-        const R ut_kx = R(0.0f) + ustr3 * rps * CT.grdsig[KX - 1];
-        const R vt_kx = R(0.0f) + vstr3 * rps * CT.grdsig[KX - 1];
-        ttend[KX - 1] = ttend[KX - 1] + shf3 * rps * CT.grdscp[KX - 1];
+        const R ut_kx = R(0.0f) + ustr3 * rps * vert<R>(vc::grdsig, KX - 1);
+        const R vt_kx = R(0.0f) + vstr3 * rps * vert<R>(vc::grdsig, KX - 1);
+        ttend[KX - 1] = ttend[KX - 1] + shf3 * rps * vert<R>(vc::grdscp, KX - 1);
         const size_t okx = o3 + static_cast<size_t>(NG) * (KX - 1);
         const double ud = FUSED ? park_uv[0][lane] : a.utend[okx], vd = FUSED ? park_uv[1][lane] : a.vtend[okx];
-        const R qkx = qtend_kx + evap3 * rps * CT.grdsig[KX - 1];
+        const R qkx = qtend_kx + evap3 * rps * vert<R>(vc::grdsig, KX - 1);
         // (above the lowest level the physics leaves the wind tendencies alone: ut_pbl, vt_pbl are zero there)
         stream_store(&a.utend[okx], finish(MIXED ? ut_kx : static_cast<R>(ud) + ut_kx, ud, KX - 1));
         stream_store(&a.vtend[okx], finish(MIXED ? vt_kx : static_cast<R>(vd) + vt_kx, vd, KX - 1));

@@ -47,8 +47,7 @@ constexpr int kSpecPerLane = (NSPEC + kThreads - 1) / kThreads;      // 2 x 16 B
 constexpr int kGridPerLane = (NGRID / 2 + kThreads - 1) / kThreads;  // 5 x 16 B per lane stage a grid field
 constexpr int kPlanePerLane = (kRows * MX + kThreads - 1) / kThreads;  // 3 x 16 B per lane stage a Fourier plane (Legendre stage alone)
 constexpr int kHalfPlanePerLane = (IY * MX + kThreads - 1) / kThreads; // 2 x (16 + 16) B per lane: a wavenumber of a latitude and its mirror
-constexpr int kInvLanes = MX * 12;              // inverse Legendre tasks: (m, two latitude pairs); row length of the table
-static_assert(MX * 16 <= kThreads, "16 lanes per zonal wavenumber");
+constexpr int kInvLanes = MX * 12;              // inverse Legendre tasks: (m, pair-of-latitude-pairs)
 constexpr size_t kLdsBytes = (kCBufDoubles + 2 * NSPEC) * sizeof(double);  // 40 064
 static_assert(kRows * kRowStride <= kCBufDoubles + 2 * NSPEC, "R must fit inside C + S");
 
@@ -68,56 +67,6 @@ __device__ inline int pos_re(int m) { return m == 0 ? 0 : 2 * m - 1; }
 __device__ inline int pos_im(int m) { return m == 0 ? 61 : 2 * m; }
 
 __device__ inline int wave_id() { return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6); }
-
-// Which 16 bytes of the FFT row buffer R a lane moves when a grid field is staged (16 B per lane to / from memory, two 8-byte LDS
-// accesses per lane: the rows of R are only 8-byte aligned).  A lane's accesses are 4 dwords apart from its neighbour's, so lanes
-// of ONE row cover every other bank pair only; the lanes an LDS cycle serves together are therefore split over two ADJACENT rows
-// -- 97 doubles = 2 dwords (mod 32 and mod 64) apart -- and fill the gaps (tools/lds_banks.py: 2-way conflicts before).
-//   grid_piece: item -> (row, piece) for reads (32 lanes per cycle: 16 pieces of row 2p, the same 16 of row 2p + 1)
-//   pair_piece: item -> (latitude pair, piece) for stores (16 lanes per cycle: 8 pieces of pair 2p, the same 8 of pair 2p + 1)
-__device__ __forceinline__ void grid_piece(int item, int &row, int &piece) {
-    if (!(SPD_LDS_MAP & 2)) {
-        row = item / (IX / 2);
-        piece = item - row * (IX / 2);
-        return;
-    }
-    const int g32 = item >> 5, l = item & 31, pair = g32 / 3, chunk = g32 - 3 * pair;
-    row = 2 * pair + (l >> 4);
-    piece = chunk * 16 + (l & 15);
-}
-__device__ __forceinline__ void pair_piece(int item, int &j, int &piece) {
-    if (!(SPD_LDS_MAP & 4)) {
-        j = item / (IX / 2);
-        piece = item - j * (IX / 2);
-        return;
-    }
-    const int g16 = item >> 4, l = item & 15, pp = g16 / 6, chunk = g16 - 6 * pp;
-    j = 2 * pp + (l >> 3);
-    piece = chunk * 8 + (l & 7);
-}
-// ... and the same idea for a Fourier plane staged 16 B per lane = one zonal wavenumber of one latitude (the Legendre stage on its
-// own): item -> (row, m), the lanes of one LDS cycle split over two adjacent rows of C (63 doubles = -2 dwords apart); m >= 31: idle
-__device__ __forceinline__ void plane_piece_read(int item, int &row, int &m) {   // 32 lanes per cycle, 3 x 512 items
-    if (!(SPD_LDS_MAP & 8)) {
-        row = item / MX;
-        m = item - row * MX;
-        return;
-    }
-    const int g32 = item >> 5, l = item & 31;
-    row = 2 * (g32 >> 1) + (l >> 4);
-    m = (g32 & 1) * 16 + (l & 15);
-}
-__device__ __forceinline__ void plane_piece_store(int item, int &j, int &m) {    // 16 lanes per cycle, 2 x 512 items (768 used)
-    if (!(SPD_LDS_MAP & 8)) {
-        j = item / MX;
-        m = item - j * MX;
-        return;
-    }
-    const int g16 = item >> 4, l = item & 15;
-    j = 2 * (g16 >> 2) + (l >> 3);
-    m = (g16 & 3) * 8 + (l & 7);
-}
-static_assert((IL / 2) * 3 * 32 == NGRID / 2 && (IY / 2) * 6 * 16 == IY * (IX / 2), "the piece mappings are permutations");
 
 // Phase timing for kernel tuning (compiled only with -DSPD_TRACE, see tools/trace_transforms.py): thread 0 of every
 // workgroup adds the shader-clock time spent up to each phase boundary to a device-global table.
@@ -204,18 +153,14 @@ __device__ __forceinline__ void spec2grid_body(const double *__restrict__ src, d
         __syncthreads();
         TRACE_MARK(0, 0);
 
-        // ---- inverse Legendre (legendre.f90:130-169): lane = (m, jq), latitude pairs jq and jq + 12 ----
-        // 16 lanes per zonal wavenumber, 12 of them at work: the 16 lanes one ds_write_b64 cycle serves then hold ONE m and 12
-        // different rows, and with the odd row stride of C every lane of the group lands on a bank pair of its own.  (Round 5 had
-        // 12 lanes per m and the pairs 2 jq, 2 jq + 1: both strides even, every epilogue store a 2- to 3-way bank conflict --
-        // tools/lds_banks.py enumerates both.)  All eight wavefronts now take part (four m each) instead of six.
-        const int m = (SPD_LDS_MAP & 1) ? tid >> 4 : tid / 12, jq = (SPD_LDS_MAP & 1) ? tid & 15 : tid - 12 * m;
-        if (m < MX && jq < 12) {
+        // ---- inverse Legendre (legendre.f90:130-169): lane = (m, jq), latitude pairs 2jq, 2jq+1 ----
+        if (tid < kInvLanes) {
+            const int m = tid / 12, jq = tid - 12 * m;
             // total wavenumbers needed by this wavefront: its smallest m needs 32 - m of them (nsh2, legendre.f90:73)
-            const int m_first = __builtin_amdgcn_readfirstlane((SPD_LDS_MAP & 1) ? (tid & ~63) >> 4 : (tid & ~63) / 12);
+            const int m_first = __builtin_amdgcn_readfirstlane((tid & ~63) / 12);
             const int ncount = ((32 - m_first) + 1) & ~1;
             double ev[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, od[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-            const d2 *pol = reinterpret_cast<const d2 *>(T.pinv) + (m * 12 + jq);  // [n][372] x {pair jq, pair jq + 12}
+            const d2 *pol = reinterpret_cast<const d2 *>(T.pinv) + tid;  // [n][372] x {pair 2jq, pair 2jq+1}
 #pragma unroll 4
             for (int n = 0; n < ncount; n += 2) {
                 const d2 pe = pol[n * kInvLanes], po = pol[(n + 1) * kInvLanes];
@@ -230,7 +175,7 @@ __device__ __forceinline__ void spec2grid_body(const double *__restrict__ src, d
             const bool keep_im = (m != 0) || (ST == Stage::LegendreOnly);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int js = SPD_INV_PAIR(jq, q), jn = kRows - 1 - js;  // reference j and il+1-j
+                const int js = 2 * jq + q, jn = kRows - 1 - js;  // reference j and il+1-j
                 double *rs = cbuf + js * kCStride, *rn = cbuf + jn * kCStride;
                 rn[pr] = ev[q][0] + od[q][0];
                 rs[pr] = ev[q][0] - od[q][0];
@@ -257,22 +202,18 @@ __device__ __forceinline__ void spec2grid_body(const double *__restrict__ src, d
         // lane's LDS reads before its first store, past the L2 like every output a later kernel consumes
         gd2_out g = (gd2_out)dst;
         d2 v[kPlanePerLane];
-        static_assert(kPlanePerLane * kThreads == (kRows / 2) * 2 * 32, "plane_piece_read covers three rounds of the workgroup");
 #pragma unroll
         for (int it = 0; it < kPlanePerLane; ++it) {
-            int row, m;
-            plane_piece_read(tid + it * kThreads, row, m);
-            if (row < kRows && m < MX) {
+            const int item = tid + it * kThreads;
+            if (item < kRows * MX) {
+                const int row = item / MX, m = item - row * MX;
                 const double *c = cbuf + row * kCStride;
                 v[it] = d2{c[pos_re(m)], c[pos_im(m)]};
             }
         }
 #pragma unroll
-        for (int it = 0; it < kPlanePerLane; ++it) {
-            int row, m;
-            plane_piece_read(tid + it * kThreads, row, m);
-            if (row < kRows && m < MX) __builtin_nontemporal_store(v[it], &g[row * MX + m]);
-        }
+        for (int it = 0; it < kPlanePerLane; ++it)
+            if (tid + it * kThreads < kRows * MX) __builtin_nontemporal_store(v[it], &g[tid + it * kThreads]);
         return;
     }
 
@@ -326,18 +267,14 @@ __device__ __forceinline__ void spec2grid_body(const double *__restrict__ src, d
     double cs[kGridPerLane];
 #pragma unroll
     for (int it = 0; it < kGridPerLane; ++it) {
-        const int item = tid + it * kThreads;
-        int r, ip;
-        grid_piece(item, r, ip);
-        cs[it] = (kcos != 1 && item < NGRID / 2) ? T.cosgr[r] : 1.0;
+        const int idx = tid + it * kThreads;
+        cs[it] = (kcos != 1 && idx < NGRID / 2) ? T.cosgr[idx / (IX / 2)] : 1.0;
     }
 #pragma unroll
     for (int it = 0; it < kGridPerLane; ++it) {
-        const int item = tid + it * kThreads;
-        if (item < NGRID / 2) {
-            int r, ip;
-            grid_piece(item, r, ip);
-            const int idx = r * (IX / 2) + ip;
+        const int idx = tid + it * kThreads;
+        if (idx < NGRID / 2) {
+            const int r = idx / (IX / 2), ip = idx - r * (IX / 2);
             const double *a = rows + r * kRowStride + 2 * ip;
             d2 v{a[0], a[1]};
             if (kcos != 1) {
@@ -390,8 +327,7 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
         for (int it = 0; it < kPairPerLane; ++it) {
             const int idx = tid + it * kThreads;
             if (idx < kPairTasks) {
-                int j, ip;
-                pair_piece(idx, j, ip);
+                const int j = idx / (IX / 2), ip = idx - j * (IX / 2);
                 gn[it] = __builtin_nontemporal_load(&g[(kRows - 1 - j) * (IX / 2) + ip]);  // read once, by this workgroup only
                 gs[it] = __builtin_nontemporal_load(&g[j * (IX / 2) + ip]);
                 wj[it] = T.wt[j];
@@ -403,8 +339,7 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
         for (int it = 0; it < kPairPerLane; ++it) {
             const int idx = tid + it * kThreads;
             if (idx < kPairTasks) {
-                int j, ip;
-                pair_piece(idx, j, ip);
+                const int j = idx / (IX / 2), ip = idx - j * (IX / 2);
                 d2 n = gn[it], so = gs[it];
                 if (prescale != 0) {  // rows times cosgr / cosgr2 first (spectral.f90:229-243), then the pair's Gaussian weight
                     n.x *= cn[it];
@@ -429,18 +364,15 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
         const double *ctab = (prescale == 1) ? T.cosgr : T.cosgr2;
 #pragma unroll
         for (int it = 0; it < kGridPerLane; ++it) {
-            const int item = tid + it * kThreads;
-            int r, ip;
-            grid_piece(item, r, ip);
-            if (item < NGRID / 2) gv[it] = __builtin_nontemporal_load(&g[r * (IX / 2) + ip]);  // read once, by this workgroup only
-            cs[it] = (prescale != 0 && item < NGRID / 2) ? ctab[r] : 1.0;
+            const int idx = tid + it * kThreads;
+            if (idx < NGRID / 2) gv[it] = __builtin_nontemporal_load(&g[idx]);  // read once, by this workgroup only
+            cs[it] = (prescale != 0 && idx < NGRID / 2) ? ctab[idx / (IX / 2)] : 1.0;
         }
 #pragma unroll
         for (int it = 0; it < kGridPerLane; ++it) {
-            const int item = tid + it * kThreads;
-            if (item < NGRID / 2) {
-                int r, ip;
-                grid_piece(item, r, ip);
+            const int idx = tid + it * kThreads;
+            if (idx < NGRID / 2) {
+                const int r = idx / (IX / 2), ip = idx - r * (IX / 2);
                 d2 v = gv[it];
                 if (prescale != 0) {
                     v.x *= cs[it];
@@ -512,9 +444,9 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
         double w[kHalfPlanePerLane];
 #pragma unroll
         for (int it = 0; it < kHalfPlanePerLane; ++it) {
-            int j, m;
-            plane_piece_store(tid + it * kThreads, j, m);
-            if (j < IY && m < MX) {
+            const int item = tid + it * kThreads;
+            if (item < IY * MX) {
+                const int j = item / MX, m = item - j * MX;
                 // (plain loads: with the streaming hint the same kernel is 20 % slower while its input still sits in the 256 MB
                 // Infinity Cache -- batches up to 4096 fields -- and no faster beyond, profiles/r05_legendre_only.txt)
                 nv[it] = g[(kRows - 1 - j) * MX + m];
@@ -525,9 +457,9 @@ __device__ __forceinline__ void grid2spec_body(const double *__restrict__ src, d
         for (int idx = tid; idx < NSPEC; idx += kThreads) s[idx] = d2{0.0, 0.0};  // (step 2 only writes what the reference fills)
 #pragma unroll
         for (int it = 0; it < kHalfPlanePerLane; ++it) {
-            int j, m;
-            plane_piece_store(tid + it * kThreads, j, m);
-            if (j < IY && m < MX) {
+            const int item = tid + it * kThreads;
+            if (item < IY * MX) {
+                const int j = item / MX, m = item - j * MX;
                 const int pr = pos_re(m), pi = pos_im(m);
                 double *rn = cbuf + (kRows - 1 - j) * kCStride, *rs = cbuf + j * kCStride;
                 rn[pr] = (nv[it].x + sv[it].x) * w[it];

@@ -271,10 +271,11 @@ class EnsembleModel:
         block = C.c_int32(0)
         check(self._lib.spd_model_get_option(self._m, b"block_members", C.byref(block)), "spd_model_get_option")
         streams, M = cfg[2], self.nmembers
-        # (as spd_model_step forms them: rounds of `chunks` x `block_members` members from 4 x block_members members up)
+        # (as spd_model_step forms them: rounds of `chunks` x `block_members` members from 4 x block_members members up; not while
+        # profiling or with separate dynamics / physics launches, which step everybody as one group)
         rounds = 1
-        if streams > 1 and block.value > 0 and M >= 4 * block.value:
-            rounds = (M + streams * block.value - 1) // (streams * block.value)
+        if block.value > 0 and M >= 4 * block.value and not cfg[3]:
+            rounds = (M + max(streams, 1) * block.value - 1) // (max(streams, 1) * block.value)
         return dict(inv_per_member=cfg[0], diag_every_step=bool(cfg[1]), chunks=cfg[2], split_dyn=bool(cfg[3]),
                     fold_geo=bool(cfg[4]), coupler_in_spectral=bool(cfg[5]), physics_fp32=bool(cfg[6]),
                     physics_storage32=bool(cfg[7]), group_streams=created.value, group_streams_apart=bool(apart.value),

@@ -6,8 +6,9 @@ against `speedy_driver` (the `_speedy` function set) exactly as the reference is
 
 * to_dataframe() returns a `pyspeedy_amd.dataset.Dataset` (xarray is not a dependency); it carries the same variables,
   dimension order (time, [ens,] lev, lat, lon; lev top-down reversed), float32 dtype and attributes, and writes NetCDF-3.
-* Boundary conditions: the packaged example_bc (converted from the reference's example_bc.nc), an .npz / NetCDF-3 file,
-  or a mapping of arrays.  The reference's default SST-anomaly file is not distributed with it (.MISSING_LARGE_BLOBS),
+* Boundary conditions: the packaged example_bc (converted from the reference's example_bc.nc), an .npz / NetCDF-3 file, the
+  reference's own NetCDF-4 / HDF5 files when netCDF4, h5py or xarray is importable (none is required; the error names the
+  converter otherwise), an xarray.Dataset, or a mapping of arrays.  The reference's default SST-anomaly file is not distributed with it (.MISSING_LARGE_BLOBS),
   so `sst_anomaly=None` means zero anomalies; a mapping / file with `ssta` (lon, lat, time) and `time` works as upstream.
 * SpeedyEns members are slots of ONE batched device model (speedy_driver.modelstate_init_ensemble): `SpeedyEns.run`
   advances all members with one set of kernel launches per step.  A member of an ensemble cannot `run()` on its own.
@@ -54,8 +55,69 @@ _last_file = [None, None]  # (path, mtime, size) and the fields of the file read
 _CACHE_LIMIT_BYTES = 32 << 20  # a boundary-condition file is 7 MB as float64; a multi-decade SST-anomaly record is not kept
 
 
+_HDF5_SIGNATURE = b"\x89HDF\r\n\x1a\n"
+
+
+def _read_hdf5(path):
+    """name -> array of every variable of a NetCDF-4 / HDF5 file -- the format of the reference's own boundary files
+    (pyspeedy/data/example_bc.nc, read there with xr.load_dataset(bc_file, engine="netcdf4"), speedy.py:277) -- through whichever
+    of netCDF4, h5py or xarray can be imported; none of them is a dependency of this package.  `time` comes back as datetime64."""
+    reasons = []
+    try:
+        import netCDF4
+        with netCDF4.Dataset(str(path), "r") as f:
+            out = {}
+            for name, v in f.variables.items():
+                values = np.asarray(v[...])
+                if name == "time" and hasattr(v, "units"):
+                    dates = netCDF4.num2date(values, v.units, getattr(v, "calendar", "standard"), only_use_cftime_datetimes=False)
+                    values = np.asarray([np.datetime64(d) for d in np.atleast_1d(dates)], dtype="datetime64[s]")
+                out[name] = values
+            return out
+    except ImportError as exc:
+        reasons.append("netCDF4: %s" % exc)
+    try:
+        import h5py
+        from .dataset import _decode_time
+        with h5py.File(str(path), "r") as f:
+            out = {}
+            for name, v in f.items():
+                if not isinstance(v, h5py.Dataset):
+                    continue
+                values = np.asarray(v[...])
+                units = v.attrs.get("units")
+                units = units.decode() if isinstance(units, bytes) else units
+                if name == "time" and isinstance(units, str) and " since " in units:
+                    values = _decode_time(values, units)
+                out[name] = values
+            return out
+    except ImportError as exc:
+        reasons.append("h5py: %s" % exc)
+    try:
+        import xarray
+        ds = xarray.load_dataset(str(path))
+        return {str(name): np.asarray(v.values) for name, v in ds.variables.items()}
+    except ImportError as exc:
+        reasons.append("xarray: %s" % exc)
+    raise RuntimeError(
+        "%s is a NetCDF-4 / HDF5 file, and none of netCDF4, h5py and xarray can be imported here (%s).  Install one of them, or "
+        "convert the file once with `python tools/convert_bc.py %s` under an interpreter that has one: pyspeedy_amd itself reads .npz "
+        "and NetCDF-3 classic files." % (path, "; ".join(reasons), path))
+
+
+def _is_hdf5(path):
+    with open(path, "rb") as fh:
+        return fh.read(8) == _HDF5_SIGNATURE
+
+
+def _dataset_like(source):
+    """an xarray.Dataset (or anything shaped like one: a mapping of names to objects with `.values`), without importing xarray"""
+    variables = getattr(source, "variables", None)
+    return variables is not None and hasattr(variables, "items") and not isinstance(source, Dataset)
+
+
 def _load_fields(source):
-    """Mapping name -> array from an .npz file, a NetCDF-3 file, a Dataset or a plain mapping.  A FILE's arrays come back as
+    """Mapping name -> array from an .npz file, a NetCDF-3 or NetCDF-4 / HDF5 file, a Dataset (ours or xarray's) or a plain mapping.  A FILE's arrays come back as
     float64 in Fortran order and READ-ONLY (this module only copies them into state containers).  The file read last is kept
     while it is small (a boundary-condition file: the reference's `for member in ens: member.set_bc()` reads the same file once
     per member, and decompressing it costs more than everything else a member's set_bc does); anything larger than
@@ -70,6 +132,8 @@ def _load_fields(source):
         if str(source).endswith(".npz"):
             with np.load(source) as z:
                 fields = {k: z[k] for k in z.files}
+        elif _is_hdf5(source):  # the reference's own files (speedy.py:277, 321-331)
+            fields = _read_hdf5(source)
         else:
             fields = {k: np.asarray(v.values) for k, v in open_dataset(source).variables.items()}
         # (as the state containers take them: float64, Fortran order -- converting costs as much as a member's 12 transfers)
@@ -83,6 +147,8 @@ def _load_fields(source):
         return dict(fields)
     if isinstance(source, Dataset):
         return {k: v.values for k, v in source.variables.items()}
+    if _dataset_like(source):  # an xarray.Dataset, as the reference's set_bc accepts for the SST anomalies (speedy.py:321-331)
+        return {str(k): np.asarray(v.values) for k, v in source.variables.items()}
     return dict(source)
 
 
@@ -251,10 +317,12 @@ class Speedy:
         _own(callbacks, True)
         intervals = _hook_intervals(callbacks)
         if intervals is not None:  # the hooks' schedule is known: the steps between two due hooks are one device call
+            rest = []  # what the hooks of the last boundary left to be done once the next stretch is on the device
             try:
                 while self.current_date < end_date:
                     k = _stretch(self._step_in_run, intervals, self.current_date, end_date)
                     token = _speedy.parallel_steps_begin([self._state_cnt], [self._control_cnt], k)
+                    _do_rest(rest)
                     codes, done = _speedy.parallel_steps_end(token)
                     if (codes < 0).any():  # the date of the step before the one that failed, as the reference's loop leaves it
                         self._step_in_run += int(done[0])
@@ -262,28 +330,33 @@ class Speedy:
                         _raise_step_failure(codes)
                     self._step_in_run += k
                     self.current_date += k * _DT_STEP
-                    for act in _callbacks_due(callbacks, self):
-                        act(self)
+                    _act(_callbacks_due(callbacks, self), self, rest)
             finally:
                 self._step_in_run = None
-                _finish_all(callbacks)
+                _finish_all(callbacks, rest)
             return
         pending = None  # the range check of a step is collected after the next step has been enqueued (GPU never idles)
+        first_date, first_step, accepted = self.current_date, self._step_in_run, 0  # accepted: steps whose check has come back good
         try:
             while self.current_date < end_date:
                 token = _speedy.parallel_step_begin([self._state_cnt], [self._control_cnt])
                 previous, pending = pending, token
-                self._collect(previous)
+                accepted += self._collect(previous)
                 self._step_in_run += 1
                 self.current_date += _DT_STEP
                 due = _callbacks_due(callbacks, self)
                 if due:
                     previous, pending = pending, None
-                    self._collect(previous)
-                    for act in due:
-                        act(self)
+                    accepted += self._collect(previous)
+                    _act(due, self, None)
             previous, pending = pending, None
-            self._collect(previous)
+            accepted += self._collect(previous)
+        except RuntimeError:
+            if first_step is not None and self._step_in_run is not None and accepted < self._step_in_run - first_step:
+                # a step failed its check: the reference's loop raises before it advances the date (speedy.py:398-401), and the
+                # loop above had moved it on while the check was still out
+                self.current_date = first_date + accepted * _DT_STEP
+            raise
         finally:
             self._step_in_run = None
             self._drain(pending)  # (a step that was begun behind the one that failed: end it, its code no longer matters)
@@ -291,10 +364,13 @@ class Speedy:
 
     @staticmethod
     def _collect(token):
-        if token is not None:
-            codes = _speedy.parallel_step_end(token)
-            if (codes < 0).any():
-                _raise_step_failure(codes)
+        """end a step that was begun (None: nothing to end) -> the number of steps it accepted (0 or 1); raises on a failed check"""
+        if token is None:
+            return 0
+        codes = _speedy.parallel_step_end(token)
+        if (codes < 0).any():
+            _raise_step_failure(codes)
+        return 1
 
     @staticmethod
     def _drain(token):
@@ -378,6 +454,23 @@ def _raise_step_failure(codes):
                        if len(codes) > 1 else ERROR_CODES[int(codes[0])])
 
 
+def _act(due, model, rest):
+    """let the due hooks act; what one of them leaves to be done without the model's state (a callable returned by `fire`,
+    callbacks.BaseCallback.fire) goes on the list `rest` -- or, without a list, happens at once"""
+    for act in due:
+        left = act(model)
+        if callable(left):
+            if rest is None:
+                left()
+            else:
+                rest.append(left)
+
+
+def _do_rest(rest):
+    while rest:
+        rest.pop(0)()
+
+
 def _own(callbacks, yes):
     """tell the hooks that a run owns them (XarrayExporter then writes behind the time loop: the run will call finish())"""
     for cb in callbacks:
@@ -399,13 +492,15 @@ def _finish(callbacks):
         raise failure
 
 
-def _finish_all(callbacks):
-    """_finish from the `finally` of a time loop: a failure of the run itself is not replaced by what a writer could not do -- the
-    writer's error is attached to it (__context__ does that) and the run's exception travels on; without one, the writer's is raised"""
+def _finish_all(callbacks, rest=None):
+    """_finish from the `finally` of a time loop, after what the hooks of the last boundary left to be done: a failure of the run
+    itself is not replaced by what a writer could not do -- the writer's error is attached to it (__context__ does that) and the
+    run's exception travels on; without one, the writer's is raised"""
     import sys
     running = sys.exc_info()[1]
     _own(callbacks, False)
     try:
+        _do_rest(rest or [])
         _finish(callbacks)
     except BaseException as exc:  # noqa: B902
         if running is None:
@@ -454,15 +549,21 @@ def _build_dataset(model, arrays, members, date, packed=False):
             attrs["units"] = meta.units
         data[meta.alt_name] = Variable(lead + dims, values, attrs)
     coords = {}
+    # (lon, lat and lev are tables of the geometry, the same for every model and every step: asked for once per model object -- each
+    # `model[c]` is a synchronous copy from the device, which an export that otherwise only enqueues work would have to wait for)
+    cached = model.__dict__.setdefault("_export_coords", {})
     for c, axis in (("lon", "X"), ("lat", "Y"), ("lev", None)):
         meta = REGISTRY[c]
-        vals = model[c][::-1] if c == "lev" else model[c]
+        if c not in cached:
+            vals = model[c][::-1] if c == "lev" else model[c]
+            cached[c] = np.ascontiguousarray(vals, dtype=np.float32)
+            cached[c].setflags(write=False)
         attrs = {"long_name": meta.long_name, "standard_name": c}
         if meta.units is not None:
             attrs["units"] = meta.units
         if axis:
             attrs["axis"] = axis
-        coords[c] = Variable((c,), np.ascontiguousarray(vals, dtype=np.float32), attrs)
+        coords[c] = Variable((c,), cached[c], attrs)
     coords["time"] = Variable(("time",), np.array([np.datetime64(date, "s")]), {"axis": "T", "standard_name": "time"})
     if members is not None:
         coords["ens"] = Variable(("ens",), np.array(members, dtype=np.int32))
@@ -477,7 +578,9 @@ class SpeedyEns:
 
     def __init__(self, num_of_members, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 2), devices=None):
         self.n_members = int(num_of_members)
-        cnts = _speedy.modelstate_init_ensemble(self.n_members, devices=None if devices is None else int(devices))
+        # (ONE device model per GPU: `run` hands the steps between two due callbacks over as one call, and the model's own multi-step
+        # plan forms the member groups and rounds; a host that steps one by one gets two models per GPU from 32 members up)
+        cnts = _speedy.modelstate_init_ensemble(self.n_members, devices=None if devices is None else int(devices), whole=True)
         self.members = [Speedy(start_date=start_date, end_date=end_date, member=i, _state_cnt=c) for i, c in enumerate(cnts)]
         self.current_date = self.members[0].current_date
 
@@ -512,20 +615,28 @@ class SpeedyEns:
             member.spectral2grid()
             member._initialized_bc = True
 
-    def to_dataframe(self, variables=None, packed=False, slot=0, buffers=None):
+    def to_dataframe(self, variables=None, packed=False, slot=0, buffers=None, wait=True):
         """All members along the `ens` dimension: one batched spectral -> grid conversion and one device-to-host copy per
-        variable (the device layout [member][lev][lat][lon] is already the export order).  packed=True: see Speedy.to_dataframe."""
+        variable (the device layout [member][lev][lat][lon] is already the export order).  packed=True: see Speedy.to_dataframe;
+        with wait=False (packed only) the Dataset comes back as soon as the work is enqueued and carries `ready`, the events after
+        which its arrays hold the payload (speedy_driver.ensemble_export_arrays)."""
         variables = DEFAULT_OUTPUT_VARS if variables is None else variables
         for var in variables:
             _exportable(var)
         cnts = [m._state_cnt for m in self]
-        arrays = (_speedy.ensemble_export_arrays(cnts, list(variables), slot=slot, buffers=buffers) if packed else
-                  _speedy.ensemble_grid_arrays(cnts, list(variables)))
-        return _build_dataset(self.members[0], arrays, [m.member_id for m in self], self.current_date, packed=packed)
+        ready = []
+        if packed and not wait:
+            arrays, ready = _speedy.ensemble_export_arrays(cnts, list(variables), slot=slot, buffers=buffers, wait=False)
+        else:
+            arrays = (_speedy.ensemble_export_arrays(cnts, list(variables), slot=slot, buffers=buffers) if packed else
+                      _speedy.ensemble_grid_arrays(cnts, list(variables)))
+        frame = _build_dataset(self.members[0], arrays, [m.member_id for m in self], self.current_date, packed=packed)
+        frame.ready = ready
+        return frame
 
     def _device_models(self):
         """[(EnsembleModel view, member_id of the container that is member 0 of that model)] for the device models the
-        ensemble lives in (one; two from 32 members up; per GPU with `devices=k`)."""
+        ensemble lives in (one per GPU; two from 32 members of a GPU up once it has been stepped one step at a time)."""
         found = {}
         for m in self.members:
             model, index = _speedy.device_model(m._state_cnt)
@@ -565,38 +676,39 @@ class SpeedyEns:
         _own(callbacks, True)
         intervals = _hook_intervals(callbacks)
         if intervals is not None:  # (see Speedy.run)
+            rest = []
             try:
                 while self.current_date < end_date:
                     k = _stretch(step, intervals, self.current_date, end_date)
                     token = _speedy.parallel_steps_begin(state_cnts, control_cnts, k)
+                    _do_rest(rest)
                     codes, done = _speedy.parallel_steps_end(token)
                     if (codes < 0).any():
-                        # the reference's loop stops at the first step any member fails: the ensemble's date is the one before it
+                        # The reference's loop (speedy.py:572-586) stops at the first step any member fails; it has moved the
+                        # ENSEMBLE's date past that step by then and not yet handed it to the members, who keep the date before it.
                         first = int(done[codes < 0].min())
-                        step += first
-                        self.current_date += first * _DT_STEP
-                        for member, d in zip(self, done):
-                            member.current_date = member.current_date + int(d) * _DT_STEP
-                            member._step_in_run = None
+                        for member in self:
+                            member.current_date = self.current_date + first * _DT_STEP
+                        self.current_date += (first + 1) * _DT_STEP
                         _raise_step_failure(codes)
                     step += k
                     self.current_date += k * _DT_STEP
                     for member in self:
                         member.current_date = self.current_date
                         member._step_in_run = step
-                    for act in _callbacks_due(callbacks, self):
-                        act(self)
+                    _act(_callbacks_due(callbacks, self), self, rest)
             finally:
                 for member in self:
                     member._step_in_run = None
-                _finish_all(callbacks)
+                _finish_all(callbacks, rest)
             return
         pending = None
+        first_date, first_step, accepted = self.current_date, step, 0
         try:
             while self.current_date < end_date:
                 token = _speedy.parallel_step_begin(state_cnts, control_cnts)
                 previous, pending = pending, token
-                Speedy._collect(previous)
+                accepted += Speedy._collect(previous)
                 step += 1
                 self.current_date += _DT_STEP
                 for member in self:
@@ -605,11 +717,16 @@ class SpeedyEns:
                 due = _callbacks_due(callbacks, self)
                 if due:
                     previous, pending = pending, None
-                    Speedy._collect(previous)
-                    for act in due:
-                        act(self)
+                    accepted += Speedy._collect(previous)
+                    _act(due, self, None)
             previous, pending = pending, None
-            Speedy._collect(previous)
+            accepted += Speedy._collect(previous)
+        except RuntimeError:
+            if accepted < step - first_step:  # a step failed its check: the dates as the reference's loop leaves them (see above)
+                for member in self:
+                    member.current_date = first_date + accepted * _DT_STEP
+                self.current_date = first_date + (accepted + 1) * _DT_STEP
+            raise
         finally:
             for member in self:
                 member._step_in_run = None

@@ -67,12 +67,15 @@ def modelstate_init():
     return c.value
 
 
-def modelstate_init_ensemble(nmembers, devices=None):
+def modelstate_init_ensemble(nmembers, devices=None, whole=False):
     """n containers batched from the start.  devices=None: the process-wide placement (set_device_placement /
     PYSPEEDY_AMD_DEVICES; by default the current device); devices=k: blocks over GPUs 0 .. k-1 (0: the current device)
-    without touching that placement."""
+    without touching that placement.  whole=True: ONE device model per device whatever the number of members (for hosts that hand
+    over many steps at once: parallel_steps_begin); otherwise two from 32 members of a device up."""
     arr = (C.c_int64 * int(nmembers))()
-    if devices is None:
+    if whole:
+        _ok(_L().spd_modelstate_init_ensemble_whole(arr, int(nmembers), -1 if devices is None else int(devices)), "modelstate_init_ensemble_whole")
+    elif devices is None:
         _ok(_L().spd_modelstate_init_ensemble(arr, int(nmembers)), "modelstate_init_ensemble")
     else:
         _ok(_L().spd_modelstate_init_ensemble_on(arr, int(nmembers), int(devices)), "modelstate_init_ensemble_on")
@@ -297,6 +300,23 @@ def device_model(state_cnt):
                                   max(n_months, 1)), member.value
 
 
+def _group_by_model(state_cnts):
+    """(order of first appearance, {model handle: (EnsembleModel view, positions in state_cnts, member indices)}): one
+    spd_driver_model per container, one view per device model (a 64-member export asks once per simulated day)"""
+    lib = _L()
+    handle, member, members = C.c_void_p(), C.c_int32(), C.c_int32()
+    groups, order = {}, []
+    for pos, cnt in enumerate(state_cnts):
+        _ok(lib.spd_driver_model(int(cnt), C.byref(handle), C.byref(member), C.byref(members)), "device_model")
+        key = handle.value
+        if key not in groups:
+            groups[key] = (device_model(cnt)[0], [], [])
+            order.append(key)
+        groups[key][1].append(pos)
+        groups[key][2].append(member.value)
+    return order, groups
+
+
 def ensemble_device_view(state_cnts, name, spectral2grid=False):
     """Extension: the registry variable `name` of the given containers as ONE device tensor [member, *reversed reference
     shape] in the order of `state_cnts`.  Zero-copy when the containers are, in that order, all the members of one device
@@ -338,37 +358,41 @@ def ensemble_grid_arrays(state_cnts, names):
     return {n: np.stack([models[key][n][member] for key, member in where]) for n in names}
 
 
-_export_stages = {}  # device -> uint8 staging tensor on that device (grown on demand)
+_export_stages = {}  # (device, slot) -> uint8 staging tensor on that device (grown on demand)
+_export_copy_streams = {}  # device -> the stream the copies to pinned memory of a packed export run on when the caller does not wait
 
 
-def _export_stage(device, nbytes):
+def _export_stage(device, nbytes, slot=0):
     import torch
-    have = _export_stages.get(device)
+    have = _export_stages.get((device, slot))
     if have is None or have.numel() < nbytes:
-        have = _export_stages[device] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        have = _export_stages[(device, slot)] = torch.empty(nbytes, dtype=torch.uint8, device=device)
     return have
+
+
+def _export_copy_stream(device):
+    import torch
+    if device not in _export_copy_streams:
+        _export_copy_streams[device] = torch.cuda.Stream(device=device)  # (non-blocking: it does not order itself against the step's streams)
+    return _export_copy_streams[device]
 
 
 _export_buffers = {}  # (bytes, slot) -> pinned uint8 tensor, kept for the life of the process (a day's output of 64 members: 48 MB)
 
 
-def ensemble_export_arrays(state_cnts, names, slot=0, buffers=None):
+def ensemble_export_arrays(state_cnts, names, slot=0, buffers=None, wait=True):
     """Extension, for writing files: the grid-space variables `names` of the given containers as they go into a NetCDF-3 file --
     float32, BIG-endian, vertical levels bottom-up (the reference's export convention, speedy.py:415-477) -- dict name -> numpy
     array of dtype '>f4' [member, (lev,) lat, lon] in the order of `state_cnts`.  Narrowing, level reversal and byte order happen
     on the GPU; what crosses PCIe is the file's payload itself (half the bytes of the fp64 fields), into pinned host memory.
     The arrays alias a pinned buffer that the next call with the same `slot` overwrites: the process-wide one of that slot, or --
-    `buffers`, a dict the caller owns (an exporter that writes its files in the background keeps two of its own) -- buffers[slot]."""
+    `buffers`, a dict the caller owns (an exporter that writes its files in the background keeps two of its own) -- buffers[slot].
+    wait=False: returns (arrays, events) as soon as the transforms and the pack kernels are ENQUEUED; the copies to pinned memory
+    run on a stream of their own beside whatever the caller enqueues next (the next stretch of the time loop), and the arrays hold
+    the payload once every event of the list has completed (`event.synchronize()`, e.g. in the thread that writes the file).  The
+    device staging area is per slot then: a slot must not be asked for again before its events have completed."""
     import torch
-    groups, order = {}, []
-    for pos, cnt in enumerate(state_cnts):
-        model, member = device_model(cnt)
-        key = model._m.value
-        if key not in groups:
-            groups[key] = (model, [], [])
-            order.append(key)
-        groups[key][1].append(pos)
-        groups[key][2].append(member)
+    order, groups = _group_by_model(state_cnts)
     n = len(state_cnts)
     first = groups[order[0]][0]
     # (from the registry, not from a device view: spd_model_device_ptr drops what the model derived from its state -- the day's
@@ -384,6 +408,7 @@ def ensemble_export_arrays(state_cnts, names, slot=0, buffers=None):
     for name in names:
         offsets[name] = at
         at += sizes[name]
+    events, asynchronous = [], not wait
     for k in order:
         model, positions, members = groups[k]
         model.spectral2grid()
@@ -392,19 +417,36 @@ def ensemble_export_arrays(state_cnts, names, slot=0, buffers=None):
         if contiguous and run:
             # the usual case (all members of a model, in order): one kernel per variable forms the payload on the device
             # (spd_model_export_pack), one copy takes it to the pinned buffer
-            stage = _export_stage(model.sp.device, sum(sizes[name] // n for name in names) * len(members))
-            at = 0
+            # (the staging area is laid out like the pinned buffer: the device models of a call write to disjoint parts of it, so
+            # the copies of one -- which, unwaited for, run on another stream -- are not overtaken by the pack kernels of the next)
+            stage = _export_stage(model.sp.device, total, slot if not wait else 0)
             with torch.cuda.device(model.sp.device):
-                stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                here = torch.cuda.current_stream()
+                stream = C.c_void_p(here.cuda_stream)
+                pieces = []
                 for name in names:
                     per_member = sizes[name] // n
                     nbytes = per_member * len(members)
-                    _ok(_L().spd_model_export_pack(model._m, name.encode(), members[0], len(members),
-                                                   C.c_void_p(stage.data_ptr() + at), nbytes, stream), "export_pack")
                     start = offsets[name] + positions[0] * per_member
-                    buf[start:start + nbytes].copy_(stage[at:at + nbytes], non_blocking=True)
-                    at += nbytes
+                    _ok(_L().spd_model_export_pack(model._m, name.encode(), members[0], len(members),
+                                                   C.c_void_p(stage.data_ptr() + start), nbytes, stream), "export_pack")
+                    if wait:
+                        buf[start:start + nbytes].copy_(stage[start:start + nbytes], non_blocking=True)
+                    else:
+                        pieces.append((start, nbytes))
+                if not wait:  # the copies behind the pack kernels, on a stream that does not hold up what the caller enqueues next
+                    packed = torch.cuda.Event()
+                    packed.record(here)
+                    side = _export_copy_stream(model.sp.device)
+                    side.wait_event(packed)
+                    with torch.cuda.stream(side):
+                        for start, nbytes in pieces:
+                            buf[start:start + nbytes].copy_(stage[start:start + nbytes], non_blocking=True)
+                        done = torch.cuda.Event()
+                        done.record(side)
+                    events.append(done)
             continue
+        asynchronous = False  # (a selection of members in another order goes through torch ops on the current stream: waited for)
         index = torch.as_tensor(members, device=model.sp.device)
         for name in names:
             v = model.device_view(name).index_select(0, index)
@@ -419,10 +461,13 @@ def ensemble_export_arrays(state_cnts, names, slot=0, buffers=None):
                 flat = be.reshape(len(positions), per_member)
                 for row, pos in enumerate(positions):
                     buf[offsets[name] + pos * per_member:offsets[name] + (pos + 1) * per_member].copy_(flat[row], non_blocking=True)
-    for k in order:
-        torch.cuda.synchronize(groups[k][0].sp.device)
+    if not asynchronous:
+        for k in order:
+            torch.cuda.synchronize(groups[k][0].sp.device)
+        events = []
     host = buf.numpy()
-    return {name: host[offsets[name]:offsets[name] + sizes[name]].view(">f4").reshape((n,) + shapes[name]) for name in names}
+    arrays = {name: host[offsets[name]:offsets[name] + sizes[name]].view(">f4").reshape((n,) + shapes[name]) for name in names}
+    return arrays if wait else (arrays, events)
 
 
 def driver_stats(state_cnt=0):

@@ -509,6 +509,30 @@ void single_thread() {
         for (int k = 0; k < 5; ++k) step_all(ep);
         EXPECT(models_alive() == 4);
         for (auto &x : e) verify(x);
+        {   // a multi-step call merges the two device models of each device into ONE (the model's own multi-step plan then forms
+            // the member groups); a host that goes back to single steps gets the two halves back
+            Lists l(ep);
+            int64_t t = 0;
+            std::vector<int32_t> done(70, -1);
+            EXPECT(spd_parallel_steps_begin(l.s.data(), l.c.data(), 70, 6, &t) == 0);
+            EXPECT(models_alive() == 2);
+            EXPECT(spd_parallel_steps_end(t, l.codes.data(), done.data()) == 0);
+            for (int i = 0; i < 70; ++i) {
+                EXPECT(l.codes[i] == 0 && done[i] == 6);
+                for (int k = 0; k < 6; ++k) e[i].predict_step();
+            }
+            for (auto &x : e) verify(x);
+            EXPECT(spd_parallel_steps_begin(l.s.data(), l.c.data(), 70, 3, &t) == 0);  // (the kept plan: nothing is re-cut)
+            EXPECT(models_alive() == 2);
+            EXPECT(spd_parallel_steps_end(t, l.codes.data(), done.data()) == 0);
+            for (int i = 0; i < 70; ++i)
+                for (int k = 0; k < 3; ++k) e[i].predict_step();
+            step_all(ep);
+            EXPECT(models_alive() == 4);
+            step_all(ep);
+            EXPECT(models_alive() == 4);
+            for (auto &x : e) verify(x);
+        }
         stub_set_current_device(0);
         EXPECT(spd_modelstate_init_ensemble(ids.data(), 3) == 0);  // no placement: the current device
         EXPECT(spd_modelstate_device(ids[2], &dev) == 0 && dev == 0);

@@ -98,6 +98,8 @@ struct spd_model {
     std::atomic<bool> unsettled[2] = {{false}, {false}};
     int next_slot = 0;
     std::vector<int32_t> slot_codes[2];
+    int member_groups = 2;              // spd_model_get_option / _set_option
+    int groups_of_last_checked_call = 0;  // ... as it stood when the last checked multi-step call was issued
     std::atomic<int> steps_pending{0};  // spd_model_step_checked_begin / _end
     std::vector<int32_t> steps_failed, steps_accepted;
     // a model is driven by one host thread at a time (the contract of the boundary): two threads inside one model are a bug of
@@ -330,6 +332,7 @@ int spd_model_step_checked_begin(spd_model_handle m, int nsteps, void *) {
     if (t_device != m->device) return spd_set_error(SPD_E_DEVICE, "spd_model_step_checked_begin: wrong current device");
     if (g_fail_next_steps_begin.load() > 0 && g_fail_next_steps_begin.fetch_sub(1) > 0)
         return spd_set_error(SPD_E_DEVICE, "spd_model_step_checked_begin: injected device error");
+    m->groups_of_last_checked_call = m->member_groups;
     m->steps_failed.assign(m->M, -1);
     m->steps_accepted.assign(static_cast<size_t>(m->M) * 7, 0);
     auto note = [&](int i) {
@@ -364,6 +367,21 @@ int spd_model_step_checked_end(spd_model_handle m, int32_t *first_failed_step, i
     m->steps_pending = 0;
     std::memcpy(first_failed_step, m->steps_failed.data(), sizeof(int32_t) * m->M);
     if (accepted) std::memcpy(accepted, m->steps_accepted.data(), sizeof(int32_t) * 7 * m->M);
+    return SPD_OK;
+}
+
+// (the launch plan is the model's own business: the stub keeps the one switch the driver touches)
+int spd_model_get_option(spd_model_handle m, const char *name, int32_t *value) {
+    if (!m || !name || !value) return spd_set_error(SPD_E_ARG, "spd_model_get_option: null argument");
+    if (std::string(name) != "member_groups") return spd_set_error(SPD_E_ARG, "spd_model_get_option: unknown option");
+    *value = m->member_groups;
+    return SPD_OK;
+}
+int spd_model_set_option(spd_model_handle m, const char *name, int32_t value) {
+    if (!m || !name) return spd_set_error(SPD_E_ARG, "spd_model_set_option: null argument");
+    if (std::string(name) == "prepare_multi_step" && value == 1) return SPD_OK;
+    if (std::string(name) != "member_groups" || value < 1 || value > 4) return spd_set_error(SPD_E_ARG, "spd_model_set_option: unknown option");
+    m->member_groups = value;
     return SPD_OK;
 }
 

@@ -186,7 +186,8 @@ def test_a_hanging_one_process_child_does_not_cost_the_line():
     res = _result(subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "6", "--warmup", "3", "--regions", "2",
                                   "--no-cpu-baseline", "--budget", "1"], capture_output=True, text=True, timeout=600, env=env))
     assert res["value"] > 0 and res["one_process"] == {"skipped": "budget"} and res["cfg4_strong"] == {"skipped": "budget"}
-    assert {k["leg"] for k in res["budget"]["skipped"]} == {"cfg4_strong", "one_process"}
+    assert {k["leg"] for k in res["budget"]["skipped"]} == {"cfg4_strong", "one_process", "stream_ceiling"}
+    assert res["roofline"]["stream_ceiling"] == {"skipped": "budget"}
 
 
 @pytest.mark.gpu

@@ -154,8 +154,8 @@ def test_fp32_physics_ensemble_stays_inside_the_fp64_envelope(spectral, members)
 
 
 def test_cfg5_through_the_ensemble_facade_equals_the_batched_model(spectral):
-    """SpeedyEns.set_sppt / set_physics_precision reach every device model the ensemble lives in (34 members: two models of 17)
-    with the members' global ids: after six steps every member equals, bit for bit, the same member of ONE 34-member model
+    """SpeedyEns.set_sppt / set_physics_precision reach every device model the ensemble lives in (34 members: two models of 17
+    once it has been stepped one step at a time) with the members' global ids: after six steps every member equals, bit for bit, the same member of ONE 34-member model
     stepped with the same seed -- the noise does not depend on the grouping."""
     from datetime import datetime
     import pyspeedy_amd
@@ -166,14 +166,20 @@ def test_cfg5_through_the_ensemble_facade_equals_the_batched_model(spectral):
     ens = SpeedyEns(M, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 1, 4, 0))
     for member in ens:
         member.set_bc()
+    # (SpeedyEns makes one device model per GPU; a plain step taken one by one re-cuts it into the two halves a host of that habit
+    # is served by, and with SPPT on -- its generator is keyed by the member ids of the model it was set up for -- they stay two)
+    assert len({drv.device_model(m._state_cnt)[0]._m.value for m in ens}) == 1
+    assert (drv.parallel_step([m._state_cnt for m in ens], [m._control_cnt for m in ens]) == 0).all()
     assert len({drv.device_model(m._state_cnt)[0]._m.value for m in ens}) == 2
     ens.set_sppt(True, seed=11)
     ens.set_physics_precision(True)
     ens.run()
+    assert len({drv.device_model(m._state_cnt)[0]._m.value for m in ens}) == 2
     one = EnsembleModel(spectral, M)
     one.init_sst_anom(1)
     with np.load(pyspeedy_amd.example_bc_file()) as z:
         one.set_bc({k: z[k] for k in z.files})
+    one.run(1)
     one.set_sppt(True, seed=11, first_member_id=0)
     one.set_physics_precision(True)
     one.run(6)

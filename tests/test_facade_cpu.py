@@ -248,3 +248,96 @@ def test_what_is_due_at_a_step():
         act(model)
     assert Counts.fired == 1 and OwnCall.called == 1 and seen == [model]
     assert _callbacks_due([], model) == []
+
+
+def _hdf5_like_file(tmp_path):
+    """a file that starts like the reference's boundary files do (NetCDF-4 is HDF5: the 8-byte signature)"""
+    path = tmp_path / "example_bc.nc"
+    path.write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+    return path
+
+
+def test_the_references_hdf5_boundary_files_are_read_through_whatever_reader_is_there(tmp_path, monkeypatch):
+    """pyspeedy/speedy.py:277 reads the boundary conditions with xr.load_dataset(bc_file, engine="netcdf4"): the reference's packaged
+    example_bc.nc is NetCDF-4 / HDF5.  `_load_fields` recognises the signature and reads through netCDF4, h5py or xarray --
+    whichever can be imported; none is a dependency.  Here: a stand-in `h5py` on sys.path (the other two made unimportable)."""
+    import sys
+    import textwrap
+    from pyspeedy_amd import speedy as S
+    fake = tmp_path / "fake_readers"
+    fake.mkdir()
+    (fake / "h5py.py").write_text(textwrap.dedent('''
+        import numpy as np
+        class Dataset:
+            def __init__(self, values, attrs=None):
+                self._values, self.attrs = values, dict(attrs or {})
+            def __getitem__(self, key):
+                assert key is Ellipsis
+                return self._values
+        class Group:
+            pass
+        class File:
+            opened = []
+            def __init__(self, path, mode):
+                assert mode == "r"
+                File.opened.append(path)
+            def __enter__(self):
+                return self
+            def __exit__(self, *exc):
+                return False
+            def items(self):
+                yield "orog", Dataset(np.full((96, 48), 3.0, dtype=np.float32))
+                yield "sst", Dataset(np.arange(96 * 48 * 12, dtype=np.float32).reshape(96, 48, 12))
+                yield "time", Dataset(np.array([0.0, 31.0]), {"units": b"days since 1982-01-01 00:00:00"})
+                yield "a_group", Group()
+    '''))
+    monkeypatch.syspath_prepend(str(fake))
+    for name in ("netCDF4", "xarray"):
+        monkeypatch.setitem(sys.modules, name, None)  # (import of a name mapped to None raises ImportError)
+    monkeypatch.delitem(sys.modules, "h5py", raising=False)
+    monkeypatch.setattr(S, "_last_file", [None, None])
+    path = _hdf5_like_file(tmp_path)
+    fields = S._load_fields(str(path))
+    assert set(fields) == {"orog", "sst", "time"}
+    assert fields["orog"].dtype == np.float64 and fields["orog"].flags.f_contiguous and float(fields["orog"][5, 7]) == 3.0
+    assert fields["sst"].shape == (96, 48, 12) and fields["sst"][1, 0, 0] == 48 * 12
+    assert fields["time"][1] == np.datetime64("1982-02-01")
+    import h5py
+    assert h5py.File.opened == [str(path)]
+    # ... and a NetCDF-3 file with the same name ending still goes through the package's own reader
+    from pyspeedy_amd.dataset import Dataset, Variable
+    classic = tmp_path / "classic.nc"
+    Dataset({"orog": Variable(("lon", "lat"), np.ones((96, 48)))}, {}).to_netcdf(str(classic))
+    assert not S._is_hdf5(str(classic)) and S._load_fields(str(classic))["orog"].shape == (96, 48)
+
+
+def test_an_hdf5_file_without_any_reader_names_the_converter(tmp_path, monkeypatch):
+    import sys
+    from pyspeedy_amd import speedy as S
+    for name in ("netCDF4", "h5py", "xarray"):
+        monkeypatch.setitem(sys.modules, name, None)
+    monkeypatch.setattr(S, "_last_file", [None, None])
+    path = _hdf5_like_file(tmp_path)
+    with pytest.raises(RuntimeError) as failure:
+        S._load_fields(str(path))
+    text = str(failure.value)
+    assert "NetCDF-4 / HDF5" in text and "tools/convert_bc.py" in text and str(path) in text
+    assert all(name in text for name in ("netCDF4", "h5py", "xarray"))
+    assert os.path.isfile(os.path.join(os.path.dirname(GOLD), "..", "tools", "convert_bc.py"))
+
+
+def test_an_xarray_dataset_is_accepted_for_the_sst_anomalies():
+    """pyspeedy/speedy.py:321-331 takes a path or an xr.Dataset for the SST anomalies: anything shaped like one (a `variables`
+    mapping of objects with `.values`) is read without importing xarray."""
+    from pyspeedy_amd import speedy as S
+
+    class Var:
+        def __init__(self, values):
+            self.values = values
+
+    class FakeXarrayDataset:
+        def __init__(self):
+            self.variables = {"ssta": Var(np.zeros((96, 48, 3))), "time": Var(np.array(["1981-12-01", "1982-01-01", "1982-02-01"],
+                                                                                      dtype="datetime64[ns]"))}
+    fields = S._load_fields(FakeXarrayDataset())
+    assert set(fields) == {"ssta", "time"} and fields["ssta"].shape == (96, 48, 3) and fields["time"].dtype.kind == "M"
