@@ -50,5 +50,12 @@ python3 $R/tools/pmc_summary.py $OUT/pmcleg $OUT/${TAG}_pmc_legendre_only.json "
 rm -rf $OUT/leg/run_kernel_trace.csv $OUT/pmcleg
 rm -rf $OUT/k64/run_kernel_trace.csv $OUT/k8/run_kernel_trace.csv $OUT/k1/run_kernel_trace.csv $OUT/k32c5/run_kernel_trace.csv $OUT/pmc/fetch $OUT/pmc/write $OUT/pmc5_0 $OUT/pmc5_1
 python3 $R/tools/copy_rate.py > $OUT/${TAG}_device_copy_rate.txt 2>&1 || true
+# round 6: the streaming ceiling with the library's own probe kernels, the column kernel at whole and fractional rounds of the
+# machine, the facade's time loop (stretches, export) and the cost of a pause between two stretches
+python3 $R/tools/stream_ceiling.py --json $OUT/${TAG}_stream_ceiling.json > $OUT/${TAG}_stream_ceiling.txt 2>&1 || true
+python3 $R/tools/exp_tail.py > $OUT/${TAG}_column_tail.txt 2>&1 || true
+python3 $R/tools/experiments/r06_facade_plans.py 32 64 256 > $OUT/${TAG}_facade_run.txt 2>&1 || true
+python3 $R/tools/perf_facade_export.py 64 5 > $OUT/${TAG}_facade_export.txt 2>&1 || true
+python3 $R/tools/experiments/r06_idle_gap.py > $OUT/${TAG}_idle_gap.txt 2>&1 || true
 echo "all done"
 ls -la $OUT
