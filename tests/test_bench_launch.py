@@ -262,6 +262,9 @@ def test_the_one_gpu_line_carries_the_drop_in_and_every_store_legs():
         assert f[key]["members"] == members and 0 < f[key]["run_ms_per_step"] and 0 < f[key]["run_daily_export_ms_per_step"]
         assert f[key]["files_written"] == f[key]["run_daily_export_steps"] // 36 and f[key]["megabytes_written"] > 0.7 * members * f[key]["files_written"]
     assert f["ens64"]["run_ms_per_step"] < f["ens64"]["run_daily_export_ms_per_step"]  # (48 MB per simulated day)
+    # ... and a large ensemble through the facade: its stretches are multi-step calls, so the members go in rounds of 64
+    assert f["ens256"]["members"] == 256 and abs(f["ens256"]["us_per_member_step"] - f["ens256"]["run_ms_per_step"] / 256 * 1e3) < 1e-9
+    assert f["ens256"]["us_per_member_step"] < 1.15 * f["ens64"]["run_ms_per_step"] / 64 * 1e3
     cfg = res["config"]
     assert cfg["step_contract_ms_per_step_sync_8"] == d["sync_ms_per_step"] and cfg["step_contract_ms_per_step_begin_end_8"] == d["begin_end_ms_per_step"]
     assert cfg["step_contract_ms_per_step_sync_1"] == d["containers_1"]["sync_ms_per_step"]
@@ -279,6 +282,23 @@ def test_the_one_gpu_line_carries_the_drop_in_and_every_store_legs():
     assert dom["share_of_kernel_time"] > 0.25 and 0 < dom["frac"] < 1 and dom["traffic"] > 0
     assert abs(dom["achieved"] - dom["algorithmic_bytes_per_launch"] / (dom["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * dom["achieved"]
     assert res["cpu_baseline"]["all_cores"]["cores"] >= 1 and res["vs_baseline"] > 0
+    # the ceiling the fractions of 8 TB/s are to be read against, measured with the library's own probe kernels on this box
+    sc = res["roofline"]["stream_ceiling"]
+    for mix in ("copy_1r1w", "column_2r1w", "mix_3r2w", "read", "write"):
+        assert 2.0 < sc[mix] < 9.0 and 2.0 < sc[mix + "_column_shape"] <= sc[mix] + 1e-9 and sc[mix + "_shape"], (mix, sc)
+    twin = sc["column_twin"]  # the column kernel's launch with the arithmetic taken out: the kernel cannot be faster than that
+    assert twin["us"] > 0 and twin["column_kernel_over_twin"] > 0.9 and twin["bytes"] > 0
+    assert all("frac_of_stream_ceiling" in k for k in res["roofline"]["kernels"] if k["kernel"] in ("spec2grid", "column", "grid2spec"))
+    assert 0 < dom["frac_of_stream_ceiling"] < dom["frac_of_stream_ceiling_in_its_shape"] and dom["frac"] < dom["frac_of_stream_ceiling"]
+    assert res["roofline"]["frac_of_stream_ceiling"] > res["roofline"]["frac"]
+    # the committed PMC traffic is tied to the device sources it was taken with
+    sys.path.insert(0, ROOT)
+    import bench
+    assert res["roofline"]["kernel_sources_sha"] == bench.kernel_sources_sha() and res["roofline"]["traffic_stale"] in (True, False, None)
+    assert dom["traffic_stale"] in (True, False, None)
+    # the line's kernel where nothing of its traffic can sit in the Infinity Cache (256 members)
+    b = res["roofline"]["beyond_infinity_cache"]
+    assert b["members"] == 256 and 0 < res["roofline"]["frac_beyond_infinity_cache"] == b["frac"] < 1
     # every BASELINE config on the same clock (SURVEY 8d "Configs as concrete inputs")
     for key, members in (("cfg3", 1), ("cfg4_shard8", 8), ("cfg5", 32)):
         leg = res[key]
@@ -356,3 +376,109 @@ def test_bench_under_torchrun_measures_the_host_baseline_on_rank_0():
     res = _result(subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env))
     assert res["n_gpus"] == 2 and res["config"]["members_total"] == 8
     assert res["cpu_baseline"]["all_cores"]["cores"] >= 1 and res["vs_baseline"] > 0
+    # the ceiling the fractions of 8 TB/s are to be read against, measured with the library's own probe kernels on this box
+    sc = res["roofline"]["stream_ceiling"]
+    for mix in ("copy_1r1w", "column_2r1w", "mix_3r2w", "read", "write"):
+        assert 2.0 < sc[mix] < 9.0 and 2.0 < sc[mix + "_column_shape"] <= sc[mix] + 1e-9 and sc[mix + "_shape"], (mix, sc)
+    twin = sc["column_twin"]  # the column kernel's launch with the arithmetic taken out: the kernel cannot be faster than that
+    assert twin["us"] > 0 and twin["column_kernel_over_twin"] > 0.9 and twin["bytes"] > 0
+    assert all("frac_of_stream_ceiling" in k for k in res["roofline"]["kernels"] if k["kernel"] in ("spec2grid", "column", "grid2spec"))
+    assert 0 < dom["frac_of_stream_ceiling"] < dom["frac_of_stream_ceiling_in_its_shape"] and dom["frac"] < dom["frac_of_stream_ceiling"]
+    assert res["roofline"]["frac_of_stream_ceiling"] > res["roofline"]["frac"]
+    # the committed PMC traffic is tied to the device sources it was taken with
+    sys.path.insert(0, ROOT)
+    import bench
+    assert res["roofline"]["kernel_sources_sha"] == bench.kernel_sources_sha() and res["roofline"]["traffic_stale"] in (True, False, None)
+    assert dom["traffic_stale"] in (True, False, None)
+    # the line's kernel where nothing of its traffic can sit in the Infinity Cache (256 members)
+    b = res["roofline"]["beyond_infinity_cache"]
+    assert b["members"] == 256 and 0 < res["roofline"]["frac_beyond_infinity_cache"] == b["frac"] < 1
+
+
+def _line(n, value, **config):
+    """a bench line as tools/check_scale.py reads it: the contract's scalars and `config` only (what the driver's records keep)"""
+    return {"metric": "simulated-years/day (whole node), T30L8", "value": value, "n_gpus": n, "scaling": "weak",
+            "config": dict({"group_streams_side_by_side_by_rank": [True] * n}, **config)}
+
+
+def _good(n, value):
+    return _line(n, value, collective_backend="nccl", collective_ranks_seen=n, collective_distinct_gpus=n,
+                 collective_boundary_checksum_equal=True, collective_rccl_preflight_ok=True, collective_backend_fallback=None,
+                 one_process_boundary_broadcast_note="one RCCL broadcast to %d other device(s)" % (n - 1))
+
+
+def test_check_scale_reads_the_first_multi_gpu_record_as_design_says(tmp_path, capsys):
+    """tools/check_scale.py: the reading rules of the scaling record as code.  On the committed 4-rank rehearsal (four ranks on
+    ONE GPU over gloo) it reports exactly the deviations such a rehearsal must show; on a record as the design expects it --
+    weak scaling flat, cfg 4 as worded at its projection, RCCL everywhere -- none; and it names what is off when something is."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_scale
+    rehearsal = os.path.join(ROOT, "profiles", "r05_bench_rehearsal_4ranks_one_gpu.json")
+    assert check_scale.main(["--line", rehearsal]) == 1
+    out = capsys.readouterr().out
+    deviations = [ln for ln in out.splitlines() if ln.startswith("DEVIATION")]
+    assert len(deviations) == 3 and "3 deviation(s)" in out
+    assert "distinct GPUs: 1 of 4" in deviations[0] and "backend 'gloo'" in deviations[1] and "local copies only" in deviations[2]
+    assert "ok         N=4 ranks that met in the collective layer: 4 of 4" in out and "member groups side by side on every rank" in out
+    one = _line(1, 1.70e6, projected_8gpu_cfg4_value=7.4e6)
+    runs = [{"n": 1, "parsed": one}] + [{"n": n, "parsed": _good(n, 1.70e6 * n * f)} for n, f in ((2, 0.99), (4, 1.01), (8, 0.98))]
+    runs[3]["parsed"]["config"]["cfg4_strong_value"] = 7.2e6
+    scale, bench_file = tmp_path / "SCALE.json", tmp_path / "BENCH.json"
+    scale.write_text(json.dumps({"runs": runs}))
+    bench_file.write_text(json.dumps({"n": 1, "parsed": _line(1, 1.66e6)}))
+    assert check_scale.main([str(scale), str(bench_file)]) == 0
+    out = capsys.readouterr().out
+    assert "0 deviation(s)" in out and "4.24 x" in out and "N=1 of the scaling record against BENCH" in out
+    # ... a node where RCCL fell back at 8 ranks, two ranks shared a GPU and the weak curve sags
+    bad = json.loads(scale.read_text())
+    cfg8 = bad["runs"][3]["parsed"]["config"]
+    cfg8.update(collective_backend="gloo", collective_rccl_preflight_ok=False, collective_backend_fallback="RCCL did not pass", collective_distinct_gpus=7)
+    bad["runs"][3]["parsed"]["value"] = 1.70e6 * 8 * 0.90
+    cfg8["one_process_boundary_broadcast_note"] = "peer copies, because: RCCL not loadable"
+    scale.write_text(json.dumps(bad))
+    assert check_scale.main([str(scale), str(bench_file)]) == 1
+    out = capsys.readouterr().out
+    assert "DEVIATION  weak scaling at N=8 flat" in out and "DEVIATION  N=8 distinct GPUs: 7 of 8" in out
+    assert "DEVIATION  N=8 RCCL pre-flight passed" in out and "DEVIATION  N=8 one process: ONE RCCL broadcast" in out
+    assert check_scale.main([os.path.join(ROOT, "SCALE_r05.json")]) == 0  # (a skipped record is said to be one)
+
+
+def test_scaling_facts_travel_flat_in_config_and_the_traffic_is_tied_to_the_sources(tmp_path, monkeypatch):
+    """What check_scale reads is repeated as flat scalars in `config` (the driver's records keep the contract's objects only), the
+    host-side meeting points of the ranks carry a nonce per launch attempt, and the committed PMC traffic says when it was taken
+    with other device sources than the tree's."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    flat = bench.scaling_keys({"backend": "nccl", "ranks_seen": 8, "distinct_gpus": 8, "boundary_checksum_equal": True,
+                               "rccl_preflight": {"ok": True, "seconds": 3.0}},
+                              {"cfg4_strong": {"value": 7.1e6, "ms_per_step": 0.058, "members_per_gpu": 8},
+                               "one_process": {"ms_per_step": 0.3, "value": 1.0e7, "devices_used": 8, "containers": 512,
+                                               "boundary_broadcast": {"note": "one RCCL broadcast to 7 other device(s)"},
+                                               "cfg4_strong": {"value": 6.9e6}}})
+    assert flat["collective_ranks_seen"] == 8 and flat["collective_rccl_preflight_ok"] is True and flat["collective_backend_fallback"] is None
+    assert flat["cfg4_strong_value"] == 7.1e6 and flat["one_process_cfg4_strong_value"] == 6.9e6
+    assert flat["one_process_boundary_broadcast_note"].startswith("one RCCL broadcast to 7")
+    assert all(not isinstance(v, (dict, list)) for v in flat.values())
+    # the meeting points of one launch attempt
+    monkeypatch.setenv("MASTER_PORT", "29123")
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "0")
+    first = bench.job_file("rccl")
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "1")
+    assert bench.job_file("rccl") != first and "29123" in first and str(os.getppid()) in first
+    # the stamp of the PMC files
+    sha = bench.kernel_sources_sha()
+    assert len(sha) == 16 and sha == bench.kernel_sources_sha()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    kernels = {"spd::spec2grid_table_kernel": {"hbm_bytes_per_launch": 4928 * 50000, "fields_per_launch": 4928}}
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_sources_sha", lambda: sha)
+    for stamp, want in ((sha, False), ("0" * 16, True), (None, None)):
+        doc = {"kernels": kernels}
+        if stamp:
+            doc["kernel_sources_sha"] = stamp
+        (prof / bench.PMC_FILES[0]).write_text(json.dumps(doc))
+        traffic, source, stale = bench.load_traffic(4928)
+        assert traffic == 4928 * 50000 and bench.PMC_FILES[0] in source and stale is want

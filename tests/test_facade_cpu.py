@@ -341,3 +341,81 @@ def test_an_xarray_dataset_is_accepted_for_the_sst_anomalies():
                                                                                       dtype="datetime64[ns]"))}
     fields = S._load_fields(FakeXarrayDataset())
     assert set(fields) == {"ssta", "time"} and fields["ssta"].shape == (96, 48, 3) and fields["time"].dtype.kind == "M"
+
+
+def test_the_stretches_of_the_time_loops_follow_the_hooks_schedule():
+    """Speedy.run / SpeedyEns.run hand the steps between two due callbacks to the device as one call.  The schedule is known for
+    hooks with the reference's gating (BaseCallback: interval / spinup_date); anything else -- a plain callable, a hook that
+    overrides __call__ or skip_flag, an interval that is not a positive integer -- may act at every step: no stretches then."""
+    from datetime import timedelta
+    from pyspeedy_amd import speedy as S
+    from pyspeedy_amd.callbacks import BaseCallback, DiagnosticCheck, ModelCheckpoint, XarrayExporter
+
+    class Own(BaseCallback):
+        def skip_flag(self, model_instance):
+            return False
+
+    class Caller(BaseCallback):
+        def __call__(self, model_instance):
+            pass
+
+    assert S._hook_intervals([]) == []
+    assert S._hook_intervals([DiagnosticCheck(36), XarrayExporter(interval=6), ModelCheckpoint(interval=7)]) == [36, 6, 7]
+    for odd in ([lambda m: None], [Own(interval=3)], [Caller(interval=3)], [BaseCallback(interval=0)], [BaseCallback(interval=2.0)],
+                [BaseCallback(interval=True)], [DiagnosticCheck(36), print]):
+        assert S._hook_intervals(odd) is None, odd
+    start, dt = datetime(1982, 1, 1), timedelta(minutes=40)
+    # from step 0: the next multiple of every interval, the end of the run, or ten model days
+    assert S._stretch(0, [36, 7], start, start + 100 * dt) == 7
+    assert S._stretch(7, [36, 7], start + 7 * dt, start + 100 * dt) == 7 and S._stretch(35, [36, 7], start, start + 100 * dt) == 1
+    assert S._stretch(36, [36], start, start + 20 * dt) == 20 and S._stretch(0, [], start, start + 1000 * dt) == S._MAX_STRETCH == 360
+    assert S._stretch(0, [36], start, start + timedelta(minutes=50)) == 2  # (an end date between two steps: the loop runs past it, as upstream)
+    assert S._stretch(5, [36], start, start) == 1  # (never less than a step: the loop's own condition ends the run)
+    # hooks may leave what no longer needs the state to the time loop; called by hand it happens at once
+    done = []
+
+    class Late(BaseCallback):
+        def fire(self, model_instance):
+            done.append("fire")
+            return lambda: done.append("rest")
+
+    class Model:
+        current_date = start
+
+        def get_current_step(self):
+            return 4
+
+    Late(interval=2)(Model())
+    assert done == ["fire", "rest"]
+    rest = []
+    S._act([Late(interval=2).fire, lambda m: done.append("plain")], Model(), rest)
+    assert done == ["fire", "rest", "fire", "plain"] and len(rest) == 1
+    S._do_rest(rest)
+    assert done[-1] == "rest" and rest == []
+
+
+def test_a_failing_writer_does_not_replace_the_runs_own_exception():
+    """_finish_all runs in the `finally` of the time loops: every hook gets its finish(); when the run itself failed, that is the
+    exception that travels on (the writer's is attached to it), when it did not, the writer's is raised."""
+    from pyspeedy_amd import speedy as S
+
+    class Hook:
+        def __init__(self, fail):
+            self.fail, self.finished, self._in_run = fail, 0, True
+
+        def finish(self):
+            self.finished += 1
+            if self.fail:
+                raise OSError("disk full")
+
+    hooks = [Hook(True), Hook(False)]
+    with pytest.raises(OSError):
+        S._finish_all(hooks)
+    assert [h.finished for h in hooks] == [1, 1] and not any(h._in_run for h in hooks)
+    hooks = [Hook(True), Hook(False)]
+    with pytest.raises(RuntimeError) as failure:
+        try:
+            raise RuntimeError("the model left the accepted range")
+        finally:
+            S._finish_all(hooks, [lambda: None])
+    assert isinstance(failure.value.__context__, OSError) and [h.finished for h in hooks] == [1, 1]
