@@ -234,6 +234,7 @@ static int usable(const spd_model *m, const char *who, bool about_to_init = fals
 static int apply_storage(spd_model *m, bool want32);  // (with spd_model_set_physics_precision)
 static int settle_deferred_check(spd_model *m);        // (with spd_model_check_defer)
 static int ensure_group_streams(spd_model *m, int G);  // (with spd_model_step)
+static int ensure_steps_record(spd_model *m, int nsteps);
 
 // (A failed runtime call also leaves its code behind as the thread's "last error", and the launch wrappers of the kernels report
 // hipGetLastError(): a hipMalloc that ran out of memory would come back as the "failure" of the next launch of an unrelated model.
@@ -1292,6 +1293,24 @@ int spd_model_init(spd_model_handle m, int year, int month, int day, int hour, i
     return SPD_OK;
 }
 
+// the pinned [steps][members] array the range checks of a checked multi-step call publish their codes in, and the event behind the call
+static int ensure_steps_record(spd_model *m, int nsteps) {
+    M_HIP(hipSetDevice(m->ctx->device));
+    if (m->steps_cap < nsteps) {
+        if (m->h_steps_err) M_HIP(hipHostFree(m->h_steps_err));
+        m->h_steps_err = nullptr;
+        m->steps_cap = 0;
+        void *p = nullptr;
+        const int cap = nsteps < 64 ? 64 : nsteps;
+        M_HIP(hipHostMalloc(&p, sizeof(int) * static_cast<size_t>(cap) * m->M, hipHostMallocCoherent));
+        m->h_steps_err = static_cast<int *>(p);
+        m->steps_cap = cap;
+        std::memset(m->h_steps_err, 0, sizeof(int) * static_cast<size_t>(cap) * m->M);
+    }
+    if (!m->steps_event) M_HIP(hipEventCreateWithFlags(&m->steps_event, hipEventDisableTiming));
+    return SPD_OK;
+}
+
 // The streams the member groups of multi-step calls are issued on (and their events), made once per model: at its first multi-step
 // call, or before when a host that knows it will make such calls says so (option "prepare_multi_step": a millisecond per stream
 // and the measurement that it runs side by side with the others then belong to setting the model up, not to the first stretch of
@@ -1514,19 +1533,7 @@ int spd_model_step_checked_begin(spd_model_handle m, int nsteps, void *stream) {
     if (!m) return m_fail(SPD_E_ARG, std::string(who) + ": null model");
     if (nsteps < 1 || nsteps > 4096) return m_fail(SPD_E_ARG, std::string(who) + ": 1 ... 4096 steps per call");
     if (m->steps_pending) return m_fail(SPD_E_ARG, std::string(who) + ": a checked multi-step call is in flight already");
-    M_HIP(hipSetDevice(m->ctx->device));
-    if (m->steps_cap < nsteps) {
-        if (m->h_steps_err) M_HIP(hipHostFree(m->h_steps_err));
-        m->h_steps_err = nullptr;
-        m->steps_cap = 0;
-        void *p = nullptr;
-        const int cap = nsteps < 64 ? 64 : nsteps;
-        M_HIP(hipHostMalloc(&p, sizeof(int) * static_cast<size_t>(cap) * m->M, hipHostMallocCoherent));
-        m->h_steps_err = static_cast<int *>(p);
-        m->steps_cap = cap;
-        std::memset(m->h_steps_err, 0, sizeof(int) * static_cast<size_t>(cap) * m->M);
-    }
-    if (!m->steps_event) M_HIP(hipEventCreateWithFlags(&m->steps_event, hipEventDisableTiming));
+    if (int rc = ensure_steps_record(m, nsteps)) return rc;
     m->steps_ticket = next_ticket(m);
     if (int rc = step_impl(m, nsteps, stream, true, who)) return rc;
     // (step_impl has joined the group streams into the caller's stream: the event is behind every launch of the call)
@@ -1728,7 +1735,8 @@ int spd_model_set_option(spd_model_handle m, const char *name, int32_t value) {
     else if (key == "member_groups" && value >= 1 && value <= 4) m->nchunks = value < m->M ? value : m->M;
     else if (key == "block_members" && value >= 0) m->block_members = value;
     else if (key == "fail_launch_after" && value >= -1) m->fail_launch_after = value;  // (fault injection: tests)
-    else if (key == "prepare_multi_step" && value == 1) {  // the group streams of multi-step calls now, not at the first such call
+    else if (key == "prepare_multi_step" && value == 1) {  // what multi-step calls need once per model, now instead of at the first one
+        if (int rc = ensure_steps_record(m, 360)) return rc;  // (a stretch of the facade's time loops is at most 360 steps long)
         if (m->nchunks > 1 && !m->split_dyn_physics) return ensure_group_streams(m, m->nchunks);
     }
     else if (key == "physics_storage32" && flag) {

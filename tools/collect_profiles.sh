@@ -2,7 +2,7 @@
 # Collects the round's final evidence in ONE session on an MI355X box (boxes differ by up to 10 %: numbers that are quoted
 # together must come from the same box).  Run through gpurun from the repository root:
 #     gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r04 > gpurun_out/collect.log 2>&1'
-# and copy gpurun_out/final/* into profiles/ afterwards.
+# and copy gpurun_out/final/<TAG>_* into profiles/ afterwards.
 # The per-kernel evidence (rocprofv3 kernel stats, PMC traffic) is taken with `--serial-plan --no-legs`: every launch of a kernel
 # then has one size and shares the GPU with nothing, which is also how bench.py itself measures its `roofline` object.
 set -e
@@ -11,13 +11,6 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/final
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# the default line carries every BASELINE config since round 4 (cfg3, cfg4_shard8, cfg5, cfg2_transforms legs)
-python3 $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
-python3 $R/bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_20.json 2>> $OUT/bench.err
-python3 $R/bench.py --serial-plan --no-legs --no-cpu-baseline > $OUT/${TAG}_bench_serial_plan.json 2>> $OUT/bench.err
-python3 $R/bench.py --config cfg5 --no-cpu-baseline --no-legs > $OUT/${TAG}_bench_cfg5.json 2>> $OUT/bench.err
-python3 $R/bench.py --one-process --gpus 1 --no-cpu-baseline --steps 360 > $OUT/${TAG}_bench_one_process.json 2>> $OUT/bench.err
-echo "bench lines done"
 SER="--serial-plan --no-legs --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k64 -o run -- python3 $R/bench.py $SER > $OUT/k64.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k8 -o run -- python3 $R/bench.py --scaling strong --members 8 $SER > $OUT/k8.log 2>&1
@@ -41,6 +34,17 @@ for st in 1 0; do
   python3 $R/tools/pmc_summary.py $OUT/pmc5_$st $OUT/${TAG}_pmc_cfg5_storage32_$st.json "PYSPEEDY_AMD_PHYS_STORE32=$st python3 bench.py --config cfg5 $PMC (32 members)" 8
 done
 unset PYSPEEDY_AMD_PHYS_STORE32
+# The bench lines AFTER the PMC passes: roofline.traffic of a line is the committed PMC figure, and the one this session has just
+# taken (stamped with the sha of the device sources: traffic_stale = false) is put where bench.py looks for it -- on this box only;
+# the copy that is committed comes back through gpurun_out/final like everything else.
+mkdir -p $R/profiles && cp $OUT/${TAG}_pmc_model_step.json $OUT/${TAG}_pmc_cfg5_storage32_1.json $R/profiles/ 2>/dev/null || true
+# the default line carries every BASELINE config since round 4 (cfg3, cfg4_shard8, cfg5, cfg2_transforms legs)
+python3 $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+python3 $R/bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_20.json 2>> $OUT/bench.err
+python3 $R/bench.py --serial-plan --no-legs --no-cpu-baseline > $OUT/${TAG}_bench_serial_plan.json 2>> $OUT/bench.err
+python3 $R/bench.py --config cfg5 --no-cpu-baseline --no-legs > $OUT/${TAG}_bench_cfg5.json 2>> $OUT/bench.err
+python3 $R/bench.py --one-process --gpus 1 --no-cpu-baseline --steps 360 > $OUT/${TAG}_bench_one_process.json 2>> $OUT/bench.err
+echo "bench lines done"
 # the Legendre stage on its own at 16 384 fields (north_star's literal target): kernel stats, then the two PMC passes
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/leg -o run -- python3 $R/tools/perf_legendre_only.py > $OUT/${TAG}_legendre_only.txt 2>&1
 cp $OUT/leg/run_kernel_stats.csv $OUT/${TAG}_legendre_only_kernel_stats.csv
