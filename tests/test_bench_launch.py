@@ -376,23 +376,13 @@ def test_bench_under_torchrun_measures_the_host_baseline_on_rank_0():
     res = _result(subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env))
     assert res["n_gpus"] == 2 and res["config"]["members_total"] == 8
     assert res["cpu_baseline"]["all_cores"]["cores"] >= 1 and res["vs_baseline"] > 0
-    # the ceiling the fractions of 8 TB/s are to be read against, measured with the library's own probe kernels on this box
+    # (the streaming ceiling is rank 0's; the 256-member leg belongs to the one-GPU line)
     sc = res["roofline"]["stream_ceiling"]
-    for mix in ("copy_1r1w", "column_2r1w", "mix_3r2w", "read", "write"):
-        assert 2.0 < sc[mix] < 9.0 and 2.0 < sc[mix + "_column_shape"] <= sc[mix] + 1e-9 and sc[mix + "_shape"], (mix, sc)
-    twin = sc["column_twin"]  # the column kernel's launch with the arithmetic taken out: the kernel cannot be faster than that
-    assert twin["us"] > 0 and twin["column_kernel_over_twin"] > 0.9 and twin["bytes"] > 0
-    assert all("frac_of_stream_ceiling" in k for k in res["roofline"]["kernels"] if k["kernel"] in ("spec2grid", "column", "grid2spec"))
-    assert 0 < dom["frac_of_stream_ceiling"] < dom["frac_of_stream_ceiling_in_its_shape"] and dom["frac"] < dom["frac_of_stream_ceiling"]
-    assert res["roofline"]["frac_of_stream_ceiling"] > res["roofline"]["frac"]
-    # the committed PMC traffic is tied to the device sources it was taken with
-    sys.path.insert(0, ROOT)
-    import bench
-    assert res["roofline"]["kernel_sources_sha"] == bench.kernel_sources_sha() and res["roofline"]["traffic_stale"] in (True, False, None)
-    assert dom["traffic_stale"] in (True, False, None)
-    # the line's kernel where nothing of its traffic can sit in the Infinity Cache (256 members)
-    b = res["roofline"]["beyond_infinity_cache"]
-    assert b["members"] == 256 and 0 < res["roofline"]["frac_beyond_infinity_cache"] == b["frac"] < 1
+    assert 2.0 < sc["copy_1r1w"] < 9.0 and sc["column_twin"]["us"] > 0
+    assert res["roofline"]["frac_beyond_infinity_cache"] is None and res["roofline"]["traffic_stale"] in (True, False, None)
+    # ... and what tools/check_scale.py reads travels flat in `config`
+    cfg = res["config"]
+    assert cfg["collective_ranks_seen"] == 2 and cfg["collective_backend"] == "gloo" and cfg["collective_boundary_checksum_equal"] is True
 
 
 def _line(n, value, **config):
