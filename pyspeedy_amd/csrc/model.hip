@@ -1377,9 +1377,10 @@ static int step_impl(spd_model *m, int nsteps, void *stream, bool record, const 
     // latency-bound transforms run beside the other's streaming column / spectral kernels.  Measured at 64 members: 0.241 ms
     // per step every time, against 0.243 ... 0.250 when left to chance (profiles/r03_member_groups.txt); 96 members -2.8 %;
     // nothing at 32 / 48 members or with 3 groups.  It costs a call the time its first and last three quarters of a step run
-    // alone; applied to calls of at least 72 steps (PYSPEEDY_AMD_GROUP_OFFSET=n: from n steps, 0: never -- in 20-step calls it
-    // measured 0 ... +1.5 %).
-    static const int offset_from = getenv("PYSPEEDY_AMD_GROUP_OFFSET") ? atoi(getenv("PYSPEEDY_AMD_GROUP_OFFSET")) : 72;
+    // alone; applied to calls of at least 36 steps (PYSPEEDY_AMD_GROUP_OFFSET=n: from n steps, 0: never -- in 20-step calls it
+    // measured 0 ... +1.5 %; in the 36-step calls of a time loop with daily hooks -1.8 %: 9.58 -> 9.41 ms per simulated day,
+    // round 6; 72 until then).
+    static const int offset_from = getenv("PYSPEEDY_AMD_GROUP_OFFSET") ? atoi(getenv("PYSPEEDY_AMD_GROUP_OFFSET")) : 36;
     const bool offset = offset_from > 0 && G == 2 && nsteps >= offset_from;
     if (offset && !m->ev_offset) M_HIP(hipEventCreateWithFlags(&m->ev_offset, hipEventDisableTiming));
     // rounds (see block_members): the members of a round go through all steps of the call before the next round starts

@@ -402,7 +402,7 @@ def ensemble_export_arrays(state_cnts, names, slot=0, buffers=None, wait=True):
     total = sum(sizes.values())
     pool, key = (_export_buffers, (total, slot)) if buffers is None else (buffers, slot)
     if key not in pool or pool[key].numel() != total:
-        pool[key] = torch.empty(total, dtype=torch.uint8).pin_memory()
+        pool[key] = torch.empty(total, dtype=torch.uint8, pin_memory=True)  # (allocated pinned: .pin_memory() would allocate twice and copy)
     buf = pool[key]
     offsets, at = {}, 0
     for name in names:
@@ -439,8 +439,15 @@ def ensemble_export_arrays(state_cnts, names, slot=0, buffers=None, wait=True):
                     packed.record(here)
                     side = _export_copy_stream(model.sp.device)
                     side.wait_event(packed)
+                    pieces.sort()
+                    merged = [list(pieces[0])]
+                    for start, nbytes in pieces[1:]:  # (a model that holds every member in order: ONE copy of the whole payload)
+                        if start == merged[-1][0] + merged[-1][1]:
+                            merged[-1][1] += nbytes
+                        else:
+                            merged.append([start, nbytes])
                     with torch.cuda.stream(side):
-                        for start, nbytes in pieces:
+                        for start, nbytes in merged:
                             buf[start:start + nbytes].copy_(stage[start:start + nbytes], non_blocking=True)
                         done = torch.cuda.Event()
                         done.record(side)
