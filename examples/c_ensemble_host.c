@@ -3,7 +3,7 @@
  * the boundary file read ONCE into container 0 and handed to the others device to device (spd_broadcast_boundary: one RCCL
  * broadcast across GPUs, local copies on each), every device model initialised in one pass (spd_init_ensemble), and the time
  * loop in the overlapped form (spd_parallel_step_begin / _end: the range check of step k is collected after step k + 1 has
- * been enqueued).  Same arguments, same input and same output as examples/c_host.c, which does the same run with the
+ * been enqueued) for its first half and as ONE stretch (spd_parallel_steps_begin / _end) for its second.  Same arguments, same input and same output as examples/c_host.c, which does the same run with the
  * reference's own call sequence -- and the same bits in the result.
  *
  *     c_ensemble_host <bc.bin> <out.bin> <nsteps> [n_members = 2]
@@ -75,16 +75,28 @@ int main(int argc, char **argv) {
     }
     check(spd_init_ensemble(states, controls, codes, n), "init_ensemble");
     all_fine(codes, n, 0);
-    /* the time loop, two steps in flight */
-    check(spd_parallel_step_begin(states, controls, n, &token), "parallel_step_begin");
-    for (int it = 1; it < nsteps; ++it) {
-        check(spd_parallel_step_begin(states, controls, n, &next_token), "parallel_step_begin");
+    /* the time loop: the first half two steps in flight (a host that looks at every step's codes), the second half handed over as
+     * ONE stretch (a host that will not look at the state before it is over: every step's range check is recorded on the device) */
+    const int single = nsteps / 2, stretch = nsteps - single;
+    if (single > 0) {
+        check(spd_parallel_step_begin(states, controls, n, &token), "parallel_step_begin");
+        for (int it = 1; it < single; ++it) {
+            check(spd_parallel_step_begin(states, controls, n, &next_token), "parallel_step_begin");
+            check(spd_parallel_step_end(token, codes), "parallel_step_end");
+            all_fine(codes, n, it);
+            token = next_token;
+        }
         check(spd_parallel_step_end(token, codes), "parallel_step_end");
-        all_fine(codes, n, it);
-        token = next_token;
+        all_fine(codes, n, single);
     }
-    check(spd_parallel_step_end(token, codes), "parallel_step_end");
-    all_fine(codes, n, nsteps);
+    if (stretch > 0) {
+        int32_t done[MAX_MEMBERS];
+        check(spd_parallel_steps_begin(states, controls, n, stretch, &token), "parallel_steps_begin");
+        check(spd_parallel_steps_end(token, codes, done), "parallel_steps_end");
+        all_fine(codes, n, nsteps);
+        for (int m = 0; m < n; ++m)
+            if (done[m] != stretch) return 1;
+    }
     int32_t ymdhm[5], month_idx, code;
     check(spd_controlparams_get_model_datetime(controls[n - 1], ymdhm, &month_idx), "get_model_datetime");
     check(spd_driver_stats(states[0], &alive, &members), "driver_stats");

@@ -6,7 +6,9 @@
 !!
 !! One process, all GPUs of the node: spd_set_device_placement(spd_device_count) spreads the containers over the devices
 !! round-robin; member 1 reads the boundary file, spd_broadcast_boundary hands its fields to the other members device to
-!! device (xGMI); a single parallel_step then drives every device, enqueueing all of them before it waits for any.
+!! device (xGMI); a single parallel_step then drives every device, enqueueing all of them before it waits for any.  The last
+!! twelve steps are handed over as ONE stretch (spd_parallel_steps_begin / _end: a time loop in which nothing looks at the state
+!! in between; the range check of every step is recorded on the device).
 !!
 !!   fortran_ensemble_host <bc.bin> <out.bin> <nsteps>
 !! bc.bin as for fortran_host; member m gets its SST raised by 0.25 (m - 1) K.  out.bin: t_grid (96,48,8) of member 1,
@@ -19,8 +21,9 @@ program fortran_ensemble_host
     character(len=16), parameter :: names(12) = [character(len=16) :: "orog", "fmask_orig", "alb0", "veg_high", "veg_low", &
             "stl12", "snowd12", "soil_wc_l1", "soil_wc_l2", "soil_wc_l3", "sst12", "sea_ice_frac12"]
     integer, parameter :: planes(12) = [1, 1, 1, 1, 1, 12, 12, 12, 12, 12, 12, 12]
-    integer(c_int64_t) :: states(n), controls(n), d_start, d_end
-    integer(c_int32_t) :: codes(n), code, alive, members, y, mo, d, h, mi, ndev, dev
+    integer(c_int64_t) :: states(n), controls(n), d_start, d_end, token
+    integer(c_int32_t) :: codes(n), done(n), code, alive, members, y, mo, d, h, mi, ndev, dev
+    integer, parameter :: stretch = 12
     real(c_double), allocatable :: field(:, :, :), t_grid(:, :, :)
     character(len=512) :: arg
     integer :: i, m, istep, nsteps, u, uo
@@ -59,10 +62,16 @@ program fortran_ensemble_host
         if (code /= 0) stop "init failed"
     end do
 
-    do istep = 1, nsteps
+    do istep = 1, max(nsteps - stretch, 0)
         call check(spd_parallel_step(states, controls, codes, int(n, c_int32_t)), "parallel_step")
         if (any(codes /= 0)) stop "model variables out of range"
     end do
+    if (nsteps > 0) then
+        call check(spd_parallel_steps_begin(states, controls, int(n, c_int32_t), int(min(nsteps, stretch), c_int32_t), token), &
+                   "parallel_steps_begin")
+        call check(spd_parallel_steps_end(token, codes, done), "parallel_steps_end")
+        if (any(codes /= 0) .or. any(done /= min(nsteps, stretch))) stop "model variables out of range inside the stretch"
+    end if
     call check(spd_driver_stats(states(2), alive, members), "driver_stats")
     call check(spd_get_datetime(d_start, y, mo, d, h, mi), "get_datetime")
 

@@ -240,6 +240,20 @@ module pyspeedy_amd_c
             integer(c_int64_t), value :: token
             integer(c_int32_t), intent(out) :: error_codes(*)
         end function
+        ! extension: n_steps steps as ONE call, the range check of every step recorded on the device (the stretch of a time loop in
+        ! which nothing looks at the state); steps_done: the steps a member completed before its first failing one
+        integer(c_int) function spd_parallel_steps_begin(state_cnts, control_cnts, n_members, n_steps, token) &
+                bind(C, name="spd_parallel_steps_begin")
+            import :: c_int, c_int64_t, c_int32_t
+            integer(c_int64_t), intent(in) :: state_cnts(*), control_cnts(*)
+            integer(c_int32_t), value :: n_members, n_steps
+            integer(c_int64_t), intent(out) :: token
+        end function
+        integer(c_int) function spd_parallel_steps_end(token, error_codes, steps_done) bind(C, name="spd_parallel_steps_end")
+            import :: c_int, c_int64_t, c_int32_t
+            integer(c_int64_t), value :: token
+            integer(c_int32_t), intent(out) :: error_codes(*), steps_done(*)
+        end function
         integer(c_int) function spd_check(state_cnt, error_code) bind(C, name="spd_check")
             import :: c_int, c_int64_t, c_int32_t
             integer(c_int64_t), value :: state_cnt
@@ -293,6 +307,12 @@ module pyspeedy_amd_c
             import :: c_int, c_int64_t, c_int32_t
             integer(c_int64_t), intent(out) :: state_cnts(*)
             integer(c_int32_t), value :: n_members, n_devices   ! n_devices 0: the current device; k: blocks on devices 0 .. k-1
+        end function
+        integer(c_int) function spd_modelstate_init_ensemble_whole(state_cnts, n_members, n_devices) &
+                bind(C, name="spd_modelstate_init_ensemble_whole")
+            import :: c_int, c_int64_t, c_int32_t
+            integer(c_int64_t), intent(out) :: state_cnts(*)
+            integer(c_int32_t), value :: n_members, n_devices   ! ONE device model per device; n_devices < 0: the process-wide placement
         end function
         integer(c_int) function spd_driver_stats(state_cnt, models_alive, members_in_model) bind(C, name="spd_driver_stats")
             import :: c_int, c_int64_t, c_int32_t
