@@ -493,20 +493,29 @@ def _finish(callbacks):
 
 
 def _finish_all(callbacks, rest=None):
-    """_finish from the `finally` of a time loop, after what the hooks of the last boundary left to be done: a failure of the run
-    itself is not replaced by what a writer could not do -- the writer's error is attached to it (__context__ does that) and the
-    run's exception travels on; without one, the writer's is raised"""
+    """_finish from the `finally` of a time loop, after what the hooks of the last boundary left to be done (every item gets its
+    turn, and the hooks' finish() is called whatever one of them did): a failure of the run itself is not replaced by what a
+    writer could not do -- the writer's error is attached to it (__context__ does that) and the run's exception travels on;
+    without one, the first failure of the clean-up is raised"""
     import sys
     running = sys.exc_info()[1]
     _own(callbacks, False)
+    failure = None
+    while rest:
+        try:
+            rest.pop(0)()
+        except BaseException as exc:  # noqa: B902
+            failure = failure or exc
     try:
-        _do_rest(rest or [])
         _finish(callbacks)
     except BaseException as exc:  # noqa: B902
-        if running is None:
-            raise
-        if running.__context__ is None and exc is not running:
-            running.__context__ = exc
+        failure = failure or exc
+    if failure is None:
+        return
+    if running is None:
+        raise failure
+    if running.__context__ is None and failure is not running:
+        running.__context__ = failure
 
 
 def _callbacks_due(callbacks, model):

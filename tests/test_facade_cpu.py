@@ -419,3 +419,11 @@ def test_a_failing_writer_does_not_replace_the_runs_own_exception():
         finally:
             S._finish_all(hooks, [lambda: None])
     assert isinstance(failure.value.__context__, OSError) and [h.finished for h in hooks] == [1, 1]
+    # what a hook left to the loop is done first, every item of it, and a failure there does not keep the writers from being joined
+    hooks, done = [Hook(False)], []
+
+    def broken():
+        raise ValueError("header")
+    with pytest.raises(ValueError):
+        S._finish_all(hooks, [broken, lambda: done.append(1)])
+    assert done == [1] and hooks[0].finished == 1
