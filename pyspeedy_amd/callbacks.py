@@ -55,7 +55,17 @@ class DiagnosticCheck(BaseCallback):
         super().__init__(interval=interval)
 
     def fire(self, model_instance):
-        for member in ([model_instance] if isinstance(model_instance, Speedy) else model_instance):
+        members = [model_instance] if isinstance(model_instance, Speedy) else list(model_instance)
+        if len(members) > 1:
+            # one check per device model first; only when that finds something (or cannot be made) the reference's loop over the
+            # members (callbacks.py:96-112), which reports and raises as the reference does
+            from . import speedy_driver as _speedy
+            try:
+                if not _speedy.ensemble_check([member._state_cnt for member in members]).any():
+                    return
+            except RuntimeError:
+                pass
+        for member in members:
             member.check()
 
 
@@ -106,21 +116,30 @@ class XarrayExporter(_GridOutput):
         self._failure = None
         self._in_run = False  # set by the time loops of speedy.py around the run that owns this hook
 
+    def _behind(self, model_instance):
+        # (a single model's day is 0.8 MB: handing it to a thread costs more than writing it)
+        behind = self._in_run if self.background is None else bool(self.background)
+        return behind and getattr(model_instance, "n_members", 1) >= 8
+
+    def acts_ahead(self, model_instance):
+        """True when all `fire` will do with the model's state is enqueue device work (the transforms, the pack kernels and the
+        copies behind them): the time loop may then call it while the stretch of steps that ends at this output is still running
+        on the device (speedy._act_ahead), and drops what it returns if one of those steps fails its range check."""
+        return self._in_run and self._behind(model_instance)
+
     def fire(self, model_instance):
         target = os.path.join(self.output_dir, model_instance.current_date.strftime(self.filename_fmt))
         os.makedirs(self.output_dir, exist_ok=True)
         self.print_msg("Saving model output at: %s." % target)
-        # (a single model's day is 0.8 MB: handing it to a thread costs more than writing it)
-        behind = self._in_run if self.background is None else bool(self.background)
-        if not behind or getattr(model_instance, "n_members", 1) < 8:
+        if not self._behind(model_instance):
             model_instance.to_dataframe(variables=self.variables, packed=True, buffers=self._buffers).to_netcdf(target)
             return
         import threading
         slot = self._turn
         self._turn = 1 - slot
         self._wait(slot)  # (the buffer this output goes into may still be on its way to disk)
-        # (wait=False: the transforms and pack kernels are enqueued, the copies to this slot's pinned buffer run on a stream of their
-        # own beside the next stretch of the time loop; the writer waits for them)
+        # (wait=False: the transforms and pack kernels are enqueued; the writer thread waits for them, has the payload copied to
+        # this slot's pinned buffer by an SDMA engine beside the next stretch of the time loop, and writes the file)
         frame = model_instance.to_dataframe(variables=self.variables, packed=True, slot=slot, buffers=self._buffers, wait=False)
         ready = list(getattr(frame, "ready", ()))
         def hand_over():
@@ -130,8 +149,8 @@ class XarrayExporter(_GridOutput):
 
             def write():
                 try:
-                    for event in ready:
-                        event.synchronize()
+                    for copy in ready:
+                        copy.synchronize()
                     _dataset.write_prepared(target, prepared)
                 except BaseException as exc:  # noqa: B902 -- handed to the thread that owns the exporter
                     self._failure = exc

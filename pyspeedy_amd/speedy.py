@@ -321,16 +321,26 @@ class Speedy:
             try:
                 while self.current_date < end_date:
                     k = _stretch(self._step_in_run, intervals, self.current_date, end_date)
+                    before, step_before = self.current_date, self._step_in_run
                     token = _speedy.parallel_steps_begin([self._state_cnt], [self._control_cnt], k)
-                    _do_rest(rest)
+                    try:
+                        _do_rest(rest)
+                        self._step_in_run += k
+                        self.current_date += k * _DT_STEP
+                        due = _callbacks_due(callbacks, self)
+                        early = _act_ahead(due, self)  # (hooks that only enqueue device work do so behind the stretch, now)
+                    except BaseException:
+                        _end_quietly(token)
+                        raise
                     codes, done = _speedy.parallel_steps_end(token)
                     if (codes < 0).any():  # the date of the step before the one that failed, as the reference's loop leaves it
-                        self._step_in_run += int(done[0])
-                        self.current_date += int(done[0]) * _DT_STEP
-                        _raise_step_failure(codes)
-                    self._step_in_run += k
-                    self.current_date += k * _DT_STEP
-                    _act(_callbacks_due(callbacks, self), self, rest)
+                        self._step_in_run = step_before + int(done[0])
+                        self.current_date = before + int(done[0]) * _DT_STEP
+                        _raise_step_failure(codes)  # (what hooks enqueued ahead is dropped: nothing of it was written)
+                    if early is None:
+                        _act(due, self, rest)
+                    else:
+                        rest.extend(early)
             finally:
                 self._step_in_run = None
                 _finish_all(callbacks, rest)
@@ -469,6 +479,34 @@ def _act(due, model, rest):
 def _do_rest(rest):
     while rest:
         rest.pop(0)()
+
+
+def _act_ahead(due, model):
+    """The hooks due at the END of the stretch that has just been handed to the device, fired before the host waits for it --
+    possible when every one of them says (`acts_ahead(model)`, callbacks.XarrayExporter) that all its `fire` does with the model's
+    state is to ENQUEUE device work: that work then runs right behind the stretch's last step, in stream order, instead of after the
+    host has woken up, looked at the range checks and walked through the hook.  Returns what the hooks left to be done (the list
+    for `rest`) -- to be thrown away by the caller if a step of the stretch turns out to have failed its check: as in the reference
+    (speedy.py:398-405) nothing a hook produces ever comes from a state that failed it -- or None: some hook needs the state on
+    the host, all of them act after the stretch has been waited for, as before."""
+    if not due:
+        return []
+    for act in due:
+        ahead = getattr(getattr(act, "__self__", None), "acts_ahead", None)
+        if not callable(ahead) or not ahead(model):
+            return None
+    left = []
+    _act(due, model, left)
+    return left
+
+
+def _end_quietly(token):
+    """a stretch that was begun is ended on every way out of the loop (its device model takes no other call before that); the
+    exception that is under way is the one to report"""
+    try:
+        _speedy.parallel_steps_end(token)
+    except Exception:
+        pass
 
 
 def _own(callbacks, yes):
@@ -627,8 +665,9 @@ class SpeedyEns:
     def to_dataframe(self, variables=None, packed=False, slot=0, buffers=None, wait=True):
         """All members along the `ens` dimension: one batched spectral -> grid conversion and one device-to-host copy per
         variable (the device layout [member][lev][lat][lon] is already the export order).  packed=True: see Speedy.to_dataframe;
-        with wait=False (packed only) the Dataset comes back as soon as the work is enqueued and carries `ready`, the events after
-        which its arrays hold the payload (speedy_driver.ensemble_export_arrays)."""
+        with wait=False (packed only) the Dataset comes back as soon as the transforms and pack kernels are enqueued and carries
+        `ready`: its arrays hold the payload once `synchronize()` of every item of that list has returned -- which is also what
+        copies it out of the device (speedy_driver.ensemble_export_arrays; to be called from the thread that writes the file)."""
         variables = DEFAULT_OUTPUT_VARS if variables is None else variables
         for var in variables:
             _exportable(var)
@@ -689,23 +728,33 @@ class SpeedyEns:
             try:
                 while self.current_date < end_date:
                     k = _stretch(step, intervals, self.current_date, end_date)
+                    before = self.current_date
                     token = _speedy.parallel_steps_begin(state_cnts, control_cnts, k)
-                    _do_rest(rest)
+                    try:
+                        _do_rest(rest)
+                        step += k
+                        self.current_date += k * _DT_STEP
+                        for member in self:
+                            member.current_date = self.current_date
+                            member._step_in_run = step
+                        due = _callbacks_due(callbacks, self)
+                        early = _act_ahead(due, self)  # (see Speedy.run)
+                    except BaseException:
+                        _end_quietly(token)
+                        raise
                     codes, done = _speedy.parallel_steps_end(token)
                     if (codes < 0).any():
                         # The reference's loop (speedy.py:572-586) stops at the first step any member fails; it has moved the
                         # ENSEMBLE's date past that step by then and not yet handed it to the members, who keep the date before it.
                         first = int(done[codes < 0].min())
                         for member in self:
-                            member.current_date = self.current_date + first * _DT_STEP
-                        self.current_date += (first + 1) * _DT_STEP
+                            member.current_date = before + first * _DT_STEP
+                        self.current_date = before + (first + 1) * _DT_STEP
                         _raise_step_failure(codes)
-                    step += k
-                    self.current_date += k * _DT_STEP
-                    for member in self:
-                        member.current_date = self.current_date
-                        member._step_in_run = step
-                    _act(_callbacks_due(callbacks, self), self, rest)
+                    if early is None:
+                        _act(due, self, rest)
+                    else:
+                        rest.extend(early)
             finally:
                 for member in self:
                     member._step_in_run = None

@@ -273,6 +273,20 @@ def check(state_cnt):
     return code.value
 
 
+def ensemble_check(state_cnts):
+    """Extension: `check` for many containers at once -- ONE range check per device model instead of one per container (each of
+    which checks its whole model and picks its member: 64 launches and waits for a 64-member ensemble).  int32 codes in the order
+    of `state_cnts`; nothing is printed: a caller that finds a failure asks `check` of that container for the reference's report."""
+    import torch
+    order, groups = _group_by_model(state_cnts)
+    codes = np.zeros(len(state_cnts), dtype=np.int32)
+    for k in order:
+        model, positions, members = groups[k]
+        with torch.cuda.device(model.sp.device):
+            codes[positions] = model.check(time_level=1)[members]  # (time level 1, as spd_check)
+    return codes
+
+
 def transform_spectral2grid(state_cnt):
     _ok(_L().spd_transform_spectral2grid(int(state_cnt)), "transform_spectral2grid")
 
@@ -377,6 +391,30 @@ def _export_copy_stream(device):
     return _export_copy_streams[device]
 
 
+class _CopyOut:
+    """The copy of a packed output from its device staging area to the pinned buffer, for whoever writes the file: `synchronize()`
+    waits for the pack kernels, THEN hands the copy to the runtime on a stream that has nothing pending, and waits for it.
+    The order matters.  A hipMemcpyAsync enqueued behind a pending command of its stream (the wait for the pack kernels) is carried
+    out by the runtime's blit kernel, and a kernel that writes host memory holds up every other kernel on the GPU for as long as
+    it runs -- the next steps of the time loop lost the copy's whole 0.9 ms per simulated day at 64 members, with any number of
+    workgroups (profiles/r06_export_copy_out.txt); on an idle stream the same call goes to an SDMA engine and costs the steps
+    nothing.  Waiting first needs a host thread: the file writer's (callbacks.XarrayExporter), not the time loop's."""
+
+    def __init__(self, device, packed, buf, stage, pieces, side):
+        self.device, self.packed, self.buf, self.stage, self.pieces, self.side = device, packed, buf, stage, pieces, side
+
+    def synchronize(self):
+        import torch
+        if self.pieces is None:
+            return
+        pieces, self.pieces = self.pieces, None
+        self.packed.synchronize()
+        with torch.cuda.device(self.device), torch.cuda.stream(self.side):
+            for start, nbytes in pieces:
+                self.buf[start:start + nbytes].copy_(self.stage[start:start + nbytes], non_blocking=True)
+        self.side.synchronize()
+
+
 _export_buffers = {}  # (bytes, slot) -> pinned uint8 tensor, kept for the life of the process (a day's output of 64 members: 48 MB)
 
 
@@ -387,10 +425,11 @@ def ensemble_export_arrays(state_cnts, names, slot=0, buffers=None, wait=True):
     on the GPU; what crosses PCIe is the file's payload itself (half the bytes of the fp64 fields), into pinned host memory.
     The arrays alias a pinned buffer that the next call with the same `slot` overwrites: the process-wide one of that slot, or --
     `buffers`, a dict the caller owns (an exporter that writes its files in the background keeps two of its own) -- buffers[slot].
-    wait=False: returns (arrays, events) as soon as the transforms and the pack kernels are ENQUEUED; the copies to pinned memory
-    run on a stream of their own beside whatever the caller enqueues next (the next stretch of the time loop), and the arrays hold
-    the payload once every event of the list has completed (`event.synchronize()`, e.g. in the thread that writes the file).  The
-    device staging area is per slot then: a slot must not be asked for again before its events have completed."""
+    wait=False: returns (arrays, copies) as soon as the transforms and the pack kernels are ENQUEUED -- nothing has been copied
+    yet.  Every item of `copies` has a `synchronize()` that waits for the pack kernels, copies that device model's part of the
+    payload to the pinned buffer and waits for it (_CopyOut: from a thread of the caller's, e.g. the one that writes the file,
+    while the time loop goes on); the arrays hold the payload when all of them have returned.  The device staging area is per
+    slot then: a slot must not be asked for again before that."""
     import torch
     order, groups = _group_by_model(state_cnts)
     n = len(state_cnts)
@@ -437,8 +476,6 @@ def ensemble_export_arrays(state_cnts, names, slot=0, buffers=None, wait=True):
                 if not wait:  # the copies behind the pack kernels, on a stream that does not hold up what the caller enqueues next
                     packed = torch.cuda.Event()
                     packed.record(here)
-                    side = _export_copy_stream(model.sp.device)
-                    side.wait_event(packed)
                     pieces.sort()
                     merged = [list(pieces[0])]
                     for start, nbytes in pieces[1:]:  # (a model that holds every member in order: ONE copy of the whole payload)
@@ -446,12 +483,7 @@ def ensemble_export_arrays(state_cnts, names, slot=0, buffers=None, wait=True):
                             merged[-1][1] += nbytes
                         else:
                             merged.append([start, nbytes])
-                    with torch.cuda.stream(side):
-                        for start, nbytes in merged:
-                            buf[start:start + nbytes].copy_(stage[start:start + nbytes], non_blocking=True)
-                        done = torch.cuda.Event()
-                        done.record(side)
-                    events.append(done)
+                    events.append(_CopyOut(model.sp.device, packed, buf, stage, merged, _export_copy_stream(model.sp.device)))
             continue
         asynchronous = False  # (a selection of members in another order goes through torch ops on the current stream: waited for)
         index = torch.as_tensor(members, device=model.sp.device)

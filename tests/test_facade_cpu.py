@@ -427,3 +427,42 @@ def test_a_failing_writer_does_not_replace_the_runs_own_exception():
     with pytest.raises(ValueError):
         S._finish_all(hooks, [broken, lambda: done.append(1)])
     assert done == [1] and hooks[0].finished == 1
+
+
+def test_hooks_that_only_enqueue_device_work_act_while_the_stretch_is_still_running():
+    """speedy._act_ahead: the hooks due at the end of a stretch fire before the host waits for it when ALL of them declare
+    (`acts_ahead`) that they only enqueue device work; one that needs the state on the host keeps every hook behind the wait, in
+    the order given.  XarrayExporter declares it only for what it writes in the background of a run that owns it."""
+    from pyspeedy_amd import speedy as S
+    from pyspeedy_amd.callbacks import BaseCallback, DiagnosticCheck, XarrayExporter
+    done = []
+
+    class Ahead(BaseCallback):
+        def acts_ahead(self, model_instance):
+            return True
+
+        def fire(self, model_instance):
+            done.append("enqueued")
+            return lambda: done.append("written")
+
+    class Model:
+        n_members = 64
+
+    assert S._act_ahead([], Model()) == []  # (nothing due: nothing to wait with)
+    left = S._act_ahead([Ahead().fire, Ahead().fire], Model())
+    assert done == ["enqueued", "enqueued"] and len(left) == 2
+    S._do_rest(left)
+    assert done[2:] == ["written", "written"]
+    del done[:]
+    assert S._act_ahead([Ahead().fire, DiagnosticCheck(36).fire], Model()) is None and done == []
+    assert S._act_ahead([lambda m: None], Model()) is None
+    exporter = XarrayExporter(interval=36)
+    assert not exporter.acts_ahead(Model())  # called by hand it writes inside the call
+    exporter._in_run = True
+    assert exporter.acts_ahead(Model())
+    Model.n_members = 1
+    assert not exporter.acts_ahead(Model())  # (a single model's file is written at once)
+    Model.n_members = 64
+    assert not XarrayExporter(background=False).acts_ahead(Model())
+    by_hand = XarrayExporter(background=True)
+    assert not by_hand.acts_ahead(Model())  # (outside a run there is no time loop to be ahead of)

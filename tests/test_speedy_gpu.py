@@ -158,6 +158,34 @@ def test_exceptions(gold, capfd):
         model["no_such_variable"]
 
 
+def test_diagnostic_check_of_an_ensemble_is_one_check_per_device_model(capfd, monkeypatch):
+    """callbacks.DiagnosticCheck on a SpeedyEns: the reference loops over the members (callbacks.py:96-112), each of which would
+    launch and wait for a check of its whole device model; here ONE check per device model answers for all of them, and only a
+    failure goes through the reference's loop -- same RuntimeError, same two lines on stderr."""
+    from pyspeedy_amd.callbacks import DiagnosticCheck
+    from pyspeedy_amd.error_codes import ERROR_CODES
+    from pyspeedy_amd.speedy import SpeedyEns
+    ens = SpeedyEns(5, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 1, 2, 0))
+    ens.set_bc()
+    ens.run()
+    from pyspeedy_amd import speedy_driver
+    asked, per_container = [], speedy_driver.check
+    monkeypatch.setattr(speedy_driver, "check", lambda cnt: asked.append(cnt) or per_container(cnt))
+    DiagnosticCheck(interval=1)(ens)
+    assert asked == []  # (no container was asked on its own)
+    assert list(speedy_driver.ensemble_check([m._state_cnt for m in ens])) == [0] * 5
+    t = ens.members[3]["t"]
+    t[:] = 0
+    ens.members[3]["t"] = t
+    assert list(speedy_driver.ensemble_check([m._state_cnt for m in reversed(ens.members)])) == [0, -2, 0, 0, 0]
+    capfd.readouterr()
+    with pytest.raises(RuntimeError) as failure:
+        DiagnosticCheck(interval=1)(ens)
+    assert str(failure.value) == ERROR_CODES[-2]
+    assert asked == [m._state_cnt for m in ens.members[:4]]  # the reference's loop, up to the member that fails
+    assert capfd.readouterr().err == " Model variables out of accepted range\n step =%12d\n" % 3
+
+
 @pytest.mark.parametrize("variables", export_variables)
 def test_speedy_variable_export(variables):
     from pyspeedy_amd.callbacks import XarrayExporter
@@ -510,6 +538,20 @@ def test_a_range_failure_in_the_middle_of_a_stretch_is_the_reference_loops_failu
     # members, speedy.py:572-586: they keep the date before that step)
     assert ens.current_date == start + (f + 1) * dt and probe.seen == []
     assert all(member.current_date == start + f * dt for member in ens)
+    # an exporter that writes in the background enqueues its transforms and copies BEHIND the stretch, before the host has seen the
+    # stretch's range checks (speedy._act_ahead): of the stretch in which a member fails, nothing reaches the disk
+    from pyspeedy_amd.callbacks import XarrayExporter
+    ens = SpeedyEns(8, start_date=start, end_date=datetime(1982, 1, 3))
+    for i, member in enumerate(ens):
+        member.set_bc(bc_file=hot if i == 5 else None)
+    ens.members[5]["t"] = _heat(ens.members[5]["t"])
+    with tempfile.TemporaryDirectory() as tmp:
+        exporter = XarrayExporter(output_dir=tmp, interval=4)
+        with pytest.raises(RuntimeError):
+            ens.run(callbacks=[exporter])
+        capfd.readouterr()
+        assert sorted(os.listdir(tmp)) == [(start + s * dt).strftime("%Y-%m-%d_%H%M.nc") for s in range(4, f + 1, 4)]
+        assert ens.current_date == start + (f + 1) * dt and not exporter._in_run and exporter._pending == [None, None]
 
 
 def test_stretches_between_due_callbacks_leave_the_state_of_the_step_by_step_loop():

@@ -41,7 +41,11 @@ DS.prepare_netcdf = timed("export: NetCDF header", DS.prepare_netcdf)
 DS.write_prepared = timed("writer thread: write the file", DS.write_prepared)
 CB.XarrayExporter.fire = timed("export: fire() in all", CB.XarrayExporter.fire)
 
-for export in (False, True, True, True):  # (the first run of each kind pays what a process pays once: pinned buffers, code objects)
+_act_ahead = SP._act_ahead
+# (the first run of each kind pays what a process pays once: pinned buffers, code objects; ahead = the exporter enqueues its device
+# work behind the stretch before the host has waited for it, speedy._act_ahead -- off: it acts after the wait, as until round 6)
+for export, ahead in ((False, True), (True, False), (True, False), (True, False), (True, True), (True, True), (True, True)):
+    SP._act_ahead = _act_ahead if ahead else (lambda due, model: None if due else [])
     ens = SP.SpeedyEns(M, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 1) + timedelta(days=days))
     ens.set_bc()
     with tempfile.TemporaryDirectory(prefix="pyspeedy_perf_", dir=where) as tmp:
@@ -52,7 +56,8 @@ for export in (False, True, True, True):  # (the first run of each kind pays wha
         torch.cuda.synchronize()
         total = time.perf_counter() - t0
         nbytes = sum(os.path.getsize(os.path.join(tmp, f)) for f in os.listdir(tmp))
-    print("%d members, %d days, daily export %s: %.4f ms per step, %.1f MB written" % (M, days, "on" if export else "off", total / (36 * days) * 1e3, nbytes / 1e6))
+    print("%d members, %d days, daily export %s%s: %.4f ms per step, %.1f MB written"
+          % (M, days, "on" if export else "off", (", enqueued ahead" if ahead else ", after the wait") if export else "", total / (36 * days) * 1e3, nbytes / 1e6))
     for name, ts in sorted(acc.items()):
         print("   %-62s n=%3d  total %8.2f ms  mean %8.3f ms  max %8.3f ms" % (name, len(ts), sum(ts) * 1e3, sum(ts) / len(ts) * 1e3, max(ts) * 1e3))
     del ens
