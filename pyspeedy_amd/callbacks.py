@@ -98,12 +98,15 @@ class XarrayExporter(_GridOutput):
     """Writes the selected grid-space variables to `output_dir/<model date formatted with filename_fmt>`.
 
     The file's payload (float32, big-endian, levels bottom-up) is formed on the GPU and copied out as such
-    (`to_dataframe(packed=True)`).  `background=None` (the default): while a `Speedy.run` / `SpeedyEns.run` owns the hook, the file
-    of an ensemble of 8 members or more is written by a thread of this exporter while the model goes on stepping -- two output
-    buffers alternate, a third output waits for the first file to be finished -- and the run calls `finish()` when it ends, also
-    when it ends with an exception: every file is on disk then (and what the writer could not do is raised).  Called by hand,
-    outside a run, the hook writes inside the call, as the reference's exporter does: the file is complete when it returns.
-    `background=True` writes in the background wherever it is called (the caller owes a `finish()`), `background=False` never."""
+    (`to_dataframe(packed=True)`).  `background=None` (the default): while a `Speedy.run` / `SpeedyEns.run` owns the hook, `fire`
+    only enqueues the transforms and the pack kernels (the run may call it while the steps that lead to this output are still on
+    the device, `acts_ahead`); the copy to pinned memory, the header and the file follow once the next stretch of steps has been
+    handed to the device -- for an ensemble of 8 members or more in a thread of this exporter (two output buffers alternate, a
+    third output waits for the first file to be finished), for anything smaller in the time loop's own thread.  The run calls
+    `finish()` when it ends, also when it ends with an exception: every file is on disk then (and what the writer could not do is
+    raised).  Called by hand, outside a run, the hook writes inside the call, as the reference's exporter does: the file is
+    complete when it returns.  `background=True` defers wherever it is called (the caller owes a `finish()`), `background=False`
+    never does."""
 
     def __init__(self, interval=36, verbose=False, spinup_date=None, variables=None, output_dir="./",
                  filename_fmt="%Y-%m-%d_%H%M.nc", background=None):
@@ -116,32 +119,40 @@ class XarrayExporter(_GridOutput):
         self._failure = None
         self._in_run = False  # set by the time loops of speedy.py around the run that owns this hook
 
-    def _behind(self, model_instance):
-        # (a single model's day is 0.8 MB: handing it to a thread costs more than writing it)
-        behind = self._in_run if self.background is None else bool(self.background)
-        return behind and getattr(model_instance, "n_members", 1) >= 8
+    def _deferred(self):
+        """whether the file is finished after `fire` has returned (the run that owns the hook, or the caller, owes a finish())"""
+        return self._in_run if self.background is None else bool(self.background)
 
     def acts_ahead(self, model_instance):
-        """True when all `fire` will do with the model's state is enqueue device work (the transforms, the pack kernels and the
-        copies behind them): the time loop may then call it while the stretch of steps that ends at this output is still running
-        on the device (speedy._act_ahead), and drops what it returns if one of those steps fails its range check."""
-        return self._in_run and self._behind(model_instance)
+        """True when all `fire` will do with the model's state is enqueue device work (the transforms and the pack kernels): the
+        time loop may then call it while the stretch of steps that ends at this output is still running on the device
+        (speedy._act_ahead), and drops what it returns if one of those steps fails its range check."""
+        return self._in_run and self._deferred()
 
     def fire(self, model_instance):
         target = os.path.join(self.output_dir, model_instance.current_date.strftime(self.filename_fmt))
         os.makedirs(self.output_dir, exist_ok=True)
         self.print_msg("Saving model output at: %s." % target)
-        if not self._behind(model_instance):
+        if not self._deferred():
             model_instance.to_dataframe(variables=self.variables, packed=True, buffers=self._buffers).to_netcdf(target)
             return
-        import threading
         slot = self._turn
         self._turn = 1 - slot
         self._wait(slot)  # (the buffer this output goes into may still be on its way to disk)
-        # (wait=False: the transforms and pack kernels are enqueued; the writer thread waits for them, has the payload copied to
-        # this slot's pinned buffer by an SDMA engine beside the next stretch of the time loop, and writes the file)
+        # (wait=False: the transforms and pack kernels are enqueued, nothing else; whoever writes the file waits for them and has
+        # the payload copied to this slot's pinned buffer -- by an SDMA engine, beside the next stretch of the time loop)
         frame = model_instance.to_dataframe(variables=self.variables, packed=True, slot=slot, buffers=self._buffers, wait=False)
         ready = list(getattr(frame, "ready", ()))
+        if getattr(model_instance, "n_members", 1) < 8:
+            # (a single model's day is 0.8 MB: handing it to a thread costs more than writing it -- the time loop's own thread
+            # does, once the next stretch is on the device)
+            def write_now():
+                for copy in ready:
+                    copy.synchronize()
+                _dataset.write_prepared(target, _dataset.prepare_netcdf(frame))
+            return write_now
+        import threading
+
         def hand_over():
             # (the header is made here, not in the writer: a thread that runs Python code competes with the time loop for the
             # interpreter lock, one that only waits and writes bytes does not)
@@ -156,8 +167,7 @@ class XarrayExporter(_GridOutput):
                     self._failure = exc
             self._pending[slot] = threading.Thread(target=write, name="pyspeedy_amd-export", daemon=False)
             self._pending[slot].start()
-        # (what needed the state -- transforms, pack kernels, the copies behind them -- is enqueued; the rest is the time loop's to
-        # call once the next stretch is on the device)
+        # (what needed the state is enqueued; the rest is the time loop's to call once the next stretch is on the device)
         return hand_over
 
     def _wait(self, slot):

@@ -404,18 +404,21 @@ class Speedy:
             raise RuntimeError(ERROR_CODES[code])
 
     # ---- export ----------------------------------------------------------------------------------------------
-    def to_dataframe(self, variables=None, packed=False, slot=0, buffers=None):
+    def to_dataframe(self, variables=None, packed=False, slot=0, buffers=None, wait=True):
         """Current model state as a Dataset following the export conventions of the reference (speedy.py:415-477).
         packed=True (extension, what XarrayExporter asks for): the data variables come as they go into a NetCDF-3 file -- float32,
         big-endian, narrowed and ordered on the GPU -- and alias a buffer that the next packed call with the same `slot` (of the same
-        `buffers` dict, when the caller brings its own) overwrites."""
+        `buffers` dict, when the caller brings its own) overwrites.  wait=False (packed only): see SpeedyEns.to_dataframe."""
         variables = DEFAULT_OUTPUT_VARS if variables is None else variables
         if packed:
             for var in variables:
                 _exportable(var)
-            arrays = _speedy.ensemble_export_arrays([self._state_cnt], list(variables), slot=slot, buffers=buffers)
+            arrays = _speedy.ensemble_export_arrays([self._state_cnt], list(variables), slot=slot, buffers=buffers, wait=wait)
+            arrays, ready = arrays if not wait else (arrays, [])
             members = [self.member_id] if self.is_ensemble_member else None
-            return _build_dataset(self, arrays, members, self.current_date, packed=True)
+            frame = _build_dataset(self, arrays, members, self.current_date, packed=True)
+            frame.ready = ready
+            return frame
         self.spectral2grid()
         arrays = {}
         for var in variables:

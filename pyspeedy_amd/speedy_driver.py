@@ -376,11 +376,14 @@ _export_stages = {}  # (device, slot) -> uint8 staging tensor on that device (gr
 _export_copy_streams = {}  # device -> the stream the copies to pinned memory of a packed export run on when the caller does not wait
 
 
-def _export_stage(device, nbytes, slot=0):
+def _export_stage(pool, device, nbytes, slot=0):
+    """the device staging area of a packed export: the process-wide one of (device, slot), or -- `pool`, the caller's own `buffers`
+    dict -- that caller's (two exporters of one run must not pack into the same area: with wait=False the copy out of it comes later)"""
     import torch
-    have = _export_stages.get((device, slot))
+    pool, key = (_export_stages, (device, slot)) if pool is None else (pool, ("stage", device, slot))
+    have = pool.get(key)
     if have is None or have.numel() < nbytes:
-        have = _export_stages[(device, slot)] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        have = pool[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
     return have
 
 
@@ -424,7 +427,8 @@ def ensemble_export_arrays(state_cnts, names, slot=0, buffers=None, wait=True):
     array of dtype '>f4' [member, (lev,) lat, lon] in the order of `state_cnts`.  Narrowing, level reversal and byte order happen
     on the GPU; what crosses PCIe is the file's payload itself (half the bytes of the fp64 fields), into pinned host memory.
     The arrays alias a pinned buffer that the next call with the same `slot` overwrites: the process-wide one of that slot, or --
-    `buffers`, a dict the caller owns (an exporter that writes its files in the background keeps two of its own) -- buffers[slot].
+    `buffers`, a dict the caller owns (an exporter that writes its files in the background keeps two of its own) -- buffers[slot]
+    (the device staging areas of that caller live in the same dict).
     wait=False: returns (arrays, copies) as soon as the transforms and the pack kernels are ENQUEUED -- nothing has been copied
     yet.  Every item of `copies` has a `synchronize()` that waits for the pack kernels, copies that device model's part of the
     payload to the pinned buffer and waits for it (_CopyOut: from a thread of the caller's, e.g. the one that writes the file,
@@ -458,7 +462,7 @@ def ensemble_export_arrays(state_cnts, names, slot=0, buffers=None, wait=True):
             # (spd_model_export_pack), one copy takes it to the pinned buffer
             # (the staging area is laid out like the pinned buffer: the device models of a call write to disjoint parts of it, so
             # the copies of one -- which, unwaited for, run on another stream -- are not overtaken by the pack kernels of the next)
-            stage = _export_stage(model.sp.device, total, slot if not wait else 0)
+            stage = _export_stage(buffers, model.sp.device, total, slot if not wait else 0)
             with torch.cuda.device(model.sp.device):
                 here = torch.cuda.current_stream()
                 stream = C.c_void_p(here.cuda_stream)

@@ -461,7 +461,7 @@ def test_hooks_that_only_enqueue_device_work_act_while_the_stretch_is_still_runn
     exporter._in_run = True
     assert exporter.acts_ahead(Model())
     Model.n_members = 1
-    assert not exporter.acts_ahead(Model())  # (a single model's file is written at once)
+    assert exporter.acts_ahead(Model())  # (a single model's file is written by the time loop itself, behind the next stretch)
     Model.n_members = 64
     assert not XarrayExporter(background=False).acts_ahead(Model())
     by_hand = XarrayExporter(background=True)

@@ -427,6 +427,28 @@ def test_packed_export_writes_the_same_file():
         np.testing.assert_array_equal(some[name], want.astype(np.float32))
 
 
+def test_unwaited_packed_export_is_the_waited_one_and_callers_do_not_share_a_staging_area():
+    """speedy_driver.ensemble_export_arrays(wait=False) only enqueues the transforms and the pack kernels; `synchronize()` of what it
+    returns copies the payload out (by then another caller may have packed its own output: each caller's `buffers` holds its own
+    device staging area) and may be called again."""
+    from pyspeedy_amd import speedy_driver
+    from pyspeedy_amd.speedy import SpeedyEns
+    ens = SpeedyEns(3, start_date=datetime(1982, 1, 1), end_date=datetime(1982, 1, 1, 2, 0))
+    ens.set_bc()
+    ens.run()
+    cnts, names = [m._state_cnt for m in ens], ["t_grid", "ps_grid", "u_grid"]
+    waited = {k: v.copy() for k, v in speedy_driver.ensemble_export_arrays(cnts, names).items()}
+    mine, other = {}, {}
+    arrays, copies = speedy_driver.ensemble_export_arrays(cnts, names, slot=1, buffers=mine, wait=False)
+    arrays2, copies2 = speedy_driver.ensemble_export_arrays(cnts, ["u_grid", "v_grid", "ps_grid"], slot=1, buffers=other, wait=False)
+    assert len(copies) == 1 and any(isinstance(k, tuple) and k[0] == "stage" for k in mine)
+    for copy in copies + copies2 + copies:
+        copy.synchronize()
+    for k in names:
+        assert arrays[k].dtype == np.dtype(">f4") and np.array_equal(arrays[k], waited[k]), k
+    assert np.array_equal(arrays2["u_grid"], waited["u_grid"]) and np.array_equal(arrays2["ps_grid"], waited["ps_grid"])
+
+
 def test_background_writer_leaves_the_same_files():
     """XarrayExporter writes its files from a thread of its own while the model steps on (two buffers in turn); `run` returns when
     all of them are on disk.  Seven outputs of an 8-member ensemble, byte for byte the files of the in-callback writer; a writer
