@@ -83,15 +83,26 @@ class _GridOutput(BaseCallback):
 
 
 class ModelCheckpoint(_GridOutput):
-    """Accumulates the selected grid-space variables as a time series in memory (`dataframe`)."""
+    """Accumulates the selected grid-space variables as a time series in memory (`dataframe`).  The reference joins every new
+    snapshot to the series at once (callbacks.py:175-180, an outer merge: a copy of everything kept so far per output); here the snapshots are
+    kept as they come and joined when `dataframe` is read -- the same Dataset, one copy."""
 
     def __init__(self, interval=36, verbose=False, spinup_date=None, variables=None, output_dir="./"):
         super().__init__(interval, verbose, spinup_date, variables, output_dir)
-        self.dataframe = None
+        self._frames = []
+
+    @property
+    def dataframe(self):
+        if len(self._frames) > 1:
+            self._frames = [_dataset.concat(self._frames, "time")]
+        return self._frames[0] if self._frames else None
+
+    @dataframe.setter
+    def dataframe(self, value):
+        self._frames = [] if value is None else [value]
 
     def fire(self, model_instance):
-        now = self.snapshot(model_instance)
-        self.dataframe = now if self.dataframe is None else _dataset.concat((self.dataframe, now), "time")
+        self._frames.append(self.snapshot(model_instance))
 
 
 class XarrayExporter(_GridOutput):

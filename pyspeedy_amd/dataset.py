@@ -144,10 +144,11 @@ def concat(datasets, dim):
     labels = np.concatenate([d.coords[dim].values for d in datasets])
     order = np.argsort(labels, kind="stable")
     data = {}
+    in_order = bool((order == np.arange(len(order))).all())  # (the usual case, a time series in the making: no second copy)
     for name, v in first.data_vars.items():
         ax = v.dims.index(dim)
-        data[name] = Variable(v.dims, np.take(np.concatenate([d.data_vars[name].values for d in datasets], axis=ax), order, axis=ax),
-                              v.attrs)
+        joined = np.concatenate([d.data_vars[name].values for d in datasets], axis=ax)
+        data[name] = Variable(v.dims, joined if in_order else np.take(joined, order, axis=ax), v.attrs)
     coords = dict(first.coords)
     coords[dim] = Variable((dim,), labels[order], first.coords[dim].attrs)
     return Dataset(data, coords, first.attrs)

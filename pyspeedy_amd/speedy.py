@@ -679,9 +679,11 @@ class SpeedyEns:
         if packed and not wait:
             arrays, ready = _speedy.ensemble_export_arrays(cnts, list(variables), slot=slot, buffers=buffers, wait=False)
         else:
+            # (not packed: float32 with the levels bottom-up all the same, formed on the GPU -- in the host's byte order and in
+            # memory of the Dataset's own, for hooks that keep what they are given)
             arrays = (_speedy.ensemble_export_arrays(cnts, list(variables), slot=slot, buffers=buffers) if packed else
-                      _speedy.ensemble_grid_arrays(cnts, list(variables)))
-        frame = _build_dataset(self.members[0], arrays, [m.member_id for m in self], self.current_date, packed=packed)
+                      _speedy.ensemble_grid_arrays(cnts, list(variables), narrow=True))
+        frame = _build_dataset(self.members[0], arrays, [m.member_id for m in self], self.current_date, packed=True)
         frame.ready = ready
         return frame
 

@@ -353,23 +353,36 @@ def ensemble_device_view(state_cnts, name, spectral2grid=False):
     return torch.stack([models[key][member].to(device) for key, member in where])
 
 
-def ensemble_grid_arrays(state_cnts, names):
+def ensemble_grid_arrays(state_cnts, names, narrow=False):
     """Extension: the grid-space variables `names` of the given containers (one container: of ALL members of the batched model
     it belongs to), after one batched spectral2grid per device model: dict name -> float64 array [member, (lev,) lat, lon]
-    in the order of `state_cnts` (one device-to-host copy per variable and device model)."""
+    in the order of `state_cnts` (one device-to-host copy per variable and device model).  narrow=True: as a Dataset of the
+    reference carries them (speedy.py:415-477) -- float32, vertical levels bottom-up --, narrowed and turned on the GPU: half the
+    bytes cross PCIe and the host makes no pass of its own over them (IEEE rounding to nearest either way: the same values)."""
+    import torch
+
+    def fetch(model, name):
+        v = model.device_view(name)
+        if narrow:
+            v = (v.flip(1) if v.ndim == 4 else v).to(torch.float32)
+        return v.cpu().numpy()
     if np.ndim(state_cnts) == 0:
         model, _ = device_model(state_cnts)
         model.spectral2grid()
-        return {n: model.device_view(n).cpu().numpy() for n in names}
-    models, where = {}, []
-    for cnt in state_cnts:
-        model, member = device_model(cnt)
-        key = model._m.value
-        if key not in models:
-            model.spectral2grid()
-            models[key] = {n: model.device_view(n).cpu().numpy() for n in names}
-        where.append((key, member))
-    return {n: np.stack([models[key][n][member] for key, member in where]) for n in names}
+        return {n: fetch(model, n) for n in names}
+    order, groups = _group_by_model(state_cnts)
+    for k in order:
+        groups[k][0].spectral2grid()
+    if len(order) == 1 and groups[order[0]][2] == list(range(groups[order[0]][0].nmembers)):
+        return {n: fetch(groups[order[0]][0], n) for n in names}  # (every member of ONE model, in order: the copy itself)
+    out = {}
+    for n in names:
+        parts = {k: fetch(groups[k][0], n) for k in order}
+        first = parts[order[0]]
+        out[n] = np.empty((len(state_cnts),) + first.shape[1:], dtype=first.dtype)
+        for k in order:
+            out[n][groups[k][1]] = parts[k][groups[k][2]]
+    return out
 
 
 _export_stages = {}  # (device, slot) -> uint8 staging tensor on that device (grown on demand)

@@ -466,3 +466,39 @@ def test_hooks_that_only_enqueue_device_work_act_while_the_stretch_is_still_runn
     assert not XarrayExporter(background=False).acts_ahead(Model())
     by_hand = XarrayExporter(background=True)
     assert not by_hand.acts_ahead(Model())  # (outside a run there is no time loop to be ahead of)
+
+
+def test_model_checkpoint_joins_its_snapshots_when_the_series_is_read():
+    """callbacks.ModelCheckpoint keeps the snapshots as they come and joins them when `dataframe` is read (the reference merges at
+    every output, callbacks.py:175-180: the same Dataset in the end); dataset.concat orders by the coordinate, and a series that is
+    in order already is not copied a second time."""
+    from pyspeedy_amd.callbacks import ModelCheckpoint
+    from pyspeedy_amd.dataset import Dataset, Variable, concat
+
+    def frame(day, value):
+        return Dataset({"t": Variable(("time", "lat"), np.full((1, 3), value, dtype=np.float32))},
+                       {"time": Variable(("time",), np.array([np.datetime64("1982-01-%02d" % day, "s")])),
+                        "lat": Variable(("lat",), np.arange(3, dtype=np.float32))})
+
+    class Model:
+        def __init__(self):
+            self.day = 0
+
+        def to_dataframe(self, variables=None):
+            self.day += 1
+            return frame(self.day, float(self.day))
+
+    keep, model = ModelCheckpoint(interval=1), Model()
+    assert keep.dataframe is None
+    for _ in range(3):
+        keep.fire(model)
+    assert len(keep._frames) == 3
+    series = keep.dataframe
+    assert series["t"].values.shape == (3, 3) and list(series["t"].values[:, 0]) == [1.0, 2.0, 3.0]
+    assert keep.dataframe is series and len(keep._frames) == 1  # (joined once)
+    keep.fire(model)
+    assert keep.dataframe["t"].values.shape == (4, 3) and keep.copy().dataframe["t"].values.shape == (4, 3)
+    keep.dataframe = None
+    assert keep.dataframe is None and keep._frames == []
+    mixed = concat([frame(3, 3.0), frame(1, 1.0), frame(2, 2.0)], "time")
+    assert list(mixed["t"].values[:, 0]) == [1.0, 2.0, 3.0] and list(mixed["time"].values) == sorted(mixed["time"].values)
