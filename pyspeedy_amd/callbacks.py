@@ -138,7 +138,11 @@ class XarrayExporter(_GridOutput):
         """True when all `fire` will do with the model's state is enqueue device work (the transforms and the pack kernels): the
         time loop may then call it while the stretch of steps that ends at this output is still running on the device
         (speedy._act_ahead), and drops what it returns if one of those steps fails its range check."""
-        return self._in_run and self._deferred()
+        if not (self._in_run and self._deferred()):
+            return False
+        from . import speedy_driver as _speedy
+        members = [model_instance] if isinstance(model_instance, Speedy) else list(model_instance)
+        return _speedy.on_default_streams([member._state_cnt for member in members])  # (what is enqueued must be ORDERED behind the steps)
 
     def fire(self, model_instance):
         target = os.path.join(self.output_dir, model_instance.current_date.strftime(self.filename_fmt))

@@ -273,6 +273,16 @@ def check(state_cnt):
     return code.value
 
 
+def on_default_streams(state_cnts):
+    """True when, on every device the given containers live on, torch's current stream is the default (null) stream.  The models
+    are stepped on blocking streams of the library's own, which order themselves against the null stream and against no other:
+    work a host enqueues for a state that is still being computed (speedy._act_ahead) is in order only there."""
+    import torch
+    order, groups = _group_by_model(state_cnts)
+    devices = {groups[k][0].sp.device for k in order}
+    return all(torch.cuda.current_stream(d) == torch.cuda.default_stream(d) for d in devices)
+
+
 def ensemble_check(state_cnts):
     """Extension: `check` for many containers at once -- ONE range check per device model instead of one per container (each of
     which checks its whole model and picks its member: 64 launches and waits for a 64-member ensemble).  int32 codes in the order

@@ -429,7 +429,7 @@ def test_a_failing_writer_does_not_replace_the_runs_own_exception():
     assert done == [1] and hooks[0].finished == 1
 
 
-def test_hooks_that_only_enqueue_device_work_act_while_the_stretch_is_still_running():
+def test_hooks_that_only_enqueue_device_work_act_while_the_stretch_is_still_running(monkeypatch):
     """speedy._act_ahead: the hooks due at the end of a stretch fire before the host waits for it when ALL of them declare
     (`acts_ahead`) that they only enqueue device work; one that needs the state on the host keeps every hook behind the wait, in
     the order given.  XarrayExporter declares it only for what it writes in the background of a run that owns it."""
@@ -456,10 +456,22 @@ def test_hooks_that_only_enqueue_device_work_act_while_the_stretch_is_still_runn
     del done[:]
     assert S._act_ahead([Ahead().fire, DiagnosticCheck(36).fire], Model()) is None and done == []
     assert S._act_ahead([lambda m: None], Model()) is None
+    # (the model's steps run on streams that order themselves against the null stream only: ahead of them only from there)
+    from pyspeedy_amd import speedy_driver
+    asked, on_default = [], [True]
+    monkeypatch.setattr(speedy_driver, "on_default_streams", lambda cnts: asked.append(list(cnts)) or on_default[0])
+
+    class Member:
+        def __init__(self, cnt):
+            self._state_cnt = cnt
+    Model.__iter__ = lambda self: iter([Member(7), Member(8)])
     exporter = XarrayExporter(interval=36)
     assert not exporter.acts_ahead(Model())  # called by hand it writes inside the call
     exporter._in_run = True
-    assert exporter.acts_ahead(Model())
+    assert exporter.acts_ahead(Model()) and asked == [[7, 8]]
+    on_default[0] = False
+    assert not exporter.acts_ahead(Model())
+    on_default[0] = True
     Model.n_members = 1
     assert exporter.acts_ahead(Model())  # (a single model's file is written by the time loop itself, behind the next stretch)
     Model.n_members = 64

@@ -449,6 +449,33 @@ def test_unwaited_packed_export_is_the_waited_one_and_callers_do_not_share_a_sta
     assert np.array_equal(arrays2["u_grid"], waited["u_grid"]) and np.array_equal(arrays2["ps_grid"], waited["ps_grid"])
 
 
+def test_a_run_under_a_stream_of_the_hosts_own_writes_the_same_files():
+    """The exporter enqueues its device work behind a stretch that is still running only from the null stream (the models' streams
+    order themselves against that one and no other: speedy_driver.on_default_streams); under `torch.cuda.stream(s)` it waits for
+    the stretch first, as before round 6 -- the same files byte for byte."""
+    import torch
+    from pyspeedy_amd import speedy_driver
+    from pyspeedy_amd.callbacks import XarrayExporter
+    from pyspeedy_amd.speedy import SpeedyEns
+    start, end = datetime(1982, 1, 1), datetime(1982, 1, 1, 8, 0)  # 12 steps, an output every fourth
+    files = {}
+    for own_stream in (False, True):
+        ens = SpeedyEns(8, start_date=start, end_date=end)
+        ens.set_bc()
+        cnts = [m._state_cnt for m in ens]
+        with tempfile.TemporaryDirectory() as tmp:
+            if own_stream:
+                with torch.cuda.stream(torch.cuda.Stream()):
+                    assert not speedy_driver.on_default_streams(cnts)
+                    ens.run(callbacks=[XarrayExporter(output_dir=tmp, interval=4)])
+            else:
+                assert speedy_driver.on_default_streams(cnts)
+                ens.run(callbacks=[XarrayExporter(output_dir=tmp, interval=4)])
+            torch.cuda.synchronize()
+            files[own_stream] = {n: open(os.path.join(tmp, n), "rb").read() for n in sorted(os.listdir(tmp))}
+    assert len(files[False]) == 3 and files[True] == files[False]
+
+
 def test_background_writer_leaves_the_same_files():
     """XarrayExporter writes its files from a thread of its own while the model steps on (two buffers in turn); `run` returns when
     all of them are on disk.  Seven outputs of an 8-member ensemble, byte for byte the files of the in-callback writer; a writer
