@@ -22,7 +22,9 @@ of kernel launches per step for all of them afterwards) -- see include/pyspeedy_
 
 Extensions (no counterpart in the reference): `modelstate_init_ensemble(n)` (containers batched from the start),
 `parallel_step_begin / parallel_step_end` (range check overlapped with the next step), `device_model(state_cnt)` (the batched
-device model behind a container, for zero-copy access to the state), `ensemble_device_view`, `ensemble_grid_arrays`, the
+device model behind a container, for zero-copy access to the state), `ensemble_device_view`, `ensemble_grid_arrays`,
+`ensemble_export_arrays` (a NetCDF file's payload formed on the GPU), `parallel_steps_begin / parallel_steps_end` (the steps
+between two due callbacks as one device call), `ensemble_check` (one range check per device model), `on_default_streams`, the
 one-process-several-GPUs placement functions.
 """
 import ctypes as C
