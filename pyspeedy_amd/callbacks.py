@@ -84,25 +84,54 @@ class _GridOutput(BaseCallback):
 
 class ModelCheckpoint(_GridOutput):
     """Accumulates the selected grid-space variables as a time series in memory (`dataframe`).  The reference joins every new
-    snapshot to the series at once (callbacks.py:175-180, an outer merge: a copy of everything kept so far per output); here the snapshots are
-    kept as they come and joined when `dataframe` is read -- the same Dataset, one copy."""
+    snapshot to the series at once (callbacks.py:175-180, an outer merge: a copy of everything kept so far per output); here the
+    snapshots are kept as they come and joined when `dataframe` is read -- the same Dataset, one copy.  While a `SpeedyEns.run`
+    owns the hook, the snapshots of an ensemble that lives in one device model stay ON THE GPU until then (float32, 48 MB per day
+    of 64 members with the default variables; `device_bytes`, 8 GiB by default, is how much of them may wait there -- beyond it the
+    oldest are copied out): taking one only enqueues device work, and the run may ask for it while the steps that lead to it are
+    still on the device (`acts_ahead`; dropped, like every hook's output, if one of those steps fails its range check)."""
 
-    def __init__(self, interval=36, verbose=False, spinup_date=None, variables=None, output_dir="./"):
+    def __init__(self, interval=36, verbose=False, spinup_date=None, variables=None, output_dir="./", device_bytes=8 << 30):
         super().__init__(interval, verbose, spinup_date, variables, output_dir)
+        self.device_bytes = device_bytes
         self._frames = []
+        self._in_run = False  # set by the time loops of speedy.py around the run that owns this hook
 
     @property
     def dataframe(self):
-        if len(self._frames) > 1:
-            self._frames = [_dataset.concat(self._frames, "time")]
-        return self._frames[0] if self._frames else None
+        if not self._frames:
+            return None
+        if len(self._frames) > 1 or not isinstance(self._frames[0], _dataset.Dataset):
+            frames = [f if isinstance(f, _dataset.Dataset) else f.resolve() for f in self._frames]
+            self._frames = [frames[0] if len(frames) == 1 else _dataset.concat(frames, "time")]
+        return self._frames[0]
 
     @dataframe.setter
     def dataframe(self, value):
         self._frames = [] if value is None else [value]
 
+    def _on_device(self, model_instance):
+        """whether this output is taken on the GPU: inside a run, of a model that offers it, with the stock `snapshot`"""
+        return (self._in_run and self.device_bytes > 0 and callable(getattr(model_instance, "snapshot_on_device", None))
+                and type(self).snapshot is _GridOutput.snapshot)
+
+    def acts_ahead(self, model_instance):
+        if not self._on_device(model_instance):
+            return False
+        from . import speedy_driver as _speedy
+        return _speedy.on_default_streams([member._state_cnt for member in model_instance])
+
     def fire(self, model_instance):
-        self._frames.append(self.snapshot(model_instance))
+        frame = model_instance.snapshot_on_device(self.variables) if self._on_device(model_instance) else None
+        if frame is None:
+            frame = self.snapshot(model_instance)
+
+        def keep():  # (not before the state has passed its range check: the time loop calls this, or drops it)
+            self._frames.append(frame)
+            waiting = [f for f in self._frames if not isinstance(f, _dataset.Dataset)]
+            while waiting and sum(f.nbytes for f in waiting) > self.device_bytes:
+                waiting.pop(0).resolve()
+        return keep
 
 
 class XarrayExporter(_GridOutput):

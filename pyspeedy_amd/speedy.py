@@ -620,6 +620,22 @@ def _build_dataset(model, arrays, members, date, packed=False):
     return Dataset(data, coords)
 
 
+class PendingFrame:
+    """A snapshot of an ensemble that is still on the GPU (SpeedyEns.snapshot_on_device): `resolve()` copies it out and returns the
+    Dataset `to_dataframe` would have returned at the time it was taken; `nbytes` is what it holds on the device until then."""
+
+    def __init__(self, model, tensors, members, date):
+        self._model, self._tensors, self._members, self._date, self._frame = model, tensors, members, date, None
+        self.nbytes = sum(t.numel() * t.element_size() for t in tensors.values())
+
+    def resolve(self):
+        if self._frame is None:
+            arrays = {name: t.cpu().numpy() for name, t in self._tensors.items()}
+            self._frame = _build_dataset(self._model, arrays, self._members, self._date, packed=True)
+            self._tensors, self.nbytes = None, 0
+        return self._frame
+
+
 class SpeedyEns:
     """Ensemble of Speedy members that live in one batched device model -- or, with `devices=k`, in one batched model on
     each of the GPUs 0 .. k-1 of this process (members in blocks, member e of n on device e k / n): `run` then drives all
@@ -686,6 +702,19 @@ class SpeedyEns:
         frame = _build_dataset(self.members[0], arrays, [m.member_id for m in self], self.current_date, packed=True)
         frame.ready = ready
         return frame
+
+    def snapshot_on_device(self, variables=None):
+        """Extension: what `to_dataframe(variables)` would return, kept on the GPU until it is read -- a PendingFrame whose
+        `resolve()` is that Dataset -- or None when the ensemble does not live in one device model (callers then ask
+        `to_dataframe`).  Only enqueues device work (speedy_driver.ensemble_export_tensors); for hooks that keep a time series
+        (callbacks.ModelCheckpoint)."""
+        variables = DEFAULT_OUTPUT_VARS if variables is None else variables
+        for var in variables:
+            _exportable(var)
+        tensors = _speedy.ensemble_export_tensors([m._state_cnt for m in self], list(variables))
+        if tensors is None:
+            return None
+        return PendingFrame(self.members[0], tensors, [m.member_id for m in self], self.current_date)
 
     def _device_models(self):
         """[(EnsembleModel view, member_id of the container that is member 0 of that model)] for the device models the

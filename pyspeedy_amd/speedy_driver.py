@@ -538,6 +538,37 @@ def ensemble_export_arrays(state_cnts, names, slot=0, buffers=None, wait=True):
     return arrays if wait else (arrays, events)
 
 
+def ensemble_export_tensors(state_cnts, names):
+    """Extension, for hooks that KEEP outputs: the grid-space variables `names` of the given containers as a Dataset of the
+    reference carries them (float32, vertical levels bottom-up) in DEVICE tensors of their own -- dict name -> torch.float32
+    [member, (lev,) lat, lon] -- or None when the containers are not, in order, all the members of one device model (the caller
+    then takes the host path).  Only enqueues (one transform, one pack kernel per variable, one pass that turns the file's byte
+    order back into the host's): the tensors may be asked for while the steps that lead to this state are still running on the
+    device (speedy._act_ahead), and a day of 64 members costs 48 MB of the GPU's 288 GB until somebody reads it."""
+    import torch
+    order, groups = _group_by_model(state_cnts)
+    if len(order) != 1:
+        return None
+    model, positions, members = groups[order[0]]
+    if members != list(range(model.nmembers)):
+        return None
+    n = len(state_cnts)
+    shapes = {name: tuple(reversed(model.shape(name)[1])) for name in names}
+    sizes = {name: 4 * n * int(np.prod(shapes[name])) for name in names}
+    with torch.cuda.device(model.sp.device):
+        packed = torch.empty(sum(sizes.values()), dtype=torch.uint8, device=model.sp.device)
+        model.spectral2grid()
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        at, where = 0, {}
+        for name in names:
+            _ok(_L().spd_model_export_pack(model._m, name.encode(), 0, n, C.c_void_p(packed.data_ptr() + at), sizes[name], stream),
+                "export_pack")
+            where[name] = at
+            at += sizes[name]
+        native = packed.view(-1, 4).flip(1).contiguous().view(torch.float32)  # (big-endian, as a file wants it -> the host's order)
+    return {name: native[where[name] // 4:(where[name] + sizes[name]) // 4].view((n,) + shapes[name]) for name in names}
+
+
 def driver_stats(state_cnt=0):
     """(device models alive, members in the model of `state_cnt`)"""
     alive, members = C.c_int32(), C.c_int32()

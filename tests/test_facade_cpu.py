@@ -500,17 +500,94 @@ def test_model_checkpoint_joins_its_snapshots_when_the_series_is_read():
             self.day += 1
             return frame(self.day, float(self.day))
 
+    class Step:
+        """the part of a model the gating asks for, around the fake's to_dataframe"""
+        current_date = datetime(1982, 1, 1)
+
+        def __init__(self, model):
+            self.to_dataframe = model.to_dataframe
+
+        def get_current_step(self):
+            return 0
+
     keep, model = ModelCheckpoint(interval=1), Model()
     assert keep.dataframe is None
     for _ in range(3):
-        keep.fire(model)
+        keep(Step(model))  # (by hand: what `fire` leaves to be done happens inside the call)
     assert len(keep._frames) == 3
+    dropped = keep.fire(model)  # a time loop that finds the state refused by the range check drops what `fire` returned
+    assert callable(dropped) and len(keep._frames) == 3
+    model.day -= 1
     series = keep.dataframe
     assert series["t"].values.shape == (3, 3) and list(series["t"].values[:, 0]) == [1.0, 2.0, 3.0]
     assert keep.dataframe is series and len(keep._frames) == 1  # (joined once)
-    keep.fire(model)
+    keep(Step(model))
     assert keep.dataframe["t"].values.shape == (4, 3) and keep.copy().dataframe["t"].values.shape == (4, 3)
     keep.dataframe = None
     assert keep.dataframe is None and keep._frames == []
     mixed = concat([frame(3, 3.0), frame(1, 1.0), frame(2, 2.0)], "time")
     assert list(mixed["t"].values[:, 0]) == [1.0, 2.0, 3.0] and list(mixed["time"].values) == sorted(mixed["time"].values)
+
+
+def test_model_checkpoint_keeps_an_ensembles_snapshots_on_the_device_while_a_run_owns_it(monkeypatch):
+    """Inside a run ModelCheckpoint asks a model that offers it for snapshots that stay on the GPU (SpeedyEns.snapshot_on_device:
+    only enqueues) -- so it may act ahead of a running stretch --, copies the oldest out when more than `device_bytes` wait there,
+    and `dataframe` is the same series as ever.  By hand, with a snapshot() of the user's own, or with device_bytes=0: the host path."""
+    from pyspeedy_amd import speedy_driver
+    from pyspeedy_amd.callbacks import ModelCheckpoint
+    from pyspeedy_amd.dataset import Dataset, Variable
+    monkeypatch.setattr(speedy_driver, "on_default_streams", lambda cnts: True)
+    resolved = []
+
+    def frame(day):
+        return Dataset({"t": Variable(("time", "lat"), np.full((1, 3), float(day), dtype=np.float32))},
+                       {"time": Variable(("time",), np.array([np.datetime64("1982-01-%02d" % day, "s")])),
+                        "lat": Variable(("lat",), np.arange(3, dtype=np.float32))})
+
+    class Pending:
+        def __init__(self, day):
+            self.day, self.nbytes = day, 100
+
+        def resolve(self):
+            if self.nbytes:
+                resolved.append(self.day)
+                self.nbytes = 0
+            return frame(self.day)
+
+    class Member:
+        _state_cnt = 5
+
+    class Ens:
+        day, host = 0, 0
+
+        def __iter__(self):
+            return iter([Member()])
+
+        def snapshot_on_device(self, variables):
+            self.day += 1
+            return Pending(self.day)
+
+        def to_dataframe(self, variables=None):
+            self.day += 1
+            self.host += 1
+            return frame(self.day)
+
+    keep, ens = ModelCheckpoint(interval=1, device_bytes=250), Ens()
+    assert not keep.acts_ahead(ens)  # by hand: the host path, at once
+    keep.fire(ens)()
+    assert ens.host == 1 and isinstance(keep._frames[0], Dataset)
+    keep._in_run = True
+    assert keep.acts_ahead(ens)
+    for _ in range(3):
+        keep.fire(ens)()
+    assert ens.host == 1 and resolved == [2]  # (three of 100 bytes against 250: the oldest went to the host)
+    assert list(keep.dataframe["t"].values[:, 0]) == [1.0, 2.0, 3.0, 4.0] and resolved == [2, 3, 4]
+
+    class Own(ModelCheckpoint):
+        def snapshot(self, model_instance):
+            return model_instance.to_dataframe()
+    own = Own(interval=1)
+    own._in_run = True
+    assert not own.acts_ahead(ens) and not ModelCheckpoint(device_bytes=0).acts_ahead(ens)
+    own.fire(ens)()
+    assert ens.host == 2

@@ -449,6 +449,47 @@ def test_unwaited_packed_export_is_the_waited_one_and_callers_do_not_share_a_sta
     assert np.array_equal(arrays2["u_grid"], waited["u_grid"]) and np.array_equal(arrays2["ps_grid"], waited["ps_grid"])
 
 
+def test_model_checkpoint_of_an_ensemble_waits_on_the_device_and_reads_as_the_host_path():
+    """callbacks.ModelCheckpoint inside SpeedyEns.run: the snapshots stay on the GPU (speedy.PendingFrame) until `dataframe` is read;
+    the series is the one the host path gives -- `to_dataframe()` at every output, float64 narrowed on the host -- value for value,
+    in stretches and step by step; a small `device_bytes` spills the oldest to the host on the way."""
+    from pyspeedy_amd.callbacks import BaseCallback, ModelCheckpoint
+    from pyspeedy_amd.dataset import Dataset
+    from pyspeedy_amd.speedy import PendingFrame, SpeedyEns
+    start, end = datetime(1982, 1, 1), datetime(1982, 1, 1, 12, 0)  # 18 steps, an output every sixth
+
+    class HostPath(BaseCallback):
+        def __init__(self):
+            super().__init__(interval=6)
+            self.frames = []
+
+        def fire(self, model):
+            self.frames.append(model.to_dataframe(variables=["t_grid", "ps_grid", "precnv"]))
+
+    series = {}
+    for mode in ("stretches", "stepwise", "spill"):
+        ens = SpeedyEns(5, start_date=start, end_date=end)
+        ens.set_bc()
+        t = ens.members[2]["t"]
+        t[3, 3] *= 1.001
+        ens.members[2]["t"] = t
+        keep = ModelCheckpoint(interval=6, variables=["t_grid", "ps_grid", "precnv"], device_bytes=1 if mode == "spill" else 8 << 30)
+        host = HostPath()
+        ens.run(callbacks=[keep, host] + ([lambda m: None] if mode == "stepwise" else []))
+        assert len(keep._frames) == 3 and all(isinstance(f, PendingFrame) for f in keep._frames)
+        assert [f.nbytes > 0 for f in keep._frames] == ([False, False, False] if mode == "spill" else [True, True, True])
+        frame = keep.dataframe
+        assert isinstance(frame, Dataset) and frame["t"].values.shape == (3, 5, 8, 48, 96) and frame["t"].values.dtype == np.float32
+        assert keep._frames == [frame] and not keep._in_run
+        for k, at in enumerate(host.frames):
+            for v in ("t", "ps", "precnv"):
+                assert np.array_equal(frame[v].values[k], at[v].values[0]), (mode, k, v)
+        assert list(frame["time"].values) == [np.datetime64(start + timedelta(minutes=40 * 6 * (k + 1)), "s") for k in range(3)]
+        assert not np.array_equal(frame["t"].values[2, 2], frame["t"].values[2, 1])  # (members, not one member five times)
+        series[mode] = frame["t"].values
+    assert np.array_equal(series["stretches"], series["stepwise"]) and np.array_equal(series["stretches"], series["spill"])
+
+
 def test_a_run_under_a_stream_of_the_hosts_own_writes_the_same_files():
     """The exporter enqueues its device work behind a stretch that is still running only from the null stream (the models' streams
     order themselves against that one and no other: speedy_driver.on_default_streams); under `torch.cuda.stream(s)` it waits for
