@@ -119,7 +119,8 @@ class ModelCheckpoint(_GridOutput):
         if not self._on_device(model_instance):
             return False
         from . import speedy_driver as _speedy
-        return _speedy.on_default_streams([member._state_cnt for member in model_instance])
+        members = [model_instance] if isinstance(model_instance, Speedy) else list(model_instance)
+        return _speedy.on_default_streams([member._state_cnt for member in members])
 
     def fire(self, model_instance):
         frame = model_instance.snapshot_on_device(self.variables) if self._on_device(model_instance) else None

@@ -429,6 +429,17 @@ class Speedy:
         return _build_dataset(self, arrays, members, self.current_date)
 
 
+    def snapshot_on_device(self, variables=None):
+        """Extension: see SpeedyEns.snapshot_on_device (None for a member of a device model that holds other members as well)."""
+        variables = DEFAULT_OUTPUT_VARS if variables is None else variables
+        for var in variables:
+            _exportable(var)
+        tensors = _speedy.ensemble_export_tensors([self._state_cnt], list(variables))
+        if tensors is None:
+            return None
+        return PendingFrame(self, tensors, [self.member_id] if self.is_ensemble_member else None, self.current_date)
+
+
 # The time loops below take the steps between two due callbacks as ONE device call (speedy_driver.parallel_steps_begin / _end): the
 # device then runs its multi-step plan -- member groups on streams of their own, large ensembles in rounds -- instead of being
 # asked once per 40 simulated minutes, and the range check the reference makes after every step (speedy.py:398-400) is still

@@ -488,6 +488,18 @@ def test_model_checkpoint_of_an_ensemble_waits_on_the_device_and_reads_as_the_ho
         assert not np.array_equal(frame["t"].values[2, 2], frame["t"].values[2, 1])  # (members, not one member five times)
         series[mode] = frame["t"].values
     assert np.array_equal(series["stretches"], series["stepwise"]) and np.array_equal(series["stretches"], series["spill"])
+    # a single model: the same, without the member axis
+    from pyspeedy_amd.speedy import Speedy
+    model = Speedy(start_date=start, end_date=end)
+    model.set_bc()
+    keep, host = ModelCheckpoint(interval=6, variables=["t_grid", "ps_grid", "precnv"]), HostPath()
+    model.run(callbacks=[keep, host])
+    assert all(isinstance(f, PendingFrame) for f in keep._frames)
+    frame = keep.dataframe
+    assert frame["t"].dims == ("time", "lev", "lat", "lon") and frame["t"].values.shape == (3, 8, 48, 96)
+    for k, at in enumerate(host.frames):
+        for v in ("t", "ps", "precnv"):
+            assert np.array_equal(frame[v].values[k], at[v].values[0]), (k, v)
 
 
 def test_a_run_under_a_stream_of_the_hosts_own_writes_the_same_files():
