@@ -770,7 +770,7 @@ def facade_leg():
     import tempfile
     from datetime import datetime, timedelta
     import torch
-    from pyspeedy_amd.callbacks import XarrayExporter
+    from pyspeedy_amd.callbacks import ModelCheckpoint, XarrayExporter
     from pyspeedy_amd.speedy import Speedy, SpeedyEns
     start = datetime(1982, 1, 1)
 
@@ -791,7 +791,7 @@ def facade_leg():
     def timed(members, days, export):
         model = make(members, days)
         with tempfile.TemporaryDirectory(prefix="pyspeedy_bench_") as tmp:
-            callbacks = [XarrayExporter(output_dir=tmp)] if export else []
+            callbacks = ([ModelCheckpoint()] if export == "checkpoint" else [XarrayExporter(output_dir=tmp)]) if export else []
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             model.run(callbacks=callbacks)
@@ -818,11 +818,14 @@ def facade_leg():
         out[key] = {"members": members, "run_ms_per_step": plain, "run_steps": 36 * days_plain,
                     "run_daily_export_ms_per_step": exported, "run_daily_export_steps": 36 * days_export, "files_written": files,
                     "megabytes_written": written / 1e6}
+        if key == "ens64":  # (the reference's in-memory hook: the snapshots wait on the GPU until the series is read)
+            out[key]["run_daily_checkpoint_ms_per_step"] = min(timed(members, days_export, "checkpoint")[0] for _ in range(2))
     out["note"] = ("SpeedyEns(64).run() / Speedy().run() of the facade (pyspeedy_amd/speedy.py = the reference's classes over the C "
                    "boundary): wall time of run() per model step; the steps between two due callbacks are ONE call "
                    "(spd_parallel_steps_begin / _end) with the range check of every step recorded on the device; "
                    "run_daily_export = with callbacks=[XarrayExporter()] (defaults: every 36 steps, u v t q phi ps, NetCDF-3 files, "
-                   "written behind the time loop); ens256: the same for 256 members (rounds of 64 inside every call)")
+                   "written behind the time loop); run_daily_checkpoint = with callbacks=[ModelCheckpoint()] (the same variables kept "
+                   "as a time series in memory); ens256: the same for 256 members (rounds of 64 inside every call)")
     return out
 
 
@@ -847,6 +850,8 @@ def step_contract_keys(legs, headline_ms, members_total):
             flat["facade_%s_run_ms_per_step" % key] = f[key]["run_ms_per_step"]
             if "run_daily_export_ms_per_step" in f[key]:
                 flat["facade_%s_run_daily_export_ms_per_step" % key] = f[key]["run_daily_export_ms_per_step"]
+            if "run_daily_checkpoint_ms_per_step" in f[key]:
+                flat["facade_%s_run_daily_checkpoint_ms_per_step" % key] = f[key]["run_daily_checkpoint_ms_per_step"]
     pr = legs.get("projected_8gpu_cfg4") or {}
     for key in ("value", "speedup_over_1gpu", "efficiency"):
         if key in pr:
