@@ -315,12 +315,12 @@ class Speedy:
         end_date = self.end_date
         self._step_in_run = self["current_step"]
         _own(callbacks, True)
-        intervals = _hook_intervals(callbacks)
+        intervals, spinups = _hook_intervals(callbacks), _hook_spinups(callbacks)
         if intervals is not None:  # the hooks' schedule is known: the steps between two due hooks are one device call
             rest = []  # what the hooks of the last boundary left to be done once the next stretch is on the device
             try:
                 while self.current_date < end_date:
-                    k = _stretch(self._step_in_run, intervals, self.current_date, end_date)
+                    k = _stretch(self._step_in_run, intervals, self.current_date, end_date, spinups)
                     before, step_before = self.current_date, self._step_in_run
                     token = _speedy.parallel_steps_begin([self._state_cnt], [self._control_cnt], k)
                     try:
@@ -464,12 +464,24 @@ def _hook_intervals(callbacks):
     return intervals
 
 
-def _stretch(step, intervals, current_date, end_date):
-    """steps until the next one at which a hook may act, the end of the run or _MAX_STRETCH, whichever comes first"""
+def _hook_spinups(callbacks):
+    """[spinup_date of every hook] (None: acts from the start), beside _hook_intervals"""
+    return [getattr(cb, "spinup_date", None) for cb in callbacks]
+
+
+def _stretch(step, intervals, current_date, end_date, spinups=None):
+    """steps until the next one at which a hook may act, the end of the run or _MAX_STRETCH, whichever comes first.  A hook that is
+    still spinning up (callbacks.py:52-70: silent while the model's date is before its `spinup_date`) may act at the first multiple
+    of its interval whose date is not: the multiples before that one do not end a stretch."""
     remaining = -((current_date - end_date) // _DT_STEP)  # ceil((end - current) / dt)
     k = min(int(remaining), _MAX_STRETCH)
-    for interval in intervals:
-        k = min(k, interval - step % interval)
+    for n, interval in enumerate(intervals):
+        k_hook = interval - step % interval
+        spinup = spinups[n] if spinups else None
+        if spinup is not None and current_date + k_hook * _DT_STEP < spinup:
+            first = step + int(-((current_date - spinup) // _DT_STEP))  # the first step whose date is not before the spin-up date
+            k_hook = first + (-first) % interval - step
+        k = min(k, k_hook)
     return max(k, 1)
 
 
@@ -767,12 +779,12 @@ class SpeedyEns:
                 raise RuntimeError("The SPEEDY model was not initialized. Call the `set_bc` method of every member.")
         step = self.members[0]["current_step"]
         _own(callbacks, True)
-        intervals = _hook_intervals(callbacks)
+        intervals, spinups = _hook_intervals(callbacks), _hook_spinups(callbacks)
         if intervals is not None:  # (see Speedy.run)
             rest = []
             try:
                 while self.current_date < end_date:
-                    k = _stretch(step, intervals, self.current_date, end_date)
+                    k = _stretch(step, intervals, self.current_date, end_date, spinups)
                     before = self.current_date
                     token = _speedy.parallel_steps_begin(state_cnts, control_cnts, k)
                     try:

@@ -371,6 +371,30 @@ def test_the_stretches_of_the_time_loops_follow_the_hooks_schedule():
     assert S._stretch(36, [36], start, start + 20 * dt) == 20 and S._stretch(0, [], start, start + 1000 * dt) == S._MAX_STRETCH == 360
     assert S._stretch(0, [36], start, start + timedelta(minutes=50)) == 2  # (an end date between two steps: the loop runs past it, as upstream)
     assert S._stretch(5, [36], start, start) == 1  # (never less than a step: the loop's own condition ends the run)
+    # a hook that is still spinning up does not end a stretch: the first multiple of its interval whose date is not before its
+    # spinup_date does (checked against the hook's own gate, step by step)
+    spin = start + 100 * dt + timedelta(minutes=10)  # between steps 100 and 101: step 108 is the first of interval 36 that may act
+    assert S._stretch(0, [36], start, start + 500 * dt, [spin]) == 108 and S._stretch(0, [36, 50], start, start + 500 * dt, [spin, None]) == 50
+    assert S._stretch(100, [36], start + 100 * dt, start + 500 * dt, [spin]) == 8
+    assert S._stretch(108, [36], start + 108 * dt, start + 500 * dt, [spin]) == 36
+    assert S._stretch(0, [36], start, start + 500 * dt, [start + 72 * dt]) == 72  # (a date that IS a step's date: that step acts)
+    assert S._hook_spinups([DiagnosticCheck(36), ModelCheckpoint(interval=7, spinup_date=spin)]) == [None, spin]
+    hook = ModelCheckpoint(interval=36, spinup_date=spin)
+
+    class At:
+        def __init__(self, step):
+            self.step, self.current_date = step, start + step * dt
+
+        def get_current_step(self):
+            return self.step
+    step, acted = 0, []
+    while step < 300:
+        k = S._stretch(step, [36], start + step * dt, start + 300 * dt, [spin])
+        assert not any(not hook.skip_flag(At(s)) for s in range(step + 1, step + k)), (step, k)  # nothing due inside the stretch
+        step += k
+        if not hook.skip_flag(At(step)):
+            acted.append(step)
+    assert acted == [108, 144, 180, 216, 252, 288]
     # hooks may leave what no longer needs the state to the time loop; called by hand it happens at once
     done = []
 
