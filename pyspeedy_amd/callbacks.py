@@ -119,8 +119,9 @@ class ModelCheckpoint(_GridOutput):
         if not self._on_device(model_instance):
             return False
         from . import speedy_driver as _speedy
-        members = [model_instance] if isinstance(model_instance, Speedy) else list(model_instance)
-        return _speedy.on_default_streams([member._state_cnt for member in members])
+        cnts = [member._state_cnt for member in ([model_instance] if isinstance(model_instance, Speedy) else model_instance)]
+        # (an ensemble spread over several device models takes the host path, which waits for the state: not ahead of it)
+        return _speedy.whole_device_model(cnts) and _speedy.on_default_streams(cnts)
 
     def fire(self, model_instance):
         frame = model_instance.snapshot_on_device(self.variables) if self._on_device(model_instance) else None

@@ -538,6 +538,12 @@ def ensemble_export_arrays(state_cnts, names, slot=0, buffers=None, wait=True):
     return arrays if wait else (arrays, events)
 
 
+def whole_device_model(state_cnts):
+    """True when the containers are, in order, all the members of ONE device model (what ensemble_export_tensors needs)"""
+    order, groups = _group_by_model(state_cnts)
+    return len(order) == 1 and groups[order[0]][2] == list(range(groups[order[0]][0].nmembers))
+
+
 def ensemble_export_tensors(state_cnts, names):
     """Extension, for hooks that KEEP outputs: the grid-space variables `names` of the given containers as a Dataset of the
     reference carries them (float32, vertical levels bottom-up) in DEVICE tensors of their own -- dict name -> torch.float32
@@ -551,7 +557,7 @@ def ensemble_export_tensors(state_cnts, names):
         return None
     model, positions, members = groups[order[0]]
     if members != list(range(model.nmembers)):
-        return None
+        return None  # (as whole_device_model)
     n = len(state_cnts)
     shapes = {name: tuple(reversed(model.shape(name)[1])) for name in names}
     sizes = {name: 4 * n * int(np.prod(shapes[name])) for name in names}

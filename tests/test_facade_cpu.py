@@ -561,6 +561,8 @@ def test_model_checkpoint_keeps_an_ensembles_snapshots_on_the_device_while_a_run
     from pyspeedy_amd.callbacks import ModelCheckpoint
     from pyspeedy_amd.dataset import Dataset, Variable
     monkeypatch.setattr(speedy_driver, "on_default_streams", lambda cnts: True)
+    whole = [True]
+    monkeypatch.setattr(speedy_driver, "whole_device_model", lambda cnts: whole[0])
     resolved = []
 
     def frame(day):
@@ -601,6 +603,9 @@ def test_model_checkpoint_keeps_an_ensembles_snapshots_on_the_device_while_a_run
     keep.fire(ens)()
     assert ens.host == 1 and isinstance(keep._frames[0], Dataset)
     keep._in_run = True
+    whole[0] = False
+    assert not keep.acts_ahead(ens)  # (spread over several device models: the host path, after the wait)
+    whole[0] = True
     assert keep.acts_ahead(ens)
     for _ in range(3):
         keep.fire(ens)()
