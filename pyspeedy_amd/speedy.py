@@ -604,9 +604,23 @@ def _exportable(var):
     return meta
 
 
+def _export_coords(model):
+    """lon, lat and lev as a Dataset carries them.  Tables of the geometry, the same for every step: asked for once per model object
+    -- each `model[c]` is a synchronous copy from the device, which an export that otherwise only enqueues work would have to
+    wait for."""
+    cached = model.__dict__.setdefault("_export_coords", {})
+    for c in ("lon", "lat", "lev"):
+        if c not in cached:
+            vals = model[c][::-1] if c == "lev" else model[c]
+            cached[c] = np.ascontiguousarray(vals, dtype=np.float32)
+            cached[c].setflags(write=False)
+    return cached
+
+
 def _build_dataset(model, arrays, members, date, packed=False):
     """arrays: var -> [member, (lev,) lat, lon] float64 in model level order -- or, packed, float32 with the levels already
-    bottom-up (speedy_driver.ensemble_export_arrays); members: list of ids or None (single run)."""
+    bottom-up (speedy_driver.ensemble_export_arrays); members: list of ids or None (single run); model: the Speedy object the
+    coordinates are asked of, or the dict _export_coords made of them."""
     lead = ("time", "ens") if members is not None else ("time",)
     data = {}
     for var, values in arrays.items():
@@ -622,15 +636,9 @@ def _build_dataset(model, arrays, members, date, packed=False):
             attrs["units"] = meta.units
         data[meta.alt_name] = Variable(lead + dims, values, attrs)
     coords = {}
-    # (lon, lat and lev are tables of the geometry, the same for every model and every step: asked for once per model object -- each
-    # `model[c]` is a synchronous copy from the device, which an export that otherwise only enqueues work would have to wait for)
-    cached = model.__dict__.setdefault("_export_coords", {})
+    cached = model if isinstance(model, dict) else _export_coords(model)
     for c, axis in (("lon", "X"), ("lat", "Y"), ("lev", None)):
         meta = REGISTRY[c]
-        if c not in cached:
-            vals = model[c][::-1] if c == "lev" else model[c]
-            cached[c] = np.ascontiguousarray(vals, dtype=np.float32)
-            cached[c].setflags(write=False)
         attrs = {"long_name": meta.long_name, "standard_name": c}
         if meta.units is not None:
             attrs["units"] = meta.units
@@ -648,13 +656,15 @@ class PendingFrame:
     Dataset `to_dataframe` would have returned at the time it was taken; `nbytes` is what it holds on the device until then."""
 
     def __init__(self, model, tensors, members, date):
-        self._model, self._tensors, self._members, self._date, self._frame = model, tensors, members, date, None
+        # (the coordinates, not the model: a hook that holds frames is copied with them -- callbacks.BaseCallback.copy -- and a
+        # model object owns its containers)
+        self._coords, self._tensors, self._members, self._date, self._frame = _export_coords(model), tensors, members, date, None
         self.nbytes = sum(t.numel() * t.element_size() for t in tensors.values())
 
     def resolve(self):
         if self._frame is None:
             arrays = {name: t.cpu().numpy() for name, t in self._tensors.items()}
-            self._frame = _build_dataset(self._model, arrays, self._members, self._date, packed=True)
+            self._frame = _build_dataset(self._coords, arrays, self._members, self._date, packed=True)
             self._tensors, self.nbytes = None, 0
         return self._frame
 

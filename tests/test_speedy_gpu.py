@@ -478,7 +478,9 @@ def test_model_checkpoint_of_an_ensemble_waits_on_the_device_and_reads_as_the_ho
         ens.run(callbacks=[keep, host] + ([lambda m: None] if mode == "stepwise" else []))
         assert len(keep._frames) == 3 and all(isinstance(f, PendingFrame) for f in keep._frames)
         assert [f.nbytes > 0 for f in keep._frames] == ([False, False, False] if mode == "spill" else [True, True, True])
+        twin = keep.copy()  # (a copy holds frames of its own -- on the device too -- and no model)
         frame = keep.dataframe
+        assert all(isinstance(f, PendingFrame) for f in twin._frames) and np.array_equal(twin.dataframe["t"].values, frame["t"].values)
         assert isinstance(frame, Dataset) and frame["t"].values.shape == (3, 5, 8, 48, 96) and frame["t"].values.dtype == np.float32
         assert keep._frames == [frame] and not keep._in_run
         for k, at in enumerate(host.frames):
